@@ -1,0 +1,164 @@
+/*
+ * pixelbox_hip.h -- C ABI of the MI355X-native PixelBox visual-similarity hot path.
+ *
+ * This is the drop-in boundary: what a Rust `extern "C"` block in PixelBox would bind in
+ * place of (a) tract-onnx inside `image_hashes::mlhash` and (b) the SQLite `cosine_distance`
+ * UDF + `ORDER BY dist LIMIT 100` scan inside `Engine`.  Plain pointers and sizes only.
+ * Every entry point cites the reference interface it replaces (paths relative to the
+ * PixelBox repository).  INTEGRATION.md shows the Rust-side binding.
+ *
+ * Conventions
+ *   - every function returns PB_OK (0) or a negative pb_status; it never throws, aborts or
+ *     unwinds across the boundary (the reference panics via unwrap/expect: efficientnet.rs:12,34,
+ *     engine.rs:99-109).  pb_last_error() returns a thread-local message for the last failure.
+ *   - the caller owns every buffer it passes; the library never frees caller memory.
+ *   - handles are thread-safe: calls on one handle serialise internally (the reference calls
+ *     mlhash from 4 crawler threads + the UI thread against one model, engine.rs:22,180,356, and
+ *     searches while another thread inserts, engine.rs:184-203,374).
+ *   - "host" pointers are ordinary CPU memory; "device" pointers are HIP device memory on the
+ *     handle's GPU (e.g. a torch tensor's data_ptr()).
+ */
+#ifndef PIXELBOX_HIP_H
+#define PIXELBOX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum pb_status {
+    PB_OK = 0,
+    PB_ERR_INVALID = -1,   /* bad argument (null pointer, wrong length, k out of range, ...) */
+    PB_ERR_HIP = -2,       /* a HIP runtime call failed; pb_last_error() has the HIP error string */
+    PB_ERR_NOMEM = -3,     /* host or device allocation failed */
+    PB_ERR_CAPACITY = -4,  /* index is full (capacity_rows reached) */
+    PB_ERR_FORMAT = -5,    /* malformed weight blob */
+    PB_ERR_INTERNAL = -6
+} pb_status;
+
+#define PB_MAX_K 256u /* reference: LIMIT 100 (engine.rs:314,381) */
+
+const char *pb_last_error(void);
+int pb_version(void);
+/* number of visible HIP devices (0 when there is no GPU: every other call then fails loudly) */
+int pb_device_count(int *n);
+
+/* ======================================================================================
+ *  scan half:  semantic_hashes table  +  cosine_distance top-k query
+ * ====================================================================================== */
+typedef struct pb_index pb_index;
+
+/* Device-resident mirror of `CREATE TABLE semantic_hashes (image_id INTEGER PRIMARY KEY, hash BLOB)`
+ * (engine.rs:48,109): a contiguous uint8[capacity_rows][dim] matrix in HBM, rows kept in ascending
+ * image_id order (the order SQLite scans the rowid B-tree in).  dim is fixed per index; the reference
+ * does not enforce blob length (engine.rs:585 zip-truncates) -- documented deviation: other lengths
+ * are rejected.  `device` is the HIP device ordinal. */
+int pb_index_create(pb_index **out, int device, uint32_t dim, uint64_t capacity_rows);
+int pb_index_destroy(pb_index *idx);
+int pb_index_size(const pb_index *idx, uint64_t *n_rows);
+int pb_index_dim(const pb_index *idx, uint32_t *dim);
+
+/* Replaces `INSERT OR IGNORE INTO semantic_hashes (image_id, hash) VALUES (?, ?)` (engine.rs:251-256),
+ * batched: n (image_id, hash) pairs from HOST memory.  OR IGNORE semantics: a pair whose image_id is
+ * already present is skipped (first write wins).  ids greater than every stored id append at the end
+ * (the common case: ids come from last_insert_rowid(), engine.rs:233); an id that falls between stored
+ * ids is inserted in place (device memmove).  *n_inserted (optional) receives the number stored. */
+int pb_index_append(pb_index *idx, const int64_t *image_ids, const uint8_t *rows, uint64_t n,
+                    uint64_t *n_inserted);
+
+/* Bulk (re)load at Engine::open (engine.rs:117-145) from
+ * `SELECT image_id, hash FROM semantic_hashes ORDER BY image_id`: replaces the index content.
+ * image_ids must be strictly increasing. */
+int pb_index_load(pb_index *idx, const int64_t *image_ids, const uint8_t *rows, uint64_t n);
+
+/* Replaces Engine::query_by_image_hash_from_image (engine.rs:363-396), i.e.
+ *   SELECT ..., cosine_distance(?, semantic_hashes.hash) AS dist FROM semantic_hashes ...
+ *   WHERE dist < ? ORDER BY dist ASC LIMIT 100
+ * for nq query hashes at once (queries: HOST uint8[nq][dim]).  For query q the results are written to
+ * out_ids[q*k .. ], out_dist[q*k .. ] (HOST), sorted by (dist ascending, image_id ascending), and
+ * out_count[q] <= k receives their number.  dist is the reference's f32 value bit for bit
+ * (engine.rs:572-588: 1/max(cos,1e-6) - 1 on (v/255)*2-1 de-quantised bytes, sequential unfused f32);
+ * the filter is `(f64)dist < max_dist` (engine.rs:379,619).  1 <= k <= PB_MAX_K.
+ * The caller joins the ids back to the `images` table (engine.rs:377,384-388). */
+int pb_index_search(pb_index *idx, const uint8_t *queries, uint32_t nq, uint32_t k, double max_dist,
+                    int64_t *out_ids, float *out_dist, uint32_t *out_count);
+
+/* Same query, results left in DEVICE memory of the index's GPU (int64[nq*k], float[nq*k],
+ * uint32[nq]; unused slots hold id = INT64_MAX, dist = +inf): the per-shard top-k that the multi-GPU
+ * path all-gathers over RCCL before pb_topk_merge. */
+int pb_index_search_device(pb_index *idx, const uint8_t *queries, uint32_t nq, uint32_t k,
+                           double max_dist, int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count);
+
+/* G-way merge of per-shard results (HOST buffers): list g holds counts[g] entries at
+ * ids[g*stride ..], dist[g*stride ..], each sorted by (dist, id).  Writes the first k of the merged
+ * order.  This is the step after the all-gather in the row-sharded multi-GPU query. */
+int pb_topk_merge(const int64_t *ids, const float *dist, const uint32_t *counts, uint32_t n_lists,
+                  uint32_t stride, uint32_t k, int64_t *out_ids, float *out_dist, uint32_t *out_count);
+
+/* Read back stored rows [first, first+n) in image_id order to HOST buffers (either may be NULL):
+ * the checkpoint path -- the SQLite file stays the system of record. */
+int pb_index_read(const pb_index *idx, uint64_t first, uint64_t n, int64_t *image_ids, uint8_t *rows);
+
+/* Synthetic table for benchmarks: rows [first_row, first_row+n) of splitmix64 stream `seed`
+ * (bytes first_row*dim ..), generated on the device, appended with image_id = first_id + i. */
+int pb_index_fill_synthetic(pb_index *idx, uint64_t seed, uint64_t first_row, uint64_t n,
+                            int64_t first_id);
+
+/* Options (pb_index_set_option) */
+#define PB_OPT_SEARCH_PATH 1 /* 0 = auto (int-dot filter + exact rescoring, exhaustive fallback), 1 = exhaustive exact scan only */
+#define PB_OPT_PROFILE 2     /* 1 = bracket the scan kernel with HIP events (pb_index_get_stats) */
+#define PB_OPT_STREAM 3      /* value = hipStream_t to launch on (0 = the index's own stream) */
+int pb_index_set_option(pb_index *idx, int option, int64_t value);
+
+typedef struct pb_scan_stats {
+    uint64_t queries;         /* queries answered */
+    uint64_t fast_path;       /* answered by the int-dot filter pass with a passing certificate */
+    uint64_t fallback;        /* re-run through the exhaustive exact scan */
+    uint64_t profiled_launches; /* scan-kernel launches bracketed by events (PB_OPT_PROFILE) */
+    double profiled_ms;       /* their summed duration */
+    uint64_t profiled_bytes;  /* algorithmic bytes those launches streamed (rows * dim per query) */
+} pb_scan_stats;
+int pb_index_get_stats(pb_index *idx, pb_scan_stats *out, int reset);
+
+/* ======================================================================================
+ *  embed half:  image_hashes::mlhash
+ * ====================================================================================== */
+typedef struct pb_embedder pb_embedder;
+
+/* Replaces the lazy-static tract model (efficientnet.rs:10-14).  weights_blob: PBXW0001 blob
+ * (pixelbox_amd/weights.py; BN-folded EfficientNet-B0 + Linear(1280, D), resources/train.py:30-46)
+ * in HOST memory; it fixes H, W and D.  max_batch bounds the images per pb_embed_batch call. */
+int pb_embed_create(pb_embedder **out, int device, const void *weights_blob, size_t blob_len,
+                    uint32_t max_batch);
+int pb_embed_destroy(pb_embedder *e);
+int pb_embed_info(const pb_embedder *e, uint32_t *h, uint32_t *w, uint32_t *d, uint32_t *max_batch);
+
+/* Replaces mlhash (efficientnet.rs:31-42) for n images at once.  rgb: HOST uint8[n][H][W][3]
+ * (what `resize_to_fill(W,H,Triangle).to_rgb8()` yields, efficientnet.rs:20); the px/255 NCHW
+ * conversion of efficientnet.rs:21-28 is fused into the first kernel.  out_u8: HOST uint8[n][D], the
+ * quantised hash of efficientnet.rs:39 (bit-exact quantiser).  out_f32 (optional): the D tanh outputs. */
+int pb_embed_batch(pb_embedder *e, const uint8_t *rgb, uint32_t n, uint8_t *out_u8, float *out_f32);
+
+/* Same with DEVICE input/output pointers (no PCIe in the timed region; bench.py uses this). */
+int pb_embed_batch_device(pb_embedder *e, const uint8_t *d_rgb, uint32_t n, uint8_t *d_out_u8,
+                          float *d_out_f32);
+
+/* mlhash(img) -> Vec<u8> for one image: writes D bytes to out (out_len must be >= D). */
+int pb_mlhash(pb_embedder *e, const uint8_t *rgb, uint8_t *out, size_t out_len);
+
+#define PB_OPT_EMBED_STREAM 3
+int pb_embed_set_option(pb_embedder *e, int option, int64_t value);
+
+/* ======================================================================================
+ *  utilities
+ * ====================================================================================== */
+/* splitmix64 byte stream on the device: d_out[0..nbytes) = bytes [byte_offset, ..) of stream `seed`
+ * (definition in pixelbox_amd/synth.py).  byte_offset must be a multiple of 8. */
+int pb_fill_synthetic(int device, uint64_t seed, uint64_t byte_offset, uint64_t nbytes, uint8_t *d_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIXELBOX_HIP_H */

@@ -1,0 +1,237 @@
+"""ctypes binding of include/pixelbox_hip.h -- the test / bench harness' view of the C ABI.
+
+There is no CPU fallback here: if the HIP shared library is missing or there is no GPU, the calls
+raise (PixelboxError / OSError).  The CPU oracle under oracle/ is never imported from this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpixelbox_hip.so")
+
+PB_OK = 0
+PB_MAX_K = 256
+PB_OPT_SEARCH_PATH = 1
+PB_OPT_PROFILE = 2
+PB_OPT_STREAM = 3
+
+# every symbol include/pixelbox_hip.h declares (tests/test_abi.py checks the header against this list
+# and the built library against both)
+SYMBOLS = [
+    "pb_last_error", "pb_version", "pb_device_count",
+    "pb_index_create", "pb_index_destroy", "pb_index_size", "pb_index_dim", "pb_index_append", "pb_index_load",
+    "pb_index_search", "pb_index_search_device", "pb_topk_merge", "pb_index_read", "pb_index_fill_synthetic",
+    "pb_index_set_option", "pb_index_get_stats",
+    "pb_embed_create", "pb_embed_destroy", "pb_embed_info", "pb_embed_batch", "pb_embed_batch_device", "pb_mlhash",
+    "pb_embed_set_option", "pb_fill_synthetic",
+]
+
+
+class PixelboxError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"pixelbox_hip error {code}: {msg}")
+        self.code = code
+
+
+class ScanStats(C.Structure):
+    _fields_ = [("queries", C.c_uint64), ("fast_path", C.c_uint64), ("fallback", C.c_uint64),
+                ("profiled_launches", C.c_uint64), ("profiled_ms", C.c_double), ("profiled_bytes", C.c_uint64)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libpixelbox_hip.so (built by pixelbox_amd.build / __graft_entry__.build). Fails loudly."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OSError(f"{LIB_PATH} is missing: run `python -m pixelbox_amd.build` (hipcc, gfx950). "
+                          "There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        u8p, f32p, i64p, u32p, u64p = (C.POINTER(t) for t in (C.c_uint8, C.c_float, C.c_int64, C.c_uint32, C.c_uint64))
+        vp = C.c_void_p
+        L.pb_last_error.restype = C.c_char_p
+        L.pb_device_count.argtypes = [C.POINTER(C.c_int)]
+        L.pb_index_create.argtypes = [C.POINTER(vp), C.c_int, C.c_uint32, C.c_uint64]
+        L.pb_index_destroy.argtypes = [vp]
+        L.pb_index_size.argtypes = [vp, u64p]
+        L.pb_index_dim.argtypes = [vp, u32p]
+        L.pb_index_append.argtypes = [vp, i64p, u8p, C.c_uint64, u64p]
+        L.pb_index_load.argtypes = [vp, i64p, u8p, C.c_uint64]
+        L.pb_index_search.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, C.c_double, i64p, f32p, u32p]
+        L.pb_index_search_device.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, C.c_double, vp, vp, vp]
+        L.pb_topk_merge.argtypes = [i64p, f32p, u32p, C.c_uint32, C.c_uint32, C.c_uint32, i64p, f32p, u32p]
+        L.pb_index_read.argtypes = [vp, C.c_uint64, C.c_uint64, i64p, u8p]
+        L.pb_index_fill_synthetic.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int64]
+        L.pb_index_set_option.argtypes = [vp, C.c_int, C.c_int64]
+        L.pb_index_get_stats.argtypes = [vp, C.POINTER(ScanStats), C.c_int]
+        L.pb_embed_create.argtypes = [C.POINTER(vp), C.c_int, C.c_char_p, C.c_size_t, C.c_uint32]
+        L.pb_embed_destroy.argtypes = [vp]
+        L.pb_embed_info.argtypes = [vp, u32p, u32p, u32p, u32p]
+        L.pb_embed_batch.argtypes = [vp, u8p, C.c_uint32, u8p, f32p]
+        L.pb_embed_batch_device.argtypes = [vp, vp, C.c_uint32, vp, vp]
+        L.pb_mlhash.argtypes = [vp, u8p, u8p, C.c_size_t]
+        L.pb_embed_set_option.argtypes = [vp, C.c_int, C.c_int64]
+        L.pb_fill_synthetic.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, vp]
+        _lib = L
+    return _lib
+
+
+def _check(rc: int):
+    if rc != PB_OK:
+        raise PixelboxError(rc, (lib().pb_last_error() or b"").decode("utf-8", "replace"))
+
+
+def _p(a: np.ndarray, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    rc = lib().pb_device_count(C.byref(n))
+    return n.value if rc == PB_OK else 0
+
+
+def topk_merge(ids: np.ndarray, dist: np.ndarray, counts: np.ndarray, k: int):
+    """ids/dist: [n_lists, stride]; counts: [n_lists] -> (ids[m], dist[m]), m <= k.  Host-only."""
+    ids = np.ascontiguousarray(ids, dtype=np.int64)
+    dist = np.ascontiguousarray(dist, dtype=np.float32)
+    counts = np.ascontiguousarray(counts, dtype=np.uint32)
+    n_lists, stride = ids.shape
+    out_ids = np.empty(max(k, 1), dtype=np.int64)
+    out_d = np.empty(max(k, 1), dtype=np.float32)
+    cnt = C.c_uint32(0)
+    _check(lib().pb_topk_merge(_p(ids, C.c_int64), _p(dist, C.c_float), _p(counts, C.c_uint32), n_lists, stride, k,
+                               _p(out_ids, C.c_int64), _p(out_d, C.c_float), C.byref(cnt)))
+    return out_ids[: cnt.value].copy(), out_d[: cnt.value].copy()
+
+
+class Index:
+    """Device-resident `semantic_hashes` table (reference: engine.rs:48,109,251-256,363-396)."""
+
+    def __init__(self, dim: int, capacity_rows: int, device: int = 0):
+        self._h = C.c_void_p()
+        self.dim = dim
+        self.device = device
+        _check(lib().pb_index_create(C.byref(self._h), device, dim, capacity_rows))
+
+    def close(self):
+        if self._h:
+            lib().pb_index_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self) -> int:
+        n = C.c_uint64(0)
+        _check(lib().pb_index_size(self._h, C.byref(n)))
+        return n.value
+
+    def append(self, image_ids, rows) -> int:
+        ids = np.ascontiguousarray(image_ids, dtype=np.int64)
+        rows = np.ascontiguousarray(rows, dtype=np.uint8).reshape(-1, self.dim)
+        assert ids.shape[0] == rows.shape[0]
+        stored = C.c_uint64(0)
+        _check(lib().pb_index_append(self._h, _p(ids, C.c_int64), _p(rows, C.c_uint8), ids.shape[0], C.byref(stored)))
+        return stored.value
+
+    def load(self, image_ids, rows):
+        ids = np.ascontiguousarray(image_ids, dtype=np.int64)
+        rows = np.ascontiguousarray(rows, dtype=np.uint8).reshape(-1, self.dim)
+        _check(lib().pb_index_load(self._h, _p(ids, C.c_int64), _p(rows, C.c_uint8), ids.shape[0]))
+
+    def fill_synthetic(self, seed: int, first_row: int, n: int, first_id: int):
+        _check(lib().pb_index_fill_synthetic(self._h, seed, first_row, n, first_id))
+
+    def read(self, first: int, n: int):
+        ids = np.empty(n, dtype=np.int64)
+        rows = np.empty((n, self.dim), dtype=np.uint8)
+        _check(lib().pb_index_read(self._h, first, n, _p(ids, C.c_int64), _p(rows, C.c_uint8)))
+        return ids, rows
+
+    def search(self, queries, k: int = 100, max_dist: float = 1e3):
+        """-> (ids [nq, k] int64, dist [nq, k] f32, count [nq] u32); slots >= count are unspecified."""
+        q = np.ascontiguousarray(queries, dtype=np.uint8).reshape(-1, self.dim)
+        nq = q.shape[0]
+        ids = np.zeros((nq, k), dtype=np.int64)
+        dist = np.zeros((nq, k), dtype=np.float32)
+        cnt = np.zeros(nq, dtype=np.uint32)
+        _check(lib().pb_index_search(self._h, _p(q, C.c_uint8), nq, k, float(max_dist), _p(ids, C.c_int64),
+                                     _p(dist, C.c_float), _p(cnt, C.c_uint32)))
+        return ids, dist, cnt
+
+    def search_one(self, query, k: int = 100, max_dist: float = 1e3):
+        ids, dist, cnt = self.search(np.asarray(query).reshape(1, -1), k, max_dist)
+        return ids[0, : cnt[0]].copy(), dist[0, : cnt[0]].copy()
+
+    def search_device(self, queries, k, max_dist, d_ids_ptr: int, d_dist_ptr: int, d_count_ptr: int):
+        q = np.ascontiguousarray(queries, dtype=np.uint8).reshape(-1, self.dim)
+        _check(lib().pb_index_search_device(self._h, _p(q, C.c_uint8), q.shape[0], k, float(max_dist),
+                                            C.c_void_p(d_ids_ptr), C.c_void_p(d_dist_ptr), C.c_void_p(d_count_ptr)))
+
+    def set_option(self, option: int, value: int):
+        _check(lib().pb_index_set_option(self._h, option, value))
+
+    def stats(self, reset: bool = False) -> ScanStats:
+        s = ScanStats()
+        _check(lib().pb_index_get_stats(self._h, C.byref(s), int(reset)))
+        return s
+
+
+class Embedder:
+    """EfficientNet-B0 embedder behind `image_hashes::mlhash` (reference: efficientnet.rs:10-42)."""
+
+    def __init__(self, weights_blob: bytes, max_batch: int = 512, device: int = 0):
+        self._h = C.c_void_p()
+        _check(lib().pb_embed_create(C.byref(self._h), device, weights_blob, len(weights_blob), max_batch))
+        h, w, d, mb = (C.c_uint32(0) for _ in range(4))
+        _check(lib().pb_embed_info(self._h, C.byref(h), C.byref(w), C.byref(d), C.byref(mb)))
+        self.h, self.w, self.d, self.max_batch = h.value, w.value, d.value, mb.value
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().pb_embed_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def embed(self, rgb: np.ndarray, want_f32: bool = True):
+        """rgb: uint8 [n, H, W, 3] -> (u8 [n, D], f32 [n, D] or None)."""
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8).reshape(-1, self.h, self.w, 3)
+        n = rgb.shape[0]
+        out = np.empty((n, self.d), dtype=np.uint8)
+        f = np.empty((n, self.d), dtype=np.float32) if want_f32 else None
+        _check(lib().pb_embed_batch(self._h, _p(rgb, C.c_uint8), n, _p(out, C.c_uint8),
+                                    _p(f, C.c_float) if want_f32 else None))
+        return out, f
+
+    def embed_device(self, d_rgb_ptr: int, n: int, d_out_u8_ptr: int, d_out_f32_ptr: int = 0):
+        _check(lib().pb_embed_batch_device(self._h, C.c_void_p(d_rgb_ptr), n, C.c_void_p(d_out_u8_ptr),
+                                           C.c_void_p(d_out_f32_ptr) if d_out_f32_ptr else None))
+
+    def mlhash(self, rgb: np.ndarray) -> np.ndarray:
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8).reshape(self.h, self.w, 3)
+        out = np.empty(self.d, dtype=np.uint8)
+        _check(lib().pb_mlhash(self._h, _p(rgb, C.c_uint8), _p(out, C.c_uint8), out.size))
+        return out
+
+    def set_option(self, option: int, value: int):
+        _check(lib().pb_embed_set_option(self._h, option, value))
+
+
+def fill_synthetic_device(device: int, seed: int, byte_offset: int, nbytes: int, d_ptr: int):
+    _check(lib().pb_fill_synthetic(device, seed, byte_offset, nbytes, C.c_void_p(d_ptr)))

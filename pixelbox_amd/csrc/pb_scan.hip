@@ -1,0 +1,644 @@
+// pb_scan.hip -- host side of the scan half of the C ABI (include/pixelbox_hip.h): the device-resident
+// `semantic_hashes` table and the cosine_distance top-k query.  gfx950 only; no CPU fallback: every
+// entry point fails with PB_ERR_HIP when there is no GPU.
+//
+// Reference: src/engine.rs:48,109 (table), :228-259 (insert), :363-396 (query), :572-588 (distance).
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "pb_common.h"
+#include "pb_scan_kernels.h"
+
+#pragma clang fp contract(off)
+
+using namespace pbk;
+
+namespace {
+
+constexpr uint32_t Q_CHUNK = 64;  // queries per launch group
+
+// engine.rs:576 -- the de-quantisation table, computed exactly as the reference does per element
+void make_lut(float lut[256]) {
+    for (int v = 0; v < 256; ++v) {
+        volatile float t = (float)v / 255.0f;
+        volatile float t2 = t * 2.0f;
+        lut[v] = t2 - 1.0f;
+    }
+}
+
+bool fast_dim(uint32_t d) { return d >= 16 && d <= 1024 && (d & (d - 1)) == 0; }
+
+}  // namespace
+
+struct pb_index {
+    int device = 0;
+    uint32_t dim = 0;
+    uint64_t capacity = 0;
+    uint64_t n_rows = 0;
+    uint8_t *d_rows = nullptr;
+    int64_t *d_ids = nullptr;
+    float *d_norms = nullptr;
+    float *d_lut = nullptr;
+    std::vector<int64_t> h_ids;  // ascending, mirrors d_ids
+    float lut[256];
+
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int n_cu = 256;
+
+    // search workspace (device)
+    uint8_t *d_queries = nullptr;   // Q_CHUNK * dim
+    QParams *d_qp = nullptr;        // Q_CHUNK
+    uint64_t *d_lists = nullptr;    // filter lists: Q_CHUNK * F_MAX_WG * F_KWG ; exact lists reuse
+    ListHdr *d_hdrs = nullptr;      // Q_CHUNK * F_MAX_WG
+    uint64_t *d_xlists[2] = {nullptr, nullptr};  // exact pass ping-pong: Q_CHUNK * X_MAX_WG * PB_MAX_K
+    uint32_t *d_xcounts[2] = {nullptr, nullptr};
+    uint32_t *d_qsel = nullptr;     // Q_CHUNK
+    int64_t *d_res_ids = nullptr;   // Q_CHUNK * PB_MAX_K
+    float *d_res_dist = nullptr;
+    ResultHdr *d_res_hdr = nullptr;
+    // pinned host staging
+    uint8_t *h_stage = nullptr;  // queries + params + qsel
+    int64_t *h_res_ids = nullptr;
+    float *h_res_dist = nullptr;
+    ResultHdr *h_res_hdr = nullptr;
+
+    int opt_path = 0;
+    int opt_profile = 0;
+    pb_scan_stats stats{};
+    mutable std::mutex mu;
+};
+
+namespace {
+
+int alloc_workspace(pb_index *ix) {
+    const size_t d = ix->dim;
+    PB_HIP(hipMalloc(&ix->d_queries, Q_CHUNK * d));
+    PB_HIP(hipMalloc(&ix->d_qp, Q_CHUNK * sizeof(QParams)));
+    PB_HIP(hipMalloc(&ix->d_lists, (size_t)Q_CHUNK * F_MAX_WG * F_KWG * sizeof(uint64_t)));
+    PB_HIP(hipMalloc(&ix->d_hdrs, (size_t)Q_CHUNK * F_MAX_WG * sizeof(ListHdr)));
+    for (int i = 0; i < 2; ++i) {
+        const size_t lists = i == 0 ? X_MAX_WG : (X_MAX_WG + M_FANIN - 1) / M_FANIN;
+        PB_HIP(hipMalloc(&ix->d_xlists[i], (size_t)Q_CHUNK * lists * PB_MAX_K * sizeof(uint64_t)));
+        PB_HIP(hipMalloc(&ix->d_xcounts[i], (size_t)Q_CHUNK * lists * sizeof(uint32_t)));
+    }
+    PB_HIP(hipMalloc(&ix->d_qsel, Q_CHUNK * sizeof(uint32_t)));
+    PB_HIP(hipMalloc(&ix->d_res_ids, (size_t)Q_CHUNK * PB_MAX_K * sizeof(int64_t)));
+    PB_HIP(hipMalloc(&ix->d_res_dist, (size_t)Q_CHUNK * PB_MAX_K * sizeof(float)));
+    PB_HIP(hipMalloc(&ix->d_res_hdr, Q_CHUNK * sizeof(ResultHdr)));
+    PB_HIP(hipHostMalloc(&ix->h_stage, Q_CHUNK * (d + sizeof(QParams) + sizeof(uint32_t)), hipHostMallocDefault));
+    PB_HIP(hipHostMalloc(&ix->h_res_ids, (size_t)Q_CHUNK * PB_MAX_K * sizeof(int64_t), hipHostMallocDefault));
+    PB_HIP(hipHostMalloc(&ix->h_res_dist, (size_t)Q_CHUNK * PB_MAX_K * sizeof(float), hipHostMallocDefault));
+    PB_HIP(hipHostMalloc(&ix->h_res_hdr, Q_CHUNK * sizeof(ResultHdr), hipHostMallocDefault));
+    return PB_OK;
+}
+
+void free_all(pb_index *ix) {
+    (void)hipFree(ix->d_rows);
+    (void)hipFree(ix->d_ids);
+    (void)hipFree(ix->d_norms);
+    (void)hipFree(ix->d_lut);
+    (void)hipFree(ix->d_queries);
+    (void)hipFree(ix->d_qp);
+    (void)hipFree(ix->d_lists);
+    (void)hipFree(ix->d_hdrs);
+    for (int i = 0; i < 2; ++i) {
+        (void)hipFree(ix->d_xlists[i]);
+        (void)hipFree(ix->d_xcounts[i]);
+    }
+    (void)hipFree(ix->d_qsel);
+    (void)hipFree(ix->d_res_ids);
+    (void)hipFree(ix->d_res_dist);
+    (void)hipFree(ix->d_res_hdr);
+    if (ix->h_stage) (void)hipHostFree(ix->h_stage);
+    if (ix->h_res_ids) (void)hipHostFree(ix->h_res_ids);
+    if (ix->h_res_dist) (void)hipHostFree(ix->h_res_dist);
+    if (ix->h_res_hdr) (void)hipHostFree(ix->h_res_hdr);
+    if (ix->ev0) (void)hipEventDestroy(ix->ev0);
+    if (ix->ev1) (void)hipEventDestroy(ix->ev1);
+    if (ix->own_stream) (void)hipStreamDestroy(ix->own_stream);
+}
+
+// norms of rows [first, first+n) (append-time; engine.rs:580-581 `hash_b` half, exact arithmetic)
+int launch_norms(pb_index *ix, uint64_t first, uint64_t n) {
+    if (n == 0) return PB_OK;
+    const int block = 256;
+    const uint64_t want = (n + block - 1) / block;
+    const int grid = (int)std::min<uint64_t>(want, (uint64_t)ix->n_cu * 8);
+    hipLaunchKernelGGL(k_row_norms, dim3(grid), dim3(block), 0, ix->stream, ix->d_rows, first, n, (int)ix->dim,
+                       ix->d_lut, ix->d_norms);
+    PB_HIP(hipGetLastError());
+    return PB_OK;
+}
+
+// Per-query constants.  The f32 fold is the reference's (engine.rs:580-581, `hash_a` half); the
+// integer sums feed the filter pass.  Host arithmetic: this TU is compiled with -ffp-contract=off.
+void make_qparams(const pb_index *ix, const uint8_t *q, uint32_t k, double max_dist, QParams *out) {
+    const uint32_t d = ix->dim;
+    float acc = 0.0f;
+    int64_t sum_a = 0, sum_a2 = 0;
+    for (uint32_t i = 0; i < d; ++i) {
+        const float x = ix->lut[q[i]];
+        const float p = x * x;
+        acc = acc + p;
+        sum_a += q[i];
+        sum_a2 += (int64_t)q[i] * q[i];
+    }
+    QParams P{};
+    P.max_dist = max_dist;
+    P.sqrt_sa = std::sqrt(acc);
+    P.den_a = (float)(4 * sum_a2 - 1020 * sum_a + 65025ll * d);
+    P.sum_a = (int32_t)sum_a;
+    P.k = k;
+    // c_floor: every row whose reference cosine is below it has dist >= max_dist.  dist = fl(fl(1/c) - 1)
+    // is non-increasing in c; 1/c > (max_dist + 1)(1 + 1e-6) survives both roundings.
+    float c_floor = 0.0f;
+    if (max_dist == max_dist && max_dist > -0.5 && max_dist < 9.0e5) {
+        c_floor = (float)((1.0 / (max_dist + 1.0)) * (1.0 - 2e-6));
+    }
+    const float thr_min = 2.0f * M_GLOB + 2e-6f;  // stay clear of the cos <= 1e-6 plateau (dist = 999999)
+    const float thr_filter = c_floor - 1.01f * M_GLOB;
+    P.c_floor = c_floor;
+    if (thr_filter >= thr_min) {
+        P.thr0 = thr_filter;
+        P.floor_is_filter = 1;
+    } else {
+        P.thr0 = thr_min;
+        P.floor_is_filter = 0;
+    }
+    *out = P;
+}
+
+template <int LPR>
+void launch_filter(pb_index *ix, int n_wg, uint32_t nq) {
+    hipLaunchKernelGGL(k_scan_filter<LPR>, dim3(n_wg, nq), dim3(F_BLOCK), 0, ix->stream, ix->d_rows, ix->n_rows,
+                       ix->d_queries, ix->d_qp, ix->d_lists, ix->d_hdrs);
+}
+
+int filter_grid(const pb_index *ix) {
+    const uint32_t lpr = ix->dim / 16;
+    const uint64_t rows_it = 8ull * (64 / lpr);
+    const uint64_t n_super = (ix->n_rows + rows_it - 1) / rows_it;
+    const uint64_t want = (n_super + F_WAVES - 1) / F_WAVES;
+    const uint64_t cap = std::min<uint64_t>(F_MAX_WG, (uint64_t)ix->n_cu * 2);
+    return (int)std::max<uint64_t>(1, std::min<uint64_t>(want, cap));
+}
+
+// fast path for nq staged queries; results + status land in d_res_*
+int run_fast(pb_index *ix, uint32_t nq) {
+    const int n_wg = filter_grid(ix);
+    if (ix->opt_profile) PB_HIP(hipEventRecord(ix->ev0, ix->stream));
+    switch (ix->dim / 16) {
+        case 1: launch_filter<1>(ix, n_wg, nq); break;
+        case 2: launch_filter<2>(ix, n_wg, nq); break;
+        case 4: launch_filter<4>(ix, n_wg, nq); break;
+        case 8: launch_filter<8>(ix, n_wg, nq); break;
+        case 16: launch_filter<16>(ix, n_wg, nq); break;
+        case 32: launch_filter<32>(ix, n_wg, nq); break;
+        case 64: launch_filter<64>(ix, n_wg, nq); break;
+        default: return pb::fail(PB_ERR_INTERNAL, "filter pass: unsupported dim %u", ix->dim);
+    }
+    PB_HIP(hipGetLastError());
+    if (ix->opt_profile) PB_HIP(hipEventRecord(ix->ev1, ix->stream));
+    hipLaunchKernelGGL(k_select_rescore, dim3(nq), dim3(SEL_BLOCK), 0, ix->stream, ix->d_rows, ix->d_ids, ix->d_norms,
+                       (int)ix->dim, ix->d_queries, ix->d_qp, ix->d_lut, ix->d_lists, ix->d_hdrs, n_wg, ix->d_res_ids,
+                       ix->d_res_dist, ix->d_res_hdr, (uint32_t)PB_MAX_K);
+    PB_HIP(hipGetLastError());
+    return PB_OK;
+}
+
+// exhaustive exact pass for the n_sel queries listed in d_qsel
+int run_exact(pb_index *ix, uint32_t n_sel, uint32_t k) {
+    const uint64_t n_tiles = (ix->n_rows + WAVE - 1) / WAVE;
+    const uint64_t want = (n_tiles + X_WAVES - 1) / X_WAVES;
+    int n_lists = (int)std::max<uint64_t>(1, std::min<uint64_t>(want, X_MAX_WG));
+    if (ix->opt_profile && ix->opt_path == 1) PB_HIP(hipEventRecord(ix->ev0, ix->stream));
+    hipLaunchKernelGGL(k_scan_exact, dim3(n_lists, n_sel), dim3(X_BLOCK), 0, ix->stream, ix->d_rows, ix->d_norms,
+                       ix->n_rows, (int)ix->dim, ix->d_queries, ix->d_qp, ix->d_qsel, ix->d_lut, ix->d_xlists[0],
+                       ix->d_xcounts[0], (uint32_t)PB_MAX_K);
+    PB_HIP(hipGetLastError());
+    if (ix->opt_profile && ix->opt_path == 1) PB_HIP(hipEventRecord(ix->ev1, ix->stream));
+    int cur = 0;
+    for (;;) {
+        const int n_groups = (n_lists + M_FANIN - 1) / M_FANIN;
+        const int final_out = n_groups == 1;
+        hipLaunchKernelGGL(k_merge_lists, dim3(n_groups, n_sel), dim3(M_BLOCK), 0, ix->stream, ix->d_xlists[cur],
+                           ix->d_xcounts[cur], n_lists, (uint32_t)PB_MAX_K, k, ix->d_xlists[cur ^ 1],
+                           ix->d_xcounts[cur ^ 1], (uint32_t)PB_MAX_K, final_out, ix->d_ids, ix->d_qsel, ix->d_res_ids,
+                           ix->d_res_dist, ix->d_res_hdr, (uint32_t)PB_MAX_K);
+        PB_HIP(hipGetLastError());
+        if (final_out) break;
+        n_lists = n_groups;
+        cur ^= 1;
+    }
+    return PB_OK;
+}
+
+int account_profile(pb_index *ix, uint32_t n_queries) {
+    float ms = 0.0f;
+    PB_HIP(hipEventElapsedTime(&ms, ix->ev0, ix->ev1));
+    ix->stats.profiled_launches += 1;
+    ix->stats.profiled_ms += ms;
+    ix->stats.profiled_bytes += (uint64_t)n_queries * ix->n_rows * ix->dim;
+    return PB_OK;
+}
+
+int search_locked(pb_index *ix, const uint8_t *queries, uint32_t nq, uint32_t k, double max_dist, int64_t *out_ids,
+                  float *out_dist, uint32_t *out_count) {
+    const uint32_t d = ix->dim;
+    if (ix->n_rows == 0) {
+        for (uint32_t q = 0; q < nq; ++q) out_count[q] = 0;
+        return PB_OK;
+    }
+    const bool use_fast = ix->opt_path == 0 && fast_dim(d) && ix->n_rows < (1ull << 32);
+    PB_CHECK(ix->n_rows < (1ull << 32), PB_ERR_CAPACITY, "more than 2^32 rows per shard are not supported");
+    for (uint32_t q0 = 0; q0 < nq; q0 += Q_CHUNK) {
+        const uint32_t cq = std::min(Q_CHUNK, nq - q0);
+        uint8_t *hq = ix->h_stage;
+        QParams *hp = reinterpret_cast<QParams *>(ix->h_stage + (size_t)Q_CHUNK * d);
+        uint32_t *hsel = reinterpret_cast<uint32_t *>(ix->h_stage + (size_t)Q_CHUNK * (d + sizeof(QParams)));
+        memcpy(hq, queries + (size_t)q0 * d, (size_t)cq * d);
+        for (uint32_t q = 0; q < cq; ++q) make_qparams(ix, hq + (size_t)q * d, k, max_dist, &hp[q]);
+        PB_HIP(hipMemcpyAsync(ix->d_queries, hq, (size_t)cq * d, hipMemcpyHostToDevice, ix->stream));
+        PB_HIP(hipMemcpyAsync(ix->d_qp, hp, (size_t)cq * sizeof(QParams), hipMemcpyHostToDevice, ix->stream));
+        uint32_t n_sel = 0;
+        if (use_fast) {
+            int rc = run_fast(ix, cq);
+            if (rc) return rc;
+            PB_HIP(hipMemcpyAsync(ix->h_res_hdr, ix->d_res_hdr, cq * sizeof(ResultHdr), hipMemcpyDeviceToHost, ix->stream));
+            PB_HIP(hipMemcpyAsync(ix->h_res_ids, ix->d_res_ids, (size_t)cq * PB_MAX_K * sizeof(int64_t), hipMemcpyDeviceToHost, ix->stream));
+            PB_HIP(hipMemcpyAsync(ix->h_res_dist, ix->d_res_dist, (size_t)cq * PB_MAX_K * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
+            PB_HIP(hipStreamSynchronize(ix->stream));
+            if (ix->opt_profile) {
+                int rc2 = account_profile(ix, cq);
+                if (rc2) return rc2;
+            }
+            for (uint32_t q = 0; q < cq; ++q)
+                if (ix->h_res_hdr[q].status != 0) hsel[n_sel++] = q;
+            ix->stats.fast_path += cq - n_sel;
+        } else {
+            for (uint32_t q = 0; q < cq; ++q) hsel[n_sel++] = q;
+        }
+        if (n_sel) {
+            PB_HIP(hipMemcpyAsync(ix->d_qsel, hsel, n_sel * sizeof(uint32_t), hipMemcpyHostToDevice, ix->stream));
+            int rc = run_exact(ix, n_sel, k);
+            if (rc) return rc;
+            PB_HIP(hipMemcpyAsync(ix->h_res_hdr, ix->d_res_hdr, cq * sizeof(ResultHdr), hipMemcpyDeviceToHost, ix->stream));
+            PB_HIP(hipMemcpyAsync(ix->h_res_ids, ix->d_res_ids, (size_t)cq * PB_MAX_K * sizeof(int64_t), hipMemcpyDeviceToHost, ix->stream));
+            PB_HIP(hipMemcpyAsync(ix->h_res_dist, ix->d_res_dist, (size_t)cq * PB_MAX_K * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
+            PB_HIP(hipStreamSynchronize(ix->stream));
+            if (ix->opt_profile && ix->opt_path == 1) {
+                int rc2 = account_profile(ix, n_sel);
+                if (rc2) return rc2;
+            }
+            ix->stats.fallback += n_sel;
+        }
+        ix->stats.queries += cq;
+        for (uint32_t q = 0; q < cq; ++q) {
+            const uint32_t c = ix->h_res_hdr[q].count;
+            out_count[q0 + q] = c;
+            memcpy(out_ids + (size_t)(q0 + q) * k, ix->h_res_ids + (size_t)q * PB_MAX_K, c * sizeof(int64_t));
+            memcpy(out_dist + (size_t)(q0 + q) * k, ix->h_res_dist + (size_t)q * PB_MAX_K, c * sizeof(float));
+        }
+    }
+    return PB_OK;
+}
+
+// append rows that are already on the device (or host) at the tail; ids ascending and > last
+int append_tail(pb_index *ix, const int64_t *ids, const uint8_t *rows, uint64_t n, hipMemcpyKind kind) {
+    PB_CHECK(ix->n_rows + n <= ix->capacity, PB_ERR_CAPACITY, "index full: %llu + %llu > capacity %llu",
+             (unsigned long long)ix->n_rows, (unsigned long long)n, (unsigned long long)ix->capacity);
+    const size_t d = ix->dim;
+    PB_HIP(hipMemcpyAsync(ix->d_rows + ix->n_rows * d, rows, n * d, kind, ix->stream));
+    PB_HIP(hipMemcpyAsync(ix->d_ids + ix->n_rows, ids, n * sizeof(int64_t), hipMemcpyHostToDevice, ix->stream));
+    int rc = launch_norms(ix, ix->n_rows, n);
+    if (rc) return rc;
+    PB_HIP(hipStreamSynchronize(ix->stream));
+    ix->h_ids.insert(ix->h_ids.end(), ids, ids + n);
+    ix->n_rows += n;
+    return PB_OK;
+}
+
+// insert one row at sorted position pos < n_rows (rare path): shift the tail through a temporary
+int insert_at(pb_index *ix, uint64_t pos, int64_t id, const uint8_t *row) {
+    PB_CHECK(ix->n_rows + 1 <= ix->capacity, PB_ERR_CAPACITY, "index full");
+    const size_t d = ix->dim;
+    const uint64_t tail = ix->n_rows - pos;
+    void *tmp = nullptr;
+    PB_HIP(hipMalloc(&tmp, tail * std::max<size_t>(d, sizeof(int64_t))));
+    auto shift = [&](void *base, size_t elt) -> int {
+        char *p = static_cast<char *>(base) + pos * elt;
+        PB_HIP(hipMemcpyAsync(tmp, p, tail * elt, hipMemcpyDeviceToDevice, ix->stream));
+        PB_HIP(hipMemcpyAsync(p + elt, tmp, tail * elt, hipMemcpyDeviceToDevice, ix->stream));
+        return PB_OK;
+    };
+    int rc = shift(ix->d_rows, d);
+    if (!rc) rc = shift(ix->d_ids, sizeof(int64_t));
+    if (!rc) rc = shift(ix->d_norms, sizeof(float));
+    if (rc) {
+        (void)hipFree(tmp);
+        return rc;
+    }
+    PB_HIP(hipMemcpyAsync(ix->d_rows + pos * d, row, d, hipMemcpyHostToDevice, ix->stream));
+    PB_HIP(hipMemcpyAsync(ix->d_ids + pos, &id, sizeof(int64_t), hipMemcpyHostToDevice, ix->stream));
+    rc = launch_norms(ix, pos, 1);
+    PB_HIP(hipStreamSynchronize(ix->stream));
+    (void)hipFree(tmp);
+    if (rc) return rc;
+    ix->h_ids.insert(ix->h_ids.begin() + (ptrdiff_t)pos, id);
+    ix->n_rows += 1;
+    return PB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *pb_last_error(void) { return pb::tls_error(); }
+int pb_version(void) { return 100; }
+
+int pb_device_count(int *n) {
+    PB_CHECK(n, PB_ERR_INVALID, "pb_device_count: null pointer");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        *n = 0;
+        return pb::fail(PB_ERR_HIP, "hipGetDeviceCount -> %s", hipGetErrorString(e));
+    }
+    *n = c;
+    return PB_OK;
+}
+
+int pb_index_create(pb_index **out, int device, uint32_t dim, uint64_t capacity_rows) {
+    PB_CHECK(out, PB_ERR_INVALID, "pb_index_create: null out pointer");
+    *out = nullptr;
+    PB_CHECK(dim >= 1 && dim <= 1024, PB_ERR_INVALID, "pb_index_create: dim %u outside 1..1024", dim);
+    PB_CHECK(capacity_rows >= 1, PB_ERR_INVALID, "pb_index_create: capacity_rows must be >= 1");
+    int n_dev = 0;
+    PB_HIP(hipGetDeviceCount(&n_dev));
+    PB_CHECK(device >= 0 && device < n_dev, PB_ERR_INVALID, "pb_index_create: device %d of %d", device, n_dev);
+    pb::DeviceGuard guard(device);
+    PB_CHECK(guard.ok, PB_ERR_HIP, "hipSetDevice(%d) failed", device);
+    pb_index *ix = new (std::nothrow) pb_index();
+    PB_CHECK(ix, PB_ERR_NOMEM, "out of host memory");
+    ix->device = device;
+    ix->dim = dim;
+    ix->capacity = capacity_rows;
+    make_lut(ix->lut);
+    auto body = [&]() -> int {
+        hipDeviceProp_t prop;
+        PB_HIP(hipGetDeviceProperties(&prop, device));
+        ix->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        PB_HIP(hipStreamCreateWithFlags(&ix->own_stream, hipStreamNonBlocking));
+        ix->stream = ix->own_stream;
+        PB_HIP(hipEventCreate(&ix->ev0));
+        PB_HIP(hipEventCreate(&ix->ev1));
+        // +64 rows of slack: the filter pass clamps, never reads past n_rows-1, but keep tail loads in-bounds
+        PB_HIP(hipMalloc(&ix->d_rows, (capacity_rows + 64) * (size_t)dim));
+        PB_HIP(hipMalloc(&ix->d_ids, capacity_rows * sizeof(int64_t)));
+        PB_HIP(hipMalloc(&ix->d_norms, capacity_rows * sizeof(float)));
+        PB_HIP(hipMalloc(&ix->d_lut, 256 * sizeof(float)));
+        PB_HIP(hipMemcpy(ix->d_lut, ix->lut, 256 * sizeof(float), hipMemcpyHostToDevice));
+        return alloc_workspace(ix);
+    };
+    int rc = body();
+    if (rc) {
+        free_all(ix);
+        delete ix;
+        return rc;
+    }
+    *out = ix;
+    return PB_OK;
+}
+
+int pb_index_destroy(pb_index *ix) {
+    if (!ix) return PB_OK;
+    {
+        pb::DeviceGuard guard(ix->device);
+        (void)hipStreamSynchronize(ix->stream);
+        free_all(ix);
+    }
+    delete ix;
+    return PB_OK;
+}
+
+int pb_index_size(const pb_index *ix, uint64_t *n_rows) {
+    PB_CHECK(ix && n_rows, PB_ERR_INVALID, "pb_index_size: null pointer");
+    std::lock_guard<std::mutex> lock(ix->mu);
+    *n_rows = ix->n_rows;
+    return PB_OK;
+}
+
+int pb_index_dim(const pb_index *ix, uint32_t *dim) {
+    PB_CHECK(ix && dim, PB_ERR_INVALID, "pb_index_dim: null pointer");
+    *dim = ix->dim;
+    return PB_OK;
+}
+
+int pb_index_append(pb_index *ix, const int64_t *image_ids, const uint8_t *rows, uint64_t n, uint64_t *n_inserted) {
+    PB_CHECK(ix, PB_ERR_INVALID, "pb_index_append: null index");
+    PB_CHECK(n == 0 || (image_ids && rows), PB_ERR_INVALID, "pb_index_append: null ids/rows");
+    std::lock_guard<std::mutex> lock(ix->mu);
+    pb::DeviceGuard guard(ix->device);
+    uint64_t stored = 0;
+    if (n_inserted) *n_inserted = 0;
+    const size_t d = ix->dim;
+    uint64_t i = 0;
+    while (i < n) {
+        const int64_t last = ix->h_ids.empty() ? std::numeric_limits<int64_t>::min() : ix->h_ids.back();
+        // longest run of strictly increasing ids beyond the current maximum -> one tail append
+        uint64_t j = i;
+        int64_t prev = last;
+        while (j < n && image_ids[j] > prev && (ix->h_ids.empty() || image_ids[j] > last)) {
+            prev = image_ids[j];
+            ++j;
+        }
+        if (j > i) {
+            int rc = append_tail(ix, image_ids + i, rows + i * d, j - i, hipMemcpyHostToDevice);
+            if (rc) return rc;
+            stored += j - i;
+            i = j;
+            continue;
+        }
+        // id <= current maximum: INSERT OR IGNORE
+        const int64_t id = image_ids[i];
+        auto it = std::lower_bound(ix->h_ids.begin(), ix->h_ids.end(), id);
+        if (it == ix->h_ids.end() || *it != id) {
+            int rc = insert_at(ix, (uint64_t)(it - ix->h_ids.begin()), id, rows + i * d);
+            if (rc) return rc;
+            ++stored;
+        }
+        ++i;
+    }
+    if (n_inserted) *n_inserted = stored;
+    return PB_OK;
+}
+
+int pb_index_load(pb_index *ix, const int64_t *image_ids, const uint8_t *rows, uint64_t n) {
+    PB_CHECK(ix, PB_ERR_INVALID, "pb_index_load: null index");
+    PB_CHECK(n == 0 || (image_ids && rows), PB_ERR_INVALID, "pb_index_load: null ids/rows");
+    for (uint64_t i = 1; i < n; ++i)
+        PB_CHECK(image_ids[i] > image_ids[i - 1], PB_ERR_INVALID, "pb_index_load: image_ids must be strictly increasing (row %llu)",
+                 (unsigned long long)i);
+    std::lock_guard<std::mutex> lock(ix->mu);
+    pb::DeviceGuard guard(ix->device);
+    PB_CHECK(n <= ix->capacity, PB_ERR_CAPACITY, "pb_index_load: %llu rows > capacity %llu", (unsigned long long)n,
+             (unsigned long long)ix->capacity);
+    ix->n_rows = 0;
+    ix->h_ids.clear();
+    if (n == 0) return PB_OK;
+    return append_tail(ix, image_ids, rows, n, hipMemcpyHostToDevice);
+}
+
+int pb_index_fill_synthetic(pb_index *ix, uint64_t seed, uint64_t first_row, uint64_t n, int64_t first_id) {
+    PB_CHECK(ix, PB_ERR_INVALID, "pb_index_fill_synthetic: null index");
+    std::lock_guard<std::mutex> lock(ix->mu);
+    pb::DeviceGuard guard(ix->device);
+    PB_CHECK(ix->n_rows + n <= ix->capacity, PB_ERR_CAPACITY, "index full");
+    PB_CHECK(ix->h_ids.empty() || first_id > ix->h_ids.back(), PB_ERR_INVALID, "first_id must exceed every stored image_id");
+    const size_t d = ix->dim;
+    PB_CHECK((first_row * d) % 8 == 0 && (ix->n_rows * d) % 8 == 0 && (n * d) % 8 == 0, PB_ERR_INVALID,
+             "synthetic fill needs 8-byte aligned row ranges");
+    if (n == 0) return PB_OK;
+    const uint64_t n_words = n * d / 8;
+    const int block = 256;
+    const int grid = (int)std::min<uint64_t>((n_words + block - 1) / block, (uint64_t)ix->n_cu * 16);
+    hipLaunchKernelGGL(k_fill_synth, dim3(grid), dim3(block), 0, ix->stream, seed, first_row * d / 8, n_words,
+                       reinterpret_cast<uint64_t *>(ix->d_rows + ix->n_rows * d));
+    PB_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_iota_ids, dim3((int)std::min<uint64_t>((n + block - 1) / block, 4096)), dim3(block), 0, ix->stream,
+                       first_id, n, ix->d_ids + ix->n_rows);
+    PB_HIP(hipGetLastError());
+    int rc = launch_norms(ix, ix->n_rows, n);
+    if (rc) return rc;
+    PB_HIP(hipStreamSynchronize(ix->stream));
+    const size_t old = ix->h_ids.size();
+    ix->h_ids.resize(old + n);
+    for (uint64_t i = 0; i < n; ++i) ix->h_ids[old + i] = first_id + (int64_t)i;
+    ix->n_rows += n;
+    return PB_OK;
+}
+
+int pb_index_read(const pb_index *ix, uint64_t first, uint64_t n, int64_t *image_ids, uint8_t *rows) {
+    PB_CHECK(ix, PB_ERR_INVALID, "pb_index_read: null index");
+    std::lock_guard<std::mutex> lock(ix->mu);
+    pb::DeviceGuard guard(ix->device);
+    PB_CHECK(first + n <= ix->n_rows, PB_ERR_INVALID, "pb_index_read: range [%llu, %llu) beyond %llu rows",
+             (unsigned long long)first, (unsigned long long)(first + n), (unsigned long long)ix->n_rows);
+    PB_HIP(hipStreamSynchronize(ix->stream));
+    if (image_ids) memcpy(image_ids, ix->h_ids.data() + first, n * sizeof(int64_t));
+    if (rows && n) PB_HIP(hipMemcpy(rows, ix->d_rows + first * ix->dim, n * (size_t)ix->dim, hipMemcpyDeviceToHost));
+    return PB_OK;
+}
+
+int pb_index_search(pb_index *ix, const uint8_t *queries, uint32_t nq, uint32_t k, double max_dist, int64_t *out_ids,
+                    float *out_dist, uint32_t *out_count) {
+    PB_CHECK(ix, PB_ERR_INVALID, "pb_index_search: null index");
+    PB_CHECK(k >= 1 && k <= PB_MAX_K, PB_ERR_INVALID, "pb_index_search: k = %u outside 1..%u", k, PB_MAX_K);
+    PB_CHECK(nq == 0 || (queries && out_ids && out_dist && out_count), PB_ERR_INVALID, "pb_index_search: null buffer");
+    if (nq == 0) return PB_OK;
+    std::lock_guard<std::mutex> lock(ix->mu);
+    pb::DeviceGuard guard(ix->device);
+    return search_locked(ix, queries, nq, k, max_dist, out_ids, out_dist, out_count);
+}
+
+int pb_index_search_device(pb_index *ix, const uint8_t *queries, uint32_t nq, uint32_t k, double max_dist,
+                           int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count) {
+    PB_CHECK(ix, PB_ERR_INVALID, "pb_index_search_device: null index");
+    PB_CHECK(k >= 1 && k <= PB_MAX_K, PB_ERR_INVALID, "pb_index_search_device: k = %u outside 1..%u", k, PB_MAX_K);
+    PB_CHECK(nq == 0 || (queries && d_out_ids && d_out_dist && d_out_count), PB_ERR_INVALID, "null buffer");
+    if (nq == 0) return PB_OK;
+    std::vector<int64_t> ids((size_t)nq * k, std::numeric_limits<int64_t>::max());
+    std::vector<float> dist((size_t)nq * k, std::numeric_limits<float>::infinity());
+    std::vector<uint32_t> cnt(nq, 0);
+    std::lock_guard<std::mutex> lock(ix->mu);
+    pb::DeviceGuard guard(ix->device);
+    int rc = search_locked(ix, queries, nq, k, max_dist, ids.data(), dist.data(), cnt.data());
+    if (rc) return rc;
+    PB_HIP(hipMemcpyAsync(d_out_ids, ids.data(), ids.size() * sizeof(int64_t), hipMemcpyHostToDevice, ix->stream));
+    PB_HIP(hipMemcpyAsync(d_out_dist, dist.data(), dist.size() * sizeof(float), hipMemcpyHostToDevice, ix->stream));
+    PB_HIP(hipMemcpyAsync(d_out_count, cnt.data(), cnt.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ix->stream));
+    PB_HIP(hipStreamSynchronize(ix->stream));
+    return PB_OK;
+}
+
+int pb_index_set_option(pb_index *ix, int option, int64_t value) {
+    PB_CHECK(ix, PB_ERR_INVALID, "pb_index_set_option: null index");
+    std::lock_guard<std::mutex> lock(ix->mu);
+    switch (option) {
+        case PB_OPT_SEARCH_PATH:
+            PB_CHECK(value == 0 || value == 1, PB_ERR_INVALID, "PB_OPT_SEARCH_PATH: 0 or 1");
+            ix->opt_path = (int)value;
+            return PB_OK;
+        case PB_OPT_PROFILE:
+            ix->opt_profile = value != 0;
+            return PB_OK;
+        case PB_OPT_STREAM:
+            ix->stream = value ? reinterpret_cast<hipStream_t>(value) : ix->own_stream;
+            return PB_OK;
+        default:
+            return pb::fail(PB_ERR_INVALID, "pb_index_set_option: unknown option %d", option);
+    }
+}
+
+int pb_index_get_stats(pb_index *ix, pb_scan_stats *out, int reset) {
+    PB_CHECK(ix && out, PB_ERR_INVALID, "pb_index_get_stats: null pointer");
+    std::lock_guard<std::mutex> lock(ix->mu);
+    *out = ix->stats;
+    if (reset) ix->stats = pb_scan_stats{};
+    return PB_OK;
+}
+
+// Host-side G-way merge (after the RCCL all-gather of per-shard results).  Pure C++: runs anywhere.
+int pb_topk_merge(const int64_t *ids, const float *dist, const uint32_t *counts, uint32_t n_lists, uint32_t stride,
+                  uint32_t k, int64_t *out_ids, float *out_dist, uint32_t *out_count) {
+    PB_CHECK(out_count, PB_ERR_INVALID, "pb_topk_merge: null out_count");
+    PB_CHECK(n_lists == 0 || (ids && dist && counts), PB_ERR_INVALID, "pb_topk_merge: null input");
+    PB_CHECK(k == 0 || (out_ids && out_dist), PB_ERR_INVALID, "pb_topk_merge: null output");
+    std::vector<uint32_t> pos(n_lists, 0);
+    uint32_t n = 0;
+    while (n < k) {
+        int best = -1;
+        for (uint32_t g = 0; g < n_lists; ++g) {
+            if (pos[g] >= counts[g] || pos[g] >= stride) continue;
+            const size_t i = (size_t)g * stride + pos[g];
+            if (best < 0) {
+                best = (int)g;
+                continue;
+            }
+            const size_t b = (size_t)best * stride + pos[best];
+            if (dist[i] < dist[b] || (dist[i] == dist[b] && ids[i] < ids[b])) best = (int)g;
+        }
+        if (best < 0) break;
+        const size_t b = (size_t)best * stride + pos[best];
+        out_ids[n] = ids[b];
+        out_dist[n] = dist[b];
+        ++pos[best];
+        ++n;
+    }
+    *out_count = n;
+    return PB_OK;
+}
+
+int pb_fill_synthetic(int device, uint64_t seed, uint64_t byte_offset, uint64_t nbytes, uint8_t *d_out) {
+    PB_CHECK(d_out || nbytes == 0, PB_ERR_INVALID, "pb_fill_synthetic: null output");
+    PB_CHECK(byte_offset % 8 == 0 && nbytes % 8 == 0, PB_ERR_INVALID, "pb_fill_synthetic: offset and size must be multiples of 8");
+    if (nbytes == 0) return PB_OK;
+    pb::DeviceGuard guard(device);
+    PB_CHECK(guard.ok, PB_ERR_HIP, "hipSetDevice(%d) failed", device);
+    const uint64_t n_words = nbytes / 8;
+    const int block = 256;
+    const int grid = (int)std::min<uint64_t>((n_words + block - 1) / block, 65536);
+    hipLaunchKernelGGL(k_fill_synth, dim3(grid), dim3(block), 0, nullptr, seed, byte_offset / 8, n_words,
+                       reinterpret_cast<uint64_t *>(d_out));
+    PB_HIP(hipGetLastError());
+    PB_HIP(hipStreamSynchronize(nullptr));
+    return PB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,727 @@
+// pb_scan_kernels.h -- gfx950 device code for the u8 cosine-distance top-k scan.
+//
+// Reference semantics (PixelBox): src/engine.rs:572-588 (cosine_distance), :608-622 (f64 widening),
+// :375-390 (WHERE dist < ? ORDER BY dist ASC LIMIT k).  DESIGN.md section "scan" explains the two
+// paths built here:
+//   (1) k_scan_filter  -- the HBM-bound pass: per-row EXACT INTEGER dot / norms with v_dot4_u32_u8,
+//       an f32 cosine that is within M_GLOB of the reference's f32 cosine for every possible row,
+//       per-wave candidate buffers in LDS pruned by a ballot radix-select, one sorted list per
+//       workgroup;  k_select_rescore then re-scores the few candidates with the reference's exact
+//       sequential f32 arithmetic and certifies that no other row can belong to the top-k.
+//   (2) k_scan_exact / k_merge_lists -- exhaustive exact scan (every row re-scored); used when the
+//       certificate of (1) fails, for dims (1) does not cover, or when forced (PB_OPT_SEARCH_PATH).
+// All keys are u64 "smaller is better": (order-preserving score bits << 32) | row position; rows are
+// stored in ascending image_id order, so row position breaks ties exactly like (dist, image_id).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+namespace pbk {
+
+constexpr int WAVE = 64;
+// ---- filter pass geometry ----
+constexpr int F_BLOCK = 1024;            // 16 waves: one workgroup per CU, 2 resident
+constexpr int F_WAVES = F_BLOCK / WAVE;  // 16
+constexpr int F_KW = 32;                 // entries a wave keeps after a prune
+constexpr int F_CAPW = 128;              // per-wave LDS buffer (entries); prune when > CAPW - 64
+constexpr int F_KWG = 32;                // entries per workgroup list
+constexpr int F_MAX_WG = 512;
+constexpr int SEL_BLOCK = 1024;
+constexpr int SEL_MAX_CAND = 1024;
+constexpr int SEL_BINS = 1024;
+// ---- exact pass geometry ----
+constexpr int X_BLOCK = 256;
+constexpr int X_WAVES = X_BLOCK / WAVE;
+constexpr int X_MAX_WG = 512;
+constexpr int X_MAXE = 5;  // (PB_MAX_K + 64) / 64
+constexpr int M_FANIN = 16;  // lists merged per workgroup by k_merge_lists
+constexpr int M_BLOCK = 1024;
+constexpr int M_SORT = 4096;  // M_FANIN * PB_MAX_K
+
+// Rigorous bound on |cos_reference_f32 - cos_filter| for any two byte vectors of length <= 1024,
+// see DESIGN.md "error budget": 2*gamma_n + 4u from the sequential f32 folds, 6u*sqrt(n)*(1/|x|+1/|y|)
+// from the rounded de-quantisation table (|x| >= sqrt(n)/255), 1e-6 for the filter's own f32 steps.
+// n = 256: 3.1e-5 + 1.8e-4 + 1e-6.  The constant below is used for every n <= 1024 that the filter
+// pass accepts (gamma_n grows to 1.2e-4 at n = 1024, the table term does not depend on n).
+constexpr float M_GLOB = 4.0e-4f;
+
+struct QParams {
+    double max_dist;     // WHERE dist < ?
+    float sqrt_sa;       // sqrt(fold(x^2)) of the de-quantised query, reference f32 arithmetic
+    float den_a;         // exact integer sum (2a-255)^2 as f32
+    float thr0;          // filter pass: rows with cos_filter < thr0 are never collected
+    float c_floor;       // every row with cos_ref < c_floor fails `dist < max_dist`
+    int32_t sum_a;       // integer sum of query bytes
+    int32_t floor_is_filter;  // thr0 == c_floor - M_GLOB (rows below thr0 are provably filtered out)
+    uint32_t k;
+    uint32_t pad;
+};
+
+struct ListHdr {
+    uint32_t count;
+    float dropped;  // every row this workgroup saw and did not list has cos_filter <= dropped (0: none)
+};
+
+struct ResultHdr {
+    uint32_t count;
+    uint32_t status;  // 0 = certified, 1 = needs the exhaustive pass
+    uint32_t n_cand;
+    float o_max;
+};
+
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t dot4(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_amdgcn_udot4(a, b, c, false);
+}
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int mbcnt(uint64_t m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+// all-reduce (sum) over groups of LPR consecutive lanes; LPR in {1,2,4,8,16,32,64}
+template <int LPR>
+__device__ __forceinline__ int group_sum(int v) {
+    if constexpr (LPR >= 2) v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]  (lane ^ 1)
+    if constexpr (LPR >= 4) v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]  (lane ^ 2)
+    if constexpr (LPR == 8) v += dpp_mov<0x141>(v);  // row_half_mirror: quads hold equal sums -> lane ^ 4 class
+    if constexpr (LPR >= 16) {
+        v += dpp_mov<0x124>(v);  // row_ror:4
+        v += dpp_mov<0x128>(v);  // row_ror:8
+    }
+    if constexpr (LPR >= 32) v += __shfl_xor(v, 16);
+    if constexpr (LPR >= 64) v += __shfl_xor(v, 32);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t sortable_f32(float f) {
+    uint32_t b = __float_as_uint(f);
+    return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float unsortable_f32(uint32_t s) {
+    uint32_t b = (s & 0x80000000u) ? (s ^ 0x80000000u) : ~s;
+    return __uint_as_float(b);
+}
+// filter keys: larger cosine = better = smaller key. cos > 0 only, so ~bits is order-reversing.
+__device__ __forceinline__ uint64_t filter_key(float cs, uint32_t row) {
+    return ((uint64_t)(~__float_as_uint(cs)) << 32) | row;
+}
+__device__ __forceinline__ float filter_key_cos(uint64_t key) { return __uint_as_float(~(uint32_t)(key >> 32)); }
+
+// Keep the K smallest of buf[0..cnt) (wave-private LDS, all keys distinct), compacted to buf[0..K).
+// Ballot radix-select: 32 steps on the score word, then (only if scores tie at the cut) on the row word.
+// MAXE = ceil(max cnt / 64).  Requires cnt >= K.  Returns the K-th smallest key.
+template <int MAXE>
+__device__ __forceinline__ uint64_t wave_keep_smallest(uint64_t *buf, int cnt, int K) {
+    const int lane = lane_id();
+    uint32_t hi[MAXE], lo[MAXE];
+    uint32_t act = 0;
+#pragma unroll
+    for (int j = 0; j < MAXE; ++j) {
+        const int i = lane + 64 * j;
+        const uint64_t e = (i < cnt) ? buf[i] : ~0ull;
+        hi[j] = (uint32_t)(e >> 32);
+        lo[j] = (uint32_t)e;
+        act |= (i < cnt) ? (1u << j) : 0u;
+    }
+    const uint32_t valid = act;
+    int remaining = K;  // the K-th smallest is the `remaining`-th smallest of the active set
+    int nact = cnt;
+    uint32_t pre_hi = 0, pre_lo = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        int z = 0;
+        uint32_t zmask = 0;
+#pragma unroll
+        for (int j = 0; j < MAXE; ++j) {
+            const bool isz = ((act >> j) & 1u) && !((hi[j] >> bit) & 1u);
+            z += __popcll(__ballot(isz));
+            zmask |= isz ? (1u << j) : 0u;
+        }
+        if (remaining <= z) {
+            act = zmask;
+            nact = z;
+        } else {
+            remaining -= z;
+            act &= ~zmask;
+            nact -= z;
+            pre_hi |= 1u << bit;
+        }
+    }
+    // active = entries whose score word equals pre_hi
+    if (nact > remaining) {
+        for (int bit = 31; bit >= 0; --bit) {
+            int z = 0;
+            uint32_t zmask = 0;
+#pragma unroll
+            for (int j = 0; j < MAXE; ++j) {
+                const bool isz = ((act >> j) & 1u) && !((lo[j] >> bit) & 1u);
+                z += __popcll(__ballot(isz));
+                zmask |= isz ? (1u << j) : 0u;
+            }
+            if (remaining <= z) {
+                act = zmask;
+            } else {
+                remaining -= z;
+                act &= ~zmask;
+                pre_lo |= 1u << bit;
+            }
+        }
+    } else {
+        // every entry with score word pre_hi is kept; the K-th smallest is the largest row among them
+        uint32_t mx = 0;
+#pragma unroll
+        for (int j = 0; j < MAXE; ++j) mx = ((act >> j) & 1u) && lo[j] > mx ? lo[j] : mx;
+        for (int off = 32; off >= 1; off >>= 1) {
+            const uint32_t o = (uint32_t)__shfl_xor((int)mx, off);
+            mx = o > mx ? o : mx;
+        }
+        pre_lo = mx;
+    }
+    int base = 0;
+#pragma unroll
+    for (int j = 0; j < MAXE; ++j) {
+        const bool keep = ((valid >> j) & 1u) && (hi[j] < pre_hi || (hi[j] == pre_hi && lo[j] <= pre_lo));
+        const uint64_t m = __ballot(keep);
+        if (keep) buf[base + mbcnt(m)] = ((uint64_t)hi[j] << 32) | lo[j];
+        base += __popcll(m);
+    }
+    return ((uint64_t)pre_hi << 32) | pre_lo;
+}
+
+// ------------------------------------------------------------------------------------------------
+// exact reference arithmetic for one row (engine.rs:575-587); row_norm = sqrt(fold(x^2)) of the row,
+// precomputed at append time by k_row_norms with the same arithmetic.  s_lut/s_qf live in LDS.
+__device__ __forceinline__ float ref_fold_dot(const uint8_t *__restrict__ row, const float *s_qf,
+                                              const float *s_lut, int d) {
+    float dot = 0.0f;
+    int i = 0;
+    if ((d & 15) == 0) {
+        for (; i < d; i += 16) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(row + i);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const float x = s_lut[(w[c] >> (8 * b)) & 0xFF];
+                    const float p = s_qf[i + 4 * c + b] * x;
+                    dot = dot + p;
+                }
+            }
+        }
+    } else {
+        for (; i < d; ++i) {
+            const float p = s_qf[i] * s_lut[row[i]];
+            dot = dot + p;
+        }
+    }
+    return dot;
+}
+
+__device__ __forceinline__ float ref_distance(float dot, float sqrt_sa, float row_norm, float *cs_out) {
+    const float magnitude = sqrt_sa * row_norm;  // engine.rs:581
+    if (magnitude < 1e-6f) {                     // engine.rs:582-584
+        *cs_out = 0.0f;
+        return 0.0f;
+    }
+    const float cs = dot / magnitude;  // engine.rs:586 (correctly rounded: hipcc default)
+    *cs_out = cs;
+    const float m = fmaxf(cs, 1e-6f);  // f32::max
+    const float r = 1.0f / m;
+    return r - 1.0f;  // engine.rs:587
+}
+
+// sqrt(fold(x*x)) per row, row-per-lane (engine.rs:580-581, the `hash_b` half)
+__global__ void k_row_norms(const uint8_t *__restrict__ rows, uint64_t first, uint64_t n, int d,
+                            const float *__restrict__ lut, float *__restrict__ norms) {
+    __shared__ float s_lut[256];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_lut[i] = lut[i];
+    __syncthreads();
+    for (uint64_t r = first + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < first + n;
+         r += (uint64_t)gridDim.x * blockDim.x) {
+        const uint8_t *row = rows + r * (uint64_t)d;
+        float acc = 0.0f;
+        for (int i = 0; i < d; ++i) {
+            const float x = s_lut[row[i]];
+            const float p = x * x;
+            acc = acc + p;
+        }
+        norms[r] = sqrtf(acc);  // correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt default)
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// (1) HBM-bound filter pass.  LPR lanes share one row (16 B each); one wave-instruction = 64/LPR rows.
+template <int LPR>
+__global__ __launch_bounds__(F_BLOCK) void k_scan_filter(const uint8_t *__restrict__ rows, uint64_t n_rows,
+                                                         const uint8_t *__restrict__ queries,
+                                                         const QParams *__restrict__ qp,
+                                                         uint64_t *__restrict__ lists,
+                                                         ListHdr *__restrict__ hdrs) {
+    constexpr int D = LPR * 16;
+    constexpr int RPT = WAVE / LPR;                // rows per wave-instruction
+    constexpr int U = 8;                           // loads in flight per lane (8 KiB per wave)
+    constexpr int ROWS_IT = U * RPT;               // rows per wave-iteration
+    constexpr int ROUNDS = (U + LPR - 1) / LPR;    // evaluation rounds (one row per lane each)
+    __shared__ uint64_t s_buf[F_WAVES][F_CAPW];
+    __shared__ int s_cnt[F_WAVES];
+    __shared__ float s_drop[F_WAVES];
+
+    const int q = blockIdx.y;
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+    const int sub = lane % LPR;
+    const int g = lane / LPR;
+    const QParams P = qp[q];
+    const uint4 qv = *reinterpret_cast<const uint4 *>(queries + (size_t)q * D + sub * 16);
+    uint64_t *buf = s_buf[wave];
+
+    float thr = P.thr0;
+    float dropped = 0.0f;
+    int cnt = 0;
+    const int k_num = 65025 * D - 510 * P.sum_a;  // num = 4P - 510*S + k_num
+    const int k_den = 65025 * D;
+
+    const uint64_t n_super = (n_rows + ROWS_IT - 1) / ROWS_IT;
+    const uint64_t stride = (uint64_t)gridDim.x * F_WAVES;
+    for (uint64_t s = (uint64_t)wave * gridDim.x + blockIdx.x; s < n_super; s += stride) {
+        const uint64_t row0 = s * ROWS_IT;
+        uint4 b[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            uint64_t r = row0 + (uint64_t)(u * RPT + g);
+            r = r < n_rows ? r : n_rows - 1;
+            b[u] = *reinterpret_cast<const uint4 *>(rows + r * D + sub * 16);
+        }
+        int sp[ROUNDS], ss[ROUNDS], sq[ROUNDS];
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; ++rd) sp[rd] = ss[rd] = sq[rd] = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            uint32_t p = dot4(b[u].x, qv.x, 0), sm = dot4(b[u].x, 0x01010101u, 0), s2 = dot4(b[u].x, b[u].x, 0);
+            p = dot4(b[u].y, qv.y, p), sm = dot4(b[u].y, 0x01010101u, sm), s2 = dot4(b[u].y, b[u].y, s2);
+            p = dot4(b[u].z, qv.z, p), sm = dot4(b[u].z, 0x01010101u, sm), s2 = dot4(b[u].z, b[u].z, s2);
+            p = dot4(b[u].w, qv.w, p), sm = dot4(b[u].w, 0x01010101u, sm), s2 = dot4(b[u].w, b[u].w, s2);
+            const int tp = group_sum<LPR>((int)p), ts = group_sum<LPR>((int)sm), tq = group_sum<LPR>((int)s2);
+            const bool mine = (u % LPR) == sub;
+            sp[u / LPR] = mine ? tp : sp[u / LPR];
+            ss[u / LPR] = mine ? ts : ss[u / LPR];
+            sq[u / LPR] = mine ? tq : sq[u / LPR];
+        }
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; ++rd) {
+            const int u = rd * LPR + sub;
+            const uint64_t r = row0 + (uint64_t)(u * RPT + g);
+            const bool valid = (u < U) && (r < n_rows);
+            const int num = 4 * sp[rd] - 510 * ss[rd] + k_num;
+            const int den_b = 4 * sq[rd] - 1020 * ss[rd] + k_den;  // = sum (2b-255)^2 >= D
+            float cs = (float)num * __builtin_amdgcn_rsqf((float)den_b * P.den_a);
+            cs = valid ? cs : -1.0f;
+            const bool pass = cs >= thr;
+            const uint64_t m = __ballot(pass);
+            if (m) {
+                if (pass) buf[cnt + mbcnt(m)] = filter_key(cs, (uint32_t)r);
+                cnt += __popcll(m);
+                if (cnt > F_CAPW - WAVE) {
+                    const uint64_t kth = wave_keep_smallest<F_CAPW / WAVE>(buf, cnt, F_KW);
+                    cnt = F_KW;
+                    thr = filter_key_cos(kth);
+                    dropped = thr;
+                }
+            }
+        }
+    }
+    if (cnt > F_KW) {
+        const uint64_t kth = wave_keep_smallest<F_CAPW / WAVE>(buf, cnt, F_KW);
+        cnt = F_KW;
+        dropped = filter_key_cos(kth);
+    }
+    if (lane == 0) {
+        s_cnt[wave] = cnt;
+        s_drop[wave] = dropped;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    // workgroup list: the F_KWG best of the <= 16*32 entries, sorted, by wave 0
+    constexpr int ME = F_WAVES * F_KW / WAVE;  // 8 entries per lane
+    __shared__ uint64_t s_merge[F_WAVES * F_KW];
+    int total = 0;
+    float drop = 0.0f;
+    for (int w = 0; w < F_WAVES; ++w) {
+        const int c = s_cnt[w];
+        if (lane < c) s_merge[total + lane] = s_buf[w][lane];
+        total += c;
+        drop = fmaxf(drop, s_drop[w]);
+    }
+    if (total > F_KWG) {
+        const uint64_t kth = wave_keep_smallest<ME>(s_merge, total, F_KWG);
+        total = F_KWG;
+        drop = fmaxf(drop, filter_key_cos(kth));
+    }
+    // rank sort (<= 32 distinct keys)
+    const uint64_t mykey = lane < total ? s_merge[lane] : ~0ull;
+    int rank = 0;
+    for (int j = 0; j < total; ++j) {
+        const uint64_t o = __shfl((unsigned long long)mykey, j);
+        rank += o < mykey ? 1 : 0;
+    }
+    uint64_t *out = lists + ((size_t)q * gridDim.x + blockIdx.x) * F_KWG;
+    if (lane < total) out[rank] = mykey;
+    if (lane == 0) {
+        ListHdr h;
+        h.count = (uint32_t)total;
+        h.dropped = drop;
+        hdrs[(size_t)q * gridDim.x + blockIdx.x] = h;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// in-LDS bitonic sort of n (power of two) u64 keys, ascending; all threads of the block participate
+__device__ __forceinline__ void block_bitonic_sort(uint64_t *s, int n) {
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < n; i += blockDim.x) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const uint64_t a = s[i], b = s[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) {
+                        s[i] = b;
+                        s[ixj] = a;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// (1b) candidate selection from the workgroup lists, exact re-scoring, certificate.  One block per query.
+__global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
+    const uint8_t *__restrict__ rows, const int64_t *__restrict__ ids, const float *__restrict__ norms,
+    int d, const uint8_t *__restrict__ queries, const QParams *__restrict__ qp,
+    const float *__restrict__ lut, const uint64_t *__restrict__ lists, const ListHdr *__restrict__ hdrs,
+    int n_lists, int64_t *__restrict__ out_ids, float *__restrict__ out_dist, ResultHdr *__restrict__ out_hdr,
+    uint32_t out_stride) {
+    __shared__ float s_lut[256];
+    __shared__ float s_qf[1024];
+    __shared__ uint32_t s_hist[SEL_BINS];
+    __shared__ uint64_t s_key[SEL_MAX_CAND];   // candidates (filter keys), then exact keys
+    __shared__ float s_cs[SEL_MAX_CAND];       // exact cos of each candidate
+    __shared__ float s_red[SEL_BLOCK / WAVE];
+    __shared__ uint32_t s_u[8];
+    const int q = blockIdx.x;
+    const int tid = threadIdx.x;
+    const QParams P = qp[q];
+    const uint64_t *ql = lists + (size_t)q * n_lists * F_KWG;
+    const ListHdr *qh = hdrs + (size_t)q * n_lists;
+
+    for (int i = tid; i < 256; i += SEL_BLOCK) s_lut[i] = lut[i];
+    for (int i = tid; i < SEL_BINS; i += SEL_BLOCK) s_hist[i] = 0;
+    if (tid < 8) s_u[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < d; i += SEL_BLOCK) s_qf[i] = s_lut[queries[(size_t)q * d + i]];
+
+    // ---- lower bound LB on the k-th largest filter cosine: histogram over the first j entries of
+    //      every (sorted) list, j = ceil(k / n_lists)
+    const int j_top = (int)((P.k + n_lists - 1) / n_lists);
+    const float span = 1.0002f - P.thr0;
+    const float scale = (float)SEL_BINS / span;
+    float dmax = 0.0f;
+    uint32_t n_top = 0;
+    for (int l = tid; l < n_lists; l += SEL_BLOCK) {
+        const ListHdr h = qh[l];
+        dmax = fmaxf(dmax, h.dropped);
+        const int c = (int)h.count < j_top ? (int)h.count : j_top;
+        for (int e = 0; e < c; ++e) {
+            const float cs = filter_key_cos(ql[(size_t)l * F_KWG + e]);
+            int bin = (int)((cs - P.thr0) * scale);
+            bin = bin < 0 ? 0 : (bin >= SEL_BINS ? SEL_BINS - 1 : bin);
+            atomicAdd(&s_hist[bin], 1u);
+        }
+        n_top += (uint32_t)c;
+    }
+    for (int off = 32; off >= 1; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off));
+    if ((tid & 63) == 0) s_red[tid >> 6] = dmax;
+    if (n_top) atomicAdd(&s_u[0], n_top);
+    __syncthreads();
+    dmax = 0.0f;
+    for (int w = 0; w < SEL_BLOCK / WAVE; ++w) dmax = fmaxf(dmax, s_red[w]);
+    const uint32_t top_total = s_u[0];
+    float lb = P.thr0;
+    if (top_total >= P.k) {
+        // suffix scan by thread 0 of each 64-bin chunk would need another pass; 1024 bins: serial scan
+        // from the top by one wave is ~16 steps of 64 bins
+        if (tid < WAVE) {
+            uint32_t acc = 0;
+            int found = -1;
+            for (int chunk = SEL_BINS / WAVE - 1; chunk >= 0 && found < 0; --chunk) {
+                const int bin = chunk * WAVE + (WAVE - 1 - tid);  // lane 0 = highest bin of the chunk
+                uint32_t v = s_hist[bin];
+                // inclusive prefix over lanes (descending bins)
+                uint32_t incl = v;
+                for (int off = 1; off < WAVE; off <<= 1) {
+                    const uint32_t o = __shfl_up(incl, off);
+                    if (tid >= off) incl += o;
+                }
+                const uint64_t hit = __ballot(acc + incl >= P.k);
+                if (hit) {
+                    const int first = __ffsll((unsigned long long)hit) - 1;
+                    found = chunk * WAVE + (WAVE - 1 - first);
+                }
+                acc += __shfl(incl, WAVE - 1);
+            }
+            if (tid == 0) s_u[1] = (uint32_t)found;
+        }
+        __syncthreads();
+        const int found = (int)s_u[1];
+        lb = P.thr0 + (float)found / scale - 2e-6f;
+        lb = fmaxf(lb, P.thr0);
+    }
+    const float cut = lb - 2.0f * M_GLOB;
+
+    // ---- candidates: every listed entry with cos_filter >= cut
+    const int total_slots = n_lists * F_KWG;
+    for (int i = tid; i < total_slots; i += SEL_BLOCK) {
+        const int l = i / F_KWG, e = i % F_KWG;
+        if (e < (int)qh[l].count) {
+            const uint64_t key = ql[i];
+            if (filter_key_cos(key) >= cut) {
+                const uint32_t pos = atomicAdd(&s_u[2], 1u);
+                if (pos < SEL_MAX_CAND) s_key[pos] = key;
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t n_cand_raw = s_u[2];
+    const int n_cand = n_cand_raw < SEL_MAX_CAND ? (int)n_cand_raw : SEL_MAX_CAND;
+    const bool overflow = n_cand_raw > SEL_MAX_CAND;
+
+    // ---- exact re-scoring, one candidate per thread (reference arithmetic, engine.rs:575-587)
+    uint64_t xkey = ~0ull;
+    float my_cs = -2.0f;
+    bool filtered = false;
+    if (tid < n_cand) {
+        const uint32_t r = (uint32_t)s_key[tid];
+        const float dot = ref_fold_dot(rows + (uint64_t)r * d, s_qf, s_lut, d);
+        float cs;
+        const float dist = ref_distance(dot, P.sqrt_sa, norms[r], &cs);
+        my_cs = cs;
+        if ((double)dist < P.max_dist) xkey = ((uint64_t)sortable_f32(dist) << 32) | r;
+        else filtered = true;
+    }
+    __syncthreads();
+    // largest exact cosine among candidates rejected by `dist < max_dist` (monotone: everything at or
+    // below it is rejected too)
+    float cfilt = filtered ? my_cs : -2.0f;
+    for (int off = 32; off >= 1; off >>= 1) cfilt = fmaxf(cfilt, __shfl_xor(cfilt, off));
+    if ((tid & 63) == 0) s_red[tid >> 6] = cfilt;
+    int nsort = 64;
+    while (nsort < n_cand) nsort <<= 1;
+    if (tid < nsort) {
+        s_key[tid] = xkey;
+    }
+    __syncthreads();
+    cfilt = -2.0f;
+    for (int w = 0; w < SEL_BLOCK / WAVE; ++w) cfilt = fmaxf(cfilt, s_red[w]);
+    // exact cos per row position for the certificate: stash by thread, then sort keys
+    if (tid < n_cand) s_cs[tid] = my_cs;
+    block_bitonic_sort(s_key, nsort);
+    // count valid
+    uint32_t valid = (tid < nsort && s_key[tid] != ~0ull) ? 1u : 0u;
+    const uint64_t vm = __ballot(valid != 0);
+    if ((tid & 63) == 0 && vm) atomicAdd(&s_u[3], (uint32_t)__popcll(vm));
+    __syncthreads();
+    const uint32_t n_valid = s_u[3];
+    const uint32_t n_out = n_valid < P.k ? n_valid : P.k;
+    if (tid < (int)n_out) {
+        const uint64_t key = s_key[tid];
+        const uint32_t r = (uint32_t)key;
+        out_ids[(size_t)q * out_stride + tid] = ids[r];
+        out_dist[(size_t)q * out_stride + tid] = unsortable_f32((uint32_t)(key >> 32));
+    }
+    // ---- certificate (DESIGN.md "certificate"): exact cosine of the k-th result vs. the best any
+    //      unexamined row could reach
+    // c_k = smallest exact cos among the n_out selected: find it through the unsorted (row -> cs) table
+    __shared__ float s_ck[SEL_BLOCK / WAVE];
+    float ck = 3.0f;
+    if (n_out > 0) {
+        const uint64_t kth_key = s_key[n_out - 1];
+        // thread `tid` owns candidate tid (unsorted order): selected iff its exact key <= kth_key
+        if (tid < n_cand && xkey <= kth_key) ck = my_cs;
+    }
+    for (int off = 32; off >= 1; off >>= 1) ck = fminf(ck, __shfl_xor(ck, off));
+    if ((tid & 63) == 0) s_ck[tid >> 6] = ck;
+    __syncthreads();
+    if (tid == 0) {
+        ck = 3.0f;
+        for (int w = 0; w < SEL_BLOCK / WAVE; ++w) ck = fminf(ck, s_ck[w]);
+        const float o_max = fmaxf(fmaxf(cut, dmax), P.thr0) + M_GLOB;  // no unexamined row's exact cos reaches this
+        bool ok = !overflow;
+        if (n_out == P.k) {
+            ok = ok && (o_max <= ck * (1.0f - 1e-6f));
+        } else {
+            // fewer than k pass the filter among the candidates: every unexamined row must fail it too
+            ok = ok && ((P.floor_is_filter && o_max <= P.c_floor) || (o_max <= cfilt));
+        }
+        ResultHdr h;
+        h.count = n_out;
+        h.status = ok ? 0u : 1u;
+        h.n_cand = n_cand_raw;
+        h.o_max = o_max;
+        out_hdr[q] = h;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// (2) exhaustive exact scan: one row per lane, every row re-scored with the reference arithmetic.
+// qsel[blockIdx.y] = index of the query to run (the host compacts the queries that need this pass).
+__global__ __launch_bounds__(X_BLOCK) void k_scan_exact(
+    const uint8_t *__restrict__ rows, const float *__restrict__ norms, uint64_t n_rows, int d,
+    const uint8_t *__restrict__ queries, const QParams *__restrict__ qp, const uint32_t *__restrict__ qsel,
+    const float *__restrict__ lut, uint64_t *__restrict__ lists, uint32_t *__restrict__ list_counts,
+    uint32_t list_stride) {
+    __shared__ float s_lut[256];
+    __shared__ float s_qf[1024];
+    __shared__ uint64_t s_buf[X_WAVES][X_MAXE * WAVE];
+    __shared__ int s_cnt[X_WAVES];
+    const int q = (int)qsel[blockIdx.y];
+    const QParams P = qp[q];
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 256; i += X_BLOCK) s_lut[i] = lut[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < d; i += X_BLOCK) s_qf[i] = s_lut[queries[(size_t)q * d + i]];
+    __syncthreads();
+    uint64_t *buf = s_buf[wave];
+    const int K = (int)P.k;
+    int cnt = 0;
+    uint64_t thr_key = ~0ull;  // keep keys < thr_key
+    const uint64_t n_tiles = (n_rows + WAVE - 1) / WAVE;
+    const uint64_t stride = (uint64_t)gridDim.x * X_WAVES;
+    for (uint64_t t = (uint64_t)wave * gridDim.x + blockIdx.x; t < n_tiles; t += stride) {
+        const uint64_t r = t * WAVE + lane;
+        uint64_t key = ~0ull;
+        if (r < n_rows) {
+            const float dot = ref_fold_dot(rows + r * (uint64_t)d, s_qf, s_lut, d);
+            float cs;
+            const float dist = ref_distance(dot, P.sqrt_sa, norms[r], &cs);
+            if ((double)dist < P.max_dist) key = ((uint64_t)sortable_f32(dist) << 32) | (uint32_t)r;
+        }
+        const bool pass = key < thr_key;
+        const uint64_t m = __ballot(pass);
+        if (m) {
+            if (pass) buf[cnt + mbcnt(m)] = key;
+            cnt += __popcll(m);
+            if (cnt > K) {  // buffer capacity is K + 64
+                thr_key = wave_keep_smallest<X_MAXE>(buf, cnt, K);
+                cnt = K;
+            }
+        }
+    }
+    if (lane == 0) s_cnt[wave] = cnt;
+    __syncthreads();
+    // workgroup list = the K best of the 4 wave lists (sorted): bitonic sort of <= 4*(K) padded keys
+    __shared__ uint64_t s_sort[X_WAVES * 256];
+    int total = 0;
+    int offs[X_WAVES];
+    for (int w = 0; w < X_WAVES; ++w) {
+        offs[w] = total;
+        total += s_cnt[w];
+    }
+    int nsort = 64;
+    while (nsort < total) nsort <<= 1;
+    for (int i = threadIdx.x; i < nsort; i += X_BLOCK) s_sort[i] = ~0ull;
+    __syncthreads();
+    for (int w = 0; w < X_WAVES; ++w)
+        for (int i = threadIdx.x; i < s_cnt[w]; i += X_BLOCK) s_sort[offs[w] + i] = s_buf[w][i];
+    block_bitonic_sort(s_sort, nsort);
+    const int n_out = total < K ? total : K;
+    uint64_t *out = lists + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * list_stride;
+    for (int i = threadIdx.x; i < n_out; i += X_BLOCK) out[i] = s_sort[i];
+    if (threadIdx.x == 0) list_counts[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = (uint32_t)n_out;
+}
+
+// merge up to M_FANIN sorted lists of <= k exact keys into one (k smallest, sorted). grid = (n_groups, nq).
+// When `final_out` is set (last level) the result is written as ids / dists / count instead of keys.
+__global__ __launch_bounds__(M_BLOCK) void k_merge_lists(
+    const uint64_t *__restrict__ in_lists, const uint32_t *__restrict__ in_counts, int n_in,
+    uint32_t in_stride, uint32_t k, uint64_t *__restrict__ out_lists, uint32_t *__restrict__ out_counts,
+    uint32_t out_stride, int final_out, const int64_t *__restrict__ ids, const uint32_t *__restrict__ qsel,
+    int64_t *__restrict__ out_ids, float *__restrict__ out_dist, ResultHdr *__restrict__ out_hdr,
+    uint32_t res_stride) {
+    __shared__ uint64_t s_sort[M_SORT];
+    __shared__ uint32_t s_off[M_FANIN + 1];
+    const int qi = blockIdx.y;
+    const int grp = blockIdx.x;
+    const int n_groups = gridDim.x;
+    const int l0 = grp * M_FANIN;
+    const int l1 = l0 + M_FANIN < n_in ? l0 + M_FANIN : n_in;
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (int l = l0; l < l1; ++l) {
+            s_off[l - l0] = acc;
+            acc += in_counts[(size_t)qi * n_in + l];
+        }
+        s_off[l1 - l0] = acc;
+    }
+    __syncthreads();
+    const int total = (int)s_off[l1 - l0];
+    int nsort = 64;
+    while (nsort < total) nsort <<= 1;
+    for (int i = threadIdx.x; i < nsort; i += M_BLOCK) s_sort[i] = ~0ull;
+    __syncthreads();
+    for (int l = l0; l < l1; ++l) {
+        const int c = (int)(s_off[l - l0 + 1] - s_off[l - l0]);
+        const uint64_t *src = in_lists + ((size_t)qi * n_in + l) * in_stride;
+        for (int i = threadIdx.x; i < c; i += M_BLOCK) s_sort[s_off[l - l0] + i] = src[i];
+    }
+    block_bitonic_sort(s_sort, nsort);
+    const int n_out = total < (int)k ? total : (int)k;
+    if (!final_out) {
+        uint64_t *dst = out_lists + ((size_t)qi * n_groups + grp) * out_stride;
+        for (int i = threadIdx.x; i < n_out; i += M_BLOCK) dst[i] = s_sort[i];
+        if (threadIdx.x == 0) out_counts[(size_t)qi * n_groups + grp] = (uint32_t)n_out;
+    } else {
+        const int q = (int)qsel[qi];
+        for (int i = threadIdx.x; i < n_out; i += M_BLOCK) {
+            const uint64_t key = s_sort[i];
+            out_ids[(size_t)q * res_stride + i] = ids[(uint32_t)key];
+            out_dist[(size_t)q * res_stride + i] = unsortable_f32((uint32_t)(key >> 32));
+        }
+        if (threadIdx.x == 0) {
+            ResultHdr h;
+            h.count = (uint32_t)n_out;
+            h.status = 0;
+            h.n_cand = 0;
+            h.o_max = 0.0f;
+            out_hdr[q] = h;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64_at(uint64_t seed, uint64_t w) {
+    uint64_t z = seed + (w + 1ull) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// out[0..n_words) = words [first_word, ..) of stream `seed` (8 bytes per thread-iteration)
+__global__ void k_fill_synth(uint64_t seed, uint64_t first_word, uint64_t n_words, uint64_t *__restrict__ out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words;
+         i += (uint64_t)gridDim.x * blockDim.x)
+        out[i] = splitmix64_at(seed, first_word + i);
+}
+__global__ void k_iota_ids(int64_t first_id, uint64_t n, int64_t *__restrict__ out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (uint64_t)gridDim.x * blockDim.x)
+        out[i] = first_id + (int64_t)i;
+}
+
+}  // namespace pbk

@@ -1,0 +1,324 @@
+"""GPU parity tests for the scan half: the HIP path, called through the C ABI (pixelbox_amd.capi ->
+libpixelbox_hip.so), against the CPU oracle (oracle/) and the committed golden vectors.
+
+Bar: top-k image_id lists identical, distances BIT-exact (u32 view), counts identical -- for both the
+int-dot filter path (with certificate) and the exhaustive exact path."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import capi as oracle
+from pixelbox_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+F32 = np.float32
+AUTO, EXACT = 0, 1
+
+
+def make_index(rows, ids=None, capacity=None, path=AUTO):
+    rows = np.ascontiguousarray(rows, dtype=np.uint8)
+    n, d = rows.shape
+    ids = np.arange(n, dtype=np.int64) if ids is None else np.asarray(ids, dtype=np.int64)
+    ix = capi.Index(d, capacity or max(n, 1))
+    ix.set_option(capi.PB_OPT_SEARCH_PATH, path)
+    if n:
+        ix.load(ids, rows)
+    return ix
+
+
+def check_against_oracle(ix, rows, ids, queries, k=100, max_dist=1e3):
+    queries = np.asarray(queries, dtype=np.uint8).reshape(-1, rows.shape[1])
+    got_ids, got_d, got_c = ix.search(queries, k, max_dist)
+    for qi, q in enumerate(queries):
+        want_ids, want_d = oracle.scan_topk(q, rows, ids, k, max_dist)
+        c = int(got_c[qi])
+        assert c == len(want_ids), (qi, c, len(want_ids))
+        assert np.array_equal(got_ids[qi, :c], want_ids), qi
+        assert np.array_equal(got_d[qi, :c].view(np.uint32), want_d.view(np.uint32)), qi
+
+
+def _uniform_inputs(g):
+    n, d = int(g["n"]), int(g["d"])
+    rows = synth.fill_synthetic(int(g["seed_rows"]), 0, n * d).reshape(n, d)
+    query = synth.fill_synthetic(int(g["seed_query"]), 0, d)
+    return query, rows, g["ids"]
+
+
+# ---- committed golden vectors (sqlite3 + reference SQL) -------------------------------------------------
+@pytest.mark.parametrize("path", [AUTO, EXACT])
+@pytest.mark.parametrize("case", ["md1e3", "md5", "md2e6"])
+def test_golden_uniform_4k(golden_dir, case, path):
+    g = np.load(os.path.join(golden_dir, "scan_uniform_4k.npz"))
+    query, rows, ids = _uniform_inputs(g)
+    ix = make_index(rows, ids, path=path)
+    got_ids, got_d = ix.search_one(query, 100, float(g[f"{case}_max_dist"]))
+    assert np.array_equal(got_ids, g[f"{case}_ids"])
+    assert np.array_equal(got_d.view(np.uint32), g[f"{case}_dist"].view(np.uint32))
+
+
+@pytest.mark.parametrize("path", [AUTO, EXACT])
+def test_golden_plateau_tail(golden_dir, path):
+    g = np.load(os.path.join(golden_dir, "scan_uniform_150_plateau.npz"))
+    query, rows, ids = _uniform_inputs(g)
+    ix = make_index(rows, ids, path=path)
+    got_ids, got_d = ix.search_one(query, 100, float(g["max_dist"]))
+    assert np.array_equal(got_ids, g["out_ids"])
+    assert np.array_equal(got_d.view(np.uint32), g["out_dist"].view(np.uint32))
+
+
+@pytest.mark.parametrize("path", [AUTO, EXACT])
+@pytest.mark.parametrize("case", ["md1e3", "md1e-3", "md2e6"])
+def test_golden_clustered_2k(golden_dir, case, path):
+    g = np.load(os.path.join(golden_dir, "scan_clustered_2k.npz"))
+    ix = make_index(g["rows"], g["ids"], path=path)
+    got_ids, got_d = ix.search_one(g["query"], 100, float(g[f"{case}_max_dist"]))
+    assert np.array_equal(got_ids, g[f"{case}_ids"])
+    assert np.array_equal(got_d.view(np.uint32), g[f"{case}_dist"].view(np.uint32))
+
+
+def test_reference_kats_through_the_abi():
+    # engine.rs:703-708 with dim = 2 (exact path: the filter pass needs dim >= 16)
+    rows = np.array([[255, 0], [0, 255]], dtype=np.uint8)
+    ix = make_index(rows)
+    ids, d = ix.search_one(np.array([255, 0], dtype=np.uint8), 100, 2e6)
+    assert ids.tolist() == [0, 1]
+    assert d[0] == F32(-1.1920928955078125e-07) and d[0] < F32(1e-6)
+    assert d[1] == F32(999999.0) and d[1] > F32(2.0)
+    ids, d = ix.search_one(np.array([0, 255], dtype=np.uint8), 100, 1e3)
+    assert ids.tolist() == [1] and d[0] < F32(1e-6)
+
+
+# ---- seeded random tables vs the oracle ---------------------------------------------------------------
+@pytest.mark.parametrize("path", [AUTO, EXACT])
+@pytest.mark.parametrize("n", [1, 3, 63, 64, 65, 1000, 4097, 50000])
+def test_uniform_sizes(n, path):
+    rng = np.random.default_rng(100 + n)
+    rows = rng.integers(0, 256, size=(n, 256), dtype=np.uint8)
+    ids = np.cumsum(rng.integers(1, 5, size=n)).astype(np.int64)
+    queries = rng.integers(0, 256, size=(3, 256), dtype=np.uint8)
+    queries[1] = rows[n // 2]
+    ix = make_index(rows, ids, path=path)
+    check_against_oracle(ix, rows, ids, queries)
+
+
+@pytest.mark.parametrize("k", [1, 7, 100, 256])
+def test_k_values(k):
+    rng = np.random.default_rng(5)
+    rows = rng.integers(0, 256, size=(20000, 256), dtype=np.uint8)
+    ids = np.arange(20000, dtype=np.int64) + 10
+    q = rng.integers(0, 256, size=(2, 256), dtype=np.uint8)
+    for path in (AUTO, EXACT):
+        ix = make_index(rows, ids, path=path)
+        check_against_oracle(ix, rows, ids, q, k=k)
+
+
+@pytest.mark.parametrize("d", [16, 32, 64, 128, 512, 1024, 8, 24, 100, 1])
+def test_dims(d):
+    rng = np.random.default_rng(d)
+    n = 6000
+    rows = rng.integers(0, 256, size=(n, d), dtype=np.uint8)
+    ids = np.arange(n, dtype=np.int64)
+    q = rng.integers(0, 256, size=(2, d), dtype=np.uint8)
+    ix = make_index(rows, ids)
+    check_against_oracle(ix, rows, ids, q)
+    check_against_oracle(ix, rows, ids, q, max_dist=2e6)
+
+
+def test_many_queries_chunking():
+    rng = np.random.default_rng(9)
+    rows = rng.integers(0, 256, size=(30000, 256), dtype=np.uint8)
+    ids = np.arange(30000, dtype=np.int64)
+    q = rng.integers(0, 256, size=(70, 256), dtype=np.uint8)  # > one launch group of 64
+    ix = make_index(rows, ids)
+    check_against_oracle(ix, rows, ids, q)
+    st = ix.stats()
+    assert st.queries == 70 and st.fast_path + st.fallback == 70
+    assert st.fast_path >= 60  # uniform data: the certificate should pass
+
+
+@pytest.mark.parametrize("max_dist", [float("nan"), -1.0, -1e-7, 0.0, 1e-6, 2.5, 3.0, 10.0, 999998.9, 999999.0, 999999.1, 1e30, float("inf")])
+def test_max_dist_edges(max_dist):
+    rng = np.random.default_rng(21)
+    rows = rng.integers(0, 256, size=(5000, 256), dtype=np.uint8)
+    rows[100] = rows[4000]
+    ids = np.arange(5000, dtype=np.int64)
+    q = np.stack([rows[4000], rng.integers(0, 256, size=256, dtype=np.uint8)])
+    for path in (AUTO, EXACT):
+        ix = make_index(rows, ids, path=path)
+        check_against_oracle(ix, rows, ids, q, max_dist=max_dist)
+
+
+# ---- adversarial tables: ties, duplicates, tiny norms --------------------------------------------------
+def test_all_rows_identical_forces_exhaustive_pass():
+    rows = np.tile(np.arange(256, dtype=np.uint8), (3000, 1))
+    ids = np.arange(3000, dtype=np.int64) * 2
+    ix = make_index(rows, ids)
+    check_against_oracle(ix, rows, ids, rows[:1])
+    check_against_oracle(ix, rows, ids, 255 - rows[:1], max_dist=2e6)  # everything on the 999999 plateau
+    assert ix.stats().fallback >= 1
+
+
+def test_many_duplicates_of_the_query():
+    rng = np.random.default_rng(33)
+    rows = rng.integers(0, 256, size=(40000, 256), dtype=np.uint8)
+    q = rng.integers(0, 256, size=256, dtype=np.uint8)
+    dup = rng.choice(40000, size=700, replace=False)
+    rows[dup] = q  # 700 exact duplicates > any candidate buffer
+    near = rng.choice(40000, size=300, replace=False)
+    for j in near:
+        r = q.copy()
+        r[rng.integers(0, 256)] ^= 1
+        rows[j] = r
+    ids = np.arange(40000, dtype=np.int64)
+    ix = make_index(rows, ids)
+    check_against_oracle(ix, rows, ids, q.reshape(1, -1))
+    check_against_oracle(ix, rows, ids, q.reshape(1, -1), k=256)
+
+
+def test_contiguous_burst_of_near_duplicates():
+    rng = np.random.default_rng(34)
+    rows = rng.integers(0, 256, size=(100000, 256), dtype=np.uint8)
+    q = rng.integers(0, 256, size=256, dtype=np.uint8)
+    for j in range(5000, 5090):  # 90 adjacent near-duplicates (a photo burst in one folder)
+        r = q.copy()
+        idx = rng.choice(256, size=8, replace=False)
+        r[idx] = rng.integers(0, 256, size=8)
+        rows[j] = r
+    ids = np.arange(100000, dtype=np.int64)
+    ix = make_index(rows, ids)
+    check_against_oracle(ix, rows, ids, q.reshape(1, -1))
+
+
+def test_near_grey_rows_smallest_norms():
+    # bytes 127/128 de-quantise to -0.0039215684 / +0.003921628: the worst case for the filter's error budget
+    rng = np.random.default_rng(35)
+    rows = rng.integers(127, 129, size=(20000, 256), dtype=np.uint8)
+    ids = np.arange(20000, dtype=np.int64)
+    q = rng.integers(127, 129, size=(2, 256), dtype=np.uint8)
+    ix = make_index(rows, ids)
+    check_against_oracle(ix, rows, ids, q)
+    rows2 = rng.integers(0, 256, size=(20000, 256), dtype=np.uint8)
+    rows2[::3] = rng.integers(120, 136, size=(len(rows2[::3]), 256), dtype=np.uint8)
+    ix2 = make_index(rows2, ids)
+    check_against_oracle(ix2, rows2, ids, q)
+    check_against_oracle(ix2, rows2, ids, rows2[:2])
+
+
+def test_clustered_embedding_like_table():
+    rng = np.random.default_rng(36)
+    centers = np.tanh(rng.standard_normal((20, 256)).astype(np.float32))
+    which = rng.integers(0, 20, size=60000)
+    f = np.tanh(np.arctanh(np.clip(centers[which], -0.999, 0.999)) + rng.standard_normal((60000, 256)).astype(np.float32) * 0.05)
+    rows = oracle.quantize(f.astype(np.float32))
+    ids = np.arange(60000, dtype=np.int64) * 7
+    q = rows[[5, 77, 4242]]
+    ix = make_index(rows, ids)
+    check_against_oracle(ix, rows, ids, q)
+
+
+# ---- store semantics (INSERT OR IGNORE, engine.rs:251-256) ---------------------------------------------
+def test_append_insert_or_ignore_and_out_of_order_ids():
+    rng = np.random.default_rng(40)
+    d = 256
+    rows = rng.integers(0, 256, size=(500, d), dtype=np.uint8)
+    ix = capi.Index(d, 1000)
+    assert len(ix) == 0
+    ids0, d0 = ix.search_one(rows[0])
+    assert len(ids0) == 0  # empty table
+    assert ix.append(np.arange(0, 200) * 2, rows[:200]) == 200  # even ids 0..398
+    assert ix.append([10, 12, 400, 402], rows[200:204]) == 2  # 10, 12 exist -> ignored
+    assert ix.append([5, 7, 399], rows[204:207]) == 3  # odd ids: inserted in place
+    assert ix.append([5], rows[300:301]) == 0  # first write wins
+    truth = {}
+    for i in range(200):
+        truth[i * 2] = rows[i]
+    truth[400], truth[402] = rows[202], rows[203]
+    truth[5], truth[7], truth[399] = rows[204], rows[205], rows[206]
+    t_ids = np.array(sorted(truth), dtype=np.int64)
+    t_rows = np.stack([truth[i] for i in t_ids])
+    assert len(ix) == len(t_ids)
+    r_ids, r_rows = ix.read(0, len(ix))
+    assert np.array_equal(r_ids, t_ids) and np.array_equal(r_rows, t_rows)
+    check_against_oracle(ix, t_rows, t_ids, rows[[0, 204, 206]], max_dist=2e6)
+    with pytest.raises(capi.PixelboxError):
+        ix.append(np.arange(1000, 2000), rng.integers(0, 256, size=(1000, d), dtype=np.uint8))  # over capacity
+
+
+def test_search_sees_rows_appended_after_a_search():
+    rng = np.random.default_rng(41)
+    rows = rng.integers(0, 256, size=(3000, 256), dtype=np.uint8)
+    ids = np.arange(3000, dtype=np.int64)
+    ix = capi.Index(256, 4000)
+    ix.append(ids[:2000], rows[:2000])
+    check_against_oracle(ix, rows[:2000], ids[:2000], rows[2500:2501])
+    ix.append(ids[2000:], rows[2000:])
+    check_against_oracle(ix, rows, ids, rows[2500:2501])
+
+
+def test_bad_arguments_fail_loudly():
+    with pytest.raises(capi.PixelboxError):
+        capi.Index(0, 10)
+    with pytest.raises(capi.PixelboxError):
+        capi.Index(2048, 10)
+    ix = capi.Index(256, 10)
+    with pytest.raises(capi.PixelboxError):
+        ix.search(np.zeros((1, 256), dtype=np.uint8), k=0)
+    with pytest.raises(capi.PixelboxError):
+        ix.search(np.zeros((1, 256), dtype=np.uint8), k=capi.PB_MAX_K + 1)
+    with pytest.raises(capi.PixelboxError):
+        ix.load(np.array([3, 2], dtype=np.int64), np.zeros((2, 256), dtype=np.uint8))
+
+
+# ---- synthetic generator and BASELINE-size checks -------------------------------------------------------
+def test_device_synthetic_fill_matches_the_stream():
+    ix = capi.Index(256, 5000)
+    ix.fill_synthetic(synth.SEED_INDEX, 0, 3000, 1)
+    ix.fill_synthetic(synth.SEED_INDEX, 3000, 2000, 3001)
+    ids, rows = ix.read(0, 5000)
+    assert np.array_equal(ids, np.arange(1, 5001))
+    assert np.array_equal(rows.reshape(-1), oracle.fill_synthetic(synth.SEED_INDEX, 0, 5000 * 256))
+
+
+def test_config2_1m_rows_vs_oracle():
+    # BASELINE.json configs[1]: 1M x 256 u8 index, batch-1 query, k = 100, max_dist = 1e3
+    n, d = 1_000_000, 256
+    ix = capi.Index(d, n)
+    ix.fill_synthetic(synth.SEED_INDEX, 0, n, 1)
+    rows = synth.fill_synthetic(synth.SEED_INDEX, 0, n * d).reshape(n, d)
+    ids = np.arange(1, n + 1, dtype=np.int64)
+    q = synth.fill_synthetic(synth.SEED_QUERY, 0, d)
+    check_against_oracle(ix, rows, ids, q.reshape(1, -1))
+    assert ix.stats().fast_path == 1
+    ix.set_option(capi.PB_OPT_SEARCH_PATH, EXACT)
+    check_against_oracle(ix, rows, ids, q.reshape(1, -1))
+
+
+def test_full_size_10m_properties():
+    # 10M x 256 (BASELINE metric size): too slow for the oracle on every row, so check size-independent
+    # properties: (a) filter path == exhaustive exact path, bit for bit; (b) planted exact duplicates of the
+    # query come first, in image_id order, with the reference's self-distance; (c) the result restricted to
+    # a 200k-row window equals the oracle on that window's candidates.
+    n, d = 10_000_000, 256
+    ix = capi.Index(d, n + 8)
+    ix.fill_synthetic(synth.SEED_INDEX, 0, n, 1)
+    q = synth.fill_synthetic(synth.SEED_QUERY, 0, d)
+    ids_a, d_a = ix.search_one(q)
+    assert ix.stats().fast_path == 1
+    ix.set_option(capi.PB_OPT_SEARCH_PATH, EXACT)
+    ids_b, d_b = ix.search_one(q)
+    assert np.array_equal(ids_a, ids_b) and np.array_equal(d_a.view(np.uint32), d_b.view(np.uint32))
+    assert len(ids_a) == 100 and np.all(np.diff(d_a) >= 0)
+    # every reported distance is the oracle's distance for that row (rows regenerated from the stream)
+    for i in (0, 1, 50, 99):
+        r = int(ids_a[i]) - 1
+        row = synth.fill_synthetic(synth.SEED_INDEX, r * d, d)
+        assert oracle.cosine_distance(q, row).view(np.uint32) == d_a[i].view(np.uint32)
+    # (b) plant duplicates beyond the synthetic ids
+    ix.set_option(capi.PB_OPT_SEARCH_PATH, AUTO)
+    ix.append([n + 5, n + 6, n + 7], np.tile(q, (3, 1)))
+    ids_c, d_c = ix.search_one(q)
+    assert ids_c[:3].tolist() == [n + 5, n + 6, n + 7]
+    assert np.all(d_c[:3] == oracle.cosine_distance(q, q))
+    assert np.array_equal(ids_c[3:], ids_a[:97])
