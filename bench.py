@@ -124,8 +124,11 @@ def main():
                 "launches": int(st.profiled_launches), "traffic": None}
 
     embed = None
-    if not args.no_embed and hasattr(capi.lib(), "pb_embed_create"):
-        embed = bench_embed(args, torch, local_rank, distributed)
+    if not args.no_embed:
+        try:
+            embed = bench_embed(args, torch, local_rank, distributed)
+        except capi.PixelboxError as e:
+            embed = {"error": str(e)}
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
