@@ -123,6 +123,9 @@ def main():
                 "bytes_per_launch": int(st.profiled_bytes // st.profiled_launches),
                 "launches": int(st.profiled_launches), "traffic": None}
 
+    if roof is not None:
+        roof["traffic"] = pmc_traffic(roof["kernel"], roof["bytes_per_launch"])
+
     embed = None
     if not args.no_embed:
         try:
@@ -156,6 +159,27 @@ def main():
         print(json.dumps(out), flush=True)
     if distributed:
         torch.distributed.destroy_process_group()
+
+
+def pmc_traffic(kernel: str, bytes_per_launch: int):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary (profiles/rNN_scan_pmc.json:
+    FETCH_SIZE x2 (gfx950 wide-stream correction) + WRITE_SIZE, separate passes, same command line).  PMC passes
+    cannot run inside this process; the number is reported only when the profiled launch had the same
+    algorithmic byte count as this run's, otherwise null."""
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_scan_pmc.json")), reverse=True):
+        try:
+            with open(path) as f:
+                summ = json.load(f)
+        except Exception:
+            continue
+        for name, d in summ.items():
+            if kernel in name and "hbm_bytes_per_launch" in d:
+                hb = int(d["hbm_bytes_per_launch"])
+                if abs(hb - bytes_per_launch) <= 0.05 * bytes_per_launch:
+                    return hb
+    return None
 
 
 def bench_embed(args, torch, device, distributed):
