@@ -81,9 +81,9 @@ class ShardedIndex:
             host[:, k : 2 * k] = np.ascontiguousarray(l_dist, dtype=np.float32).view(np.int32).astype(np.int64)
             host[:, 2 * k] = l_cnt
             packed.copy_(torch.from_numpy(host))
-        gathered = torch.empty((self.world, nq, 2 * k + 1), dtype=torch.int64, device=dev)
+        gathered = torch.empty((self.world * nq, 2 * k + 1), dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(gathered, packed, group=self.group)
-        g = gathered.cpu().numpy()
+        g = gathered.cpu().numpy().reshape(self.world, nq, 2 * k + 1)
         out_ids = np.zeros((nq, k), dtype=np.int64)
         out_dist = np.zeros((nq, k), dtype=np.float32)
         out_cnt = np.zeros(nq, dtype=np.uint32)

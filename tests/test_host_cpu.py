@@ -1,0 +1,157 @@
+"""CPU tests (no GPU): the C-ABI library loads and exports every symbol the header declares, the
+host-side merge and sharding logic are correct, the multi-process query path works over gloo
+(world_size 2), and the product path fails loudly -- never falls back -- without a GPU."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import capi as oracle
+from pixelbox_amd import capi, sharded, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _has_gpu():
+    return capi.device_count() > 0
+
+
+def test_header_symbols_are_exported_and_bound():
+    hdr = open(os.path.join(ROOT, "include", "pixelbox_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(pb_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(capi.SYMBOLS), declared ^ set(capi.SYMBOLS)
+    L = capi.lib()
+    for s in declared:
+        assert getattr(L, s) is not None
+    out = subprocess.check_output(["nm", "-D", "--defined-only", capi.LIB_PATH], text=True)
+    exported = set(re.findall(r"\bT (pb_[a-z0-9_]+)", out))
+    assert declared <= exported, declared - exported
+
+
+def test_library_embeds_gfx950_code_objects():
+    data = open(capi.LIB_PATH, "rb").read()
+    assert b"gfx950" in data
+    assert b"k_scan_filter" in data
+
+
+@pytest.mark.skipif(_has_gpu(), reason="only meaningful on a box without a GPU")
+def test_no_gpu_means_loud_failure_not_fallback():
+    with pytest.raises(capi.PixelboxError) as ei:
+        capi.Index(256, 100)
+    assert ei.value.code == -2  # PB_ERR_HIP
+    assert "hip" in str(ei.value).lower()
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "pixelbox_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
+                src = open(os.path.join(dirpath, f), errors="replace").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "pb_oracle" not in src and "libpb_oracle" not in src, f
+
+
+def _ref_merge(ids, dist, counts, k):
+    allv = [(float(dist[g, i]), int(ids[g, i])) for g in range(ids.shape[0]) for i in range(counts[g])]
+    allv.sort()
+    return np.array([v[1] for v in allv[:k]], dtype=np.int64), np.array([v[0] for v in allv[:k]], dtype=np.float32)
+
+
+def test_topk_merge_matches_sort():
+    rng = np.random.default_rng(3)
+    for n_lists, stride, k in ((1, 100, 100), (8, 100, 100), (8, 100, 7), (3, 5, 50), (4, 10, 0)):
+        ids = np.zeros((n_lists, stride), dtype=np.int64)
+        dist = np.zeros((n_lists, stride), dtype=np.float32)
+        counts = rng.integers(0, stride + 1, size=n_lists).astype(np.uint32)
+        base = 0
+        for g in range(n_lists):
+            c = int(counts[g])
+            dd = np.sort(rng.choice(np.array([0.0, 0.5, 0.5, 1.25, 3.0, 999999.0, -1.1920929e-07], dtype=np.float32), size=c))
+            ii = base + np.arange(c)
+            # sorted by (dist, id) within the list
+            order = np.lexsort((ii, dd))
+            ids[g, :c], dist[g, :c] = ii[order], dd[order]
+            base += 1000
+        got_i, got_d = capi.topk_merge(ids, dist, counts, k)
+        want_i, want_d = _ref_merge(ids, dist, counts, k)
+        assert np.array_equal(got_i, want_i) and np.array_equal(got_d, want_d)
+
+
+def test_shard_ranges_partition_the_table():
+    for n in (0, 1, 7, 8, 9, 1000, 10_000_000):
+        for world in (1, 2, 3, 4, 8):
+            spans = [sharded.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for a, b in zip(spans, spans[1:]):
+                assert a[1] == b[0]
+            assert all(lo <= hi for lo, hi in spans)
+
+
+_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np
+import torch, torch.distributed as dist
+from oracle import capi as oracle
+from pixelbox_amd import sharded, synth
+
+class OracleShard:  # stands in for the HIP shard: the test exercises the collective + merge plumbing
+    def __init__(self, d): self.d = d; self.rows = np.zeros((0, d), np.uint8); self.ids = np.zeros(0, np.int64)
+    def load(self, ids, rows): self.ids, self.rows = np.asarray(ids), np.asarray(rows)
+    def search(self, queries, k, max_dist):
+        nq = len(queries)
+        I = np.zeros((nq, k), np.int64); D = np.zeros((nq, k), np.float32); C = np.zeros(nq, np.uint32)
+        for q in range(nq):
+            i, dd = oracle.scan_topk(queries[q], self.rows, self.ids, k, max_dist) if len(self.ids) else (np.zeros(0, np.int64), np.zeros(0, np.float32))
+            C[q] = len(i); I[q, :len(i)] = i; D[q, :len(i)] = dd
+        return I, D, C
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+d, n = 64, 3001
+rows = synth.fill_synthetic(synth.SEED_INDEX, 0, n * d).reshape(n, d).copy()
+rows[1500] = rows[10]; rows[2999] = rows[10]            # ties across shards -> image_id order
+ids = np.arange(n, dtype=np.int64) * 3 + 1
+sh = sharded.ShardedIndex(d, n, rank=rank, world=world, group=dist.group.WORLD, local_index=OracleShard(d))
+sh.load(ids, rows)
+queries = np.stack([rows[10], synth.fill_synthetic(synth.SEED_QUERY, 0, d), 255 - rows[10]])
+for k, md in ((100, 1e3), (5, 1e3), (100, 2e6), (100, 1e-3)):
+    I, D, C = sh.search(queries, k, md)
+    for q in range(len(queries)):
+        wi, wd = oracle.scan_topk(queries[q], rows, ids, k, md)
+        assert C[q] == len(wi), (k, md, q, C[q], len(wi))
+        assert np.array_equal(I[q, :C[q]], wi), (k, md, q)
+        assert np.array_equal(D[q, :C[q]].view(np.uint32), wd.view(np.uint32)), (k, md, q)
+dist.barrier()
+dist.destroy_process_group()
+print("RANK", rank, "OK")
+"""
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_query_over_gloo(world, tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=ROOT))
+    port = 29500 + (os.getpid() % 2000) + world
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for pp in procs:
+                pp.kill()
+            raise
+        outs.append(out)
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, out[-2000:]
+        assert f"RANK {r} OK" in out
