@@ -1,17 +1,427 @@
-// pb_embed.hip -- embed half of the C ABI (placeholder until the EfficientNet kernels land: fails loudly).
-#include "pb_common.h"
+// pb_embed.hip -- host side of the embed half of the C ABI (include/pixelbox_hip.h): the batched
+// replacement of `image_hashes::mlhash` (src/image_hashes/efficientnet.rs:31-42).  gfx950 only; no CPU
+// fallback.  Weight blob: PBXW0001 (pixelbox_amd/weights.py) -- BN-folded EfficientNet-B0 features +
+// Linear(1280, D) exactly as resources/train.py:30-46,167-174 exports them.
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
 
-struct pb_embedder { int unused; };
+#include "pb_common.h"
+#include "pb_embed_kernels.h"
+
+using namespace pbe;
+
+namespace {
+
+struct Stage {
+    int expand, k, stride, cin, cout, repeats;
+};
+// torchvision efficientnet_b0 inverted-residual setting
+const Stage STAGES[7] = {{1, 3, 1, 32, 16, 1},  {6, 3, 2, 16, 24, 2},   {6, 5, 2, 24, 40, 2},  {6, 3, 2, 40, 80, 3},
+                         {6, 5, 1, 80, 112, 3}, {6, 5, 2, 112, 192, 4}, {6, 3, 1, 192, 320, 1}};
+
+int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+struct Gemm {  // 1x1 conv as GEMM
+    int K = 0, N = 0, Kpad = 0, Npad = 0;
+    float *wt = nullptr;    // [Kpad][Npad]
+    float *bias = nullptr;  // [Npad]
+};
+struct Block {
+    int cin, cout, e, sq, k, stride;
+    bool has_expand, residual;
+    Gemm expand, project;
+    float *dw_w = nullptr, *dw_b = nullptr;            // [k*k][e], [e]
+    float *se_w1 = nullptr, *se_b1 = nullptr;          // [sq][e], [sq]
+    float *se_w2t = nullptr, *se_b2 = nullptr;         // [sq][e], [e]
+};
+
+}  // namespace
+
+struct pb_embedder {
+    int device = 0;
+    uint32_t H = 0, W = 0, D = 0, max_batch = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    std::vector<void *> allocs;
+    float *stem_w = nullptr, *stem_b = nullptr;  // [27][32], [32]
+    std::vector<Block> blocks;
+    Gemm head;
+    float *fc_wt = nullptr, *fc_b = nullptr;  // [1280][D], [D]
+    // workspace
+    uint8_t *d_img = nullptr;
+    float *buf_x[2] = {nullptr, nullptr};
+    float *buf_e = nullptr, *buf_dw = nullptr, *buf_part = nullptr, *buf_gate = nullptr, *buf_pool = nullptr;
+    float *d_out_f32 = nullptr;
+    uint8_t *d_out_u8 = nullptr;
+    int n_cu = 256;
+    std::mutex mu;
+};
+
+namespace {
+
+template <typename T>
+int dalloc(pb_embedder *e, T **p, size_t n_elems) {
+    void *q = nullptr;
+    PB_HIP(hipMalloc(&q, std::max<size_t>(n_elems, 1) * sizeof(T)));
+    e->allocs.push_back(q);
+    *p = static_cast<T *>(q);
+    return PB_OK;
+}
+
+int upload(pb_embedder *e, float **dst, const std::vector<float> &src) {
+    int rc = dalloc(e, dst, src.size());
+    if (rc) return rc;
+    PB_HIP(hipMemcpy(*dst, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice));
+    return PB_OK;
+}
+
+// torch [N][K] (OI) -> k-major zero-padded [Kpad][Npad] + padded bias
+int make_gemm(pb_embedder *e, Gemm *g, const float *w, const float *b, int N, int K) {
+    g->K = K;
+    g->N = N;
+    g->Kpad = round_up(K, 16);
+    g->Npad = round_up(N, 16);
+    std::vector<float> wt((size_t)g->Kpad * g->Npad, 0.0f), bp(g->Npad, 0.0f);
+    for (int n = 0; n < N; ++n)
+        for (int k = 0; k < K; ++k) wt[(size_t)k * g->Npad + n] = w[(size_t)n * K + k];
+    for (int n = 0; n < N; ++n) bp[n] = b[n];
+    int rc = upload(e, &g->wt, wt);
+    if (!rc) rc = upload(e, &g->bias, bp);
+    return rc;
+}
+
+size_t blob_floats(int D) {
+    size_t n = 32 * 27 + 32;
+    for (const Stage &st : STAGES)
+        for (int r = 0; r < st.repeats; ++r) {
+            const int cin = r == 0 ? st.cin : st.cout, e = cin * st.expand, sq = std::max(1, cin / 4);
+            if (st.expand != 1) n += (size_t)e * cin + e;
+            n += (size_t)e * st.k * st.k + e;
+            n += (size_t)sq * e + sq + (size_t)e * sq + e;
+            n += (size_t)st.cout * e + st.cout;
+        }
+    n += 1280 * 320 + 1280;
+    n += (size_t)D * 1280 + D;
+    return n;
+}
+
+int load_weights(pb_embedder *e, const uint8_t *blob, size_t len) {
+    PB_CHECK(len >= 32 && memcmp(blob, "PBXW0001", 8) == 0, PB_ERR_FORMAT, "weight blob: bad magic (want PBXW0001)");
+    uint32_t hdr[4];
+    uint64_t nfl;
+    memcpy(hdr, blob + 8, 16);
+    memcpy(&nfl, blob + 24, 8);
+    e->H = hdr[0];
+    e->W = hdr[1];
+    e->D = hdr[2];
+    PB_CHECK(e->D >= 1 && e->D <= 4096, PB_ERR_FORMAT, "weight blob: D = %u outside 1..4096", e->D);
+    PB_CHECK(e->H >= 32 && e->W >= 32 && e->H % 32 == 0 && e->W % 32 == 0 && e->H <= 1024 && e->W <= 1024, PB_ERR_FORMAT,
+             "weight blob: H x W = %u x %u must be multiples of 32 in 32..1024", e->H, e->W);
+    PB_CHECK(nfl == blob_floats((int)e->D) && len == 32 + nfl * 4, PB_ERR_FORMAT, "weight blob: size mismatch");
+    const float *p = reinterpret_cast<const float *>(blob + 32);
+    int rc;
+    {  // stem [32][3][3][3] (OIHW) -> [ky][kx][ci][32]
+        std::vector<float> w(27 * 32), b(p + 27 * 32, p + 27 * 32 + 32);
+        for (int co = 0; co < 32; ++co)
+            for (int ci = 0; ci < 3; ++ci)
+                for (int ky = 0; ky < 3; ++ky)
+                    for (int kx = 0; kx < 3; ++kx) w[((ky * 3 + kx) * 3 + ci) * 32 + co] = p[((co * 3 + ci) * 3 + ky) * 3 + kx];
+        if ((rc = upload(e, &e->stem_w, w)) || (rc = upload(e, &e->stem_b, b))) return rc;
+        p += 27 * 32 + 32;
+    }
+    for (const Stage &st : STAGES)
+        for (int r = 0; r < st.repeats; ++r) {
+            Block bl{};
+            bl.cin = r == 0 ? st.cin : st.cout;
+            bl.cout = st.cout;
+            bl.stride = r == 0 ? st.stride : 1;
+            bl.e = bl.cin * st.expand;
+            bl.sq = std::max(1, bl.cin / 4);
+            bl.k = st.k;
+            bl.has_expand = st.expand != 1;
+            bl.residual = bl.stride == 1 && bl.cin == bl.cout;
+            const int E = bl.e, S = bl.sq, KK = st.k * st.k;
+            if (bl.has_expand) {
+                if ((rc = make_gemm(e, &bl.expand, p, p + (size_t)E * bl.cin, E, bl.cin))) return rc;
+                p += (size_t)E * bl.cin + E;
+            }
+            {  // dw [E][k][k] -> [k*k][E]
+                std::vector<float> w((size_t)KK * E), b(p + (size_t)E * KK, p + (size_t)E * KK + E);
+                for (int c = 0; c < E; ++c)
+                    for (int t = 0; t < KK; ++t) w[(size_t)t * E + c] = p[(size_t)c * KK + t];
+                if ((rc = upload(e, &bl.dw_w, w)) || (rc = upload(e, &bl.dw_b, b))) return rc;
+                p += (size_t)E * KK + E;
+            }
+            {
+                std::vector<float> w1(p, p + (size_t)S * E), b1(p + (size_t)S * E, p + (size_t)S * E + S);
+                if ((rc = upload(e, &bl.se_w1, w1)) || (rc = upload(e, &bl.se_b1, b1))) return rc;
+                p += (size_t)S * E + S;
+                std::vector<float> w2t((size_t)S * E), b2(p + (size_t)E * S, p + (size_t)E * S + E);
+                for (int c = 0; c < E; ++c)
+                    for (int j = 0; j < S; ++j) w2t[(size_t)j * E + c] = p[(size_t)c * S + j];
+                if ((rc = upload(e, &bl.se_w2t, w2t)) || (rc = upload(e, &bl.se_b2, b2))) return rc;
+                p += (size_t)E * S + E;
+            }
+            if ((rc = make_gemm(e, &bl.project, p, p + (size_t)bl.cout * E, bl.cout, E))) return rc;
+            p += (size_t)bl.cout * E + bl.cout;
+            e->blocks.push_back(bl);
+        }
+    if ((rc = make_gemm(e, &e->head, p, p + 1280 * 320, 1280, 320))) return rc;
+    p += 1280 * 320 + 1280;
+    {
+        const int D = (int)e->D;
+        std::vector<float> wt((size_t)1280 * D), b(p + (size_t)D * 1280, p + (size_t)D * 1280 + D);
+        for (int dd = 0; dd < D; ++dd)
+            for (int c = 0; c < 1280; ++c) wt[(size_t)c * D + dd] = p[(size_t)dd * 1280 + c];
+        if ((rc = upload(e, &e->fc_wt, wt)) || (rc = upload(e, &e->fc_b, b))) return rc;
+    }
+    return PB_OK;
+}
+
+template <int MR>
+void launch_gemm_mr(int nr, dim3 grid, hipStream_t st, const float *act, int M, const Gemm &g, const float *gate, int hw,
+                    const float *resid, int do_silu, float *out) {
+#define PB_G(NRV)                                                                                              \
+    case NRV:                                                                                                  \
+        hipLaunchKernelGGL((k_gemm1x1<MR, NRV>), grid, dim3(256), 0, st, act, M, g.K, g.wt, g.Kpad, g.Npad, g.bias, \
+                           g.N, gate, hw, resid, do_silu, out);                                                \
+        break;
+    switch (nr) {
+        PB_G(1) PB_G(2) PB_G(3) PB_G(4) PB_G(5) PB_G(6) PB_G(7) PB_G(8)
+    }
+#undef PB_G
+}
+
+int launch_gemm(pb_embedder *e, const float *act, long M, const Gemm &g, const float *gate, int hw, const float *resid,
+                int do_silu, float *out) {
+    const int tiles = g.Npad / 16;
+    int nr = 1;
+    for (int c = 8; c >= 1; --c)
+        if (tiles % c == 0) {
+            nr = c;
+            break;
+        }
+    // MR = 4 (256 rows per block) when that still fills the chip twice over, else MR = 2, else 1
+    const long n_tiles_n = tiles / nr;
+    int mr = 4;
+    if ((M + 255) / 256 * n_tiles_n < 2L * e->n_cu) mr = 2;
+    if ((M + 127) / 128 * n_tiles_n < 2L * e->n_cu) mr = 1;
+    const long rows_per_block = 64L * mr;
+    dim3 grid((unsigned)((M + rows_per_block - 1) / rows_per_block), (unsigned)n_tiles_n);
+    if (mr == 4) launch_gemm_mr<4>(nr, grid, e->stream, act, (int)M, g, gate, hw, resid, do_silu, out);
+    else if (mr == 2) launch_gemm_mr<2>(nr, grid, e->stream, act, (int)M, g, gate, hw, resid, do_silu, out);
+    else launch_gemm_mr<1>(nr, grid, e->stream, act, (int)M, g, gate, hw, resid, do_silu, out);
+    PB_HIP(hipGetLastError());
+    return PB_OK;
+}
+
+struct DwGeom {
+    int zsplit, cqpb, px_slots, n_tiles, px_per_tile;
+};
+DwGeom dw_geom(int C, int howo) {
+    DwGeom g;
+    const int cq = C / 4;
+    g.zsplit = (cq + 255) / 256;
+    while (cq % g.zsplit) ++g.zsplit;
+    g.cqpb = cq / g.zsplit;
+    g.px_slots = std::max(1, 256 / g.cqpb);
+    g.n_tiles = std::max(1, std::min(32, (howo + g.px_slots * 8 - 1) / (g.px_slots * 8)));
+    g.px_per_tile = (howo + g.n_tiles - 1) / g.n_tiles;
+    g.n_tiles = (howo + g.px_per_tile - 1) / g.px_per_tile;
+    return g;
+}
+
+int launch_dw(pb_embedder *e, const Block &bl, const float *in, int B, int H, int W, float *out, int Ho, int Wo,
+              const DwGeom &g) {
+    dim3 grid(g.n_tiles, B, g.zsplit), block(g.cqpb * g.px_slots);
+#define PB_DW(KS, S)                                                                                          \
+    hipLaunchKernelGGL((k_dwconv<KS, S>), grid, block, 0, e->stream, in, H, W, bl.e, bl.dw_w, bl.dw_b, out, Ho, Wo, \
+                       g.px_per_tile, e->buf_part, g.n_tiles, g.cqpb)
+    if (bl.k == 3 && bl.stride == 1) PB_DW(3, 1);
+    else if (bl.k == 3 && bl.stride == 2) PB_DW(3, 2);
+    else if (bl.k == 5 && bl.stride == 1) PB_DW(5, 1);
+    else PB_DW(5, 2);
+#undef PB_DW
+    PB_HIP(hipGetLastError());
+    return PB_OK;
+}
+
+// forward for n images already on the device; results to device buffers
+int forward_device(pb_embedder *e, const uint8_t *d_rgb, int n, uint8_t *d_u8, float *d_f32) {
+    int H = (int)e->H / 2, W = (int)e->W / 2;
+    {
+        const long total = (long)n * H * W * 4;
+        const int grid = (int)std::min<long>((total + 255) / 256, (long)e->n_cu * 16);
+        hipLaunchKernelGGL(k_stem, dim3(grid), dim3(256), 0, e->stream, d_rgb, n, (int)e->H, (int)e->W, e->stem_w, e->stem_b,
+                           e->buf_x[0]);
+        PB_HIP(hipGetLastError());
+    }
+    int cur = 0;
+    for (const Block &bl : e->blocks) {
+        const float *x = e->buf_x[cur];
+        const long M = (long)n * H * W;
+        const float *ein = x;
+        int rc;
+        if (bl.has_expand) {
+            if ((rc = launch_gemm(e, x, M, bl.expand, nullptr, 1, nullptr, 1, e->buf_e))) return rc;
+            ein = e->buf_e;
+        }
+        const int Ho = (H + bl.stride - 1) / bl.stride, Wo = (W + bl.stride - 1) / bl.stride;
+        const DwGeom g = dw_geom(bl.e, Ho * Wo);
+        if ((rc = launch_dw(e, bl, ein, n, H, W, e->buf_dw, Ho, Wo, g))) return rc;
+        hipLaunchKernelGGL(k_se, dim3(n), dim3(256), 0, e->stream, e->buf_part, g.n_tiles, bl.e, bl.sq, 1.0f / (float)(Ho * Wo),
+                           bl.se_w1, bl.se_b1, bl.se_w2t, bl.se_b2, e->buf_gate);
+        PB_HIP(hipGetLastError());
+        const long Mo = (long)n * Ho * Wo;
+        if ((rc = launch_gemm(e, e->buf_dw, Mo, bl.project, e->buf_gate, Ho * Wo, bl.residual ? x : nullptr, 0,
+                              e->buf_x[cur ^ 1])))
+            return rc;
+        cur ^= 1;
+        H = Ho;
+        W = Wo;
+    }
+    const long M = (long)n * H * W;
+    int rc = launch_gemm(e, e->buf_x[cur], M, e->head, nullptr, 1, nullptr, 1, e->buf_e);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_avgpool, dim3((1280 + 255) / 256, n), dim3(256), 0, e->stream, e->buf_e, H * W, 1280,
+                       1.0f / (float)(H * W), e->buf_pool);
+    PB_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_fc_tanh_quant, dim3(n), dim3(256), 0, e->stream, e->buf_pool, 1280, (int)e->D, e->fc_wt, e->fc_b,
+                       d_f32, d_u8);
+    PB_HIP(hipGetLastError());
+    return PB_OK;
+}
+
+void destroy(pb_embedder *e) {
+    for (void *p : e->allocs) (void)hipFree(p);
+    if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+}
+
+}  // namespace
 
 extern "C" {
-int pb_embed_create(pb_embedder **out, int, const void *, size_t, uint32_t) {
-    if (out) *out = nullptr;
-    return pb::fail(PB_ERR_INTERNAL, "pb_embed_create: embed kernels not built in this revision");
+
+int pb_embed_create(pb_embedder **out, int device, const void *weights_blob, size_t blob_len, uint32_t max_batch) {
+    PB_CHECK(out, PB_ERR_INVALID, "pb_embed_create: null out pointer");
+    *out = nullptr;
+    PB_CHECK(weights_blob, PB_ERR_INVALID, "pb_embed_create: null weight blob");
+    PB_CHECK(max_batch >= 1 && max_batch <= 8192, PB_ERR_INVALID, "pb_embed_create: max_batch %u outside 1..8192", max_batch);
+    int n_dev = 0;
+    PB_HIP(hipGetDeviceCount(&n_dev));
+    PB_CHECK(device >= 0 && device < n_dev, PB_ERR_INVALID, "pb_embed_create: device %d of %d", device, n_dev);
+    pb::DeviceGuard guard(device);
+    PB_CHECK(guard.ok, PB_ERR_HIP, "hipSetDevice(%d) failed", device);
+    pb_embedder *e = new (std::nothrow) pb_embedder();
+    PB_CHECK(e, PB_ERR_NOMEM, "out of host memory");
+    e->device = device;
+    e->max_batch = max_batch;
+    auto body = [&]() -> int {
+        hipDeviceProp_t prop;
+        PB_HIP(hipGetDeviceProperties(&prop, device));
+        e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        PB_HIP(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
+        e->stream = e->own_stream;
+        int rc = load_weights(e, static_cast<const uint8_t *>(weights_blob), blob_len);
+        if (rc) return rc;
+        // workspace sized for max_batch images (NHWC f32)
+        const size_t B = max_batch, h2 = e->H / 2, w2 = e->W / 2;
+        size_t max_x = h2 * w2 * 32, max_e = 0, max_dw = 0, max_part = 0;
+        size_t h = h2, w = w2;
+        for (const Block &bl : e->blocks) {
+            const size_t ho = (h + bl.stride - 1) / bl.stride, wo = (w + bl.stride - 1) / bl.stride;
+            if (bl.has_expand) max_e = std::max(max_e, h * w * bl.e);
+            max_dw = std::max(max_dw, ho * wo * bl.e);
+            max_x = std::max(max_x, ho * wo * (size_t)bl.cout);
+            const DwGeom g = dw_geom(bl.e, (int)(ho * wo));
+            max_part = std::max(max_part, (size_t)g.n_tiles * bl.e);
+            h = ho;
+            w = wo;
+        }
+        max_e = std::max(max_e, h * w * 1280);
+        if ((rc = dalloc(e, &e->d_img, B * e->H * e->W * 3))) return rc;
+        if ((rc = dalloc(e, &e->buf_x[0], B * max_x)) || (rc = dalloc(e, &e->buf_x[1], B * max_x))) return rc;
+        if ((rc = dalloc(e, &e->buf_e, B * max_e)) || (rc = dalloc(e, &e->buf_dw, B * max_dw))) return rc;
+        if ((rc = dalloc(e, &e->buf_part, B * max_part)) || (rc = dalloc(e, &e->buf_gate, B * 1152))) return rc;
+        if ((rc = dalloc(e, &e->buf_pool, B * 1280))) return rc;
+        if ((rc = dalloc(e, &e->d_out_f32, B * e->D)) || (rc = dalloc(e, &e->d_out_u8, B * e->D))) return rc;
+        return PB_OK;
+    };
+    int rc = body();
+    if (rc) {
+        destroy(e);
+        delete e;
+        return rc;
+    }
+    *out = e;
+    return PB_OK;
 }
-int pb_embed_destroy(pb_embedder *) { return PB_OK; }
-int pb_embed_info(const pb_embedder *, uint32_t *, uint32_t *, uint32_t *, uint32_t *) { return pb::fail(PB_ERR_INTERNAL, "not built"); }
-int pb_embed_batch(pb_embedder *, const uint8_t *, uint32_t, uint8_t *, float *) { return pb::fail(PB_ERR_INTERNAL, "not built"); }
-int pb_embed_batch_device(pb_embedder *, const uint8_t *, uint32_t, uint8_t *, float *) { return pb::fail(PB_ERR_INTERNAL, "not built"); }
-int pb_mlhash(pb_embedder *, const uint8_t *, uint8_t *, size_t) { return pb::fail(PB_ERR_INTERNAL, "not built"); }
-int pb_embed_set_option(pb_embedder *, int, int64_t) { return pb::fail(PB_ERR_INTERNAL, "not built"); }
+
+int pb_embed_destroy(pb_embedder *e) {
+    if (!e) return PB_OK;
+    {
+        pb::DeviceGuard guard(e->device);
+        (void)hipStreamSynchronize(e->stream);
+        destroy(e);
+    }
+    delete e;
+    return PB_OK;
 }
+
+int pb_embed_info(const pb_embedder *e, uint32_t *h, uint32_t *w, uint32_t *d, uint32_t *max_batch) {
+    PB_CHECK(e, PB_ERR_INVALID, "pb_embed_info: null embedder");
+    if (h) *h = e->H;
+    if (w) *w = e->W;
+    if (d) *d = e->D;
+    if (max_batch) *max_batch = e->max_batch;
+    return PB_OK;
+}
+
+int pb_embed_batch_device(pb_embedder *e, const uint8_t *d_rgb, uint32_t n, uint8_t *d_out_u8, float *d_out_f32) {
+    PB_CHECK(e, PB_ERR_INVALID, "pb_embed_batch_device: null embedder");
+    PB_CHECK(n <= e->max_batch, PB_ERR_INVALID, "pb_embed_batch_device: n = %u > max_batch %u", n, e->max_batch);
+    PB_CHECK(n == 0 || (d_rgb && d_out_u8), PB_ERR_INVALID, "pb_embed_batch_device: null buffer");
+    if (n == 0) return PB_OK;
+    std::lock_guard<std::mutex> lock(e->mu);
+    pb::DeviceGuard guard(e->device);
+    return forward_device(e, d_rgb, (int)n, d_out_u8, d_out_f32);
+}
+
+int pb_embed_batch(pb_embedder *e, const uint8_t *rgb, uint32_t n, uint8_t *out_u8, float *out_f32) {
+    PB_CHECK(e, PB_ERR_INVALID, "pb_embed_batch: null embedder");
+    PB_CHECK(n == 0 || (rgb && out_u8), PB_ERR_INVALID, "pb_embed_batch: null buffer");
+    std::lock_guard<std::mutex> lock(e->mu);
+    pb::DeviceGuard guard(e->device);
+    const size_t img_bytes = (size_t)e->H * e->W * 3;
+    for (uint32_t i0 = 0; i0 < n; i0 += e->max_batch) {
+        const uint32_t c = std::min(e->max_batch, n - i0);
+        PB_HIP(hipMemcpyAsync(e->d_img, rgb + i0 * img_bytes, c * img_bytes, hipMemcpyHostToDevice, e->stream));
+        int rc = forward_device(e, e->d_img, (int)c, e->d_out_u8, e->d_out_f32);
+        if (rc) return rc;
+        PB_HIP(hipMemcpyAsync(out_u8 + (size_t)i0 * e->D, e->d_out_u8, (size_t)c * e->D, hipMemcpyDeviceToHost, e->stream));
+        if (out_f32)
+            PB_HIP(hipMemcpyAsync(out_f32 + (size_t)i0 * e->D, e->d_out_f32, (size_t)c * e->D * sizeof(float),
+                                  hipMemcpyDeviceToHost, e->stream));
+        PB_HIP(hipStreamSynchronize(e->stream));
+    }
+    return PB_OK;
+}
+
+int pb_mlhash(pb_embedder *e, const uint8_t *rgb, uint8_t *out, size_t out_len) {
+    PB_CHECK(e, PB_ERR_INVALID, "pb_mlhash: null embedder");
+    PB_CHECK(out_len >= e->D, PB_ERR_INVALID, "pb_mlhash: out_len %zu < D = %u", out_len, e->D);
+    return pb_embed_batch(e, rgb, 1, out, nullptr);
+}
+
+int pb_embed_set_option(pb_embedder *e, int option, int64_t value) {
+    PB_CHECK(e, PB_ERR_INVALID, "pb_embed_set_option: null embedder");
+    std::lock_guard<std::mutex> lock(e->mu);
+    if (option == PB_OPT_EMBED_STREAM) {
+        e->stream = value ? reinterpret_cast<hipStream_t>(value) : e->own_stream;
+        return PB_OK;
+    }
+    return pb::fail(PB_ERR_INVALID, "pb_embed_set_option: unknown option %d", option);
+}
+
+}  // extern "C"

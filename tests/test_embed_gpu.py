@@ -1,0 +1,122 @@
+"""GPU parity tests for the embed half: HIP EfficientNet-B0 (f32 MFMA) through the C ABI vs the CPU oracle
+(oracle/pb_oracle_effnet.c) and the torch-generated golden fixtures.
+
+Bar (embedding floats are "parity unpinned" against tract, which is absent):
+  floats within 1e-5 of the oracle on images whose outputs do not saturate (2e-4 on saturating ones, e.g.
+  flat black/white, where pre-tanh values are ~10x larger and f32 rounding scales with them -- see
+  tests/embed_tol.py); the u8 quantiser (efficientnet.rs:39) bit-exact on
+  the GPU's own floats; bytes identical to the oracle's except where the oracle's float sits within the
+  float tolerance of a k/128 truncation boundary."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import capi as oracle
+from oracle import numpy_oracle as no
+from pixelbox_amd import capi, synth
+from pixelbox_amd import weights as W
+
+pytestmark = pytest.mark.gpu
+
+from embed_tol import assert_bytes_match, assert_embeddings_close  # noqa: E402  (tests/embed_tol.py)
+
+
+@pytest.mark.parametrize("name", ["embed_128_256", "embed_64x96_16", "embed_32_8"])
+def test_golden_fixture(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    h, w, d, n = int(g["h"]), int(g["w"]), int(g["d"]), int(g["n"])
+    blob = W.synthetic_blob(int(g["weights_seed"]), h, w, d)
+    imgs = synth.synthetic_images(int(g["image_seed"]), 0, n, h, w)
+    fb, fw = int(g["flat_black"]), int(g["flat_white"])
+    imgs[fb] = 0
+    imgs[fw] = 255
+    emb = capi.Embedder(blob, max_batch=8)
+    assert (emb.h, emb.w, emb.d) == (h, w, d)
+    u8, f = emb.embed(imgs)
+    assert_embeddings_close(f, g["out_f32"])
+    assert np.array_equal(u8, no.quantize(f))  # quantiser bit-exact on the device's own floats
+    assert_bytes_match(u8, g["out_u8"], g["out_f32"])
+
+
+@pytest.mark.parametrize("n,max_batch", [(1, 1), (3, 8), (37, 16), (64, 64)])
+def test_batches_vs_oracle(n, max_batch):
+    blob = W.synthetic_blob(synth.SEED_WEIGHTS, 128, 128, 256)
+    imgs = synth.synthetic_images(synth.SEED_IMAGES, 100, n, 128, 128)
+    emb = capi.Embedder(blob, max_batch=max_batch)  # n > max_batch exercises the chunk loop
+    u8, f = emb.embed(imgs)
+    ref_u8, ref_f = oracle.mlhash_batch(blob, imgs, 256, nthreads=8)
+    assert_embeddings_close(f, ref_f)
+    assert np.array_equal(u8, no.quantize(f))
+    assert_bytes_match(u8, ref_u8, ref_f)
+    # image i's embedding does not depend on its batch position or batch size
+    u8_b, f_b = emb.embed(imgs[::-1].copy())
+    assert np.array_equal(f_b[::-1], f) and np.array_equal(u8_b[::-1], u8)
+
+
+def test_mlhash_is_deterministic_like_the_reference_test():
+    # efficientnet.rs:54-67: hamming_distance(mlhash(img), mlhash(img)) == 0
+    blob = W.synthetic_blob(synth.SEED_WEIGHTS, 128, 128, 256)
+    img = synth.synthetic_images(synth.SEED_IMAGES, 7, 1, 128, 128)[0]
+    emb = capi.Embedder(blob, max_batch=4)
+    a, b = emb.mlhash(img), emb.mlhash(img)
+    assert oracle.hamming_distance(a, b) == 0.0
+    u8, _ = emb.embed(img[None])
+    assert np.array_equal(a, u8[0])
+    ref_u8, ref_f = oracle.mlhash_batch(blob, img[None], 256, nthreads=1)
+    assert_bytes_match(a[None], ref_u8, ref_f)
+
+
+def test_reference_head_shape_224_latent8():
+    # the reference HEAD constants: 224x224 input, latent 8 (efficientnet.rs:6-8, train.py:178-182)
+    blob = W.synthetic_blob(synth.SEED_WEIGHTS, 224, 224, 8)
+    imgs = synth.synthetic_images(synth.SEED_IMAGES, 0, 2, 224, 224)
+    emb = capi.Embedder(blob, max_batch=2)
+    u8, f = emb.embed(imgs)
+    ref_u8, ref_f = oracle.mlhash_batch(blob, imgs, 8, nthreads=2)
+    assert_embeddings_close(f, ref_f)
+    assert_bytes_match(u8, ref_u8, ref_f)
+
+
+def test_device_pointer_entry_point():
+    import torch
+
+    blob = W.synthetic_blob(synth.SEED_WEIGHTS, 128, 128, 256)
+    n = 5
+    imgs = synth.synthetic_images(synth.SEED_IMAGES, 0, n, 128, 128)
+    emb = capi.Embedder(blob, max_batch=8)
+    ref_u8, ref_f = emb.embed(imgs)
+    d_img = torch.from_numpy(imgs).cuda()
+    d_u8 = torch.zeros((n, 256), dtype=torch.uint8, device="cuda")
+    d_f = torch.zeros((n, 256), dtype=torch.float32, device="cuda")
+    emb.set_option(capi.PB_OPT_STREAM, torch.cuda.current_stream().cuda_stream)
+    emb.embed_device(d_img.data_ptr(), n, d_u8.data_ptr(), d_f.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(d_u8.cpu().numpy(), ref_u8) and np.array_equal(d_f.cpu().numpy(), ref_f)
+
+
+def test_bad_blobs_fail_loudly():
+    blob = W.synthetic_blob(synth.SEED_WEIGHTS, 128, 128, 256)
+    for bad in (blob[:-4], b"XXXX" + blob[4:], blob[:40]):
+        with pytest.raises(capi.PixelboxError) as ei:
+            capi.Embedder(bad, max_batch=2)
+        assert ei.value.code == -5  # PB_ERR_FORMAT
+    emb = capi.Embedder(blob, max_batch=2)
+    with pytest.raises(capi.PixelboxError):
+        emb.embed_device(1, 3, 1)  # n > max_batch
+
+
+def test_embed_then_search_end_to_end():
+    # config 1 in miniature: embed synthetic images, store the hashes, query with image #0's hash -> id(#0) first
+    blob = W.synthetic_blob(synth.SEED_WEIGHTS, 128, 128, 256)
+    n = 200
+    imgs = synth.synthetic_images(synth.SEED_IMAGES, 0, n, 128, 128)
+    emb = capi.Embedder(blob, max_batch=64)
+    u8, _ = emb.embed(imgs, want_f32=False)
+    ix = capi.Index(256, n)
+    ids = np.arange(1, n + 1, dtype=np.int64)
+    ix.append(ids, u8)
+    got_ids, got_d = ix.search_one(u8[0])
+    want_ids, want_d = oracle.scan_topk(u8[0], u8, ids, 100, 1e3)
+    assert np.array_equal(got_ids, want_ids) and np.array_equal(got_d.view(np.uint32), want_d.view(np.uint32))
+    assert got_ids[0] == 1 and got_d[0] <= 1e-6
