@@ -191,17 +191,25 @@ def bench_embed(args, torch, device, distributed):
     imgs = torch.empty((nb, 128, 128, 3), dtype=torch.uint8, device=f"cuda:{device}")
     capi.fill_synthetic_device(device, synth.SEED_IMAGES, 0, imgs.numel(), imgs.data_ptr())
     out = torch.empty((nb, 256), dtype=torch.uint8, device=f"cuda:{device}")
-    emb.set_option(capi.PB_OPT_STREAM, torch.cuda.current_stream().cuda_stream)
-    for _ in range(2):
-        emb.embed_device(imgs.data_ptr(), nb, out.data_ptr())
+    # a dedicated (non-null) torch stream: the kernels are launched on it, and the events that time them
+    # are recorded on it (torch.cuda.Event only sees the stream it is recorded on)
+    stream = torch.cuda.Stream(device=device)
+    emb.set_option(capi.PB_OPT_STREAM, stream.cuda_stream)
+    assert stream.cuda_stream != 0
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(args.embed_steps):
-        emb.embed_device(imgs.data_ptr(), nb, out.data_ptr())
-    e1.record()
-    torch.cuda.synchronize()
+    with torch.cuda.stream(stream):
+        for _ in range(2):
+            emb.embed_device(imgs.data_ptr(), nb, out.data_ptr())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        t0 = time.perf_counter()
+        for _ in range(args.embed_steps):
+            emb.embed_device(imgs.data_ptr(), nb, out.data_ptr())
+        e1.record(stream)
+    stream.synchronize()
+    wall_ms = (time.perf_counter() - t0) * 1e3 / args.embed_steps
     ms = e0.elapsed_time(e1) / args.embed_steps
+    assert ms > 0.5 * wall_ms - 0.05, (ms, wall_ms)  # event time must account for the wall time
     ips = nb / (ms * 1e-3)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     tf = ips * EMBED_FLOP_PER_IMAGE / 1e12

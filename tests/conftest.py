@@ -18,6 +18,15 @@ def pytest_configure(config):
 
 
 def _gpu_available() -> bool:
+    # Ask the HIP runtime through the product library itself (hipGetDeviceCount); torch is only a second
+    # opinion -- its is_available() has been seen to answer False on a box whose GPU the library can use.
+    try:
+        from pixelbox_amd import capi
+
+        if capi.device_count() > 0:
+            return True
+    except Exception:
+        pass
     try:
         import torch
 
