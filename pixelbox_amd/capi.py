@@ -49,6 +49,15 @@ def lib():
     """Load libpixelbox_hip.so (built by pixelbox_amd.build / __graft_entry__.build). Fails loudly."""
     global _lib
     if _lib is None:
+        if os.environ.get("PIXELBOX_NO_TORCH_PRELOAD") != "1":
+            # PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so).  If this library pulls in
+            # /opt/rocm's copy first, a later `import torch` in the same process finds "No HIP GPUs".  Loading
+            # torch first makes both share one runtime (same soname).  Harness-only concern: a Rust/C host
+            # never has torch in its process.
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         if not os.path.exists(LIB_PATH):
             raise OSError(f"{LIB_PATH} is missing: run `python -m pixelbox_amd.build` (hipcc, gfx950). "
                           "There is no CPU fallback.")
