@@ -4,14 +4,14 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
 Metric (BASELINE.json): similarity queries/sec over a 10M x 256-dim u8 index (plus embeddings/sec,
-reported beside it), at 1/2/4/8 GPUs.  One STEP = one batch of `--queries` (default 16) independent
+reported beside it), at 1/2/4/8 GPUs.  One STEP = one batch of `--queries` (default 64) independent
 batch-1 cosine-distance top-100 queries, each a full pass over the whole index (N*D bytes streamed per
 query: the HBM roofline of SURVEY.md section 8d), i.e. the reference's `query_by_image_hash_from_image`
-(engine.rs:363-396) 16 times.  With N > 1 the 10M rows are sharded by contiguous row range
+(engine.rs:363-396) 64 times.  With N > 1 the 10M rows are sharded by contiguous row range
 (STRONG scaling: total work fixed), each rank searches its shard, the per-shard top-100 lists are
 all-gathered over RCCL (torch.distributed, backend nccl) once per step and merged (pb_topk_merge).
 Inputs (index, queries) are resident in HBM / pinned staging before the timed region; the query bytes
-(16 x 256 B) and the results (16 x 1.2 KB) do cross PCIe inside it, as they must in any real query.
+(64 x 256 B) and the results (64 x 1.2 KB) do cross PCIe inside it, as they must in any real query.
 
 Prints ONE JSON line on rank 0 (see the task contract), with `roofline` for the dominant kernel
 (k_scan_filter, HBM-bound; achieved = algorithmic bytes / HIP-event time of that kernel measured in the
@@ -39,11 +39,11 @@ EMBED_FLOP_PER_IMAGE = 2 * 126_312_448  # SURVEY.md Appendix B, 128x128 -> 256
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=int, default=10_000_000, help="total index rows (BASELINE: 10M)")
     ap.add_argument("--dim", type=int, default=256)
-    ap.add_argument("--queries", type=int, default=16, help="independent batch-1 queries per step")
+    ap.add_argument("--queries", type=int, default=64, help="independent batch-1 queries per step")
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--max-dist", type=float, default=1e3)
     ap.add_argument("--embed-batch", type=int, default=512)
@@ -65,7 +65,9 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-    distributed = world > 1
+    # PIXELBOX_FORCE_DIST=1: run the collective path even at world size 1 (lets a 1-GPU box exercise the
+    # nccl init / all-gather / merge code that the 2-, 4- and 8-GPU runs use)
+    distributed = world > 1 or os.environ.get("PIXELBOX_FORCE_DIST") == "1"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
@@ -73,6 +75,9 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from pixelbox_amd import capi, synth
@@ -106,6 +111,14 @@ def main():
     dt = time.perf_counter() - t0
     sh.index.set_option(capi.PB_OPT_PROFILE, 0)
     st = sh.index.stats()
+    # single-query latency (one query per call, same path), outside the timed region
+    lat = []
+    for i in range(5):
+        barrier()
+        t1 = time.perf_counter()
+        sh.search(qbytes[args.warmup][i : i + 1], k, args.max_dist)
+        lat.append((time.perf_counter() - t1) * 1e3)
+    lat_ms = sorted(lat)[len(lat) // 2]
     if distributed:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -147,7 +160,7 @@ def main():
                                    f"top-{k} queries per step, max_dist={args.max_dist:g}",
                        "rows": n_total, "dim": d, "k": k, "queries_per_step": B, "parallelism": f"row-shard x{world}",
                        "search_path": "exact" if args.exact_path else "filter+rescore"},
-            "ms_per_query": round(dt / (args.steps * B) * 1e3, 4),
+            "ms_per_query": round(dt / (args.steps * B) * 1e3, 4), "latency_ms_single_query_call": round(lat_ms, 4),
             "path_counts": {"queries": int(st.queries), "filter_certified": int(st.fast_path), "exhaustive": int(st.fallback)},
             "roofline": roof, "cpu_baseline": cpu,
         }

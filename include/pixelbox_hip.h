@@ -91,6 +91,17 @@ int pb_index_search(pb_index *idx, const uint8_t *queries, uint32_t nq, uint32_t
 int pb_index_search_device(pb_index *idx, const uint8_t *queries, uint32_t nq, uint32_t k,
                            double max_dist, int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count);
 
+/* Same query, results packed for ONE all-gather and left in DEVICE memory: d_packed is int64[nq][2k+1] with
+ * [0..k) image_ids, [k..2k) the f32 distance bits (zero-extended), [2k] the count.  This is the per-rank
+ * message of the row-sharded multi-GPU query (pixelbox_amd/sharded.py). */
+int pb_index_search_packed(pb_index *idx, const uint8_t *queries, uint32_t nq, uint32_t k, double max_dist,
+                           int64_t *d_packed);
+
+/* Merge of the all-gathered messages (HOST memory): gathered is int64[n_lists][nq][2k+1] as produced by
+ * pb_index_search_packed on every rank; writes the global top-k per query, (dist, image_id) order. */
+int pb_topk_merge_packed(const int64_t *gathered, uint32_t n_lists, uint32_t nq, uint32_t k, int64_t *out_ids,
+                         float *out_dist, uint32_t *out_count);
+
 /* G-way merge of per-shard results (HOST buffers): list g holds counts[g] entries at
  * ids[g*stride ..], dist[g*stride ..], each sorted by (dist, id).  Writes the first k of the merged
  * order.  This is the step after the all-gather in the row-sharded multi-GPU query. */

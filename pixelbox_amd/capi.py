@@ -24,7 +24,7 @@ PB_OPT_STREAM = 3
 SYMBOLS = [
     "pb_last_error", "pb_version", "pb_device_count",
     "pb_index_create", "pb_index_destroy", "pb_index_size", "pb_index_dim", "pb_index_append", "pb_index_load",
-    "pb_index_search", "pb_index_search_device", "pb_topk_merge", "pb_index_read", "pb_index_fill_synthetic",
+    "pb_index_search", "pb_index_search_device", "pb_index_search_packed", "pb_topk_merge_packed", "pb_topk_merge", "pb_index_read", "pb_index_fill_synthetic",
     "pb_index_set_option", "pb_index_get_stats",
     "pb_embed_create", "pb_embed_destroy", "pb_embed_info", "pb_embed_batch", "pb_embed_batch_device", "pb_mlhash",
     "pb_embed_set_option", "pb_fill_synthetic",
@@ -74,6 +74,8 @@ def lib():
         L.pb_index_load.argtypes = [vp, i64p, u8p, C.c_uint64]
         L.pb_index_search.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, C.c_double, i64p, f32p, u32p]
         L.pb_index_search_device.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, C.c_double, vp, vp, vp]
+        L.pb_index_search_packed.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, C.c_double, vp]
+        L.pb_topk_merge_packed.argtypes = [i64p, C.c_uint32, C.c_uint32, C.c_uint32, i64p, f32p, u32p]
         L.pb_topk_merge.argtypes = [i64p, f32p, u32p, C.c_uint32, C.c_uint32, C.c_uint32, i64p, f32p, u32p]
         L.pb_index_read.argtypes = [vp, C.c_uint64, C.c_uint64, i64p, u8p]
         L.pb_index_fill_synthetic.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int64]
@@ -118,6 +120,29 @@ def topk_merge(ids: np.ndarray, dist: np.ndarray, counts: np.ndarray, k: int):
     _check(lib().pb_topk_merge(_p(ids, C.c_int64), _p(dist, C.c_float), _p(counts, C.c_uint32), n_lists, stride, k,
                                _p(out_ids, C.c_int64), _p(out_d, C.c_float), C.byref(cnt)))
     return out_ids[: cnt.value].copy(), out_d[: cnt.value].copy()
+
+
+def topk_merge_packed(gathered: np.ndarray, k: int):
+    """gathered: int64 [n_lists, nq, 2k+1] (host) -> (ids [nq, k], dist [nq, k], count [nq]).  Host-only."""
+    g = np.ascontiguousarray(gathered, dtype=np.int64)
+    n_lists, nq, row = g.shape
+    assert row == 2 * k + 1
+    ids = np.zeros((nq, k), dtype=np.int64)
+    dist = np.zeros((nq, k), dtype=np.float32)
+    cnt = np.zeros(nq, dtype=np.uint32)
+    _check(lib().pb_topk_merge_packed(_p(g, C.c_int64), n_lists, nq, k, _p(ids, C.c_int64), _p(dist, C.c_float),
+                                      _p(cnt, C.c_uint32)))
+    return ids, dist, cnt
+
+
+def pack_results(ids: np.ndarray, dist: np.ndarray, cnt: np.ndarray) -> np.ndarray:
+    """Host-side equivalent of the device packing (used by the CPU tests of the collective path)."""
+    nq, k = ids.shape
+    out = np.zeros((nq, 2 * k + 1), dtype=np.int64)
+    out[:, :k] = ids
+    out[:, k : 2 * k] = np.ascontiguousarray(dist, dtype=np.float32).view(np.uint32).astype(np.int64)
+    out[:, 2 * k] = cnt
+    return out
 
 
 class Index:
@@ -186,6 +211,10 @@ class Index:
         q = np.ascontiguousarray(queries, dtype=np.uint8).reshape(-1, self.dim)
         _check(lib().pb_index_search_device(self._h, _p(q, C.c_uint8), q.shape[0], k, float(max_dist),
                                             C.c_void_p(d_ids_ptr), C.c_void_p(d_dist_ptr), C.c_void_p(d_count_ptr)))
+
+    def search_packed(self, queries, k, max_dist, d_packed_ptr: int):
+        q = np.ascontiguousarray(queries, dtype=np.uint8).reshape(-1, self.dim)
+        _check(lib().pb_index_search_packed(self._h, _p(q, C.c_uint8), q.shape[0], k, float(max_dist), C.c_void_p(d_packed_ptr)))
 
     def set_option(self, option: int, value: int):
         _check(lib().pb_index_set_option(self._h, option, value))

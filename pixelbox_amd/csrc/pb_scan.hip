@@ -248,6 +248,52 @@ int account_profile(pb_index *ix, uint32_t n_queries) {
     return PB_OK;
 }
 
+// One chunk (<= Q_CHUNK queries, already in h_stage): run the filter path, check the certificates on the
+// host (D2H of the 16-byte headers only), re-run uncertified queries through the exhaustive pass.
+// On return d_res_ids / d_res_dist / d_res_hdr hold the final results of the chunk and h_res_hdr mirrors
+// the headers.
+int search_chunk(pb_index *ix, uint32_t cq, uint32_t k, double max_dist) {
+    const uint32_t d = ix->dim;
+    uint8_t *hq = ix->h_stage;
+    QParams *hp = reinterpret_cast<QParams *>(ix->h_stage + (size_t)Q_CHUNK * d);
+    uint32_t *hsel = reinterpret_cast<uint32_t *>(ix->h_stage + (size_t)Q_CHUNK * (d + sizeof(QParams)));
+    const bool use_fast = ix->opt_path == 0 && fast_dim(d);
+    for (uint32_t q = 0; q < cq; ++q) make_qparams(ix, hq + (size_t)q * d, k, max_dist, &hp[q]);
+    PB_HIP(hipMemcpyAsync(ix->d_queries, hq, (size_t)cq * d, hipMemcpyHostToDevice, ix->stream));
+    PB_HIP(hipMemcpyAsync(ix->d_qp, hp, (size_t)cq * sizeof(QParams), hipMemcpyHostToDevice, ix->stream));
+    uint32_t n_sel = 0;
+    if (use_fast) {
+        int rc = run_fast(ix, cq);
+        if (rc) return rc;
+        PB_HIP(hipMemcpyAsync(ix->h_res_hdr, ix->d_res_hdr, cq * sizeof(ResultHdr), hipMemcpyDeviceToHost, ix->stream));
+        PB_HIP(hipStreamSynchronize(ix->stream));
+        if (ix->opt_profile) {
+            int rc2 = account_profile(ix, cq);
+            if (rc2) return rc2;
+        }
+        for (uint32_t q = 0; q < cq; ++q)
+            if (ix->h_res_hdr[q].status != 0) hsel[n_sel++] = q;
+        ix->stats.fast_path += cq - n_sel;
+    } else {
+        for (uint32_t q = 0; q < cq; ++q) hsel[n_sel++] = q;
+    }
+    if (n_sel) {
+        PB_HIP(hipMemcpyAsync(ix->d_qsel, hsel, n_sel * sizeof(uint32_t), hipMemcpyHostToDevice, ix->stream));
+        int rc = run_exact(ix, n_sel, k);
+        if (rc) return rc;
+        PB_HIP(hipMemcpyAsync(ix->h_res_hdr, ix->d_res_hdr, cq * sizeof(ResultHdr), hipMemcpyDeviceToHost, ix->stream));
+        PB_HIP(hipStreamSynchronize(ix->stream));
+        if (ix->opt_profile && ix->opt_path == 1) {
+            int rc2 = account_profile(ix, n_sel);
+            if (rc2) return rc2;
+        }
+        ix->stats.fallback += n_sel;
+    }
+    ix->stats.queries += cq;
+    return PB_OK;
+}
+
+// results to HOST buffers
 int search_locked(pb_index *ix, const uint8_t *queries, uint32_t nq, uint32_t k, double max_dist, int64_t *out_ids,
                   float *out_dist, uint32_t *out_count) {
     const uint32_t d = ix->dim;
@@ -255,50 +301,15 @@ int search_locked(pb_index *ix, const uint8_t *queries, uint32_t nq, uint32_t k,
         for (uint32_t q = 0; q < nq; ++q) out_count[q] = 0;
         return PB_OK;
     }
-    const bool use_fast = ix->opt_path == 0 && fast_dim(d) && ix->n_rows < (1ull << 32);
     PB_CHECK(ix->n_rows < (1ull << 32), PB_ERR_CAPACITY, "more than 2^32 rows per shard are not supported");
     for (uint32_t q0 = 0; q0 < nq; q0 += Q_CHUNK) {
         const uint32_t cq = std::min(Q_CHUNK, nq - q0);
-        uint8_t *hq = ix->h_stage;
-        QParams *hp = reinterpret_cast<QParams *>(ix->h_stage + (size_t)Q_CHUNK * d);
-        uint32_t *hsel = reinterpret_cast<uint32_t *>(ix->h_stage + (size_t)Q_CHUNK * (d + sizeof(QParams)));
-        memcpy(hq, queries + (size_t)q0 * d, (size_t)cq * d);
-        for (uint32_t q = 0; q < cq; ++q) make_qparams(ix, hq + (size_t)q * d, k, max_dist, &hp[q]);
-        PB_HIP(hipMemcpyAsync(ix->d_queries, hq, (size_t)cq * d, hipMemcpyHostToDevice, ix->stream));
-        PB_HIP(hipMemcpyAsync(ix->d_qp, hp, (size_t)cq * sizeof(QParams), hipMemcpyHostToDevice, ix->stream));
-        uint32_t n_sel = 0;
-        if (use_fast) {
-            int rc = run_fast(ix, cq);
-            if (rc) return rc;
-            PB_HIP(hipMemcpyAsync(ix->h_res_hdr, ix->d_res_hdr, cq * sizeof(ResultHdr), hipMemcpyDeviceToHost, ix->stream));
-            PB_HIP(hipMemcpyAsync(ix->h_res_ids, ix->d_res_ids, (size_t)cq * PB_MAX_K * sizeof(int64_t), hipMemcpyDeviceToHost, ix->stream));
-            PB_HIP(hipMemcpyAsync(ix->h_res_dist, ix->d_res_dist, (size_t)cq * PB_MAX_K * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
-            PB_HIP(hipStreamSynchronize(ix->stream));
-            if (ix->opt_profile) {
-                int rc2 = account_profile(ix, cq);
-                if (rc2) return rc2;
-            }
-            for (uint32_t q = 0; q < cq; ++q)
-                if (ix->h_res_hdr[q].status != 0) hsel[n_sel++] = q;
-            ix->stats.fast_path += cq - n_sel;
-        } else {
-            for (uint32_t q = 0; q < cq; ++q) hsel[n_sel++] = q;
-        }
-        if (n_sel) {
-            PB_HIP(hipMemcpyAsync(ix->d_qsel, hsel, n_sel * sizeof(uint32_t), hipMemcpyHostToDevice, ix->stream));
-            int rc = run_exact(ix, n_sel, k);
-            if (rc) return rc;
-            PB_HIP(hipMemcpyAsync(ix->h_res_hdr, ix->d_res_hdr, cq * sizeof(ResultHdr), hipMemcpyDeviceToHost, ix->stream));
-            PB_HIP(hipMemcpyAsync(ix->h_res_ids, ix->d_res_ids, (size_t)cq * PB_MAX_K * sizeof(int64_t), hipMemcpyDeviceToHost, ix->stream));
-            PB_HIP(hipMemcpyAsync(ix->h_res_dist, ix->d_res_dist, (size_t)cq * PB_MAX_K * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
-            PB_HIP(hipStreamSynchronize(ix->stream));
-            if (ix->opt_profile && ix->opt_path == 1) {
-                int rc2 = account_profile(ix, n_sel);
-                if (rc2) return rc2;
-            }
-            ix->stats.fallback += n_sel;
-        }
-        ix->stats.queries += cq;
+        memcpy(ix->h_stage, queries + (size_t)q0 * d, (size_t)cq * d);
+        int rc = search_chunk(ix, cq, k, max_dist);
+        if (rc) return rc;
+        PB_HIP(hipMemcpyAsync(ix->h_res_ids, ix->d_res_ids, (size_t)cq * PB_MAX_K * sizeof(int64_t), hipMemcpyDeviceToHost, ix->stream));
+        PB_HIP(hipMemcpyAsync(ix->h_res_dist, ix->d_res_dist, (size_t)cq * PB_MAX_K * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
+        PB_HIP(hipStreamSynchronize(ix->stream));
         for (uint32_t q = 0; q < cq; ++q) {
             const uint32_t c = ix->h_res_hdr[q].count;
             out_count[q0 + q] = c;
@@ -306,6 +317,29 @@ int search_locked(pb_index *ix, const uint8_t *queries, uint32_t nq, uint32_t k,
             memcpy(out_dist + (size_t)(q0 + q) * k, ix->h_res_dist + (size_t)q * PB_MAX_K, c * sizeof(float));
         }
     }
+    return PB_OK;
+}
+
+// results packed for the all-gather, left in DEVICE memory: d_packed[q][0..k) ids, [k..2k) dist bits, [2k] count
+int search_packed_locked(pb_index *ix, const uint8_t *queries, uint32_t nq, uint32_t k, double max_dist, int64_t *d_packed) {
+    const uint32_t d = ix->dim;
+    const size_t row = 2 * (size_t)k + 1;
+    if (ix->n_rows == 0) {
+        PB_HIP(hipMemsetAsync(d_packed, 0, (size_t)nq * row * sizeof(int64_t), ix->stream));
+        PB_HIP(hipStreamSynchronize(ix->stream));
+        return PB_OK;
+    }
+    PB_CHECK(ix->n_rows < (1ull << 32), PB_ERR_CAPACITY, "more than 2^32 rows per shard are not supported");
+    for (uint32_t q0 = 0; q0 < nq; q0 += Q_CHUNK) {
+        const uint32_t cq = std::min(Q_CHUNK, nq - q0);
+        memcpy(ix->h_stage, queries + (size_t)q0 * d, (size_t)cq * d);
+        int rc = search_chunk(ix, cq, k, max_dist);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_pack_results, dim3(cq), dim3(256), 0, ix->stream, ix->d_res_ids, ix->d_res_dist, ix->d_res_hdr,
+                           (uint32_t)PB_MAX_K, k, d_packed + (size_t)q0 * row);
+        PB_HIP(hipGetLastError());
+    }
+    PB_HIP(hipStreamSynchronize(ix->stream));
     return PB_OK;
 }
 
@@ -567,6 +601,16 @@ int pb_index_search_device(pb_index *ix, const uint8_t *queries, uint32_t nq, ui
     return PB_OK;
 }
 
+int pb_index_search_packed(pb_index *ix, const uint8_t *queries, uint32_t nq, uint32_t k, double max_dist, int64_t *d_packed) {
+    PB_CHECK(ix, PB_ERR_INVALID, "pb_index_search_packed: null index");
+    PB_CHECK(k >= 1 && k <= PB_MAX_K, PB_ERR_INVALID, "pb_index_search_packed: k = %u outside 1..%u", k, PB_MAX_K);
+    PB_CHECK(nq == 0 || (queries && d_packed), PB_ERR_INVALID, "pb_index_search_packed: null buffer");
+    if (nq == 0) return PB_OK;
+    std::lock_guard<std::mutex> lock(ix->mu);
+    pb::DeviceGuard guard(ix->device);
+    return search_packed_locked(ix, queries, nq, k, max_dist, d_packed);
+}
+
 int pb_index_set_option(pb_index *ix, int option, int64_t value) {
     PB_CHECK(ix, PB_ERR_INVALID, "pb_index_set_option: null index");
     std::lock_guard<std::mutex> lock(ix->mu);
@@ -622,6 +666,44 @@ int pb_topk_merge(const int64_t *ids, const float *dist, const uint32_t *counts,
         ++n;
     }
     *out_count = n;
+    return PB_OK;
+}
+
+// merge of all-gathered packed results (HOST memory): gathered[g][q][2k+1] as written by pb_index_search_packed
+int pb_topk_merge_packed(const int64_t *gathered, uint32_t n_lists, uint32_t nq, uint32_t k, int64_t *out_ids, float *out_dist,
+                         uint32_t *out_count) {
+    PB_CHECK(nq == 0 || (gathered && out_ids && out_dist && out_count), PB_ERR_INVALID, "pb_topk_merge_packed: null buffer");
+    const size_t row = 2 * (size_t)k + 1;
+    std::vector<uint32_t> pos(n_lists);
+    for (uint32_t q = 0; q < nq; ++q) {
+        std::fill(pos.begin(), pos.end(), 0u);
+        uint32_t n = 0;
+        while (n < k) {
+            int best = -1;
+            float bd = 0.f;
+            int64_t bi = 0;
+            for (uint32_t g = 0; g < n_lists; ++g) {
+                const int64_t *p = gathered + ((size_t)g * nq + q) * row;
+                const uint32_t cnt = (uint32_t)p[2 * k];
+                if (pos[g] >= cnt || pos[g] >= k) continue;
+                const uint32_t bits = (uint32_t)p[k + pos[g]];
+                float dv;
+                memcpy(&dv, &bits, 4);
+                const int64_t iv = p[pos[g]];
+                if (best < 0 || dv < bd || (dv == bd && iv < bi)) {
+                    best = (int)g;
+                    bd = dv;
+                    bi = iv;
+                }
+            }
+            if (best < 0) break;
+            out_ids[(size_t)q * k + n] = bi;
+            out_dist[(size_t)q * k + n] = bd;
+            ++pos[best];
+            ++n;
+        }
+        out_count[q] = n;
+    }
     return PB_OK;
 }
 

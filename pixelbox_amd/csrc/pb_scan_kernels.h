@@ -705,6 +705,21 @@ __global__ __launch_bounds__(M_BLOCK) void k_merge_lists(
     }
 }
 
+// results -> the all-gather message: packed[q][0..k) = ids, [k..2k) = dist bits (zero-extended), [2k] = count
+__global__ void k_pack_results(const int64_t *__restrict__ ids, const float *__restrict__ dist,
+                               const ResultHdr *__restrict__ hdr, uint32_t res_stride, uint32_t k,
+                               int64_t *__restrict__ packed) {
+    const uint32_t q = blockIdx.x;
+    int64_t *row = packed + (size_t)q * (2 * k + 1);
+    const uint32_t c = hdr[q].count;
+    for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) {
+        const bool v = i < c;
+        row[i] = v ? ids[(size_t)q * res_stride + i] : INT64_MAX;
+        row[k + i] = v ? (int64_t)__float_as_uint(dist[(size_t)q * res_stride + i]) : (int64_t)0x7F800000u;
+    }
+    if (threadIdx.x == 0) row[2 * k] = (int64_t)c;
+}
+
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t splitmix64_at(uint64_t seed, uint64_t w) {
     uint64_t z = seed + (w + 1ull) * 0x9E3779B97F4A7C15ull;

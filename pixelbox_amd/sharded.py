@@ -2,9 +2,9 @@
 
 The scan shards naturally (rows are independent): rank r owns the contiguous row
 range [r*ceil(N/G), (r+1)*ceil(N/G)) with its slice of the image_ids; a query runs on every shard
-(`pb_index_search_device`), the per-shard top-k lists are exchanged with ONE all-gather per query batch
+(`pb_index_search_packed`), the per-shard top-k lists are exchanged with ONE all-gather per query batch
 (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo" in the CPU tests) and every rank
-runs the same G-way merge (`pb_topk_merge`, (dist, image_id) order).  The message is nq * (2k+1) * 8 B
+runs the same G-way merge (`pb_topk_merge_packed`, (dist, image_id) order).  The message is nq * (2k+1) * 8 B
 per rank (25.7 KB for 16 queries, k = 100): latency-bound, so queries are batched per collective.
 
 Reference API being replaced: Engine::query_by_image_hash_from_image (engine.rs:363-396), one table.
@@ -34,7 +34,7 @@ class ShardedIndex:
         self.device = device
         self.index = local_index if local_index is not None else capi.Index(dim, max(hi - lo, 1), device)
         self._torch = None
-        if world > 1:
+        if world > 1 or group is not None:
             import torch
 
             self._torch = torch
@@ -56,7 +56,7 @@ class ShardedIndex:
         """-> (ids [nq, k] int64, dist [nq, k] f32, count [nq]) of the GLOBAL top-k, identical on every rank."""
         queries = np.ascontiguousarray(queries, dtype=np.uint8).reshape(-1, self.dim)
         nq = queries.shape[0]
-        if self.world == 1:
+        if self.world == 1 and self.group is None:
             return self.index.search(queries, k, max_dist)
         torch = self._torch
         import torch.distributed as dist
@@ -64,35 +64,14 @@ class ShardedIndex:
         backend = dist.get_backend(self.group)
         on_gpu = backend == "nccl"
         dev = torch.device("cuda", self.device) if on_gpu else torch.device("cpu")
-        # packed per-rank message: [nq, 2k+1] int64 = ids | dist bits | count
+        # per-rank message: int64 [nq, 2k+1] = ids | dist bits | count
         packed = torch.empty((nq, 2 * k + 1), dtype=torch.int64, device=dev)
         if on_gpu and isinstance(self.index, capi.Index):
-            ids_t = torch.empty((nq, k), dtype=torch.int64, device=dev)
-            dist_t = torch.empty((nq, k), dtype=torch.float32, device=dev)
-            cnt_t = torch.empty((nq,), dtype=torch.int32, device=dev)
-            self.index.search_device(queries, k, max_dist, ids_t.data_ptr(), dist_t.data_ptr(), cnt_t.data_ptr())
-            packed[:, :k] = ids_t
-            packed[:, k : 2 * k] = dist_t.view(torch.int32).to(torch.int64)
-            packed[:, 2 * k] = cnt_t.to(torch.int64)
+            self.index.search_packed(queries, k, max_dist, packed.data_ptr())  # written on the device, synchronised
         else:
             l_ids, l_dist, l_cnt = self.index.search(queries, k, max_dist)
-            host = np.zeros((nq, 2 * k + 1), dtype=np.int64)
-            host[:, :k] = l_ids
-            host[:, k : 2 * k] = np.ascontiguousarray(l_dist, dtype=np.float32).view(np.int32).astype(np.int64)
-            host[:, 2 * k] = l_cnt
-            packed.copy_(torch.from_numpy(host))
+            packed.copy_(torch.from_numpy(capi.pack_results(l_ids[:, :k], l_dist[:, :k], l_cnt)))
         gathered = torch.empty((self.world * nq, 2 * k + 1), dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(gathered, packed, group=self.group)
         g = gathered.cpu().numpy().reshape(self.world, nq, 2 * k + 1)
-        out_ids = np.zeros((nq, k), dtype=np.int64)
-        out_dist = np.zeros((nq, k), dtype=np.float32)
-        out_cnt = np.zeros(nq, dtype=np.uint32)
-        for q in range(nq):
-            ids_q = np.ascontiguousarray(g[:, q, :k])
-            dist_q = np.ascontiguousarray(g[:, q, k : 2 * k].astype(np.int32).view(np.float32))
-            cnt_q = np.ascontiguousarray(g[:, q, 2 * k].astype(np.uint32))
-            m_ids, m_dist = capi.topk_merge(ids_q, dist_q, cnt_q, k)
-            out_cnt[q] = len(m_ids)
-            out_ids[q, : len(m_ids)] = m_ids
-            out_dist[q, : len(m_ids)] = m_dist
-        return out_ids, out_dist, out_cnt
+        return capi.topk_merge_packed(g, k)

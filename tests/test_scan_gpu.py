@@ -271,6 +271,39 @@ def test_bad_arguments_fail_loudly():
         ix.load(np.array([3, 2], dtype=np.int64), np.zeros((2, 256), dtype=np.uint8))
 
 
+def test_packed_device_results_and_merge_roundtrip():
+    import torch
+
+    rng = np.random.default_rng(50)
+    rows = rng.integers(0, 256, size=(20000, 256), dtype=np.uint8)
+    rows[7] = rows[19000]  # a tie, and a query with negative self-distance bits
+    ids = np.arange(20000, dtype=np.int64) * 2
+    q = np.stack([rows[19000], rng.integers(0, 256, size=256, dtype=np.uint8), 255 - rows[3]])
+    k = 100
+    # two shards of the same table; packed device messages; merge == oracle on the whole table
+    halves = [(rows[:10000], ids[:10000]), (rows[10000:], ids[10000:])]
+    msgs = []
+    for r, i in halves:
+        ix = make_index(r, i)
+        t = torch.zeros((len(q), 2 * k + 1), dtype=torch.int64, device="cuda")
+        ix.search_packed(q, k, 1e3, t.data_ptr())
+        torch.cuda.synchronize()
+        host = t.cpu().numpy()
+        l_ids, l_d, l_c = ix.search(q, k, 1e3)
+        assert np.array_equal(host[:, 2 * k], l_c)
+        for qi in range(len(q)):
+            c = int(l_c[qi])
+            assert np.array_equal(host[qi, :c], l_ids[qi, :c])
+            assert np.array_equal(host[qi, k : k + c].astype(np.uint32), l_d[qi, :c].view(np.uint32))
+        msgs.append(host)
+    g_ids, g_d, g_c = capi.topk_merge_packed(np.stack(msgs), k)
+    for qi in range(len(q)):
+        want_ids, want_d = oracle.scan_topk(q[qi], rows, ids, k, 1e3)
+        assert g_c[qi] == len(want_ids)
+        assert np.array_equal(g_ids[qi, : g_c[qi]], want_ids)
+        assert np.array_equal(g_d[qi, : g_c[qi]].view(np.uint32), want_d.view(np.uint32))
+
+
 # ---- synthetic generator and BASELINE-size checks -------------------------------------------------------
 def test_device_synthetic_fill_matches_the_stream():
     ix = capi.Index(256, 5000)
