@@ -34,8 +34,9 @@ struct Block {
     bool has_expand, residual;
     Gemm expand, project;
     float *dw_w = nullptr, *dw_b = nullptr;            // [k*k][e], [e]
-    float *se_w1 = nullptr, *se_b1 = nullptr;          // [sq][e], [sq]
-    float *se_w2t = nullptr, *se_b2 = nullptr;         // [sq][e], [e]
+    int sp = 0;                                        // sq rounded up to 8/16/32/48 (zero-padded rows)
+    float *se_w1 = nullptr, *se_b1 = nullptr;          // [sp][e], [sp]
+    float *se_w2t = nullptr, *se_b2 = nullptr;         // [sp][e], [e]
 };
 
 }  // namespace
@@ -48,7 +49,7 @@ struct pb_embedder {
     float *stem_w = nullptr, *stem_b = nullptr;  // [27][32], [32]
     std::vector<Block> blocks;
     Gemm head;
-    float *fc_wt = nullptr, *fc_b = nullptr;  // [1280][D], [D]
+    Gemm fc;  // Linear(1280, D) as a GEMM over the pooled features
     // workspace
     uint8_t *d_img = nullptr;
     float *buf_x[2] = {nullptr, nullptr};
@@ -155,10 +156,14 @@ int load_weights(pb_embedder *e, const uint8_t *blob, size_t len) {
                 p += (size_t)E * KK + E;
             }
             {
-                std::vector<float> w1(p, p + (size_t)S * E), b1(p + (size_t)S * E, p + (size_t)S * E + S);
+                bl.sp = S <= 8 ? 8 : (S <= 16 ? 16 : (S <= 32 ? 32 : 48));
+                PB_CHECK(S <= 48, PB_ERR_FORMAT, "squeeze width %d > 48", S);
+                std::vector<float> w1((size_t)bl.sp * E, 0.0f), b1(bl.sp, 0.0f);
+                std::copy(p, p + (size_t)S * E, w1.begin());
+                std::copy(p + (size_t)S * E, p + (size_t)S * E + S, b1.begin());
                 if ((rc = upload(e, &bl.se_w1, w1)) || (rc = upload(e, &bl.se_b1, b1))) return rc;
                 p += (size_t)S * E + S;
-                std::vector<float> w2t((size_t)S * E), b2(p + (size_t)E * S, p + (size_t)E * S + E);
+                std::vector<float> w2t((size_t)bl.sp * E, 0.0f), b2(p + (size_t)E * S, p + (size_t)E * S + E);
                 for (int c = 0; c < E; ++c)
                     for (int j = 0; j < S; ++j) w2t[(size_t)j * E + c] = p[(size_t)c * S + j];
                 if ((rc = upload(e, &bl.se_w2t, w2t)) || (rc = upload(e, &bl.se_b2, b2))) return rc;
@@ -170,13 +175,8 @@ int load_weights(pb_embedder *e, const uint8_t *blob, size_t len) {
         }
     if ((rc = make_gemm(e, &e->head, p, p + 1280 * 320, 1280, 320))) return rc;
     p += 1280 * 320 + 1280;
-    {
-        const int D = (int)e->D;
-        std::vector<float> wt((size_t)1280 * D), b(p + (size_t)D * 1280, p + (size_t)D * 1280 + D);
-        for (int dd = 0; dd < D; ++dd)
-            for (int c = 0; c < 1280; ++c) wt[(size_t)c * D + dd] = p[(size_t)dd * 1280 + c];
-        if ((rc = upload(e, &e->fc_wt, wt)) || (rc = upload(e, &e->fc_b, b))) return rc;
-    }
+    PB_CHECK(e->D % 4 == 0, PB_ERR_FORMAT, "weight blob: D = %u must be a multiple of 4", e->D);
+    if ((rc = make_gemm(e, &e->fc, p, p + (size_t)e->D * 1280, (int)e->D, 1280))) return rc;
     return PB_OK;
 }
 
@@ -218,27 +218,33 @@ int launch_gemm(pb_embedder *e, const float *act, long M, const Gemm &g, const f
 }
 
 struct DwGeom {
-    int zsplit, cqpb, px_slots, n_tiles, px_per_tile;
+    int zsplit, cqpb, slots, n_tiles, strips_per_tile;
 };
-DwGeom dw_geom(int C, int howo) {
+// strips = rows x ceil(Wo / 4) groups of 4 adjacent output pixels (k_dwconv's register tile)
+DwGeom dw_geom(int C, int ho, int wo) {
     DwGeom g;
     const int cq = C / 4;
-    g.zsplit = (cq + 255) / 256;
-    while (cq % g.zsplit) ++g.zsplit;
-    g.cqpb = cq / g.zsplit;
-    g.px_slots = std::max(1, 256 / g.cqpb);
-    g.n_tiles = std::max(1, std::min(32, (howo + g.px_slots * 8 - 1) / (g.px_slots * 8)));
-    g.px_per_tile = (howo + g.n_tiles - 1) / g.n_tiles;
-    g.n_tiles = (howo + g.px_per_tile - 1) / g.px_per_tile;
+    // channel quads per block: the largest divisor of C/4 that is <= 32 -- keeps the block's filter taps in
+    // LDS small (25 taps x 32 quads x 16 B = 12.8 KB) relative to the activations it streams
+    g.cqpb = 1;
+    for (int dv = 1; dv <= 32 && dv <= cq; ++dv)
+        if (cq % dv == 0) g.cqpb = dv;
+    g.zsplit = cq / g.cqpb;
+    g.slots = std::max(1, 256 / g.cqpb);
+    const int n_strips = ho * ((wo + 3) / 4);
+    g.n_tiles = std::max(1, std::min(32, (n_strips + g.slots * 4 - 1) / (g.slots * 4)));
+    g.strips_per_tile = (n_strips + g.n_tiles - 1) / g.n_tiles;
+    g.n_tiles = (n_strips + g.strips_per_tile - 1) / g.strips_per_tile;
     return g;
 }
 
 int launch_dw(pb_embedder *e, const Block &bl, const float *in, int B, int H, int W, float *out, int Ho, int Wo,
               const DwGeom &g) {
-    dim3 grid(g.n_tiles, B, g.zsplit), block(g.cqpb * g.px_slots);
-#define PB_DW(KS, S)                                                                                          \
-    hipLaunchKernelGGL((k_dwconv<KS, S>), grid, block, 0, e->stream, in, H, W, bl.e, bl.dw_w, bl.dw_b, out, Ho, Wo, \
-                       g.px_per_tile, e->buf_part, g.n_tiles, g.cqpb)
+    dim3 grid(g.n_tiles, B, g.zsplit), block(g.cqpb * g.slots);
+    const size_t lds = (size_t)bl.k * bl.k * g.cqpb * 16;  // filter taps of this block's channel quads
+#define PB_DW(KS, S)                                                                                            \
+    hipLaunchKernelGGL((k_dwconv<KS, S>), grid, block, lds, e->stream, in, H, W, bl.e, bl.dw_w, bl.dw_b, out, Ho, Wo, \
+                       g.strips_per_tile, e->buf_part, g.n_tiles, g.cqpb)
     if (bl.k == 3 && bl.stride == 1) PB_DW(3, 1);
     else if (bl.k == 3 && bl.stride == 2) PB_DW(3, 2);
     else if (bl.k == 5 && bl.stride == 1) PB_DW(5, 1);
@@ -269,10 +275,16 @@ int forward_device(pb_embedder *e, const uint8_t *d_rgb, int n, uint8_t *d_u8, f
             ein = e->buf_e;
         }
         const int Ho = (H + bl.stride - 1) / bl.stride, Wo = (W + bl.stride - 1) / bl.stride;
-        const DwGeom g = dw_geom(bl.e, Ho * Wo);
+        const DwGeom g = dw_geom(bl.e, Ho, Wo);
         if ((rc = launch_dw(e, bl, ein, n, H, W, e->buf_dw, Ho, Wo, g))) return rc;
-        hipLaunchKernelGGL(k_se, dim3(n), dim3(256), 0, e->stream, e->buf_part, g.n_tiles, bl.e, bl.sq, 1.0f / (float)(Ho * Wo),
-                           bl.se_w1, bl.se_b1, bl.se_w2t, bl.se_b2, e->buf_gate);
+#define PB_SE(SPV)                                                                                                 \
+    hipLaunchKernelGGL((k_se<SPV>), dim3(n), dim3(256), 0, e->stream, e->buf_part, g.n_tiles, bl.e, 1.0f / (float)(Ho * Wo), \
+                       bl.se_w1, bl.se_b1, bl.se_w2t, bl.se_b2, e->buf_gate)
+        if (bl.sp == 8) PB_SE(8);
+        else if (bl.sp == 16) PB_SE(16);
+        else if (bl.sp == 32) PB_SE(32);
+        else PB_SE(48);
+#undef PB_SE
         PB_HIP(hipGetLastError());
         const long Mo = (long)n * Ho * Wo;
         if ((rc = launch_gemm(e, e->buf_dw, Mo, bl.project, e->buf_gate, Ho * Wo, bl.residual ? x : nullptr, 0,
@@ -288,9 +300,13 @@ int forward_device(pb_embedder *e, const uint8_t *d_rgb, int n, uint8_t *d_u8, f
     hipLaunchKernelGGL(k_avgpool, dim3((1280 + 255) / 256, n), dim3(256), 0, e->stream, e->buf_e, H * W, 1280,
                        1.0f / (float)(H * W), e->buf_pool);
     PB_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_fc_tanh_quant, dim3(n), dim3(256), 0, e->stream, e->buf_pool, 1280, (int)e->D, e->fc_wt, e->fc_b,
-                       d_f32, d_u8);
-    PB_HIP(hipGetLastError());
+    if ((rc = launch_gemm(e, e->buf_pool, n, e->fc, nullptr, 1, nullptr, 0, e->buf_gate))) return rc;  // pre-tanh [n][D]
+    {
+        const long tot = (long)n * e->D;
+        hipLaunchKernelGGL(k_tanh_quant, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, e->stream, e->buf_gate, tot, d_f32,
+                           d_u8);
+        PB_HIP(hipGetLastError());
+    }
     return PB_OK;
 }
 
@@ -334,7 +350,7 @@ int pb_embed_create(pb_embedder **out, int device, const void *weights_blob, siz
             if (bl.has_expand) max_e = std::max(max_e, h * w * bl.e);
             max_dw = std::max(max_dw, ho * wo * bl.e);
             max_x = std::max(max_x, ho * wo * (size_t)bl.cout);
-            const DwGeom g = dw_geom(bl.e, (int)(ho * wo));
+            const DwGeom g = dw_geom(bl.e, (int)ho, (int)wo);
             max_part = std::max(max_part, (size_t)g.n_tiles * bl.e);
             h = ho;
             w = wo;
@@ -343,7 +359,7 @@ int pb_embed_create(pb_embedder **out, int device, const void *weights_blob, siz
         if ((rc = dalloc(e, &e->d_img, B * e->H * e->W * 3))) return rc;
         if ((rc = dalloc(e, &e->buf_x[0], B * max_x)) || (rc = dalloc(e, &e->buf_x[1], B * max_x))) return rc;
         if ((rc = dalloc(e, &e->buf_e, B * max_e)) || (rc = dalloc(e, &e->buf_dw, B * max_dw))) return rc;
-        if ((rc = dalloc(e, &e->buf_part, B * max_part)) || (rc = dalloc(e, &e->buf_gate, B * 1152))) return rc;
+        if ((rc = dalloc(e, &e->buf_part, B * max_part)) || (rc = dalloc(e, &e->buf_gate, B * std::max<size_t>(1152, e->D)))) return rc;
         if ((rc = dalloc(e, &e->buf_pool, B * 1280))) return rc;
         if ((rc = dalloc(e, &e->d_out_f32, B * e->D)) || (rc = dalloc(e, &e->d_out_u8, B * e->D))) return rc;
         return PB_OK;

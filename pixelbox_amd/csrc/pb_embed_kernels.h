@@ -15,8 +15,11 @@ namespace pbe {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+// SiLU / sigmoid: exp through ocml expf (<= 1 ulp), reciprocal through v_rcp_f32 (1 ulp) instead of the
+// ~10-instruction correctly rounded divide: ~1e-7 relative, the same scale as the f32 rounding of the
+// convolution sums feeding it (the embedding floats are compared at 1e-5, tests/embed_tol.py).
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
 
 // efficientnet.rs:39 -- 128u8.saturating_add_signed((f*128).max(-128).min(128) as i8), bit-exact
 __device__ __forceinline__ uint8_t quantize_u8(float f) {
@@ -41,8 +44,10 @@ __global__ __launch_bounds__(256) void k_stem(const uint8_t *__restrict__ img, i
                                               float *__restrict__ out) {
     __shared__ float s_w[27 * 32];
     __shared__ float s_b[32];
+    __shared__ float s_px[256];  // v as f32 / 255.0 (efficientnet.rs:27), correctly rounded, tabulated once
     for (int i = threadIdx.x; i < 27 * 32; i += blockDim.x) s_w[i] = w[i];
     if (threadIdx.x < 32) s_b[threadIdx.x] = bias[threadIdx.x];
+    s_px[threadIdx.x & 255] = (float)(threadIdx.x & 255) / 255.0f;
     __syncthreads();
     const int Ho = H / 2, Wo = W / 2;
     const long total = (long)B * Ho * Wo * 4;
@@ -67,7 +72,7 @@ __global__ __launch_bounds__(256) void k_stem(const uint8_t *__restrict__ img, i
                 const uint8_t *px = ib + ((size_t)iy * W + ix) * 3;
 #pragma unroll
                 for (int ci = 0; ci < 3; ++ci) {
-                    const float a = (float)px[ci] / 255.0f;
+                    const float a = s_px[px[ci]];
                     const float *wr = s_w + ((ky * 3 + kx) * 3 + ci) * 32 + cg * 8;
 #pragma unroll
                     for (int c = 0; c < 8; ++c) {
@@ -97,8 +102,12 @@ __global__ __launch_bounds__(256) void k_stem(const uint8_t *__restrict__ img, i
 // and the weight operand is read from LDS at that same k (the k labels only have to agree between the
 // two operands).  Weights: wt[Kpad][Npad] k-major, zero padded (Kpad % 16 == 0, Npad % 16 == 0).
 // Block = 4 waves; wave w owns MR pixel tiles of 16 rows; all waves share the weight tile in LDS.
-constexpr int G_KC = 32;  // K chunk staged in LDS per barrier pair
+constexpr int G_KC = 64;  // K chunk staged in LDS (double-buffered: one barrier per chunk)
 
+// Pipeline: (a) the weight chunk c+1 is fetched global -> registers while chunk c is computed from LDS and
+// written to the other LDS buffer afterwards (one barrier per chunk); (b) the activation operand of k-step
+// t+PD is requested before the MFMAs of k-step t (register ring), so the global-load latency of the streamed
+// operand hides behind 4*MR*NR MFMAs per step times PD steps.
 template <int MR, int NR>
 __global__ __launch_bounds__(256) void k_gemm1x1(const float *__restrict__ act, int M, int K,
                                                  const float *__restrict__ wt, int Kpad, int Npad,
@@ -108,7 +117,9 @@ __global__ __launch_bounds__(256) void k_gemm1x1(const float *__restrict__ act, 
                                                  float *__restrict__ out) {
     constexpr int NT = 16 * NR;
     constexpr int LDW = NT + 4;  // +4: rows k and k+4 land 16 banks apart (conflict-free ds_read_b32)
-    __shared__ __attribute__((aligned(16))) float s_w[G_KC * LDW];
+    constexpr int PD = MR == 4 ? 2 : 4;  // activation prefetch distance in k-steps; must divide G_KC/16 = 4 (ring slot = step % PD)
+    constexpr int WREGS = (G_KC * (NT / 4) + 255) / 256;  // float4 per thread per weight chunk
+    __shared__ __attribute__((aligned(16))) float s_w[2][G_KC * LDW];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int li = lane & 15;   // pixel within a tile (activation operand) / channel within a tile (weight operand)
@@ -133,45 +144,87 @@ __global__ __launch_bounds__(256) void k_gemm1x1(const float *__restrict__ act, 
 #pragma unroll
         for (int c = 0; c < NR; ++c) acc[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int k0 = 0; k0 < Kpad; k0 += G_KC) {
-        const int kc = (Kpad - k0) < G_KC ? (Kpad - k0) : G_KC;
-        __syncthreads();
-        // stage wt[k0 .. k0+kc)[n0 .. n0+NT) -> LDS (float4 along n)
-        for (int i = threadIdx.x; i < kc * (NT / 4); i += 256) {
-            const int kr = i / (NT / 4), c4 = i % (NT / 4);
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(wt + (size_t)(k0 + kr) * Npad + n0 + c4 * 4);
-            *reinterpret_cast<f32x4 *>(s_w + kr * LDW + c4 * 4) = v;
-        }
-        __syncthreads();
-        for (int s = 0; s < kc; s += 16) {
-            const int kbase = k0 + s + 4 * kk;  // this lane's 4 consecutive k
-            f32x4 a[MR];
+    const int n_steps = Kpad / 16;
+    const int n_chunks = (Kpad + G_KC - 1) / G_KC;
+    // activation ring: a[(t % PD)][r] holds k-step t
+    f32x4 aring[PD][MR];
+    auto load_act = [&](int t, f32x4 (&dst)[MR]) {
+        const int kbase = t * 16 + 4 * kk;
 #pragma unroll
-            for (int r = 0; r < MR; ++r) {
-                a[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (mval[r] && kbase < K) {
-                    a[r] = *reinterpret_cast<const f32x4 *>(arow[r] + kbase);
-                    if (grow[r]) {
-                        const f32x4 g = *reinterpret_cast<const f32x4 *>(grow[r] + kbase);
-                        a[r].x = a[r].x * g.x; a[r].y = a[r].y * g.y; a[r].z = a[r].z * g.z; a[r].w = a[r].w * g.w;
+        for (int r = 0; r < MR; ++r) {
+            dst[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (mval[r] && kbase < K) {
+                dst[r] = *reinterpret_cast<const f32x4 *>(arow[r] + kbase);
+                if (grow[r]) {
+                    const f32x4 g = *reinterpret_cast<const f32x4 *>(grow[r] + kbase);
+                    dst[r].x = dst[r].x * g.x; dst[r].y = dst[r].y * g.y; dst[r].z = dst[r].z * g.z; dst[r].w = dst[r].w * g.w;
+                }
+            }
+        }
+    };
+#pragma unroll
+    for (int t = 0; t < PD; ++t)
+        if (t < n_steps) load_act(t, aring[t]);
+
+    f32x4 wreg[WREGS];
+    auto load_w = [&](int chunk) {
+        const int k0 = chunk * G_KC;
+        const int kc = (Kpad - k0) < G_KC ? (Kpad - k0) : G_KC;
+#pragma unroll
+        for (int j = 0; j < WREGS; ++j) {
+            const int i = threadIdx.x + j * 256;
+            const int kr = i / (NT / 4), c4 = i % (NT / 4);
+            wreg[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (kr < kc) wreg[j] = *reinterpret_cast<const f32x4 *>(wt + (size_t)(k0 + kr) * Npad + n0 + c4 * 4);
+        }
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < WREGS; ++j) {
+            const int i = threadIdx.x + j * 256;
+            const int kr = i / (NT / 4), c4 = i % (NT / 4);
+            if (kr < G_KC) *reinterpret_cast<f32x4 *>(&s_w[buf][kr * LDW + c4 * 4]) = wreg[j];
+        }
+    };
+    load_w(0);
+    store_w(0);
+    __syncthreads();
+
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+        const int k0 = chunk * G_KC;
+        const int kc = (Kpad - k0) < G_KC ? (Kpad - k0) : G_KC;
+        if (chunk + 1 < n_chunks) load_w(chunk + 1);
+        const float *sw = s_w[chunk & 1];
+        // k-steps of this chunk; the ring slot index must be compile-time: unroll by PD
+        for (int s0 = 0; s0 < kc; s0 += 16 * PD) {
+#pragma unroll
+            for (int u = 0; u < PD; ++u) {
+                const int s = s0 + 16 * u;
+                if (s < kc) {
+                    const int t = (k0 + s) / 16;  // global k-step; t % PD == u because PD divides the 4 steps of a chunk
+                    f32x4 a[MR];
+#pragma unroll
+                    for (int r = 0; r < MR; ++r) a[r] = aring[u][r];
+                    if (t + PD < n_steps) load_act(t + PD, aring[u]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float *wrow = sw + (s + 4 * kk + e) * LDW + li;
+                        float wv[NR];
+#pragma unroll
+                        for (int c = 0; c < NR; ++c) wv[c] = wrow[c * 16];
+#pragma unroll
+                        for (int r = 0; r < MR; ++r) {
+                            const float av = e == 0 ? a[r].x : (e == 1 ? a[r].y : (e == 2 ? a[r].z : a[r].w));
+#pragma unroll
+                            for (int c = 0; c < NR; ++c)
+                                acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c], av, acc[r][c], 0, 0, 0);
+                        }
                     }
                 }
             }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float *wrow = s_w + (s + 4 * kk + e) * LDW + li;
-                float wv[NR];
-#pragma unroll
-                for (int c = 0; c < NR; ++c) wv[c] = wrow[c * 16];
-#pragma unroll
-                for (int r = 0; r < MR; ++r) {
-                    const float av = e == 0 ? a[r].x : (e == 1 ? a[r].y : (e == 2 ? a[r].z : a[r].w));
-#pragma unroll
-                    for (int c = 0; c < NR; ++c)
-                        acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c], av, acc[r][c], 0, 0, 0);
-                }
-            }
         }
+        if (chunk + 1 < n_chunks) store_w((chunk + 1) & 1);
+        __syncthreads();
     }
     // epilogue: lane holds channels n0 + 16c + 4kk .. +3 of pixel mrow[r]
 #pragma unroll
@@ -197,60 +250,86 @@ __global__ __launch_bounds__(256) void k_gemm1x1(const float *__restrict__ act, 
 // ------------------------------------------------------------------------------------------------
 // depthwise KSxKS conv, stride S, pad (KS-1)/2, + bias + SiLU, NHWC, with the squeeze-excite pooling
 // partial sums fused: part[b][tile][c] = sum of the outputs of this block's pixels (fixed order ->
-// deterministic).  Thread = (pixel slot, channel quad); block = 256 threads = PX pixel slots x CQ quads.
-// w: [KS*KS][C] tap-major.  grid = (tiles_per_image, B, zsplit); blockDim = cq_per_block * px_slots with
-// cq_per_block = (C/4) / zsplit channel quads per block (exact), px_slots = 256 / cq_per_block.
+// deterministic).  Register tiling: a thread owns a strip of TX = 4 adjacent output pixels of one row for one
+// channel quad; per filter row it loads the (TX-1)*S + KS input float4 once and reuses them across the strip
+// (5x5 s1: 40 loads per 4 outputs instead of 100), filter taps come from LDS.  Accumulation order per output is
+// (ky, kx), as in the oracle.
+// w: [KS*KS][C] tap-major.  grid = (tiles_per_image, B, zsplit); blockDim = cq_per_block * slots with
+// cq_per_block = (C/4) / zsplit channel quads per block (exact), slots = 256 / cq_per_block strips in flight.
 template <int KS, int S>
 __global__ __launch_bounds__(256) void k_dwconv(const float *__restrict__ in, int H, int W, int C,
                                                 const float *__restrict__ w, const float *__restrict__ bias,
-                                                float *__restrict__ out, int Ho, int Wo, int px_per_tile,
+                                                float *__restrict__ out, int Ho, int Wo, int strips_per_tile,
                                                 float *__restrict__ part, int n_tiles, int cq_per_block) {
     constexpr int PAD = (KS - 1) / 2;
+    constexpr int TX = 4;
+    constexpr int NX = (TX - 1) * S + KS;
     __shared__ f32x4 s_red[256];
-    const int px_slots = blockDim.x / cq_per_block;
+    extern __shared__ f32x4 s_wt[];  // [KS*KS][cq_per_block]
+    const int slots = blockDim.x / cq_per_block;
     const int cq_l = threadIdx.x % cq_per_block;
     const int slot = threadIdx.x / cq_per_block;
     const int cq = blockIdx.z * cq_per_block + cq_l;
     const int b = blockIdx.y;
     const int tile = blockIdx.x;
-    const bool cvalid = cq * 4 < C;
-    const int c0 = cvalid ? cq * 4 : 0;
-    f32x4 wreg[KS * KS];
-#pragma unroll
-    for (int t = 0; t < KS * KS; ++t) wreg[t] = *reinterpret_cast<const f32x4 *>(w + (size_t)t * C + c0);
+    const int c0 = cq * 4;
+    for (int i = threadIdx.x; i < KS * KS * cq_per_block; i += blockDim.x) {
+        const int t = i / cq_per_block, q = i % cq_per_block;
+        s_wt[i] = *reinterpret_cast<const f32x4 *>(w + (size_t)t * C + (blockIdx.z * cq_per_block + q) * 4);
+    }
+    __syncthreads();
     const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + c0);
-    const float *ib = in + (size_t)b * H * W * C;
-    float *ob = out + (size_t)b * Ho * Wo * C;
+    const float *ib = in + (size_t)b * H * W * C + c0;
+    float *ob = out + (size_t)b * Ho * Wo * C + c0;
+    const int strips_x = (Wo + TX - 1) / TX;
+    const int n_strips = Ho * strips_x;
     f32x4 psum = {0.f, 0.f, 0.f, 0.f};
-    const int p_begin = tile * px_per_tile;
-    const int p_end = (p_begin + px_per_tile) < Ho * Wo ? (p_begin + px_per_tile) : Ho * Wo;
-    for (int p = p_begin + slot; p < p_end; p += px_slots) {
-        const int y = p / Wo, x = p % Wo;
-        f32x4 acc = bv;
+    const int st_begin = tile * strips_per_tile;
+    const int st_end = (st_begin + strips_per_tile) < n_strips ? (st_begin + strips_per_tile) : n_strips;
+    for (int st = st_begin + slot; st < st_end; st += slots) {
+        const int y = st / strips_x, x0 = (st % strips_x) * TX;
+        f32x4 acc[TX];
+#pragma unroll
+        for (int t = 0; t < TX; ++t) acc[t] = bv;
 #pragma unroll
         for (int ky = 0; ky < KS; ++ky) {
             const int iy = y * S + ky - PAD;
             if (iy < 0 || iy >= H) continue;
+            const float *rowp = ib + (size_t)iy * W * C;
+            f32x4 seg[NX];
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                const int ix = x0 * S - PAD + j;
+                seg[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (ix >= 0 && ix < W) seg[j] = *reinterpret_cast<const f32x4 *>(rowp + (size_t)ix * C);
+            }
 #pragma unroll
             for (int kx = 0; kx < KS; ++kx) {
-                const int ix = x * S + kx - PAD;
-                if (ix < 0 || ix >= W) continue;
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(ib + ((size_t)iy * W + ix) * C + c0);
-                const f32x4 wv = wreg[ky * KS + kx];
-                const float p0 = v.x * wv.x, p1 = v.y * wv.y, p2 = v.z * wv.z, p3 = v.w * wv.w;
-                acc.x = acc.x + p0; acc.y = acc.y + p1; acc.z = acc.z + p2; acc.w = acc.w + p3;
+                const f32x4 wv = s_wt[(ky * KS + kx) * cq_per_block + cq_l];
+#pragma unroll
+                for (int t = 0; t < TX; ++t) {
+                    // out-of-range taps hold zeros: acc + 0*w == acc, the same value the oracle's skip gives
+                    const f32x4 v = seg[t * S + kx];
+                    const float p0 = v.x * wv.x, p1 = v.y * wv.y, p2 = v.z * wv.z, p3 = v.w * wv.w;
+                    acc[t].x = acc[t].x + p0; acc[t].y = acc[t].y + p1; acc[t].z = acc[t].z + p2; acc[t].w = acc[t].w + p3;
+                }
             }
         }
-        acc.x = silu_f(acc.x); acc.y = silu_f(acc.y); acc.z = silu_f(acc.z); acc.w = silu_f(acc.w);
-        if (cvalid) *reinterpret_cast<f32x4 *>(ob + (size_t)p * C + c0) = acc;
-        psum.x = psum.x + acc.x; psum.y = psum.y + acc.y; psum.z = psum.z + acc.z; psum.w = psum.w + acc.w;
+#pragma unroll
+        for (int t = 0; t < TX; ++t) {
+            if (x0 + t < Wo) {
+                f32x4 o = {silu_f(acc[t].x), silu_f(acc[t].y), silu_f(acc[t].z), silu_f(acc[t].w)};
+                *reinterpret_cast<f32x4 *>(ob + ((size_t)y * Wo + x0 + t) * C) = o;
+                psum.x = psum.x + o.x; psum.y = psum.y + o.y; psum.z = psum.z + o.z; psum.w = psum.w + o.w;
+            }
+        }
     }
-    // reduce the pixel slots in fixed order
+    // reduce the strip slots in fixed order
     s_red[threadIdx.x] = psum;
     __syncthreads();
-    if (slot == 0 && cvalid) {
+    if (slot == 0) {
         f32x4 t = s_red[cq_l];
-        for (int sl = 1; sl < px_slots; ++sl) {
+        for (int sl = 1; sl < slots; ++sl) {
             const f32x4 o = s_red[sl * cq_per_block + cq_l];
             t.x = t.x + o.x; t.y = t.y + o.y; t.z = t.z + o.z; t.w = t.w + o.w;
         }
@@ -261,30 +340,56 @@ __global__ __launch_bounds__(256) void k_dwconv(const float *__restrict__ in, in
 // ------------------------------------------------------------------------------------------------
 // squeeze-excite gates for one image per block: mean over pixels (sum of the tile partials in order),
 // FC(E->S)+SiLU, FC(S->E)+sigmoid.  w1: [S][E]; w2t: [S][E] (transposed se_expand); gate: [B][E].
-__global__ __launch_bounds__(256) void k_se(const float *__restrict__ part, int n_tiles, int E, int S, float inv_hw,
+// FC1 is organised so that every global load is independent (thread t owns channels t, t+256, ... and keeps
+// S partial sums in registers), then reduced across the block in a fixed order: no latency-serial chains.
+// SP = S rounded up to 8/16/32/48; w1, b1 and w2t are zero-padded to SP rows on the host, so no load is
+// conditional on a runtime value (a per-element runtime condition makes hipcc branch around every load and
+// wait for it: 48 serial L2 round trips).
+template <int SP>
+__global__ __launch_bounds__(256) void k_se(const float *__restrict__ part, int n_tiles, int E, float inv_hw,
                                             const float *__restrict__ w1, const float *__restrict__ b1,
                                             const float *__restrict__ w2t, const float *__restrict__ b2,
                                             float *__restrict__ gate) {
-    __shared__ float s_mean[1152];
-    __shared__ float s_s[64];
+    __shared__ float s_part[4][SP];
+    __shared__ float s_s[SP];
     const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float p[SP];
+#pragma unroll
+    for (int j = 0; j < SP; ++j) p[j] = 0.0f;
     for (int c = threadIdx.x; c < E; c += 256) {
         float t = 0.0f;
         for (int tl = 0; tl < n_tiles; ++tl) t = t + part[((size_t)b * n_tiles + tl) * E + c];
-        s_mean[c] = t * inv_hw;
+        const float m = t * inv_hw;
+        // issue every load of the column before the first use (hipcc otherwise pairs each load with a wait)
+        float wv[SP];
+#pragma unroll
+        for (int j = 0; j < SP; ++j) wv[j] = w1[(size_t)j * E + c];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < SP; ++j) p[j] = p[j] + m * wv[j];
+    }
+#pragma unroll
+    for (int j = 0; j < SP; ++j) {
+        float t = p[j];
+        for (int off = 32; off >= 1; off >>= 1) t = t + __shfl_xor(t, off);
+        if (lane == 0) s_part[wave][j] = t;
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int j = wave; j < S; j += 4) {
-        float t = 0.0f;
-        for (int c = lane; c < E; c += 64) t = t + s_mean[c] * w1[(size_t)j * E + c];
-        for (int off = 32; off >= 1; off >>= 1) t = t + __shfl_xor(t, off);
-        if (lane == 0) s_s[j] = silu_f(t + b1[j]);
+    if (threadIdx.x < SP) {
+        const int j = threadIdx.x;
+        const float t = ((s_part[0][j] + s_part[1][j]) + s_part[2][j]) + s_part[3][j];
+        s_s[j] = silu_f(t + b1[j]);  // padded rows: silu(0 + 0) = 0
     }
     __syncthreads();
     for (int c = threadIdx.x; c < E; c += 256) {
         float t = b2[c];
-        for (int j = 0; j < S; ++j) t = t + s_s[j] * w2t[(size_t)j * E + c];
+        float wv[SP];
+#pragma unroll
+        for (int j = 0; j < SP; ++j) wv[j] = w2t[(size_t)j * E + c];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < SP; ++j) t = t + s_s[j] * wv[j];
         gate[(size_t)b * E + c] = sigmoid_f(t);
     }
 }
@@ -300,24 +405,14 @@ __global__ void k_avgpool(const float *__restrict__ feat, int hw, int C, float i
     pooled[(size_t)b * C + c] = t * inv_hw;
 }
 
-// Linear(1280, D) + tanh + u8 quantiser.  wt: [Cin][D] (transposed).  block per image, thread per output.
-__global__ __launch_bounds__(256) void k_fc_tanh_quant(const float *__restrict__ pooled, int Cin, int D,
-                                                       const float *__restrict__ wt, const float *__restrict__ bias,
-                                                       float *__restrict__ out_f32, uint8_t *__restrict__ out_u8) {
-    __shared__ float s_x[1280];
-    const int b = blockIdx.x;
-    for (int c = threadIdx.x; c < Cin; c += blockDim.x) s_x[c] = pooled[(size_t)b * Cin + c];
-    __syncthreads();
-    for (int dd = threadIdx.x; dd < D; dd += blockDim.x) {
-        float t = bias[dd];
-        for (int c = 0; c < Cin; ++c) {
-            const float p = s_x[c] * wt[(size_t)c * D + dd];
-            t = t + p;
-        }
-        const float y = tanhf(t);
-        if (out_f32) out_f32[(size_t)b * D + dd] = y;
-        out_u8[(size_t)b * D + dd] = quantize_u8(y);
-    }
+// tanh + u8 quantiser (efficientnet.rs:39) on the Linear(1280, D) outputs (computed by k_gemm1x1, bias included)
+__global__ void k_tanh_quant(const float *__restrict__ pre, long n, float *__restrict__ out_f32,
+                             uint8_t *__restrict__ out_u8) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float y = tanhf(pre[i]);
+    if (out_f32) out_f32[i] = y;
+    out_u8[i] = quantize_u8(y);
 }
 
 }  // namespace pbe
