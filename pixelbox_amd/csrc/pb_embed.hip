@@ -3,7 +3,9 @@
 // fallback.  Weight blob: PBXW0001 (pixelbox_amd/weights.py) -- BN-folded EfficientNet-B0 features +
 // Linear(1280, D) exactly as resources/train.py:30-46,167-174 exports them.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -57,6 +59,7 @@ struct pb_embedder {
     float *d_out_f32 = nullptr;
     uint8_t *d_out_u8 = nullptr;
     int n_cu = 256;
+    std::map<std::pair<const void *, long>, std::pair<int, int>> gemm_cfg;  // (layer weights, rows) -> (MR, NR), measured
     std::mutex mu;
 };
 
@@ -180,13 +183,13 @@ int load_weights(pb_embedder *e, const uint8_t *blob, size_t len) {
     return PB_OK;
 }
 
-template <int MR>
+template <int MR, bool GATE>
 void launch_gemm_mr(int nr, dim3 grid, hipStream_t st, const float *act, int M, const Gemm &g, const float *gate, int hw,
                     const float *resid, int do_silu, float *out) {
-#define PB_G(NRV)                                                                                              \
-    case NRV:                                                                                                  \
-        hipLaunchKernelGGL((k_gemm1x1<MR, NRV>), grid, dim3(256), 0, st, act, M, g.K, g.wt, g.Kpad, g.Npad, g.bias, \
-                           g.N, gate, hw, resid, do_silu, out);                                                \
+#define PB_G(NRV)                                                                                                    \
+    case NRV:                                                                                                        \
+        hipLaunchKernelGGL((k_gemm1x1<MR, NRV, GATE>), grid, dim3(256), 0, st, act, M, g.K, g.wt, g.Kpad, g.Npad, g.bias, \
+                           g.N, gate, hw, resid, do_silu, out);                                                      \
         break;
     switch (nr) {
         PB_G(1) PB_G(2) PB_G(3) PB_G(4) PB_G(5) PB_G(6) PB_G(7) PB_G(8)
@@ -194,25 +197,66 @@ void launch_gemm_mr(int nr, dim3 grid, hipStream_t st, const float *act, int M, 
 #undef PB_G
 }
 
+// Tile choice.  NR (16-column tiles per wave) must divide Npad/16; MR in {4,2,1} (64*MR rows per block).
+// The best (MR, NR) depends on the layer shape and on the batch (memory-bound thin layers want big tiles,
+// small-M late layers want many small blocks), so it is measured: the first forward with a given row count
+// times every candidate on the real buffers (HIP events, 1 warm-up + 2 timed launches each; the outputs are
+// simply overwritten with identical values) and the winner is cached per (layer, M).
+struct GemmCfg {
+    int mr, nr;
+};
+
+void launch_gemm_cfg(pb_embedder *e, GemmCfg c, const float *act, long M, const Gemm &g, const float *gate, int hw,
+                     const float *resid, int do_silu, float *out) {
+    const int tiles = g.Npad / 16;
+    const long rows_per_block = 64L * c.mr;
+    dim3 grid((unsigned)((M + rows_per_block - 1) / rows_per_block), (unsigned)(tiles / c.nr));
+    const int nr = c.nr;
+#define PB_L(MRV)                                                                                                    \
+    (gate ? launch_gemm_mr<MRV, true>(nr, grid, e->stream, act, (int)M, g, gate, hw, resid, do_silu, out)            \
+          : launch_gemm_mr<MRV, false>(nr, grid, e->stream, act, (int)M, g, gate, hw, resid, do_silu, out))
+    if (c.mr == 4) PB_L(4);
+    else if (c.mr == 2) PB_L(2);
+    else PB_L(1);
+#undef PB_L
+}
+
 int launch_gemm(pb_embedder *e, const float *act, long M, const Gemm &g, const float *gate, int hw, const float *resid,
                 int do_silu, float *out) {
     const int tiles = g.Npad / 16;
-    int nr = 1;
-    for (int c = 8; c >= 1; --c)
-        if (tiles % c == 0) {
-            nr = c;
-            break;
+    const std::pair<const void *, long> key(g.wt, M);
+    auto it = e->gemm_cfg.find(key);
+    if (it == e->gemm_cfg.end()) {
+        GemmCfg best{1, 1};
+        float best_ms = 1e30f;
+        hipEvent_t e0, e1;
+        PB_HIP(hipEventCreate(&e0));
+        PB_HIP(hipEventCreate(&e1));
+        for (int nr = 8; nr >= 1; --nr) {
+            if (tiles % nr) continue;
+            for (int mr : {4, 2, 1}) {
+                if (mr > 1 && M <= 64L * (mr / 2)) continue;  // tile taller than the problem
+                const GemmCfg c{mr, nr};
+                launch_gemm_cfg(e, c, act, M, g, gate, hw, resid, do_silu, out);
+                PB_HIP(hipEventRecord(e0, e->stream));
+                launch_gemm_cfg(e, c, act, M, g, gate, hw, resid, do_silu, out);
+                launch_gemm_cfg(e, c, act, M, g, gate, hw, resid, do_silu, out);
+                PB_HIP(hipEventRecord(e1, e->stream));
+                PB_HIP(hipEventSynchronize(e1));
+                PB_HIP(hipGetLastError());
+                float ms = 0.f;
+                PB_HIP(hipEventElapsedTime(&ms, e0, e1));
+                if (ms < best_ms) {
+                    best_ms = ms;
+                    best = c;
+                }
+            }
         }
-    // MR = 4 (256 rows per block) when that still fills the chip twice over, else MR = 2, else 1
-    const long n_tiles_n = tiles / nr;
-    int mr = 4;
-    if ((M + 255) / 256 * n_tiles_n < 2L * e->n_cu) mr = 2;
-    if ((M + 127) / 128 * n_tiles_n < 2L * e->n_cu) mr = 1;
-    const long rows_per_block = 64L * mr;
-    dim3 grid((unsigned)((M + rows_per_block - 1) / rows_per_block), (unsigned)n_tiles_n);
-    if (mr == 4) launch_gemm_mr<4>(nr, grid, e->stream, act, (int)M, g, gate, hw, resid, do_silu, out);
-    else if (mr == 2) launch_gemm_mr<2>(nr, grid, e->stream, act, (int)M, g, gate, hw, resid, do_silu, out);
-    else launch_gemm_mr<1>(nr, grid, e->stream, act, (int)M, g, gate, hw, resid, do_silu, out);
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        it = e->gemm_cfg.emplace(key, std::make_pair(best.mr, best.nr)).first;
+    }
+    launch_gemm_cfg(e, GemmCfg{it->second.first, it->second.second}, act, M, g, gate, hw, resid, do_silu, out);
     PB_HIP(hipGetLastError());
     return PB_OK;
 }
@@ -221,7 +265,7 @@ struct DwGeom {
     int zsplit, cqpb, slots, n_tiles, strips_per_tile;
 };
 // strips = rows x ceil(Wo / 4) groups of 4 adjacent output pixels (k_dwconv's register tile)
-DwGeom dw_geom(int C, int ho, int wo) {
+DwGeom dw_geom(int C, int ho, int wo, int batch, int n_cu) {
     DwGeom g;
     const int cq = C / 4;
     // channel quads per block: the largest divisor of C/4 that is <= 32 -- keeps the block's filter taps in
@@ -232,7 +276,10 @@ DwGeom dw_geom(int C, int ho, int wo) {
     g.zsplit = cq / g.cqpb;
     g.slots = std::max(1, 256 / g.cqpb);
     const int n_strips = ho * ((wo + 3) / 4);
-    g.n_tiles = std::max(1, std::min(32, (n_strips + g.slots * 4 - 1) / (g.slots * 4)));
+    // as few tiles per image as still gives ~4 blocks per CU: every block pays a filter load + two barriers
+    const long want = (4L * n_cu + (long)batch * g.zsplit - 1) / ((long)batch * g.zsplit);
+    const int cap = std::max(1, n_strips / (g.slots * 2));  // keep >= 2 strips per slot
+    g.n_tiles = (int)std::max<long>(1, std::min<long>(std::min(32, cap), want));
     g.strips_per_tile = (n_strips + g.n_tiles - 1) / g.n_tiles;
     g.n_tiles = (n_strips + g.strips_per_tile - 1) / g.strips_per_tile;
     return g;
@@ -275,7 +322,7 @@ int forward_device(pb_embedder *e, const uint8_t *d_rgb, int n, uint8_t *d_u8, f
             ein = e->buf_e;
         }
         const int Ho = (H + bl.stride - 1) / bl.stride, Wo = (W + bl.stride - 1) / bl.stride;
-        const DwGeom g = dw_geom(bl.e, Ho, Wo);
+        const DwGeom g = dw_geom(bl.e, Ho, Wo, n, e->n_cu);
         if ((rc = launch_dw(e, bl, ein, n, H, W, e->buf_dw, Ho, Wo, g))) return rc;
 #define PB_SE(SPV)                                                                                                 \
     hipLaunchKernelGGL((k_se<SPV>), dim3(n), dim3(256), 0, e->stream, e->buf_part, g.n_tiles, bl.e, 1.0f / (float)(Ho * Wo), \
@@ -350,7 +397,7 @@ int pb_embed_create(pb_embedder **out, int device, const void *weights_blob, siz
             if (bl.has_expand) max_e = std::max(max_e, h * w * bl.e);
             max_dw = std::max(max_dw, ho * wo * bl.e);
             max_x = std::max(max_x, ho * wo * (size_t)bl.cout);
-            const DwGeom g = dw_geom(bl.e, (int)ho, (int)wo);
+            const DwGeom g = dw_geom(bl.e, (int)ho, (int)wo, 1, e->n_cu);  // batch 1 gives the most tiles
             max_part = std::max(max_part, (size_t)g.n_tiles * bl.e);
             h = ho;
             w = wo;

@@ -15,10 +15,14 @@ namespace pbe {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// SiLU / sigmoid: exp through ocml expf (<= 1 ulp), reciprocal through v_rcp_f32 (1 ulp) instead of the
-// ~10-instruction correctly rounded divide: ~1e-7 relative, the same scale as the f32 rounding of the
-// convolution sums feeding it (the embedding floats are compared at 1e-5, tests/embed_tol.py).
-__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + expf(-x)); }
+// SiLU / sigmoid in 5 VALU instructions: e^-x = v_exp_f32(x * -log2 e) (1 ulp on the exponential, plus
+// |x| * 7e-8 relative from the rounded argument), reciprocal through v_rcp_f32 (1 ulp).  Absolute error on
+// SiLU ~1e-7 * |x|, the same scale as the f32 rounding of the convolution sum feeding it; ocml expf plus a
+// correctly rounded divide costs ~25 instructions per element and made the epilogues VALU-bound.  The
+// embedding floats are compared at 1e-5 (tests/embed_tol.py).
+__device__ __forceinline__ float sigmoid_f(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+}
 __device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
 
 // efficientnet.rs:39 -- 128u8.saturating_add_signed((f*128).max(-128).min(128) as i8), bit-exact
@@ -108,7 +112,7 @@ constexpr int G_KC = 64;  // K chunk staged in LDS (double-buffered: one barrier
 // written to the other LDS buffer afterwards (one barrier per chunk); (b) the activation operand of k-step
 // t+PD is requested before the MFMAs of k-step t (register ring), so the global-load latency of the streamed
 // operand hides behind 4*MR*NR MFMAs per step times PD steps.
-template <int MR, int NR>
+template <int MR, int NR, bool GATE>
 __global__ __launch_bounds__(256) void k_gemm1x1(const float *__restrict__ act, int M, int K,
                                                  const float *__restrict__ wt, int Kpad, int Npad,
                                                  const float *__restrict__ bias, int N,
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(256) void k_gemm1x1(const float *__restrict__ act, 
         mval[r] = mrow[r] < M;
         const long mc = mval[r] ? mrow[r] : 0;
         arow[r] = act + mc * K;
-        grow[r] = gate ? gate + (mc / hw) * K : nullptr;
+        grow[r] = GATE ? gate + (mc / hw) * K : nullptr;
     }
     f32x4 acc[MR][NR];
 #pragma unroll
@@ -146,36 +150,34 @@ __global__ __launch_bounds__(256) void k_gemm1x1(const float *__restrict__ act, 
 
     const int n_steps = Kpad / 16;
     const int n_chunks = (Kpad + G_KC - 1) / G_KC;
-    // activation ring: a[(t % PD)][r] holds k-step t
+    // operand ring: slot (t % PD) holds k-step t; the SE gate travels beside it and is multiplied in only at
+    // the point of use (a multiply right after the load would make the prefetch wait for its own data)
     f32x4 aring[PD][MR];
-    auto load_act = [&](int t, f32x4 (&dst)[MR]) {
+    f32x4 gring[GATE ? PD : 1][GATE ? MR : 1];
+    auto load_act = [&](int t, int slot) {
         const int kbase = t * 16 + 4 * kk;
 #pragma unroll
         for (int r = 0; r < MR; ++r) {
-            dst[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (mval[r] && kbase < K) {
-                dst[r] = *reinterpret_cast<const f32x4 *>(arow[r] + kbase);
-                if (grow[r]) {
-                    const f32x4 g = *reinterpret_cast<const f32x4 *>(grow[r] + kbase);
-                    dst[r].x = dst[r].x * g.x; dst[r].y = dst[r].y * g.y; dst[r].z = dst[r].z * g.z; dst[r].w = dst[r].w * g.w;
-                }
-            }
+            // rows >= M and k >= K read a valid dummy address and are zeroed at use (no branch around the load)
+            const bool ok = mval[r] && kbase < K;
+            const int kb = ok ? kbase : 0;
+            aring[slot][r] = *reinterpret_cast<const f32x4 *>(arow[r] + kb);
+            if constexpr (GATE) gring[slot][r] = *reinterpret_cast<const f32x4 *>(grow[r] + kb);
         }
     };
 #pragma unroll
     for (int t = 0; t < PD; ++t)
-        if (t < n_steps) load_act(t, aring[t]);
+        if (t < n_steps) load_act(t, t);
 
     f32x4 wreg[WREGS];
     auto load_w = [&](int chunk) {
         const int k0 = chunk * G_KC;
-        const int kc = (Kpad - k0) < G_KC ? (Kpad - k0) : G_KC;
 #pragma unroll
         for (int j = 0; j < WREGS; ++j) {
             const int i = threadIdx.x + j * 256;
             const int kr = i / (NT / 4), c4 = i % (NT / 4);
-            wreg[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (kr < kc) wreg[j] = *reinterpret_cast<const f32x4 *>(wt + (size_t)(k0 + kr) * Npad + n0 + c4 * 4);
+            const int krc = (k0 + kr) < Kpad ? (k0 + kr) : (Kpad - 1);  // clamp: rows beyond Kpad are never used
+            wreg[j] = *reinterpret_cast<const f32x4 *>(wt + (size_t)krc * Npad + n0 + c4 * 4);
         }
     };
     auto store_w = [&](int buf) {
@@ -194,32 +196,46 @@ __global__ __launch_bounds__(256) void k_gemm1x1(const float *__restrict__ act, 
         const int k0 = chunk * G_KC;
         const int kc = (Kpad - k0) < G_KC ? (Kpad - k0) : G_KC;
         if (chunk + 1 < n_chunks) load_w(chunk + 1);
-        const float *sw = s_w[chunk & 1];
-        // k-steps of this chunk; the ring slot index must be compile-time: unroll by PD
+        const float *sw = s_w[chunk & 1] + li;
         for (int s0 = 0; s0 < kc; s0 += 16 * PD) {
 #pragma unroll
             for (int u = 0; u < PD; ++u) {
                 const int s = s0 + 16 * u;
                 if (s < kc) {
                     const int t = (k0 + s) / 16;  // global k-step; t % PD == u because PD divides the 4 steps of a chunk
+                    const int kbase = t * 16 + 4 * kk;
                     f32x4 a[MR];
 #pragma unroll
-                    for (int r = 0; r < MR; ++r) a[r] = aring[u][r];
-                    if (t + PD < n_steps) load_act(t + PD, aring[u]);
+                    for (int r = 0; r < MR; ++r) {
+                        a[r] = aring[u][r];
+                        if constexpr (GATE) {
+                            const f32x4 g = gring[u][r];
+                            a[r].x = a[r].x * g.x; a[r].y = a[r].y * g.y; a[r].z = a[r].z * g.z; a[r].w = a[r].w * g.w;
+                        }
+                        if (!(mval[r] && kbase < K)) a[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    }
+                    if (t + PD < n_steps) load_act(t + PD, u);
+                    // weight fragments of the whole k-step: all 4*NR LDS reads are issued before the first MFMA
+                    // (sched_barrier keeps hipcc from sinking each read next to its use, which exposes the LDS
+                    // latency between every pair of MFMAs)
+                    float wv[4][NR];
+                    const float *wbase = sw + (s + 4 * kk) * LDW;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int c = 0; c < NR; ++c) wv[e][c] = wbase[e * LDW + c * 16];
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float *wrow = sw + (s + 4 * kk + e) * LDW + li;
-                        float wv[NR];
-#pragma unroll
-                        for (int c = 0; c < NR; ++c) wv[c] = wrow[c * 16];
 #pragma unroll
                         for (int r = 0; r < MR; ++r) {
                             const float av = e == 0 ? a[r].x : (e == 1 ? a[r].y : (e == 2 ? a[r].z : a[r].w));
 #pragma unroll
                             for (int c = 0; c < NR; ++c)
-                                acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c], av, acc[r][c], 0, 0, 0);
+                                acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[e][c], av, acc[r][c], 0, 0, 0);
                         }
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
