@@ -23,7 +23,9 @@ def main():
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(path)):
             if r["Counter_Name"] == name:
-                agg[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+                # launches of different shapes (e.g. 64-query steps vs single-query latency probes) are kept apart
+                key = r["Kernel_Name"].split("(")[0].replace("void ", "") + " grid=" + r["Grid_Size"]
+                agg[key].append(float(r["Counter_Value"]))
         for k, v in agg.items():
             res[k][name + "_KiB_avg_per_launch"] = sum(v) / len(v)
             res[k][name + "_launches"] = len(v)
