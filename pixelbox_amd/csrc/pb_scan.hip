@@ -70,6 +70,11 @@ struct pb_index {
 
     int opt_path = 0;
     int opt_profile = 0;
+    int opt_variant = 0;    // tuning knob (dim 256 only): bit 0 = plain (temporal) loads, bits 1-2 = U in {8,16,4}, bit 3 = wave-fastest tiles
+    int opt_wg_per_cu = 1;  // filter-pass workgroups per CU
+    int opt_waves = F_WAVES;  // filter-pass waves per workgroup (dim 256: 16, 8, 4)
+    int opt_mode = 0;       // 0 = one filter launch per query (independent HBM passes), 1 = one launch for the whole chunk
+    int opt_grid = 0;       // explicit filter-pass grid size (0: wg_per_cu * CUs)
     pb_scan_stats stats{};
     mutable std::mutex mu;
 };
@@ -174,36 +179,81 @@ void make_qparams(const pb_index *ix, const uint8_t *q, uint32_t k, double max_d
     *out = P;
 }
 
-template <int LPR>
-void launch_filter(pb_index *ix, int n_wg, uint32_t nq) {
-    hipLaunchKernelGGL(k_scan_filter<LPR>, dim3(n_wg, nq), dim3(F_BLOCK), 0, ix->stream, ix->d_rows, ix->n_rows,
-                       ix->d_queries, ix->d_qp, ix->d_lists, ix->d_hdrs);
+// Filter pass launch.  Default (mode 0): ONE launch per query, one workgroup per CU -- each query is its own pass
+// over HBM (queries that run concurrently would share row reads through L2 / Infinity Cache and the measured
+// bandwidth would no longer be an HBM number).  The tuning knobs (options 4-7) exist for profiles/scan_sweep.py.
+template <int LPR, int U, bool NT, int NW, int MAPB>
+void launch_filter_t(pb_index *ix, int n_wg, uint32_t q_base, uint32_t nq) {
+    hipLaunchKernelGGL((k_scan_filter<LPR, U, NT, NW, MAPB>), dim3(n_wg, nq), dim3(NW * 64), 0, ix->stream, ix->d_rows,
+                       ix->n_rows, ix->d_queries, ix->d_qp, ix->d_lists, ix->d_hdrs, (int)q_base);
+}
+
+int filter_u(const pb_index *ix) {
+    if (ix->dim != 256) return 8;
+    const int sel = (ix->opt_variant >> 1) & 3;
+    return sel == 1 ? 16 : (sel == 2 ? 4 : 8);
 }
 
 int filter_grid(const pb_index *ix) {
     const uint32_t lpr = ix->dim / 16;
-    const uint64_t rows_it = 8ull * (64 / lpr);
+    const uint64_t rows_it = (uint64_t)filter_u(ix) * (64 / lpr);
     const uint64_t n_super = (ix->n_rows + rows_it - 1) / rows_it;
-    const uint64_t want = (n_super + F_WAVES - 1) / F_WAVES;
-    const uint64_t cap = std::min<uint64_t>(F_MAX_WG, (uint64_t)ix->n_cu * 2);
+    const uint64_t nw = ix->dim == 256 ? (uint64_t)ix->opt_waves : (uint64_t)F_WAVES;
+    const uint64_t want = (n_super + nw - 1) / nw;
+    uint64_t cap = std::min<uint64_t>(F_MAX_WG, (uint64_t)ix->n_cu * ix->opt_wg_per_cu);
+    if (ix->opt_grid > 0) cap = std::min<uint64_t>(F_MAX_WG, (uint64_t)ix->opt_grid);
     return (int)std::max<uint64_t>(1, std::min<uint64_t>(want, cap));
+}
+
+int launch_filter(pb_index *ix, int n_wg, uint32_t q_base, uint32_t nq) {
+    switch (ix->dim / 16) {
+        case 1: launch_filter_t<1, 8, true, F_WAVES, 0>(ix, n_wg, q_base, nq); break;
+        case 2: launch_filter_t<2, 8, true, F_WAVES, 0>(ix, n_wg, q_base, nq); break;
+        case 4: launch_filter_t<4, 8, true, F_WAVES, 0>(ix, n_wg, q_base, nq); break;
+        case 8: launch_filter_t<8, 8, true, F_WAVES, 0>(ix, n_wg, q_base, nq); break;
+        case 32: launch_filter_t<32, 8, true, F_WAVES, 0>(ix, n_wg, q_base, nq); break;
+        case 64: launch_filter_t<64, 8, true, F_WAVES, 0>(ix, n_wg, q_base, nq); break;
+        case 16: {
+            const bool nt = !(ix->opt_variant & 1);  // bit 0 set = plain (temporal) loads
+            const int u = filter_u(ix);
+            const bool mapb = ix->opt_variant & 8;
+#define PB_F(UV, NTV, NWV)                                                     \
+    do {                                                                       \
+        if (mapb) launch_filter_t<16, UV, NTV, NWV, 1>(ix, n_wg, q_base, nq);  \
+        else launch_filter_t<16, UV, NTV, NWV, 0>(ix, n_wg, q_base, nq);       \
+    } while (0)
+#define PB_FU(NTV, NWV)                            \
+    do {                                           \
+        if (u == 16) PB_F(16, NTV, NWV);           \
+        else if (u == 4) PB_F(4, NTV, NWV);        \
+        else PB_F(8, NTV, NWV);                    \
+    } while (0)
+            if (ix->opt_waves == 16) { if (nt) PB_FU(true, 16); else PB_FU(false, 16); }
+            else if (ix->opt_waves == 4) { if (nt) PB_FU(true, 4); else PB_FU(false, 4); }
+            else { if (nt) PB_FU(true, 8); else PB_FU(false, 8); }
+#undef PB_FU
+#undef PB_F
+            break;
+        }
+        default: return pb::fail(PB_ERR_INTERNAL, "filter pass: unsupported dim %u", ix->dim);
+    }
+    PB_HIP(hipGetLastError());
+    return PB_OK;
 }
 
 // fast path for nq staged queries; results + status land in d_res_*
 int run_fast(pb_index *ix, uint32_t nq) {
     const int n_wg = filter_grid(ix);
     if (ix->opt_profile) PB_HIP(hipEventRecord(ix->ev0, ix->stream));
-    switch (ix->dim / 16) {
-        case 1: launch_filter<1>(ix, n_wg, nq); break;
-        case 2: launch_filter<2>(ix, n_wg, nq); break;
-        case 4: launch_filter<4>(ix, n_wg, nq); break;
-        case 8: launch_filter<8>(ix, n_wg, nq); break;
-        case 16: launch_filter<16>(ix, n_wg, nq); break;
-        case 32: launch_filter<32>(ix, n_wg, nq); break;
-        case 64: launch_filter<64>(ix, n_wg, nq); break;
-        default: return pb::fail(PB_ERR_INTERNAL, "filter pass: unsupported dim %u", ix->dim);
+    if (ix->opt_mode == 0) {
+        for (uint32_t q = 0; q < nq; ++q) {
+            int rc = launch_filter(ix, n_wg, q, 1);
+            if (rc) return rc;
+        }
+    } else {
+        int rc = launch_filter(ix, n_wg, 0, nq);
+        if (rc) return rc;
     }
-    PB_HIP(hipGetLastError());
     if (ix->opt_profile) PB_HIP(hipEventRecord(ix->ev1, ix->stream));
     hipLaunchKernelGGL(k_select_rescore, dim3(nq), dim3(SEL_BLOCK), 0, ix->stream, ix->d_rows, ix->d_ids, ix->d_norms,
                        (int)ix->dim, ix->d_queries, ix->d_qp, ix->d_lut, ix->d_lists, ix->d_hdrs, n_wg, ix->d_res_ids,
@@ -239,10 +289,10 @@ int run_exact(pb_index *ix, uint32_t n_sel, uint32_t k) {
     return PB_OK;
 }
 
-int account_profile(pb_index *ix, uint32_t n_queries) {
+int account_profile(pb_index *ix, uint32_t n_queries, uint32_t n_launches) {
     float ms = 0.0f;
     PB_HIP(hipEventElapsedTime(&ms, ix->ev0, ix->ev1));
-    ix->stats.profiled_launches += 1;
+    ix->stats.profiled_launches += n_launches;
     ix->stats.profiled_ms += ms;
     ix->stats.profiled_bytes += (uint64_t)n_queries * ix->n_rows * ix->dim;
     return PB_OK;
@@ -268,7 +318,7 @@ int search_chunk(pb_index *ix, uint32_t cq, uint32_t k, double max_dist) {
         PB_HIP(hipMemcpyAsync(ix->h_res_hdr, ix->d_res_hdr, cq * sizeof(ResultHdr), hipMemcpyDeviceToHost, ix->stream));
         PB_HIP(hipStreamSynchronize(ix->stream));
         if (ix->opt_profile) {
-            int rc2 = account_profile(ix, cq);
+            int rc2 = account_profile(ix, cq, ix->opt_mode == 0 ? cq : 1);
             if (rc2) return rc2;
         }
         for (uint32_t q = 0; q < cq; ++q)
@@ -284,7 +334,7 @@ int search_chunk(pb_index *ix, uint32_t cq, uint32_t k, double max_dist) {
         PB_HIP(hipMemcpyAsync(ix->h_res_hdr, ix->d_res_hdr, cq * sizeof(ResultHdr), hipMemcpyDeviceToHost, ix->stream));
         PB_HIP(hipStreamSynchronize(ix->stream));
         if (ix->opt_profile && ix->opt_path == 1) {
-            int rc2 = account_profile(ix, n_sel);
+            int rc2 = account_profile(ix, n_sel, 1);
             if (rc2) return rc2;
         }
         ix->stats.fallback += n_sel;
@@ -624,6 +674,24 @@ int pb_index_set_option(pb_index *ix, int option, int64_t value) {
             return PB_OK;
         case PB_OPT_STREAM:
             ix->stream = value ? reinterpret_cast<hipStream_t>(value) : ix->own_stream;
+            return PB_OK;
+        case 4:  // PB_OPT_SCAN_VARIANT (experiments)
+            ix->opt_variant = (int)value;
+            return PB_OK;
+        case 5:  // PB_OPT_SCAN_WG_PER_CU (experiments)
+            PB_CHECK(value >= 1 && value <= 8, PB_ERR_INVALID, "workgroups per CU: 1..8");
+            ix->opt_wg_per_cu = (int)value;
+            return PB_OK;
+        case 8:  // launch mode
+            PB_CHECK(value == 0 || value == 1, PB_ERR_INVALID, "scan mode: 0 or 1");
+            ix->opt_mode = (int)value;
+            return PB_OK;
+        case 7:  // explicit grid (experiments)
+            ix->opt_grid = (int)value;
+            return PB_OK;
+        case 6:  // PB_OPT_SCAN_WAVES (experiments)
+            PB_CHECK(value == 16 || value == 8 || value == 4, PB_ERR_INVALID, "waves per workgroup: 16, 8 or 4");
+            ix->opt_waves = (int)value;
             return PB_OK;
         default:
             return pb::fail(PB_ERR_INVALID, "pb_index_set_option: unknown option %d", option);

@@ -22,8 +22,8 @@ namespace pbk {
 
 constexpr int WAVE = 64;
 // ---- filter pass geometry ----
-constexpr int F_BLOCK = 1024;            // 16 waves: one workgroup per CU, 2 resident
-constexpr int F_WAVES = F_BLOCK / WAVE;  // 16
+constexpr int F_WAVES = 8;               // default: 8 waves per workgroup, ONE workgroup per CU (measured best)
+constexpr int F_BLOCK = F_WAVES * WAVE;
 constexpr int F_KW = 32;                 // entries a wave keeps after a prune
 constexpr int F_CAPW = 128;              // per-wave LDS buffer (entries); prune when > CAPW - 64
 constexpr int F_KWG = 32;                // entries per workgroup list
@@ -256,22 +256,22 @@ __global__ void k_row_norms(const uint8_t *__restrict__ rows, uint64_t first, ui
 
 // ------------------------------------------------------------------------------------------------
 // (1) HBM-bound filter pass.  LPR lanes share one row (16 B each); one wave-instruction = 64/LPR rows.
-template <int LPR>
-__global__ __launch_bounds__(F_BLOCK) void k_scan_filter(const uint8_t *__restrict__ rows, uint64_t n_rows,
+template <int LPR, int U = 8, bool NT = true, int NW = F_WAVES, int MAPB = 0>
+__global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__restrict__ rows, uint64_t n_rows,
                                                          const uint8_t *__restrict__ queries,
                                                          const QParams *__restrict__ qp,
                                                          uint64_t *__restrict__ lists,
-                                                         ListHdr *__restrict__ hdrs) {
+                                                         ListHdr *__restrict__ hdrs, int q_base) {
     constexpr int D = LPR * 16;
     constexpr int RPT = WAVE / LPR;                // rows per wave-instruction
-    constexpr int U = 8;                           // loads in flight per lane (8 KiB per wave)
+    // U = loads in flight per lane (U KiB per wave); NT = non-temporal loads (the table is streamed once per query)
     constexpr int ROWS_IT = U * RPT;               // rows per wave-iteration
     constexpr int ROUNDS = (U + LPR - 1) / LPR;    // evaluation rounds (one row per lane each)
-    __shared__ uint64_t s_buf[F_WAVES][F_CAPW];
-    __shared__ int s_cnt[F_WAVES];
-    __shared__ float s_drop[F_WAVES];
+    __shared__ uint64_t s_buf[NW][F_CAPW];
+    __shared__ int s_cnt[NW];
+    __shared__ float s_drop[NW];
 
-    const int q = blockIdx.y;
+    const int q = q_base + blockIdx.y;
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
     const int sub = lane % LPR;
@@ -287,15 +287,23 @@ __global__ __launch_bounds__(F_BLOCK) void k_scan_filter(const uint8_t *__restri
     const int k_den = 65025 * D;
 
     const uint64_t n_super = (n_rows + ROWS_IT - 1) / ROWS_IT;
-    const uint64_t stride = (uint64_t)gridDim.x * F_WAVES;
-    for (uint64_t s = (uint64_t)wave * gridDim.x + blockIdx.x; s < n_super; s += stride) {
+    const uint64_t stride = (uint64_t)gridDim.x * NW;
+    // super-tile -> wave mapping: MAPB = 0: workgroup fastest (adjacent 8-KiB pieces on different CUs),
+    // 1: wave fastest (a workgroup reads NW adjacent pieces)
+    const uint64_t first = MAPB ? (uint64_t)blockIdx.x * NW + wave : (uint64_t)wave * gridDim.x + blockIdx.x;
+    for (uint64_t s = first; s < n_super; s += stride) {
         const uint64_t row0 = s * ROWS_IT;
         uint4 b[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             uint64_t r = row0 + (uint64_t)(u * RPT + g);
             r = r < n_rows ? r : n_rows - 1;
-            b[u] = *reinterpret_cast<const uint4 *>(rows + r * D + sub * 16);
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 *src = reinterpret_cast<const u32x4 *>(rows + r * D + sub * 16);
+            u32x4 t;
+            if constexpr (NT) t = __builtin_nontemporal_load(src);
+            else t = *src;
+            b[u] = make_uint4(t.x, t.y, t.z, t.w);
         }
         int sp[ROUNDS], ss[ROUNDS], sq[ROUNDS];
 #pragma unroll
@@ -347,11 +355,11 @@ __global__ __launch_bounds__(F_BLOCK) void k_scan_filter(const uint8_t *__restri
     __syncthreads();
     if (wave != 0) return;
     // workgroup list: the F_KWG best of the <= 16*32 entries, sorted, by wave 0
-    constexpr int ME = F_WAVES * F_KW / WAVE;  // 8 entries per lane
-    __shared__ uint64_t s_merge[F_WAVES * F_KW];
+    constexpr int ME = NW * F_KW / WAVE;  // entries per lane
+    __shared__ uint64_t s_merge[NW * F_KW];
     int total = 0;
     float drop = 0.0f;
-    for (int w = 0; w < F_WAVES; ++w) {
+    for (int w = 0; w < NW; ++w) {
         const int c = s_cnt[w];
         if (lane < c) s_merge[total + lane] = s_buf[w][lane];
         total += c;
