@@ -118,9 +118,12 @@ int pb_index_fill_synthetic(pb_index *idx, uint64_t seed, uint64_t first_row, ui
                             int64_t first_id);
 
 /* Options (pb_index_set_option) */
-#define PB_OPT_SEARCH_PATH 1 /* 0 = auto (int-dot filter + exact rescoring, exhaustive fallback), 1 = exhaustive exact scan only */
+#define PB_OPT_SEARCH_PATH 1 /* 0 = auto; 1 = exhaustive exact scan only; 2 = one filter pass per query (never the shared pass); \
+                                3 = always the concurrent-query pass (dim 256).  auto: calls with >= PB_OPT_MQ_MIN_QUERIES (default 8) \
+                                queries share ONE pass over the table (i8 MFMA), fewer get one HBM pass each */
 #define PB_OPT_PROFILE 2     /* 1 = bracket the scan kernel with HIP events (pb_index_get_stats) */
 #define PB_OPT_STREAM 3      /* value = hipStream_t to launch on (0 = the index's own stream) */
+#define PB_OPT_MQ_MIN_QUERIES 9 /* auto path: minimum queries per call for the concurrent-query pass */
 int pb_index_set_option(pb_index *idx, int option, int64_t value);
 
 typedef struct pb_scan_stats {

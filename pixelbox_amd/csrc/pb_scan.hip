@@ -42,6 +42,8 @@ struct pb_index {
     uint8_t *d_rows = nullptr;
     int64_t *d_ids = nullptr;
     float *d_norms = nullptr;
+    int32_t *d_sumb = nullptr;  // per-row integer sum of bytes, sum (2b-255)^2: side tables of the multi-query pass
+    int32_t *d_denb = nullptr;
     float *d_lut = nullptr;
     std::vector<int64_t> h_ids;  // ascending, mirrors d_ids
     float lut[256];
@@ -59,6 +61,10 @@ struct pb_index {
     uint64_t *d_xlists[2] = {nullptr, nullptr};  // exact pass ping-pong: Q_CHUNK * X_MAX_WG * PB_MAX_K
     uint32_t *d_xcounts[2] = {nullptr, nullptr};
     uint32_t *d_qsel = nullptr;     // Q_CHUNK
+    float *d_tau = nullptr;         // multi-query pass: per-query candidate threshold
+    uint64_t *d_cand = nullptr;     // Q_CHUNK * MQ_CAP
+    uint32_t *d_cand_cnt = nullptr; // Q_CHUNK
+    uint32_t *d_ghist = nullptr;    // Q_CHUNK * MQ_BINS
     int64_t *d_res_ids = nullptr;   // Q_CHUNK * PB_MAX_K
     float *d_res_dist = nullptr;
     ResultHdr *d_res_hdr = nullptr;
@@ -74,6 +80,9 @@ struct pb_index {
     int opt_wg_per_cu = 1;  // filter-pass workgroups per CU
     int opt_waves = F_WAVES;  // filter-pass waves per workgroup (dim 256: 16, 8, 4)
     int opt_mode = 0;       // 0 = one filter launch per query (independent HBM passes), 1 = one launch for the whole chunk
+    int opt_mq_min_queries = 8;  // chunks with at least this many queries take the concurrent-query pass
+    int opt_mq_wg_per_cu = 2;
+    uint64_t stats_multi = 0;
     int opt_grid = 0;       // explicit filter-pass grid size (0: wg_per_cu * CUs)
     pb_scan_stats stats{};
     mutable std::mutex mu;
@@ -93,6 +102,10 @@ int alloc_workspace(pb_index *ix) {
         PB_HIP(hipMalloc(&ix->d_xcounts[i], (size_t)Q_CHUNK * lists * sizeof(uint32_t)));
     }
     PB_HIP(hipMalloc(&ix->d_qsel, Q_CHUNK * sizeof(uint32_t)));
+    PB_HIP(hipMalloc(&ix->d_tau, Q_CHUNK * sizeof(float)));
+    PB_HIP(hipMalloc(&ix->d_cand, (size_t)Q_CHUNK * MQ_CAP * sizeof(uint64_t)));
+    PB_HIP(hipMalloc(&ix->d_cand_cnt, Q_CHUNK * sizeof(uint32_t)));
+    PB_HIP(hipMalloc(&ix->d_ghist, (size_t)Q_CHUNK * MQ_BINS * sizeof(uint32_t)));
     PB_HIP(hipMalloc(&ix->d_res_ids, (size_t)Q_CHUNK * PB_MAX_K * sizeof(int64_t)));
     PB_HIP(hipMalloc(&ix->d_res_dist, (size_t)Q_CHUNK * PB_MAX_K * sizeof(float)));
     PB_HIP(hipMalloc(&ix->d_res_hdr, Q_CHUNK * sizeof(ResultHdr)));
@@ -117,6 +130,12 @@ void free_all(pb_index *ix) {
         (void)hipFree(ix->d_xcounts[i]);
     }
     (void)hipFree(ix->d_qsel);
+    (void)hipFree(ix->d_tau);
+    (void)hipFree(ix->d_cand);
+    (void)hipFree(ix->d_cand_cnt);
+    (void)hipFree(ix->d_ghist);
+    (void)hipFree(ix->d_sumb);
+    (void)hipFree(ix->d_denb);
     (void)hipFree(ix->d_res_ids);
     (void)hipFree(ix->d_res_dist);
     (void)hipFree(ix->d_res_hdr);
@@ -136,7 +155,7 @@ int launch_norms(pb_index *ix, uint64_t first, uint64_t n) {
     const uint64_t want = (n + block - 1) / block;
     const int grid = (int)std::min<uint64_t>(want, (uint64_t)ix->n_cu * 8);
     hipLaunchKernelGGL(k_row_norms, dim3(grid), dim3(block), 0, ix->stream, ix->d_rows, first, n, (int)ix->dim,
-                       ix->d_lut, ix->d_norms);
+                       ix->d_lut, ix->d_norms, ix->d_sumb, ix->d_denb);
     PB_HIP(hipGetLastError());
     return PB_OK;
 }
@@ -298,6 +317,53 @@ int account_profile(pb_index *ix, uint32_t n_queries, uint32_t n_launches) {
     return PB_OK;
 }
 
+// concurrent-query path (dim 256): sample pass -> thresholds -> one full pass for all nq queries -> re-score
+template <int QT>
+void launch_multi(pb_index *ix, bool hist, int grid, uint32_t nq) {
+    if (hist)
+        hipLaunchKernelGGL((k_scan_multi<QT, true>), dim3(grid), dim3(MQ_WAVES * 64), 0, ix->stream, ix->d_rows, ix->d_sumb,
+                           ix->d_denb, ix->n_rows, ix->d_queries, ix->d_qp, ix->d_tau, ix->d_cand, ix->d_cand_cnt, ix->d_ghist,
+                           (int)nq);
+    else
+        hipLaunchKernelGGL((k_scan_multi<QT, false>), dim3(grid), dim3(MQ_WAVES * 64), 0, ix->stream, ix->d_rows, ix->d_sumb,
+                           ix->d_denb, ix->n_rows, ix->d_queries, ix->d_qp, ix->d_tau, ix->d_cand, ix->d_cand_cnt, ix->d_ghist,
+                           (int)nq);
+}
+
+int run_multi(pb_index *ix, uint32_t nq, uint32_t k) {
+    const int qt = (int)((nq + 15) / 16);
+    const uint64_t n_tiles = (ix->n_rows + 15) / 16;
+    PB_HIP(hipMemsetAsync(ix->d_ghist, 0, (size_t)Q_CHUNK * MQ_BINS * sizeof(uint32_t), ix->stream));
+    PB_HIP(hipMemsetAsync(ix->d_cand_cnt, 0, Q_CHUNK * sizeof(uint32_t), ix->stream));
+    auto launch = [&](bool hist) {
+        const uint64_t tiles = hist ? (n_tiles + MQ_SAMPLE - 1) / MQ_SAMPLE : n_tiles;
+        const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((tiles + MQ_WAVES - 1) / MQ_WAVES,
+                                                                         (uint64_t)ix->n_cu * (hist ? 1 : ix->opt_mq_wg_per_cu)));
+        switch (qt) {
+            case 1: launch_multi<1>(ix, hist, grid, nq); break;
+            case 2: launch_multi<2>(ix, hist, grid, nq); break;
+            case 3: launch_multi<3>(ix, hist, grid, nq); break;
+            default: launch_multi<4>(ix, hist, grid, nq); break;
+        }
+    };
+    launch(true);
+    PB_HIP(hipGetLastError());
+    // aim at ~max(3k, 384) candidates per query in the full table
+    const uint32_t target_full = std::max<uint32_t>(3 * k, 384);
+    const uint32_t target_sample = std::max<uint32_t>(2, (target_full + MQ_SAMPLE - 1) / MQ_SAMPLE);
+    hipLaunchKernelGGL(k_mq_pick_tau, dim3(nq), dim3(64), 0, ix->stream, ix->d_ghist, ix->d_qp, (int)nq, target_sample, ix->d_tau);
+    PB_HIP(hipGetLastError());
+    if (ix->opt_profile) PB_HIP(hipEventRecord(ix->ev0, ix->stream));
+    launch(false);
+    PB_HIP(hipGetLastError());
+    if (ix->opt_profile) PB_HIP(hipEventRecord(ix->ev1, ix->stream));
+    hipLaunchKernelGGL(k_mq_rescore, dim3(nq), dim3(1024), 0, ix->stream, ix->d_rows, ix->d_ids, ix->d_norms, (int)ix->dim,
+                       ix->d_queries, ix->d_qp, ix->d_lut, ix->d_tau, ix->d_cand, ix->d_cand_cnt, ix->d_res_ids, ix->d_res_dist,
+                       ix->d_res_hdr, (uint32_t)PB_MAX_K);
+    PB_HIP(hipGetLastError());
+    return PB_OK;
+}
+
 // One chunk (<= Q_CHUNK queries, already in h_stage): run the filter path, check the certificates on the
 // host (D2H of the 16-byte headers only), re-run uncertified queries through the exhaustive pass.
 // On return d_res_ids / d_res_dist / d_res_hdr hold the final results of the chunk and h_res_hdr mirrors
@@ -307,23 +373,27 @@ int search_chunk(pb_index *ix, uint32_t cq, uint32_t k, double max_dist) {
     uint8_t *hq = ix->h_stage;
     QParams *hp = reinterpret_cast<QParams *>(ix->h_stage + (size_t)Q_CHUNK * d);
     uint32_t *hsel = reinterpret_cast<uint32_t *>(ix->h_stage + (size_t)Q_CHUNK * (d + sizeof(QParams)));
-    const bool use_fast = ix->opt_path == 0 && fast_dim(d);
+    const bool use_fast = (ix->opt_path == 0 || ix->opt_path == 2 || ix->opt_path == 3) && fast_dim(d);
     for (uint32_t q = 0; q < cq; ++q) make_qparams(ix, hq + (size_t)q * d, k, max_dist, &hp[q]);
     PB_HIP(hipMemcpyAsync(ix->d_queries, hq, (size_t)cq * d, hipMemcpyHostToDevice, ix->stream));
     PB_HIP(hipMemcpyAsync(ix->d_qp, hp, (size_t)cq * sizeof(QParams), hipMemcpyHostToDevice, ix->stream));
     uint32_t n_sel = 0;
+    // concurrent-query pass: worth it from ~8 queries on a table large enough for the sample to mean something
+    const bool use_multi = use_fast && d == 256 && ix->n_rows >= 65536 &&
+                           (ix->opt_path == 3 || (ix->opt_path == 0 && cq >= (uint32_t)ix->opt_mq_min_queries));
     if (use_fast) {
-        int rc = run_fast(ix, cq);
+        int rc = use_multi ? run_multi(ix, cq, k) : run_fast(ix, cq);
         if (rc) return rc;
         PB_HIP(hipMemcpyAsync(ix->h_res_hdr, ix->d_res_hdr, cq * sizeof(ResultHdr), hipMemcpyDeviceToHost, ix->stream));
         PB_HIP(hipStreamSynchronize(ix->stream));
         if (ix->opt_profile) {
-            int rc2 = account_profile(ix, cq, ix->opt_mode == 0 ? cq : 1);
+            int rc2 = use_multi ? account_profile(ix, 1, 1) : account_profile(ix, cq, ix->opt_mode == 0 ? cq : 1);
             if (rc2) return rc2;
         }
         for (uint32_t q = 0; q < cq; ++q)
             if (ix->h_res_hdr[q].status != 0) hsel[n_sel++] = q;
         ix->stats.fast_path += cq - n_sel;
+        if (use_multi) ix->stats_multi += cq - n_sel;
     } else {
         for (uint32_t q = 0; q < cq; ++q) hsel[n_sel++] = q;
     }
@@ -424,6 +494,8 @@ int insert_at(pb_index *ix, uint64_t pos, int64_t id, const uint8_t *row) {
     int rc = shift(ix->d_rows, d);
     if (!rc) rc = shift(ix->d_ids, sizeof(int64_t));
     if (!rc) rc = shift(ix->d_norms, sizeof(float));
+    if (!rc) rc = shift(ix->d_sumb, sizeof(int32_t));
+    if (!rc) rc = shift(ix->d_denb, sizeof(int32_t));
     if (rc) {
         (void)hipFree(tmp);
         return rc;
@@ -486,6 +558,8 @@ int pb_index_create(pb_index **out, int device, uint32_t dim, uint64_t capacity_
         PB_HIP(hipMalloc(&ix->d_rows, (capacity_rows + 64) * (size_t)dim));
         PB_HIP(hipMalloc(&ix->d_ids, capacity_rows * sizeof(int64_t)));
         PB_HIP(hipMalloc(&ix->d_norms, capacity_rows * sizeof(float)));
+        PB_HIP(hipMalloc(&ix->d_sumb, (capacity_rows + 16) * sizeof(int32_t)));
+        PB_HIP(hipMalloc(&ix->d_denb, (capacity_rows + 16) * sizeof(int32_t)));
         PB_HIP(hipMalloc(&ix->d_lut, 256 * sizeof(float)));
         PB_HIP(hipMemcpy(ix->d_lut, ix->lut, 256 * sizeof(float), hipMemcpyHostToDevice));
         return alloc_workspace(ix);
@@ -666,7 +740,7 @@ int pb_index_set_option(pb_index *ix, int option, int64_t value) {
     std::lock_guard<std::mutex> lock(ix->mu);
     switch (option) {
         case PB_OPT_SEARCH_PATH:
-            PB_CHECK(value == 0 || value == 1, PB_ERR_INVALID, "PB_OPT_SEARCH_PATH: 0 or 1");
+            PB_CHECK(value >= 0 && value <= 3, PB_ERR_INVALID, "PB_OPT_SEARCH_PATH: 0..3");
             ix->opt_path = (int)value;
             return PB_OK;
         case PB_OPT_PROFILE:
@@ -681,6 +755,14 @@ int pb_index_set_option(pb_index *ix, int option, int64_t value) {
         case 5:  // PB_OPT_SCAN_WG_PER_CU (experiments)
             PB_CHECK(value >= 1 && value <= 8, PB_ERR_INVALID, "workgroups per CU: 1..8");
             ix->opt_wg_per_cu = (int)value;
+            return PB_OK;
+        case 9:  // PB_OPT_MQ_MIN_QUERIES
+            PB_CHECK(value >= 1, PB_ERR_INVALID, "min queries >= 1");
+            ix->opt_mq_min_queries = (int)value;
+            return PB_OK;
+        case 10:  // multi-query pass: workgroups per CU
+            PB_CHECK(value >= 1 && value <= 8, PB_ERR_INVALID, "1..8");
+            ix->opt_mq_wg_per_cu = (int)value;
             return PB_OK;
         case 8:  // launch mode
             PB_CHECK(value == 0 || value == 1, PB_ERR_INVALID, "scan mode: 0 or 1");

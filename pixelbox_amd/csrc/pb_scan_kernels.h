@@ -237,7 +237,8 @@ __device__ __forceinline__ float ref_distance(float dot, float sqrt_sa, float ro
 
 // sqrt(fold(x*x)) per row, row-per-lane (engine.rs:580-581, the `hash_b` half)
 __global__ void k_row_norms(const uint8_t *__restrict__ rows, uint64_t first, uint64_t n, int d,
-                            const float *__restrict__ lut, float *__restrict__ norms) {
+                            const float *__restrict__ lut, float *__restrict__ norms,
+                            int32_t *__restrict__ sum_b, int32_t *__restrict__ den_b) {
     __shared__ float s_lut[256];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_lut[i] = lut[i];
     __syncthreads();
@@ -245,12 +246,18 @@ __global__ void k_row_norms(const uint8_t *__restrict__ rows, uint64_t first, ui
          r += (uint64_t)gridDim.x * blockDim.x) {
         const uint8_t *row = rows + r * (uint64_t)d;
         float acc = 0.0f;
+        int32_t sb = 0, sb2 = 0;
         for (int i = 0; i < d; ++i) {
-            const float x = s_lut[row[i]];
+            const int v = row[i];
+            const float x = s_lut[v];
             const float p = x * x;
             acc = acc + p;
+            sb += v;
+            sb2 += v * v;
         }
         norms[r] = sqrtf(acc);  // correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt default)
+        sum_b[r] = sb;                                   // exact integers for the multi-query pass
+        den_b[r] = 4 * sb2 - 1020 * sb + 65025 * d;      // = sum (2b-255)^2
     }
 }
 
@@ -710,6 +717,257 @@ __global__ __launch_bounds__(M_BLOCK) void k_merge_lists(
             h.o_max = 0.0f;
             out_hdr[q] = h;
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// (3) concurrent queries: ONE pass over the table serves up to 64 queries (dim 256).  The integer dots of a
+// 16-row x 16-query tile come from v_mfma_i32_16x16x64_i8 (u8 -> s8 by XOR 0x80 on both operands:
+// sum (a-128)(b-128) = P - 128(A+B) + 16384 D, hence num = 4*acc + 2(A+B) - 511 D), per-row integer norms from
+// side tables filled at append time.  Two launches: HIST = true visits every MQ_SAMPLE-th tile and histograms
+// cos_filter per query (LDS, then global); k_mq_pick_tau turns that into a per-query threshold tau expected to
+// admit a few hundred rows; HIST = false streams the whole table once and appends every (row, query) with
+// cos_filter >= tau[q] to that query's candidate list.  k_mq_rescore then does what k_select_rescore does:
+// exact re-scoring, sort, certificate (every unlisted row has cos_filter < tau => cos_ref < tau + M_GLOB).
+// The sampling only steers efficiency; correctness rests on the certificate, failures fall back.
+constexpr int MQ_MAXQ = 64;
+constexpr int MQ_WAVES = 4;
+constexpr int MQ_BINS = 256;
+constexpr int MQ_CAP = 4096;
+constexpr int MQ_SAMPLE = 16;
+constexpr int MQ_LDROW = 272;  // 256 B row + 16 B pad: conflict-light ds_read_b128 in MFMA operand order
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+template <int QT, bool HIST>
+__global__ __launch_bounds__(MQ_WAVES * WAVE) void k_scan_multi(
+    const uint8_t *__restrict__ rows, const int32_t *__restrict__ sum_b, const int32_t *__restrict__ den_b,
+    uint64_t n_rows, const uint8_t *__restrict__ queries, const QParams *__restrict__ qp,
+    const float *__restrict__ tau, uint64_t *__restrict__ cand, uint32_t *__restrict__ cand_cnt,
+    uint32_t *__restrict__ ghist, int n_q) {
+    constexpr int D = 256;
+    __shared__ __attribute__((aligned(16))) uint8_t s_tile[MQ_WAVES][16 * MQ_LDROW];
+    __shared__ uint32_t s_hist[HIST ? QT * 16 * MQ_BINS : 1];
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    if constexpr (HIST) {
+        for (int i = threadIdx.x; i < QT * 16 * MQ_BINS; i += blockDim.x) s_hist[i] = 0;
+        __syncthreads();
+    }
+    // query fragments (B operand): lane (j = li, kq) holds bytes [64 s + 16 kq, +16) of query 16 qt + j, as s8
+    i32x4 bq[QT][4];
+    float den_a[QT], q_tau[QT];
+    int sum_a[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        int q = qt * 16 + li;
+        q = q < n_q ? q : n_q - 1;  // padded columns repeat the last query (their results are never read)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            i32x4 v = *reinterpret_cast<const i32x4 *>(queries + (size_t)q * D + 64 * s + 16 * kq);
+            v.x ^= 0x80808080; v.y ^= 0x80808080; v.z ^= 0x80808080; v.w ^= 0x80808080;
+            bq[qt][s] = v;
+        }
+        den_a[qt] = qp[q].den_a;
+        sum_a[qt] = qp[q].sum_a;
+        q_tau[qt] = HIST ? qp[q].thr0 : tau[q];
+    }
+    uint8_t *tile = s_tile[wave];
+    const uint64_t n_tiles = (n_rows + 15) / 16;
+    const uint64_t stride = (uint64_t)gridDim.x * MQ_WAVES;
+    for (uint64_t t = (uint64_t)wave * gridDim.x + blockIdx.x; t < n_tiles; t += stride) {
+        const uint64_t tt = HIST ? t * MQ_SAMPLE : t;  // sample pass: every MQ_SAMPLE-th tile
+        if (tt >= n_tiles) break;
+        const uint64_t row0 = tt * 16;
+        // 16 rows = 4 KiB, coalesced: instruction j loads rows 4j .. 4j+3
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 ld[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint64_t r = row0 + (uint64_t)(4 * j + kq);
+            r = r < n_rows ? r : n_rows - 1;
+            ld[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(rows + r * D + li * 16));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<u32x4 *>(tile + (4 * j + kq) * MQ_LDROW + li * 16) = ld[j];
+        i32x4 acc[QT];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) acc[qt] = (i32x4){0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            // A operand: lane (i = li, kq) holds bytes [64 s + 16 kq, +16) of row i
+            i32x4 a = *reinterpret_cast<const i32x4 *>(tile + li * MQ_LDROW + 64 * s + 16 * kq);
+            a.x ^= 0x80808080; a.y ^= 0x80808080; a.z ^= 0x80808080; a.w ^= 0x80808080;
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt)
+                acc[qt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bq[qt][s], acc[qt], 0, 0, 0);
+        }
+        // result: lane holds rows row0 + 4 kq + r (r = 0..3) of query column li
+        const uint64_t rbase = row0 + 4 * (uint64_t)kq;
+        i32x4 sb = {0, 0, 0, 0}, db = {1, 1, 1, 1};
+        if (rbase + 3 < n_rows) {
+            sb = *reinterpret_cast<const i32x4 *>(sum_b + rbase);
+            db = *reinterpret_cast<const i32x4 *>(den_b + rbase);
+        } else {  // table tail (static indices: a runtime-indexed vector would go to scratch)
+            if (rbase + 0 < n_rows) { sb.x = sum_b[rbase + 0]; db.x = den_b[rbase + 0]; }
+            if (rbase + 1 < n_rows) { sb.y = sum_b[rbase + 1]; db.y = den_b[rbase + 1]; }
+            if (rbase + 2 < n_rows) { sb.z = sum_b[rbase + 2]; db.z = den_b[rbase + 2]; }
+        }
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            const int q = qt * 16 + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int num = 4 * acc[qt][r] + 2 * (sum_a[qt] + sb[r]) - 511 * D;
+                const float cs = (float)num * __builtin_amdgcn_rsqf((float)db[r] * den_a[qt]);
+                const bool ok = (rbase + r < n_rows) && (q < n_q) && cs >= q_tau[qt];
+                if constexpr (HIST) {
+                    if (ok) {
+                        int bin = (int)(cs * (float)MQ_BINS);
+                        bin = bin < 0 ? 0 : (bin >= MQ_BINS ? MQ_BINS - 1 : bin);
+                        atomicAdd(&s_hist[(qt * 16 + li) * MQ_BINS + bin], 1u);
+                    }
+                } else {
+                    if (ok) {
+                        const uint32_t idx = atomicAdd(&cand_cnt[q], 1u);
+                        if (idx < MQ_CAP) cand[(size_t)q * MQ_CAP + idx] = filter_key(cs, (uint32_t)(rbase + r));
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (HIST) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < QT * 16 * MQ_BINS; i += blockDim.x) {
+            const uint32_t v = s_hist[i];
+            if (v) atomicAdd(&ghist[i], v);
+        }
+    }
+}
+
+// per query: tau = lower edge of the highest histogram bin at which the sampled count reaches `target_sample`
+// (never below thr0); one wave per query
+__global__ void k_mq_pick_tau(const uint32_t *__restrict__ ghist, const QParams *__restrict__ qp, int n_q,
+                              uint32_t target_sample, float *__restrict__ tau) {
+    const int q = blockIdx.x;
+    if (q >= n_q) return;
+    const int lane = lane_id();
+    uint32_t acc = 0;
+    int found = -1;
+    for (int chunk = MQ_BINS / WAVE - 1; chunk >= 0 && found < 0; --chunk) {
+        const int bin = chunk * WAVE + (WAVE - 1 - lane);
+        uint32_t incl = ghist[(size_t)q * MQ_BINS + bin];
+        for (int off = 1; off < WAVE; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off);
+            if (lane >= off) incl += o;
+        }
+        const uint64_t hit = __ballot(acc + incl >= target_sample);
+        if (hit) found = chunk * WAVE + (WAVE - 1 - (__ffsll((unsigned long long)hit) - 1));
+        acc += __shfl(incl, WAVE - 1);
+    }
+    if (lane == 0) {
+        float t = found >= 0 ? (float)found / (float)MQ_BINS - 2e-6f : 0.0f;
+        tau[q] = fmaxf(t, qp[q].thr0);
+    }
+}
+
+// exact re-scoring of one query's candidate list (<= MQ_CAP), sort, top-k, certificate.  One block per query.
+__global__ __launch_bounds__(1024) void k_mq_rescore(
+    const uint8_t *__restrict__ rows, const int64_t *__restrict__ ids, const float *__restrict__ norms, int d,
+    const uint8_t *__restrict__ queries, const QParams *__restrict__ qp, const float *__restrict__ lut,
+    const float *__restrict__ tau, const uint64_t *__restrict__ cand, const uint32_t *__restrict__ cand_cnt,
+    int64_t *__restrict__ out_ids, float *__restrict__ out_dist, ResultHdr *__restrict__ out_hdr, uint32_t out_stride) {
+    constexpr int PER = MQ_CAP / 1024;
+    __shared__ float s_lut[256];
+    __shared__ float s_qf[256];
+    __shared__ uint64_t s_sort[MQ_CAP];
+    __shared__ float s_red[16];
+    __shared__ float s_red2[16];
+    const int q = blockIdx.x;
+    const int tid = threadIdx.x;
+    const QParams P = qp[q];
+    for (int i = tid; i < 256; i += 1024) s_lut[i] = lut[i];
+    __syncthreads();
+    for (int i = tid; i < d; i += 1024) s_qf[i] = s_lut[queries[(size_t)q * d + i]];
+    const uint32_t raw = cand_cnt[q];
+    const int cnt = raw < (uint32_t)MQ_CAP ? (int)raw : MQ_CAP;
+    int nsort = 64;
+    while (nsort < cnt) nsort <<= 1;
+    __syncthreads();
+    uint64_t xkey[PER];
+    float xcs[PER];
+    float cfilt = -2.0f;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int i = tid + j * 1024;
+        xkey[j] = ~0ull;
+        xcs[j] = 3.0f;
+        if (i < cnt) {
+            const uint32_t r = (uint32_t)cand[(size_t)q * MQ_CAP + i];
+            const float dot = ref_fold_dot(rows + (uint64_t)r * d, s_qf, s_lut, d);
+            float cs;
+            const float dist = ref_distance(dot, P.sqrt_sa, norms[r], &cs);
+            xcs[j] = cs;
+            if ((double)dist < P.max_dist) xkey[j] = ((uint64_t)sortable_f32(dist) << 32) | r;
+            else cfilt = fmaxf(cfilt, cs);
+        }
+        if (i < nsort) s_sort[i] = xkey[j];
+    }
+    block_bitonic_sort(s_sort, nsort);
+    // number of valid keys = position of the first ~0 (sorted): count by ballot
+    __shared__ uint32_t s_nvalid;
+    if (tid == 0) s_nvalid = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int i = tid + j * 1024;
+        mine += (i < nsort && s_sort[i] != ~0ull) ? 1u : 0u;
+    }
+    for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor((int)mine, off);
+    if ((tid & 63) == 0 && mine) atomicAdd(&s_nvalid, mine);
+    __syncthreads();
+    const uint32_t n_valid = s_nvalid;
+    const uint32_t n_out = n_valid < P.k ? n_valid : P.k;
+    if (tid < (int)n_out) {
+        const uint64_t key = s_sort[tid];
+        out_ids[(size_t)q * out_stride + tid] = ids[(uint32_t)key];
+        out_dist[(size_t)q * out_stride + tid] = unsortable_f32((uint32_t)(key >> 32));
+    }
+    // smallest exact cosine among the selected, largest among the rejected-by-filter
+    const uint64_t kth_key = n_out ? s_sort[n_out - 1] : 0ull;
+    float ck = 3.0f;
+#pragma unroll
+    for (int j = 0; j < PER; ++j)
+        if (n_out && xkey[j] <= kth_key) ck = fminf(ck, xcs[j]);
+    for (int off = 32; off >= 1; off >>= 1) {
+        ck = fminf(ck, __shfl_xor(ck, off));
+        cfilt = fmaxf(cfilt, __shfl_xor(cfilt, off));
+    }
+    if ((tid & 63) == 0) {
+        s_red[tid >> 6] = ck;
+        s_red2[tid >> 6] = cfilt;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        ck = 3.0f;
+        cfilt = -2.0f;
+        for (int w = 0; w < 16; ++w) {
+            ck = fminf(ck, s_red[w]);
+            cfilt = fmaxf(cfilt, s_red2[w]);
+        }
+        const float o_max = fmaxf(tau[q], P.thr0) + M_GLOB;  // no unlisted row's exact cosine reaches this
+        bool ok = raw <= (uint32_t)MQ_CAP;
+        if (n_out == P.k) ok = ok && (o_max <= ck * (1.0f - 1e-6f));
+        else ok = ok && ((P.floor_is_filter && o_max <= P.c_floor) || (o_max <= cfilt));
+        ResultHdr h;
+        h.count = n_out;
+        h.status = ok ? 0u : 1u;
+        h.n_cand = raw;
+        h.o_max = o_max;
+        out_hdr[q] = h;
     }
 }
 

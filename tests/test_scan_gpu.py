@@ -14,7 +14,7 @@ from pixelbox_amd import capi, synth
 pytestmark = pytest.mark.gpu
 
 F32 = np.float32
-AUTO, EXACT = 0, 1
+AUTO, EXACT, SINGLE, MULTI = 0, 1, 2, 3
 
 
 def make_index(rows, ids=None, capacity=None, path=AUTO):
@@ -302,6 +302,58 @@ def test_packed_device_results_and_merge_roundtrip():
         assert g_c[qi] == len(want_ids)
         assert np.array_equal(g_ids[qi, : g_c[qi]], want_ids)
         assert np.array_equal(g_d[qi, : g_c[qi]].view(np.uint32), want_d.view(np.uint32))
+
+
+# ---- concurrent-query pass (i8 MFMA, one pass over the table for up to 64 queries) ----------------------
+@pytest.mark.parametrize("nq", [1, 15, 16, 17, 33, 64, 100])
+def test_multi_query_pass_vs_oracle(nq):
+    rng = np.random.default_rng(60 + nq)
+    n = 70000
+    rows = rng.integers(0, 256, size=(n, 256), dtype=np.uint8)
+    ids = np.arange(n, dtype=np.int64) * 2 + 5
+    q = rng.integers(0, 256, size=(nq, 256), dtype=np.uint8)
+    q[0] = rows[123]
+    ix = make_index(rows, ids, path=MULTI)
+    check_against_oracle(ix, rows, ids, q)
+    st = ix.stats()
+    assert st.queries == nq and st.fast_path >= nq - 2  # uniform data: the certificates should pass
+
+
+def test_multi_query_pass_tail_rows_and_auto_switch():
+    rng = np.random.default_rng(61)
+    n = 65536 + 13  # not a multiple of the 16-row tile
+    rows = rng.integers(0, 256, size=(n, 256), dtype=np.uint8)
+    rows[-1] = rows[5]
+    ids = np.arange(n, dtype=np.int64)
+    q = np.concatenate([rows[[5, n - 1, n - 2]], rng.integers(0, 256, size=(9, 256), dtype=np.uint8)])
+    ix = make_index(rows, ids)  # AUTO: 12 queries >= 8 -> shared pass
+    check_against_oracle(ix, rows, ids, q)
+    check_against_oracle(ix, rows, ids, q, k=7, max_dist=4.0)
+    ix2 = make_index(rows, ids, path=SINGLE)
+    a = ix.search(q, 100, 1e3)
+    b = ix2.search(q, 100, 1e3)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_multi_query_pass_adversarial_falls_back():
+    rng = np.random.default_rng(62)
+    n = 80000
+    rows = rng.integers(0, 256, size=(n, 256), dtype=np.uint8)
+    q = rng.integers(0, 256, size=(20, 256), dtype=np.uint8)
+    rows[rng.choice(n, size=6000, replace=False)] = q[3]  # 6000 exact duplicates of one query: candidate list overflows
+    rows[1000:1300] = 255 - q[4]
+    ids = np.arange(n, dtype=np.int64)
+    ix = make_index(rows, ids, path=MULTI)
+    check_against_oracle(ix, rows, ids, q)
+    check_against_oracle(ix, rows, ids, q[3:6], max_dist=2e6)
+    assert ix.stats().fallback >= 1
+    # clustered, embedding-like table
+    centers = np.tanh(rng.standard_normal((30, 256)).astype(np.float32))
+    which = rng.integers(0, 30, size=n)
+    f = np.tanh(np.arctanh(np.clip(centers[which], -0.999, 0.999)) + rng.standard_normal((n, 256)).astype(np.float32) * 0.05)
+    rows2 = oracle.quantize(f.astype(np.float32))
+    ix2 = make_index(rows2, ids, path=MULTI)
+    check_against_oracle(ix2, rows2, ids, rows2[rng.choice(n, size=24, replace=False)])
 
 
 # ---- synthetic generator and BASELINE-size checks -------------------------------------------------------
