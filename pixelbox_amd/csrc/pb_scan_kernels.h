@@ -757,8 +757,8 @@ __global__ __launch_bounds__(MQ_WAVES * WAVE) void k_scan_multi(
     }
     // query fragments (B operand): lane (j = li, kq) holds bytes [64 s + 16 kq, +16) of query 16 qt + j, as s8
     i32x4 bq[QT][4];
-    float den_a[QT], q_tau[QT];
-    int sum_a[QT];
+    float den_a[QT], q_tau[QT], g_tau[QT];
+    int sum_a[QT], sa2[QT];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         int q = qt * 16 + li;
@@ -772,26 +772,38 @@ __global__ __launch_bounds__(MQ_WAVES * WAVE) void k_scan_multi(
         den_a[qt] = qp[q].den_a;
         sum_a[qt] = qp[q].sum_a;
         q_tau[qt] = HIST ? qp[q].thr0 : tau[q];
+        sa2[qt] = 2 * sum_a[qt];
+        g_tau[qt] = q_tau[qt] * __builtin_amdgcn_sqrtf(den_a[qt]);  // tau > 0
     }
     uint8_t *tile = s_tile[wave];
     const uint64_t n_tiles = (n_rows + 15) / 16;
     const uint64_t stride = (uint64_t)gridDim.x * MQ_WAVES;
-    for (uint64_t t = (uint64_t)wave * gridDim.x + blockIdx.x; t < n_tiles; t += stride) {
-        const uint64_t tt = HIST ? t * MQ_SAMPLE : t;  // sample pass: every MQ_SAMPLE-th tile
-        if (tt >= n_tiles) break;
-        const uint64_t row0 = tt * 16;
-        // 16 rows = 4 KiB, coalesced: instruction j loads rows 4j .. 4j+3
-        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-        u32x4 ld[4];
+    // software pipeline: the 4 KiB of tile t+1 are requested before tile t is computed
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    auto tile_of = [&](uint64_t t) { return HIST ? t * MQ_SAMPLE : t; };
+    auto issue = [&](uint64_t tt, u32x4 (&dst)[4]) {
+        const uint64_t r0 = tt * 16;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            uint64_t r = row0 + (uint64_t)(4 * j + kq);
+            uint64_t r = r0 + (uint64_t)(4 * j + kq);
             r = r < n_rows ? r : n_rows - 1;
-            ld[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(rows + r * D + li * 16));
+            dst[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(rows + r * D + li * 16));
         }
+    };
+    u32x4 ld[4];
+    uint64_t t = (uint64_t)wave * gridDim.x + blockIdx.x;
+    if (t < n_tiles && tile_of(t) < n_tiles) issue(tile_of(t), ld);
+    for (; t < n_tiles; t += stride) {
+        const uint64_t tt = tile_of(t);
+        if (tt >= n_tiles) break;
+        const uint64_t row0 = tt * 16;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             *reinterpret_cast<u32x4 *>(tile + (4 * j + kq) * MQ_LDROW + li * 16) = ld[j];
+        {
+            const uint64_t tn = t + stride;
+            if (tn < n_tiles && tile_of(tn) < n_tiles) issue(tile_of(tn), ld);
+        }
         i32x4 acc[QT];
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) acc[qt] = (i32x4){0, 0, 0, 0};
@@ -815,24 +827,43 @@ __global__ __launch_bounds__(MQ_WAVES * WAVE) void k_scan_multi(
             if (rbase + 1 < n_rows) { sb.y = sum_b[rbase + 1]; db.y = den_b[rbase + 1]; }
             if (rbase + 2 < n_rows) { sb.z = sum_b[rbase + 2]; db.z = den_b[rbase + 2]; }
         }
+        if constexpr (HIST) {
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-            const int q = qt * 16 + li;
+            for (int qt = 0; qt < QT; ++qt) {
+                const int q = qt * 16 + li;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int num = 4 * acc[qt][r] + 2 * (sum_a[qt] + sb[r]) - 511 * D;
-                const float cs = (float)num * __builtin_amdgcn_rsqf((float)db[r] * den_a[qt]);
-                const bool ok = (rbase + r < n_rows) && (q < n_q) && cs >= q_tau[qt];
-                if constexpr (HIST) {
-                    if (ok) {
+                for (int r = 0; r < 4; ++r) {
+                    const int num = 4 * acc[qt][r] + 2 * (sum_a[qt] + sb[r]) - 511 * D;
+                    const float cs = (float)num * __builtin_amdgcn_rsqf((float)db[r] * den_a[qt]);
+                    if ((rbase + r < n_rows) && (q < n_q) && cs >= q_tau[qt]) {
                         int bin = (int)(cs * (float)MQ_BINS);
                         bin = bin < 0 ? 0 : (bin >= MQ_BINS ? MQ_BINS - 1 : bin);
                         atomicAdd(&s_hist[(qt * 16 + li) * MQ_BINS + bin], 1u);
                     }
-                } else {
-                    if (ok) {
-                        const uint32_t idx = atomicAdd(&cand_cnt[q], 1u);
-                        if (idx < MQ_CAP) cand[(size_t)q * MQ_CAP + idx] = filter_key(cs, (uint32_t)(rbase + r));
+                }
+            }
+        } else {
+            // cheap conservative pre-test in 5 instructions per (row, query): num >= tau*sqrt(den_a) * sqrt(den_b) * (1-1e-6)
+            // is implied by cos_filter >= tau; only the rare survivors evaluate cos_filter itself
+            float wr[4];
+            int cr[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                wr[r] = (rbase + r < n_rows) ? __builtin_amdgcn_sqrtf((float)db[r]) * (1.0f - 1e-6f) : 3.0e38f;
+                cr[r] = 2 * sb[r] - 511 * D;
+            }
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                const int q = qt * 16 + li;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int num = 4 * acc[qt][r] + sa2[qt] + cr[r];
+                    if ((float)num >= g_tau[qt] * wr[r]) {
+                        const float cs = (float)num * __builtin_amdgcn_rsqf((float)db[r] * den_a[qt]);
+                        if (cs >= q_tau[qt] && q < n_q) {
+                            const uint32_t idx = atomicAdd(&cand_cnt[q], 1u);
+                            if (idx < MQ_CAP) cand[(size_t)q * MQ_CAP + idx] = filter_key(cs, (uint32_t)(rbase + r));
+                        }
                     }
                 }
             }
