@@ -407,3 +407,57 @@ def test_full_size_10m_properties():
     assert ids_c[:3].tolist() == [n + 5, n + 6, n + 7]
     assert np.all(d_c[:3] == oracle.cosine_distance(q, q))
     assert np.array_equal(ids_c[3:], ids_a[:97])
+
+
+def test_concurrent_callers_like_the_reference_threads():
+    # the reference calls mlhash from 4 crawler threads + the UI thread against one model (engine.rs:22,180,356)
+    # and searches on one thread while another inserts (engine.rs:184-203,374): handles must serialise safely
+    import threading
+
+    from pixelbox_amd import weights as W
+
+    rng = np.random.default_rng(70)
+    d = 256
+    rows = rng.integers(0, 256, size=(20000, d), dtype=np.uint8)
+    ids = np.arange(20000, dtype=np.int64)
+    ix = capi.Index(d, 30000)
+    ix.load(ids[:10000], rows[:10000])
+    blob = W.synthetic_blob(synth.SEED_WEIGHTS, 64, 64, 16)
+    emb = capi.Embedder(blob, max_batch=4)
+    imgs = synth.synthetic_images(synth.SEED_IMAGES, 0, 8, 64, 64)
+    want_u8, _ = emb.embed(imgs)
+    errors = []
+
+    def hasher(t):
+        try:
+            for i in range(10):
+                j = (t + i) % 8
+                assert np.array_equal(emb.mlhash(imgs[j]), want_u8[j])
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    def inserter():
+        try:
+            for lo in range(10000, 20000, 500):
+                ix.append(ids[lo : lo + 500], rows[lo : lo + 500])
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    def searcher():
+        try:
+            for i in range(15):
+                got_ids, got_d = ix.search_one(rows[i])
+                n_now = len(ix)
+                # every result must be a valid row of some prefix >= 10000 of the table, best hit = the row itself
+                assert got_ids[0] == i and got_d[0] <= 1e-6 and got_ids.max() < max(n_now, 10000)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=hasher, args=(t,)) for t in range(4)] + [threading.Thread(target=inserter), threading.Thread(target=searcher)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert len(ix) == 20000
+    check_against_oracle(ix, rows, ids, rows[[3, 15000]])
