@@ -49,3 +49,71 @@ def test_cpp_host_mirror_end_to_end(tmp_path):
             assert np.float32(float(dist)) == want_d[j]
             assert path == f"/synthetic/img{int(rid) - 1}.png"
         pos += 1 + cnt
+
+
+def test_sqlite_persistence_bridge(tmp_path):
+    """SURVEY 8f rank 1: Engine::open rebuilds the device table from semantic_hashes, inserts write through to
+    SQLite (the system of record) and the GPU, query results are joined back to `images` by id."""
+    import sqlite3
+
+    rng = np.random.default_rng(80)
+    d, n = 64, 400
+    rows = rng.integers(0, 256, size=(n, d), dtype=np.uint8)
+    db = tmp_path / "pixelbox.db"
+    conn = sqlite3.connect(db)
+    # the reference's schema (engine.rs:30-48)
+    conn.execute("CREATE TABLE images (id INTEGER PRIMARY KEY, filename TEXT NOT NULL, path TEXT NOT NULL, image_width INTEGER, "
+                 "image_height INTEGER, thumbnail BLOB, created DATETIME, indexed DATETIME, UNIQUE(path))")
+    conn.execute("CREATE TABLE semantic_hashes (image_id INTEGER PRIMARY KEY, hash BLOB)")
+    ids = np.arange(1, n + 1, dtype=np.int64) * 2  # gaps between ids
+    for i, r in zip(ids, rows):
+        conn.execute("INSERT INTO images (id, filename, path, image_width, image_height) VALUES (?, ?, ?, 10, 10)",
+                     (int(i), f"f{i}.png", f"/old/f{i}.png"))
+        conn.execute("INSERT INTO semantic_hashes (image_id, hash) VALUES (?, ?)", (int(i), r.tobytes()))
+    conn.execute("INSERT INTO semantic_hashes (image_id, hash) VALUES (?, ?)", (5001, rows[0].tobytes()))  # orphan: no images row
+    conn.execute("INSERT INTO semantic_hashes (image_id, hash) VALUES (?, ?)", (5003, b"short"))  # wrong length: skipped
+    conn.commit()
+    conn.close()
+    new = rng.integers(0, 256, size=(3, d), dtype=np.uint8)
+    new[0] = rows[7]  # duplicate of an existing hash
+    (tmp_path / "new.u8").write_bytes(new.tobytes())
+    exe = tmp_path / "bridge"
+    libdir = os.path.dirname(capi.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "sqlite_bridge_demo.cpp"), "-o", str(exe),
+                           "-L", libdir, "-lpixelbox_hip", "-ldl", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
+    out = tmp_path / "out.txt"
+    subprocess.check_call([str(exe), str(db), str(d), str(tmp_path / "new.u8"), "3", str(out)])
+    lines = out.read_text().splitlines()
+    assert lines[0] == f"loaded {n + 1}"  # 400 + the orphan; the short blob is skipped
+    new_ids = [int(x.split()[1]) for x in lines[1:4]]
+    assert new_ids == [801, 802, 803]  # rowids continue after max(images.id) = 800; they sort BEFORE the orphan 5001
+    assert lines[4] == f"indexed {n + 4}"  # the re-insert of a known path changed nothing
+    # expected table on the device: old rows + orphan + 3 new, in image_id order
+    all_ids = np.concatenate([ids, [5001], new_ids]).astype(np.int64)
+    all_rows = np.concatenate([rows, rows[:1], new])
+    order = np.argsort(all_ids)
+    all_ids, all_rows = all_ids[order], all_rows[order]
+    pos = 5
+    for qi in range(2):
+        hdr = lines[pos].split()
+        assert hdr[:2] == ["query", str(qi)]
+        cnt = int(hdr[3])
+        want_ids, want_d = oracle.scan_topk(new[qi], all_rows, all_ids, 100, 1e3)
+        keep = want_ids != 5001  # INNER JOIN: the orphan hash has no images row
+        want_ids, want_d = want_ids[keep], want_d[keep]
+        assert cnt == len(want_ids)
+        for j in range(cnt):
+            rid, dist, path, hlen = lines[pos + 1 + j].split()
+            assert int(rid) == want_ids[j] and np.float32(float(dist)) == want_d[j] and int(hlen) == d
+            assert path == (f"/new/new{int(rid) - 801}.png" if int(rid) in new_ids else f"/old/f{int(rid)}.png")
+        pos += 1 + cnt
+    # query 0 is a duplicate of old row 7 (id 16): both tie at the reference's self-distance, smaller id first
+    first = [ln.split() for ln in lines[6:8]]
+    assert [int(first[0][0]), int(first[1][0])] == [16, 801]
+    # SQLite is the system of record: the new hashes are in the file
+    conn = sqlite3.connect(db)
+    got = dict(conn.execute("SELECT image_id, hash FROM semantic_hashes WHERE image_id >= 801 AND image_id <= 803").fetchall())
+    assert [bytes(got[i]) for i in new_ids] == [r.tobytes() for r in new]
+    assert conn.execute("SELECT COUNT(*) FROM images").fetchone()[0] == n + 3
+    conn.close()
