@@ -19,7 +19,8 @@ using namespace pbk;
 
 namespace {
 
-constexpr uint32_t Q_CHUNK = 64;  // queries per launch group
+constexpr uint32_t Q_CHUNK = 64;   // queries per launch group
+constexpr uint32_t PIPE_Q = 1024;  // queries staged / answered per host round trip on the concurrent-query path
 
 // engine.rs:576 -- the de-quantisation table, computed exactly as the reference does per element
 void make_lut(float lut[256]) {
@@ -69,7 +70,8 @@ struct pb_index {
     float *d_res_dist = nullptr;
     ResultHdr *d_res_hdr = nullptr;
     // pinned host staging
-    uint8_t *h_stage = nullptr;  // queries + params + qsel
+    uint8_t *h_stage = nullptr;  // queries + params + qsel (one chunk)
+    uint8_t *h_pipe = nullptr;   // queries + params of up to PIPE_Q queries (concurrent-query path)
     int64_t *h_res_ids = nullptr;
     float *h_res_dist = nullptr;
     ResultHdr *h_res_hdr = nullptr;
@@ -92,8 +94,8 @@ namespace {
 
 int alloc_workspace(pb_index *ix) {
     const size_t d = ix->dim;
-    PB_HIP(hipMalloc(&ix->d_queries, Q_CHUNK * d));
-    PB_HIP(hipMalloc(&ix->d_qp, Q_CHUNK * sizeof(QParams)));
+    PB_HIP(hipMalloc(&ix->d_queries, PIPE_Q * d));
+    PB_HIP(hipMalloc(&ix->d_qp, PIPE_Q * sizeof(QParams)));
     PB_HIP(hipMalloc(&ix->d_lists, (size_t)Q_CHUNK * F_MAX_WG * F_KWG * sizeof(uint64_t)));
     PB_HIP(hipMalloc(&ix->d_hdrs, (size_t)Q_CHUNK * F_MAX_WG * sizeof(ListHdr)));
     for (int i = 0; i < 2; ++i) {
@@ -106,13 +108,14 @@ int alloc_workspace(pb_index *ix) {
     PB_HIP(hipMalloc(&ix->d_cand, (size_t)Q_CHUNK * MQ_CAP * sizeof(uint64_t)));
     PB_HIP(hipMalloc(&ix->d_cand_cnt, Q_CHUNK * sizeof(uint32_t)));
     PB_HIP(hipMalloc(&ix->d_ghist, (size_t)Q_CHUNK * MQ_BINS * sizeof(uint32_t)));
-    PB_HIP(hipMalloc(&ix->d_res_ids, (size_t)Q_CHUNK * PB_MAX_K * sizeof(int64_t)));
-    PB_HIP(hipMalloc(&ix->d_res_dist, (size_t)Q_CHUNK * PB_MAX_K * sizeof(float)));
-    PB_HIP(hipMalloc(&ix->d_res_hdr, Q_CHUNK * sizeof(ResultHdr)));
+    PB_HIP(hipMalloc(&ix->d_res_ids, (size_t)PIPE_Q * PB_MAX_K * sizeof(int64_t)));
+    PB_HIP(hipMalloc(&ix->d_res_dist, (size_t)PIPE_Q * PB_MAX_K * sizeof(float)));
+    PB_HIP(hipMalloc(&ix->d_res_hdr, PIPE_Q * sizeof(ResultHdr)));
     PB_HIP(hipHostMalloc(&ix->h_stage, Q_CHUNK * (d + sizeof(QParams) + sizeof(uint32_t)), hipHostMallocDefault));
-    PB_HIP(hipHostMalloc(&ix->h_res_ids, (size_t)Q_CHUNK * PB_MAX_K * sizeof(int64_t), hipHostMallocDefault));
-    PB_HIP(hipHostMalloc(&ix->h_res_dist, (size_t)Q_CHUNK * PB_MAX_K * sizeof(float), hipHostMallocDefault));
-    PB_HIP(hipHostMalloc(&ix->h_res_hdr, Q_CHUNK * sizeof(ResultHdr), hipHostMallocDefault));
+    PB_HIP(hipHostMalloc(&ix->h_pipe, PIPE_Q * (d + sizeof(QParams)), hipHostMallocDefault));
+    PB_HIP(hipHostMalloc(&ix->h_res_ids, (size_t)PIPE_Q * PB_MAX_K * sizeof(int64_t), hipHostMallocDefault));
+    PB_HIP(hipHostMalloc(&ix->h_res_dist, (size_t)PIPE_Q * PB_MAX_K * sizeof(float), hipHostMallocDefault));
+    PB_HIP(hipHostMalloc(&ix->h_res_hdr, PIPE_Q * sizeof(ResultHdr), hipHostMallocDefault));
     return PB_OK;
 }
 
@@ -140,6 +143,7 @@ void free_all(pb_index *ix) {
     (void)hipFree(ix->d_res_dist);
     (void)hipFree(ix->d_res_hdr);
     if (ix->h_stage) (void)hipHostFree(ix->h_stage);
+    if (ix->h_pipe) (void)hipHostFree(ix->h_pipe);
     if (ix->h_res_ids) (void)hipHostFree(ix->h_res_ids);
     if (ix->h_res_dist) (void)hipHostFree(ix->h_res_dist);
     if (ix->h_res_hdr) (void)hipHostFree(ix->h_res_hdr);
@@ -319,18 +323,19 @@ int account_profile(pb_index *ix, uint32_t n_queries, uint32_t n_launches) {
 
 // concurrent-query path (dim 256): sample pass -> thresholds -> one full pass for all nq queries -> re-score
 template <int QT>
-void launch_multi(pb_index *ix, bool hist, int grid, uint32_t nq) {
+void launch_multi(pb_index *ix, bool hist, int grid, uint32_t base, uint32_t nq) {
+    const uint8_t *dq = ix->d_queries + (size_t)base * ix->dim;
+    const QParams *dp = ix->d_qp + base;
     if (hist)
         hipLaunchKernelGGL((k_scan_multi<QT, true>), dim3(grid), dim3(MQ_WAVES * 64), 0, ix->stream, ix->d_rows, ix->d_sumb,
-                           ix->d_denb, ix->n_rows, ix->d_queries, ix->d_qp, ix->d_tau, ix->d_cand, ix->d_cand_cnt, ix->d_ghist,
-                           (int)nq);
+                           ix->d_denb, ix->n_rows, dq, dp, ix->d_tau, ix->d_cand, ix->d_cand_cnt, ix->d_ghist, (int)nq);
     else
         hipLaunchKernelGGL((k_scan_multi<QT, false>), dim3(grid), dim3(MQ_WAVES * 64), 0, ix->stream, ix->d_rows, ix->d_sumb,
-                           ix->d_denb, ix->n_rows, ix->d_queries, ix->d_qp, ix->d_tau, ix->d_cand, ix->d_cand_cnt, ix->d_ghist,
-                           (int)nq);
+                           ix->d_denb, ix->n_rows, dq, dp, ix->d_tau, ix->d_cand, ix->d_cand_cnt, ix->d_ghist, (int)nq);
 }
 
-int run_multi(pb_index *ix, uint32_t nq, uint32_t k) {
+// queries [base, base + nq) of the staged device arrays; results to the same slots of d_res_*
+int run_multi(pb_index *ix, uint32_t nq, uint32_t k, uint32_t base = 0) {
     const int qt = (int)((nq + 15) / 16);
     const uint64_t n_tiles = (ix->n_rows + 15) / 16;
     PB_HIP(hipMemsetAsync(ix->d_ghist, 0, (size_t)Q_CHUNK * MQ_BINS * sizeof(uint32_t), ix->stream));
@@ -340,10 +345,10 @@ int run_multi(pb_index *ix, uint32_t nq, uint32_t k) {
         const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((tiles + MQ_WAVES - 1) / MQ_WAVES,
                                                                          (uint64_t)ix->n_cu * (hist ? 1 : ix->opt_mq_wg_per_cu)));
         switch (qt) {
-            case 1: launch_multi<1>(ix, hist, grid, nq); break;
-            case 2: launch_multi<2>(ix, hist, grid, nq); break;
-            case 3: launch_multi<3>(ix, hist, grid, nq); break;
-            default: launch_multi<4>(ix, hist, grid, nq); break;
+            case 1: launch_multi<1>(ix, hist, grid, base, nq); break;
+            case 2: launch_multi<2>(ix, hist, grid, base, nq); break;
+            case 3: launch_multi<3>(ix, hist, grid, base, nq); break;
+            default: launch_multi<4>(ix, hist, grid, base, nq); break;
         }
     };
     launch(true);
@@ -351,17 +356,24 @@ int run_multi(pb_index *ix, uint32_t nq, uint32_t k) {
     // aim at ~max(3k, 384) candidates per query in the full table
     const uint32_t target_full = std::max<uint32_t>(3 * k, 384);
     const uint32_t target_sample = std::max<uint32_t>(2, (target_full + MQ_SAMPLE - 1) / MQ_SAMPLE);
-    hipLaunchKernelGGL(k_mq_pick_tau, dim3(nq), dim3(64), 0, ix->stream, ix->d_ghist, ix->d_qp, (int)nq, target_sample, ix->d_tau);
+    hipLaunchKernelGGL(k_mq_pick_tau, dim3(nq), dim3(64), 0, ix->stream, ix->d_ghist, ix->d_qp + base, (int)nq, target_sample,
+                       ix->d_tau);
     PB_HIP(hipGetLastError());
-    if (ix->opt_profile) PB_HIP(hipEventRecord(ix->ev0, ix->stream));
+    if (ix->opt_profile && base == 0) PB_HIP(hipEventRecord(ix->ev0, ix->stream));  // the first pass of a block is timed
     launch(false);
     PB_HIP(hipGetLastError());
-    if (ix->opt_profile) PB_HIP(hipEventRecord(ix->ev1, ix->stream));
+    if (ix->opt_profile && base == 0) PB_HIP(hipEventRecord(ix->ev1, ix->stream));
     hipLaunchKernelGGL(k_mq_rescore, dim3(nq), dim3(1024), 0, ix->stream, ix->d_rows, ix->d_ids, ix->d_norms, (int)ix->dim,
-                       ix->d_queries, ix->d_qp, ix->d_lut, ix->d_tau, ix->d_cand, ix->d_cand_cnt, ix->d_res_ids, ix->d_res_dist,
-                       ix->d_res_hdr, (uint32_t)PB_MAX_K);
+                       ix->d_queries + (size_t)base * ix->dim, ix->d_qp + base, ix->d_lut, ix->d_tau, ix->d_cand, ix->d_cand_cnt,
+                       ix->d_res_ids + (size_t)base * PB_MAX_K, ix->d_res_dist + (size_t)base * PB_MAX_K, ix->d_res_hdr + base,
+                       (uint32_t)PB_MAX_K);
     PB_HIP(hipGetLastError());
     return PB_OK;
+}
+
+bool multi_eligible(const pb_index *ix, uint32_t nq) {
+    return fast_dim(ix->dim) && ix->dim == 256 && ix->n_rows >= 65536 &&
+           (ix->opt_path == 3 || (ix->opt_path == 0 && nq >= (uint32_t)ix->opt_mq_min_queries));
 }
 
 // One chunk (<= Q_CHUNK queries, already in h_stage): run the filter path, check the certificates on the
@@ -379,8 +391,9 @@ int search_chunk(pb_index *ix, uint32_t cq, uint32_t k, double max_dist) {
     PB_HIP(hipMemcpyAsync(ix->d_qp, hp, (size_t)cq * sizeof(QParams), hipMemcpyHostToDevice, ix->stream));
     uint32_t n_sel = 0;
     // concurrent-query pass: worth it from ~8 queries on a table large enough for the sample to mean something
-    const bool use_multi = use_fast && d == 256 && ix->n_rows >= 65536 &&
-                           (ix->opt_path == 3 || (ix->opt_path == 0 && cq >= (uint32_t)ix->opt_mq_min_queries));
+    // (the host-buffer entry point routes concurrent bursts through search_block_multi; this chunk path serves
+    // the packed/device entry point and small calls)
+    const bool use_multi = use_fast && multi_eligible(ix, cq);
     if (use_fast) {
         int rc = use_multi ? run_multi(ix, cq, k) : run_fast(ix, cq);
         if (rc) return rc;
@@ -413,6 +426,73 @@ int search_chunk(pb_index *ix, uint32_t cq, uint32_t k, double max_dist) {
     return PB_OK;
 }
 
+// Concurrent-query path for a block of <= PIPE_Q queries: everything is staged and launched back to back, the
+// host waits ONCE, then re-runs the (rare) uncertified queries through the exhaustive pass.  Results land in
+// h_res_ids / h_res_dist / h_res_hdr slots [0, nq).
+int search_block_multi(pb_index *ix, const uint8_t *queries, uint32_t nq, uint32_t k, double max_dist) {
+    const uint32_t d = ix->dim;
+    uint8_t *hq = ix->h_pipe;
+    QParams *hp = reinterpret_cast<QParams *>(ix->h_pipe + (size_t)PIPE_Q * d);
+    memcpy(hq, queries, (size_t)nq * d);
+    for (uint32_t q = 0; q < nq; ++q) make_qparams(ix, hq + (size_t)q * d, k, max_dist, &hp[q]);
+    PB_HIP(hipMemcpyAsync(ix->d_queries, hq, (size_t)nq * d, hipMemcpyHostToDevice, ix->stream));
+    PB_HIP(hipMemcpyAsync(ix->d_qp, hp, (size_t)nq * sizeof(QParams), hipMemcpyHostToDevice, ix->stream));
+    uint32_t n_pass = 0;
+    for (uint32_t base = 0; base < nq; base += Q_CHUNK, ++n_pass) {
+        int rc = run_multi(ix, std::min(Q_CHUNK, nq - base), k, base);
+        if (rc) return rc;
+    }
+    PB_HIP(hipMemcpyAsync(ix->h_res_hdr, ix->d_res_hdr, nq * sizeof(ResultHdr), hipMemcpyDeviceToHost, ix->stream));
+    PB_HIP(hipMemcpyAsync(ix->h_res_ids, ix->d_res_ids, (size_t)nq * PB_MAX_K * sizeof(int64_t), hipMemcpyDeviceToHost, ix->stream));
+    PB_HIP(hipMemcpyAsync(ix->h_res_dist, ix->d_res_dist, (size_t)nq * PB_MAX_K * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
+    PB_HIP(hipStreamSynchronize(ix->stream));
+    if (ix->opt_profile) {
+        int rc2 = account_profile(ix, 1, 1);
+        if (rc2) return rc2;
+    }
+    std::vector<uint32_t> failed;
+    for (uint32_t q = 0; q < nq; ++q)
+        if (ix->h_res_hdr[q].status != 0) failed.push_back(q);
+    ix->stats.queries += nq;
+    ix->stats.fast_path += nq - failed.size();
+    ix->stats_multi += nq - failed.size();
+    // exhaustive pass for the uncertified ones, a chunk at a time (uses the chunk workspace at slot 0)
+    std::vector<int64_t> keep_ids;
+    std::vector<float> keep_dist;
+    std::vector<ResultHdr> keep_hdr;
+    for (size_t f0 = 0; f0 < failed.size(); f0 += Q_CHUNK) {
+        const uint32_t cq = (uint32_t)std::min<size_t>(Q_CHUNK, failed.size() - f0);
+        if (keep_hdr.empty()) {  // the fallback overwrites slots [0, cq): save the block's results first
+            keep_ids.assign(ix->h_res_ids, ix->h_res_ids + (size_t)nq * PB_MAX_K);
+            keep_dist.assign(ix->h_res_dist, ix->h_res_dist + (size_t)nq * PB_MAX_K);
+            keep_hdr.assign(ix->h_res_hdr, ix->h_res_hdr + nq);
+        }
+        for (uint32_t i = 0; i < cq; ++i) memcpy(ix->h_stage + (size_t)i * d, queries + (size_t)failed[f0 + i] * d, d);
+        const int saved = ix->opt_path;
+        ix->opt_path = 1;
+        const uint64_t q_before = ix->stats.queries;
+        int rc = search_chunk(ix, cq, k, max_dist);
+        ix->opt_path = saved;
+        ix->stats.queries = q_before;  // already counted above
+        if (rc) return rc;
+        PB_HIP(hipMemcpyAsync(ix->h_res_ids, ix->d_res_ids, (size_t)cq * PB_MAX_K * sizeof(int64_t), hipMemcpyDeviceToHost, ix->stream));
+        PB_HIP(hipMemcpyAsync(ix->h_res_dist, ix->d_res_dist, (size_t)cq * PB_MAX_K * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
+        PB_HIP(hipStreamSynchronize(ix->stream));
+        for (uint32_t i = 0; i < cq; ++i) {
+            const uint32_t q = failed[f0 + i];
+            keep_hdr[q] = ix->h_res_hdr[i];
+            memcpy(&keep_ids[(size_t)q * PB_MAX_K], ix->h_res_ids + (size_t)i * PB_MAX_K, PB_MAX_K * sizeof(int64_t));
+            memcpy(&keep_dist[(size_t)q * PB_MAX_K], ix->h_res_dist + (size_t)i * PB_MAX_K, PB_MAX_K * sizeof(float));
+        }
+    }
+    if (!keep_hdr.empty()) {
+        memcpy(ix->h_res_ids, keep_ids.data(), keep_ids.size() * sizeof(int64_t));
+        memcpy(ix->h_res_dist, keep_dist.data(), keep_dist.size() * sizeof(float));
+        memcpy(ix->h_res_hdr, keep_hdr.data(), keep_hdr.size() * sizeof(ResultHdr));
+    }
+    return PB_OK;
+}
+
 // results to HOST buffers
 int search_locked(pb_index *ix, const uint8_t *queries, uint32_t nq, uint32_t k, double max_dist, int64_t *out_ids,
                   float *out_dist, uint32_t *out_count) {
@@ -422,6 +502,20 @@ int search_locked(pb_index *ix, const uint8_t *queries, uint32_t nq, uint32_t k,
         return PB_OK;
     }
     PB_CHECK(ix->n_rows < (1ull << 32), PB_ERR_CAPACITY, "more than 2^32 rows per shard are not supported");
+    if (multi_eligible(ix, nq)) {
+        for (uint32_t q0 = 0; q0 < nq; q0 += PIPE_Q) {
+            const uint32_t cq = std::min(PIPE_Q, nq - q0);
+            int rc = search_block_multi(ix, queries + (size_t)q0 * d, cq, k, max_dist);
+            if (rc) return rc;
+            for (uint32_t q = 0; q < cq; ++q) {
+                const uint32_t c = ix->h_res_hdr[q].count;
+                out_count[q0 + q] = c;
+                memcpy(out_ids + (size_t)(q0 + q) * k, ix->h_res_ids + (size_t)q * PB_MAX_K, c * sizeof(int64_t));
+                memcpy(out_dist + (size_t)(q0 + q) * k, ix->h_res_dist + (size_t)q * PB_MAX_K, c * sizeof(float));
+            }
+        }
+        return PB_OK;
+    }
     for (uint32_t q0 = 0; q0 < nq; q0 += Q_CHUNK) {
         const uint32_t cq = std::min(Q_CHUNK, nq - q0);
         memcpy(ix->h_stage, queries + (size_t)q0 * d, (size_t)cq * d);
