@@ -652,8 +652,10 @@ int pb_index_create(pb_index **out, int device, uint32_t dim, uint64_t capacity_
         PB_HIP(hipMalloc(&ix->d_rows, (capacity_rows + 64) * (size_t)dim));
         PB_HIP(hipMalloc(&ix->d_ids, capacity_rows * sizeof(int64_t)));
         PB_HIP(hipMalloc(&ix->d_norms, capacity_rows * sizeof(float)));
-        PB_HIP(hipMalloc(&ix->d_sumb, (capacity_rows + 16) * sizeof(int32_t)));
-        PB_HIP(hipMalloc(&ix->d_denb, (capacity_rows + 16) * sizeof(int32_t)));
+        PB_HIP(hipMalloc(&ix->d_sumb, (capacity_rows + 32) * sizeof(int32_t)));
+        PB_HIP(hipMalloc(&ix->d_denb, (capacity_rows + 32) * sizeof(int32_t)));
+        PB_HIP(hipMemset(ix->d_sumb, 0, (capacity_rows + 32) * sizeof(int32_t)));
+        PB_HIP(hipMemset(ix->d_denb, 0, (capacity_rows + 32) * sizeof(int32_t)));
         PB_HIP(hipMalloc(&ix->d_lut, 256 * sizeof(float)));
         PB_HIP(hipMemcpy(ix->d_lut, ix->lut, 256 * sizeof(float), hipMemcpyHostToDevice));
         return alloc_workspace(ix);

@@ -781,7 +781,9 @@ __global__ __launch_bounds__(MQ_WAVES * WAVE) void k_scan_multi(
     // software pipeline: the 4 KiB of tile t+1 are requested before tile t is computed
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     auto tile_of = [&](uint64_t t) { return HIST ? t * MQ_SAMPLE : t; };
-    auto issue = [&](uint64_t tt, u32x4 (&dst)[4]) {
+    // the per-row integer norms of the tile travel with it (a dependent load after the MFMAs would expose a
+    // full memory round trip per tile); the side tables have 32 entries of zeroed slack past capacity
+    auto issue = [&](uint64_t tt, u32x4 (&dst)[4], i32x4 &sbv, i32x4 &dbv) {
         const uint64_t r0 = tt * 16;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -789,10 +791,13 @@ __global__ __launch_bounds__(MQ_WAVES * WAVE) void k_scan_multi(
             r = r < n_rows ? r : n_rows - 1;
             dst[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(rows + r * D + li * 16));
         }
+        sbv = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(sum_b + r0 + 4 * (uint64_t)kq));
+        dbv = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(den_b + r0 + 4 * (uint64_t)kq));
     };
     u32x4 ld[4];
+    i32x4 sb_n = {0, 0, 0, 0}, db_n = {1, 1, 1, 1};
     uint64_t t = (uint64_t)wave * gridDim.x + blockIdx.x;
-    if (t < n_tiles && tile_of(t) < n_tiles) issue(tile_of(t), ld);
+    if (t < n_tiles && tile_of(t) < n_tiles) issue(tile_of(t), ld, sb_n, db_n);
     for (; t < n_tiles; t += stride) {
         const uint64_t tt = tile_of(t);
         if (tt >= n_tiles) break;
@@ -800,9 +805,10 @@ __global__ __launch_bounds__(MQ_WAVES * WAVE) void k_scan_multi(
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             *reinterpret_cast<u32x4 *>(tile + (4 * j + kq) * MQ_LDROW + li * 16) = ld[j];
+        i32x4 sb = sb_n, db = db_n;
         {
             const uint64_t tn = t + stride;
-            if (tn < n_tiles && tile_of(tn) < n_tiles) issue(tile_of(tn), ld);
+            if (tn < n_tiles && tile_of(tn) < n_tiles) issue(tile_of(tn), ld, sb_n, db_n);
         }
         i32x4 acc[QT];
 #pragma unroll
@@ -818,15 +824,11 @@ __global__ __launch_bounds__(MQ_WAVES * WAVE) void k_scan_multi(
         }
         // result: lane holds rows row0 + 4 kq + r (r = 0..3) of query column li
         const uint64_t rbase = row0 + 4 * (uint64_t)kq;
-        i32x4 sb = {0, 0, 0, 0}, db = {1, 1, 1, 1};
-        if (rbase + 3 < n_rows) {
-            sb = *reinterpret_cast<const i32x4 *>(sum_b + rbase);
-            db = *reinterpret_cast<const i32x4 *>(den_b + rbase);
-        } else {  // table tail (static indices: a runtime-indexed vector would go to scratch)
-            if (rbase + 0 < n_rows) { sb.x = sum_b[rbase + 0]; db.x = den_b[rbase + 0]; }
-            if (rbase + 1 < n_rows) { sb.y = sum_b[rbase + 1]; db.y = den_b[rbase + 1]; }
-            if (rbase + 2 < n_rows) { sb.z = sum_b[rbase + 2]; db.z = den_b[rbase + 2]; }
-        }
+        // rows past the end of the table: the side-table slack may hold anything; make the divisor harmless
+        db.x = (rbase + 0 < n_rows) ? db.x : 1;
+        db.y = (rbase + 1 < n_rows) ? db.y : 1;
+        db.z = (rbase + 2 < n_rows) ? db.z : 1;
+        db.w = (rbase + 3 < n_rows) ? db.w : 1;
         if constexpr (HIST) {
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
