@@ -264,6 +264,22 @@ def bench_embed(args, torch, device, distributed):
            "scaling": "weak (replicated weights, images split by rank; no collective)",
            "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None}}
+    # the boundary as the reference's callers see it: host buffers in, host buffers out (PCIe inclusive), and
+    # the batch-1 `mlhash` latency (efficientnet.rs:31-42; engine.rs:355-358 prints this for a query image)
+    host_imgs = synth.fill_synthetic(synth.SEED_IMAGES, 0, nb * 128 * 128 * 3).reshape(nb, 128, 128, 3)
+    emb.set_option(capi.PB_OPT_STREAM, 0)
+    emb.embed(host_imgs, want_f32=False)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        emb.embed(host_imgs, want_f32=False)
+    host_ms = (time.perf_counter() - t0) * 1e3 / 3
+    emb.mlhash(host_imgs[0])
+    t0 = time.perf_counter()
+    for i in range(10):
+        emb.mlhash(host_imgs[i])
+    res["host_buffers"] = {"images_per_s": round(nb / (host_ms * 1e-3), 1), "ms_per_batch": round(host_ms, 4),
+                           "note": "pb_embed_batch: H2D of 25 MB of RGB8 + forward + D2H per 512 images, copies not overlapped"}
+    res["mlhash_latency_ms"] = round((time.perf_counter() - t0) * 1e3 / 10, 4)
     if int(os.environ.get("RANK", "0")) == 0 and not args.no_cpu_baseline:
         from oracle import capi as oracle
 
