@@ -124,6 +124,13 @@ int pb_index_fill_synthetic(pb_index *idx, uint64_t seed, uint64_t first_row, ui
 #define PB_OPT_PROFILE 2     /* 1 = bracket the scan kernel with HIP events (pb_index_get_stats) */
 #define PB_OPT_STREAM 3      /* value = hipStream_t to launch on (0 = the index's own stream) */
 #define PB_OPT_MQ_MIN_QUERIES 9 /* auto path: minimum queries per call for the concurrent-query pass */
+/* tuning knobs of the filter pass (dim 256), used by profiles/scan_sweep.py; defaults are the measured best */
+#define PB_OPT_SCAN_VARIANT 4   /* bit 0: plain instead of non-temporal loads; bits 1-2: loads in flight per lane 8/16/4; bit 3: wave-fastest tiles */
+#define PB_OPT_SCAN_WG_PER_CU 5 /* workgroups per CU (default 1) */
+#define PB_OPT_SCAN_WAVES 6     /* waves per workgroup: 16, 8 (default) or 4 */
+#define PB_OPT_SCAN_GRID 7      /* explicit grid size (0 = workgroups per CU x CUs) */
+#define PB_OPT_SCAN_LAUNCH 8    /* 0 (default): one launch per query = one HBM pass each; 1: one launch for the chunk (queries share reads through the caches) */
+#define PB_OPT_MQ_WG_PER_CU 10  /* concurrent-query pass: workgroups per CU (default 2) */
 int pb_index_set_option(pb_index *idx, int option, int64_t value);
 
 typedef struct pb_scan_stats {

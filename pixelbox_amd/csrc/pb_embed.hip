@@ -41,6 +41,11 @@ struct Block {
     float *se_w2t = nullptr, *se_b2 = nullptr;         // [sp][e], [e]
 };
 
+struct DwGeom {
+    int roll;  // 0: strip kernel (k_dwconv), 1: rolling-window kernel (k_dwconv_roll)
+    int zsplit, cqpb, slots, n_tiles, strips_per_tile;  // for roll: slots = strips_x, strips_per_tile = rows per band
+};
+
 }  // namespace
 
 struct pb_embedder {
@@ -60,6 +65,7 @@ struct pb_embedder {
     uint8_t *d_out_u8 = nullptr;
     int n_cu = 256;
     std::map<std::pair<const void *, long>, std::pair<int, int>> gemm_cfg;  // (layer weights, rows) -> (MR, NR), measured
+    std::map<std::pair<const void *, long>, DwGeom> dw_cfg;      // (layer weights, batch) -> depthwise form, measured
     std::mutex mu;
 };
 
@@ -261,12 +267,10 @@ int launch_gemm(pb_embedder *e, const float *act, long M, const Gemm &g, const f
     return PB_OK;
 }
 
-struct DwGeom {
-    int zsplit, cqpb, slots, n_tiles, strips_per_tile;
-};
 // strips = rows x ceil(Wo / 4) groups of 4 adjacent output pixels (k_dwconv's register tile)
 DwGeom dw_geom(int C, int ho, int wo, int batch, int n_cu) {
     DwGeom g;
+    g.roll = 0;
     const int cq = C / 4;
     // channel quads per block: the largest divisor of C/4 that is <= 32 -- keeps the block's filter taps in
     // LDS small (25 taps x 32 quads x 16 B = 12.8 KB) relative to the activations it streams
@@ -284,21 +288,90 @@ DwGeom dw_geom(int C, int ho, int wo, int batch, int n_cu) {
     g.n_tiles = (n_strips + g.strips_per_tile - 1) / g.strips_per_tile;
     return g;
 }
+// rolling-window geometry; returns roll = 0 when the map is too narrow to be worth it
+DwGeom dw_geom_roll(int C, int k, int ho, int wo, int batch, int n_cu) {
+    DwGeom g = dw_geom(C, ho, wo, batch, n_cu);
+    const int tx = k == 3 ? 4 : 2;
+    if (wo < 16) return g;
+    const int cq = C / 4;
+    const int strips_x = (wo + tx - 1) / tx;
+    if (strips_x > 256) return g;
+    int cqpb = 1;
+    for (int dv = 1; dv <= cq; ++dv)
+        if (cq % dv == 0 && dv * strips_x <= 256 && dv <= 32) cqpb = dv;
+    g.roll = 1;
+    g.cqpb = cqpb;
+    g.zsplit = cq / cqpb;
+    g.slots = strips_x;
+    const long want = (4L * n_cu + (long)batch * g.zsplit - 1) / ((long)batch * g.zsplit);
+    g.n_tiles = (int)std::max<long>(1, std::min<long>(std::min(32, std::max(1, ho / 4)), want));
+    g.strips_per_tile = (ho + g.n_tiles - 1) / g.n_tiles;  // rows per band
+    g.n_tiles = (ho + g.strips_per_tile - 1) / g.strips_per_tile;
+    return g;
+}
 
-int launch_dw(pb_embedder *e, const Block &bl, const float *in, int B, int H, int W, float *out, int Ho, int Wo,
-              const DwGeom &g) {
+int launch_dw_geom(pb_embedder *e, const Block &bl, const float *in, int B, int H, int W, float *out, int Ho, int Wo,
+                   const DwGeom &g) {
     dim3 grid(g.n_tiles, B, g.zsplit), block(g.cqpb * g.slots);
     const size_t lds = (size_t)bl.k * bl.k * g.cqpb * 16;  // filter taps of this block's channel quads
+    if (!g.roll) {
 #define PB_DW(KS, S)                                                                                            \
     hipLaunchKernelGGL((k_dwconv<KS, S>), grid, block, lds, e->stream, in, H, W, bl.e, bl.dw_w, bl.dw_b, out, Ho, Wo, \
                        g.strips_per_tile, e->buf_part, g.n_tiles, g.cqpb)
-    if (bl.k == 3 && bl.stride == 1) PB_DW(3, 1);
-    else if (bl.k == 3 && bl.stride == 2) PB_DW(3, 2);
-    else if (bl.k == 5 && bl.stride == 1) PB_DW(5, 1);
-    else PB_DW(5, 2);
+        if (bl.k == 3 && bl.stride == 1) PB_DW(3, 1);
+        else if (bl.k == 3 && bl.stride == 2) PB_DW(3, 2);
+        else if (bl.k == 5 && bl.stride == 1) PB_DW(5, 1);
+        else PB_DW(5, 2);
 #undef PB_DW
+    } else {
+#define PB_DWR(KS, S, TX)                                                                                            \
+    hipLaunchKernelGGL((k_dwconv_roll<KS, S, TX>), grid, block, lds, e->stream, in, H, W, bl.e, bl.dw_w, bl.dw_b, out, Ho, \
+                       Wo, g.strips_per_tile, e->buf_part, g.n_tiles, g.cqpb)
+        if (bl.k == 3 && bl.stride == 1) PB_DWR(3, 1, 4);
+        else if (bl.k == 3 && bl.stride == 2) PB_DWR(3, 2, 4);
+        else if (bl.k == 5 && bl.stride == 1) PB_DWR(5, 1, 2);
+        else PB_DWR(5, 2, 2);
+#undef PB_DWR
+    }
     PB_HIP(hipGetLastError());
     return PB_OK;
+}
+
+// Depthwise launch; the kernel form (strip vs rolling window) is measured per (layer, batch) at first use.
+int launch_dw(pb_embedder *e, const Block &bl, const float *in, int B, int H, int W, float *out, int Ho, int Wo,
+              DwGeom *used) {
+    const std::pair<const void *, long> key(bl.dw_w, (long)B);
+    auto it = e->dw_cfg.find(key);
+    if (it == e->dw_cfg.end()) {
+        DwGeom cands[2] = {dw_geom(bl.e, Ho, Wo, B, e->n_cu), dw_geom_roll(bl.e, bl.k, Ho, Wo, B, e->n_cu)};
+        int best = 0;
+        if (cands[1].roll) {
+            float best_ms = 1e30f;
+            hipEvent_t e0, e1;
+            PB_HIP(hipEventCreate(&e0));
+            PB_HIP(hipEventCreate(&e1));
+            for (int c = 0; c < 2; ++c) {
+                int rc = launch_dw_geom(e, bl, in, B, H, W, out, Ho, Wo, cands[c]);
+                if (rc) return rc;
+                PB_HIP(hipEventRecord(e0, e->stream));
+                for (int rep = 0; rep < 2; ++rep)
+                    if ((rc = launch_dw_geom(e, bl, in, B, H, W, out, Ho, Wo, cands[c]))) return rc;
+                PB_HIP(hipEventRecord(e1, e->stream));
+                PB_HIP(hipEventSynchronize(e1));
+                float ms = 0.f;
+                PB_HIP(hipEventElapsedTime(&ms, e0, e1));
+                if (ms < best_ms) {
+                    best_ms = ms;
+                    best = c;
+                }
+            }
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+        }
+        it = e->dw_cfg.emplace(key, cands[best]).first;
+    }
+    *used = it->second;
+    return launch_dw_geom(e, bl, in, B, H, W, out, Ho, Wo, it->second);
 }
 
 // forward for n images already on the device; results to device buffers
@@ -322,8 +395,8 @@ int forward_device(pb_embedder *e, const uint8_t *d_rgb, int n, uint8_t *d_u8, f
             ein = e->buf_e;
         }
         const int Ho = (H + bl.stride - 1) / bl.stride, Wo = (W + bl.stride - 1) / bl.stride;
-        const DwGeom g = dw_geom(bl.e, Ho, Wo, n, e->n_cu);
-        if ((rc = launch_dw(e, bl, ein, n, H, W, e->buf_dw, Ho, Wo, g))) return rc;
+        DwGeom g;
+        if ((rc = launch_dw(e, bl, ein, n, H, W, e->buf_dw, Ho, Wo, &g))) return rc;
 #define PB_SE(SPV)                                                                                                 \
     hipLaunchKernelGGL((k_se<SPV>), dim3(n), dim3(256), 0, e->stream, e->buf_part, g.n_tiles, bl.e, 1.0f / (float)(Ho * Wo), \
                        bl.se_w1, bl.se_b1, bl.se_w2t, bl.se_b2, e->buf_gate)
@@ -397,8 +470,7 @@ int pb_embed_create(pb_embedder **out, int device, const void *weights_blob, siz
             if (bl.has_expand) max_e = std::max(max_e, h * w * bl.e);
             max_dw = std::max(max_dw, ho * wo * bl.e);
             max_x = std::max(max_x, ho * wo * (size_t)bl.cout);
-            const DwGeom g = dw_geom(bl.e, (int)ho, (int)wo, 1, e->n_cu);  // batch 1 gives the most tiles
-            max_part = std::max(max_part, (size_t)g.n_tiles * bl.e);
+            max_part = std::max(max_part, (size_t)32 * bl.e);  // both depthwise forms use at most 32 tiles / bands
             h = ho;
             w = wo;
         }

@@ -354,6 +354,102 @@ __global__ __launch_bounds__(256) void k_dwconv(const float *__restrict__ in, in
 }
 
 // ------------------------------------------------------------------------------------------------
+// depthwise conv, rolling-window form for the large early maps: a thread owns a COLUMN strip of TX adjacent
+// outputs for one channel quad and walks down the rows of its band keeping the KS x ((TX-1)*S+KS) input window
+// in registers -- every new output row loads only S new input rows (3x3 s1: 1.5 float4 loads per output quad
+// instead of 4.5; 5x5 s1: 3 instead of 10).  Same accumulation order (ky, kx), same fused bias + SiLU + SE
+// partial sums as k_dwconv.  grid = (bands, B, zsplit); blockDim = cq_per_block * strips_x.
+template <int KS, int S, int TX>
+__global__ __launch_bounds__(256) void k_dwconv_roll(const float *__restrict__ in, int H, int W, int C,
+                                                     const float *__restrict__ w, const float *__restrict__ bias,
+                                                     float *__restrict__ out, int Ho, int Wo, int rows_per_band,
+                                                     float *__restrict__ part, int n_bands, int cq_per_block) {
+    constexpr int PAD = (KS - 1) / 2;
+    constexpr int NX = (TX - 1) * S + KS;
+    __shared__ f32x4 s_red[256];
+    extern __shared__ f32x4 s_wt[];  // [KS*KS][cq_per_block]
+    const int strips_x = blockDim.x / cq_per_block;
+    const int cq_l = threadIdx.x % cq_per_block;
+    const int sx = threadIdx.x / cq_per_block;
+    const int cq = blockIdx.z * cq_per_block + cq_l;
+    const int b = blockIdx.y;
+    const int band = blockIdx.x;
+    const int c0 = cq * 4;
+    for (int i = threadIdx.x; i < KS * KS * cq_per_block; i += blockDim.x) {
+        const int t = i / cq_per_block, q = i % cq_per_block;
+        s_wt[i] = *reinterpret_cast<const f32x4 *>(w + (size_t)t * C + (blockIdx.z * cq_per_block + q) * 4);
+    }
+    __syncthreads();
+    const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + c0);
+    const float *ib = in + (size_t)b * H * W * C + c0;
+    float *ob = out + (size_t)b * Ho * Wo * C + c0;
+    const int x0 = sx * TX;
+    const int ix0 = x0 * S - PAD;
+    const int y_begin = band * rows_per_band;
+    const int y_end = (y_begin + rows_per_band) < Ho ? (y_begin + rows_per_band) : Ho;
+    f32x4 psum = {0.f, 0.f, 0.f, 0.f};
+    f32x4 win[KS][NX];
+    auto load_row = [&](int iy, f32x4 (&dst)[NX]) {
+        const bool rv = iy >= 0 && iy < H;
+        const float *rowp = ib + (size_t)(rv ? iy : 0) * W * C;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const int ix = ix0 + j;
+            dst[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (rv && ix >= 0 && ix < W) dst[j] = *reinterpret_cast<const f32x4 *>(rowp + (size_t)ix * C);
+        }
+    };
+    if (y_begin < y_end && x0 < Wo) {
+#pragma unroll
+        for (int r = 0; r < KS; ++r) load_row(y_begin * S - PAD + r, win[r]);
+        for (int y = y_begin; y < y_end; ++y) {
+            f32x4 acc[TX];
+#pragma unroll
+            for (int t = 0; t < TX; ++t) acc[t] = bv;
+#pragma unroll
+            for (int ky = 0; ky < KS; ++ky) {
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx) {
+                    const f32x4 wv = s_wt[(ky * KS + kx) * cq_per_block + cq_l];
+#pragma unroll
+                    for (int t = 0; t < TX; ++t) {
+                        const f32x4 v = win[ky][t * S + kx];
+                        const float p0 = v.x * wv.x, p1 = v.y * wv.y, p2 = v.z * wv.z, p3 = v.w * wv.w;
+                        acc[t].x = acc[t].x + p0; acc[t].y = acc[t].y + p1; acc[t].z = acc[t].z + p2; acc[t].w = acc[t].w + p3;
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < TX; ++t) {
+                if (x0 + t < Wo) {
+                    f32x4 o = {silu_f(acc[t].x), silu_f(acc[t].y), silu_f(acc[t].z), silu_f(acc[t].w)};
+                    *reinterpret_cast<f32x4 *>(ob + ((size_t)y * Wo + x0 + t) * C) = o;
+                    psum.x = psum.x + o.x; psum.y = psum.y + o.y; psum.z = psum.z + o.z; psum.w = psum.w + o.w;
+                }
+            }
+            if (y + 1 < y_end) {  // slide the window down by S rows
+#pragma unroll
+                for (int r = 0; r + S < KS; ++r)
+#pragma unroll
+                    for (int j = 0; j < NX; ++j) win[r][j] = win[r + S][j];
+#pragma unroll
+                for (int r = (KS - S > 0 ? KS - S : 0); r < KS; ++r) load_row((y + 1) * S - PAD + r, win[r]);
+            }
+        }
+    }
+    s_red[threadIdx.x] = psum;
+    __syncthreads();
+    if (sx == 0) {
+        f32x4 t = s_red[cq_l];
+        for (int sl = 1; sl < strips_x; ++sl) {
+            const f32x4 o = s_red[sl * cq_per_block + cq_l];
+            t.x = t.x + o.x; t.y = t.y + o.y; t.z = t.z + o.z; t.w = t.w + o.w;
+        }
+        *reinterpret_cast<f32x4 *>(part + ((size_t)b * n_bands + band) * C + c0) = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // squeeze-excite gates for one image per block: mean over pixels (sum of the tile partials in order),
 // FC(E->S)+SiLU, FC(S->E)+sigmoid.  w1: [S][E]; w2t: [S][E] (transposed se_expand); gate: [B][E].
 // FC1 is organised so that every global load is independent (thread t owns channels t, t+256, ... and keeps

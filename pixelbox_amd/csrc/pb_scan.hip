@@ -845,29 +845,29 @@ int pb_index_set_option(pb_index *ix, int option, int64_t value) {
         case PB_OPT_STREAM:
             ix->stream = value ? reinterpret_cast<hipStream_t>(value) : ix->own_stream;
             return PB_OK;
-        case 4:  // PB_OPT_SCAN_VARIANT (experiments)
+        case PB_OPT_SCAN_VARIANT:
             ix->opt_variant = (int)value;
             return PB_OK;
-        case 5:  // PB_OPT_SCAN_WG_PER_CU (experiments)
+        case PB_OPT_SCAN_WG_PER_CU:
             PB_CHECK(value >= 1 && value <= 8, PB_ERR_INVALID, "workgroups per CU: 1..8");
             ix->opt_wg_per_cu = (int)value;
             return PB_OK;
-        case 9:  // PB_OPT_MQ_MIN_QUERIES
+        case PB_OPT_MQ_MIN_QUERIES:
             PB_CHECK(value >= 1, PB_ERR_INVALID, "min queries >= 1");
             ix->opt_mq_min_queries = (int)value;
             return PB_OK;
-        case 10:  // multi-query pass: workgroups per CU
+        case PB_OPT_MQ_WG_PER_CU:
             PB_CHECK(value >= 1 && value <= 8, PB_ERR_INVALID, "1..8");
             ix->opt_mq_wg_per_cu = (int)value;
             return PB_OK;
-        case 8:  // launch mode
+        case PB_OPT_SCAN_LAUNCH:
             PB_CHECK(value == 0 || value == 1, PB_ERR_INVALID, "scan mode: 0 or 1");
             ix->opt_mode = (int)value;
             return PB_OK;
-        case 7:  // explicit grid (experiments)
+        case PB_OPT_SCAN_GRID:
             ix->opt_grid = (int)value;
             return PB_OK;
-        case 6:  // PB_OPT_SCAN_WAVES (experiments)
+        case PB_OPT_SCAN_WAVES:
             PB_CHECK(value == 16 || value == 8 || value == 4, PB_ERR_INVALID, "waves per workgroup: 16, 8 or 4");
             ix->opt_waves = (int)value;
             return PB_OK;

@@ -7,7 +7,8 @@ import sys
 def main(path):
     rows = list(csv.DictReader(open(path)))
     idx = [i for i, r in enumerate(rows) if "k_stem" in r["Kernel_Name"]]
-    s = idx[-1]
+    big = max(int(rows[i]["Grid_Size_X"]) for i in idx)
+    s = [i for i in idx if int(rows[i]["Grid_Size_X"]) == big][-1]  # last forward of the largest batch
     tot, by = 0.0, {}
     for r in rows[s : s + 80]:
         n = r["Kernel_Name"]
