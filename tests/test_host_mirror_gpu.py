@@ -117,3 +117,22 @@ def test_sqlite_persistence_bridge(tmp_path):
     assert [bytes(got[i]) for i in new_ids] == [r.tobytes() for r in new]
     assert conn.execute("SELECT COUNT(*) FROM images").fetchone()[0] == n + 3
     conn.close()
+
+
+def test_micro_batching_front_end(tmp_path):
+    """concurrent blocking mlhash() callers are transparently batched; every hash equals the
+    plain batched result and batches larger than one do form."""
+    n, h, w, d = 256, 64, 64, 16
+    blob = W.synthetic_blob(synth.SEED_WEIGHTS, h, w, d)
+    imgs = synth.synthetic_images(synth.SEED_IMAGES, 0, n, h, w)
+    (tmp_path / "w.pbxw").write_bytes(blob)
+    (tmp_path / "imgs.u8").write_bytes(imgs.tobytes())
+    exe = tmp_path / "batching"
+    libdir = os.path.dirname(capi.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "batching_demo.cpp"), "-o", str(exe),
+                           "-L", libdir, "-lpixelbox_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.check_output([str(exe), str(tmp_path / "w.pbxw"), str(tmp_path / "imgs.u8"), str(n), "8"], text=True)
+    f = dict(zip(out.split()[::2], out.split()[1::2]))
+    assert f["mismatches"] == "0" and int(f["images"]) == n
+    assert float(f["mean_batch"]) > 1.5, out  # 8 concurrent callers: requests do pile up into batches
