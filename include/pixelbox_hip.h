@@ -56,6 +56,15 @@ typedef struct pb_index pb_index;
  * does not enforce blob length (engine.rs:585 zip-truncates) -- documented deviation: other lengths
  * are rejected.  `device` is the HIP device ordinal. */
 int pb_index_create(pb_index **out, int device, uint32_t dim, uint64_t capacity_rows);
+/* Same table for the reference's other two blob distances: the `phashes` table has
+ * the semantic_hashes schema (engine.rs:106-109) and the UDFs byte_distance / hamming_distance are registered
+ * beside cosine_distance (engine.rs:124-128, 590-604, 624-663).  Queries on such an index return
+ * `<udf>(?, hash) AS dist ... WHERE dist < ? ORDER BY dist ASC LIMIT k` with the reference's f32 value
+ * (hamming keeps its u8 wrap-around, engine.rs:603).  These metrics use the exhaustive exact pass. */
+#define PB_METRIC_COSINE 0
+#define PB_METRIC_BYTE 1
+#define PB_METRIC_HAMMING 2
+int pb_index_create_metric(pb_index **out, int device, uint32_t dim, uint64_t capacity_rows, int metric);
 int pb_index_destroy(pb_index *idx);
 int pb_index_size(const pb_index *idx, uint64_t *n_rows);
 int pb_index_dim(const pb_index *idx, uint32_t *dim);

@@ -42,6 +42,8 @@ def lib():
         L.pbo_quantize.argtypes = [f32p, C.c_size_t, u8p]
         L.pbo_scan_topk.argtypes = [u8p, u8p, i64p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_double, i64p, f32p]
         L.pbo_scan_topk.restype = C.c_size_t
+        L.pbo_scan_topk_metric.argtypes = [C.c_int, u8p, u8p, i64p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_double, i64p, f32p]
+        L.pbo_scan_topk_metric.restype = C.c_size_t
         L.pbo_scan_all.argtypes = [u8p, u8p, C.c_size_t, C.c_size_t, f32p]
         L.pbo_fill_synthetic.argtypes = [C.c_uint64, C.c_uint64, C.c_size_t, u8p]
         L.pbo_effnet_forward.argtypes = [u8p, C.c_size_t, u8p, f32p]
@@ -112,6 +114,19 @@ def scan_topk(query, rows, ids=None, k=100, max_dist=1e3):
     out_d = np.empty(k, dtype=np.float32)
     cnt = lib().pbo_scan_topk(_u8(query), _u8(rows), _i64(ids) if ids is not None else None, n, d, k,
                               float(max_dist), _i64(out_ids), _f32(out_d))
+    return out_ids[:cnt].copy(), out_d[:cnt].copy()
+
+
+def scan_topk_metric(metric, query, rows, ids=None, k=100, max_dist=1e3):
+    query = np.ascontiguousarray(query, dtype=np.uint8)
+    rows = np.ascontiguousarray(rows, dtype=np.uint8)
+    n, d = rows.shape
+    if ids is not None:
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+    out_ids = np.empty(k, dtype=np.int64)
+    out_d = np.empty(k, dtype=np.float32)
+    cnt = lib().pbo_scan_topk_metric(metric, _u8(query), _u8(rows), _i64(ids) if ids is not None else None, n, d, k,
+                                     float(max_dist), _i64(out_ids), _f32(out_d))
     return out_ids[:cnt].copy(), out_d[:cnt].copy()
 
 

@@ -175,6 +175,36 @@ size_t pbo_scan_topk(const uint8_t *query, const uint8_t *rows, const int64_t *i
     return cnt;
 }
 
+/* the same query shape with byte_distance / hamming_distance as the UDF (engine.rs:590-604, 624-663) */
+size_t pbo_scan_topk_metric(int metric, const uint8_t *query, const uint8_t *rows, const int64_t *ids, size_t n, size_t d,
+                            size_t k, double max_dist, int64_t *out_ids, float *out_dist) {
+    if (metric == 0) return pbo_scan_topk(query, rows, ids, n, d, k, max_dist, out_ids, out_dist);
+    if (k == 0) return 0;
+    pbo_hit *best = (pbo_hit *)malloc(sizeof(pbo_hit) * k);
+    size_t cnt = 0;
+    for (size_t r = 0; r < n; ++r) {
+        float dist = metric == 1 ? pbo_byte_distance(query, d, rows + r * d, d) : pbo_hamming_distance(query, d, rows + r * d, d);
+        if (!((double)dist < max_dist)) continue;
+        pbo_hit h;
+        h.dist = dist;
+        h.id = ids ? ids[r] : (int64_t)r;
+        if (cnt == k && !hit_less(&h, &best[k - 1])) continue;
+        size_t pos = cnt < k ? cnt : k - 1;
+        while (pos > 0 && hit_less(&h, &best[pos - 1])) {
+            if (pos < k) best[pos] = best[pos - 1];
+            --pos;
+        }
+        best[pos] = h;
+        if (cnt < k) ++cnt;
+    }
+    for (size_t i = 0; i < cnt; ++i) {
+        out_ids[i] = best[i].id;
+        out_dist[i] = best[i].dist;
+    }
+    free(best);
+    return cnt;
+}
+
 /* ---- synthetic data -------------------------------------------------------- */
 uint64_t pbo_splitmix64_at(uint64_t seed, uint64_t word_index) {
     uint64_t z = seed + (word_index + 1ull) * 0x9E3779B97F4A7C15ull;

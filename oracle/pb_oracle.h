@@ -57,6 +57,10 @@ size_t pbo_scan_topk(const uint8_t *query, const uint8_t *rows, const int64_t *i
                      size_t n, size_t d, size_t k, double max_dist,
                      int64_t *out_ids, float *out_dist);
 
+/* metric: 0 cosine, 1 byte_distance, 2 hamming_distance -- the same query with another UDF */
+size_t pbo_scan_topk_metric(int metric, const uint8_t *query, const uint8_t *rows, const int64_t *ids, size_t n, size_t d,
+                            size_t k, double max_dist, int64_t *out_ids, float *out_dist);
+
 /* All n distances (for tests that need the full distance vector). */
 void pbo_scan_all(const uint8_t *query, const uint8_t *rows, size_t n, size_t d, float *out_dist);
 

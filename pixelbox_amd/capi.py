@@ -18,12 +18,13 @@ PB_MAX_K = 256
 PB_OPT_SEARCH_PATH = 1
 PB_OPT_PROFILE = 2
 PB_OPT_STREAM = 3
+PB_METRIC_COSINE, PB_METRIC_BYTE, PB_METRIC_HAMMING = 0, 1, 2
 
 # every symbol include/pixelbox_hip.h declares (tests/test_abi.py checks the header against this list
 # and the built library against both)
 SYMBOLS = [
     "pb_last_error", "pb_version", "pb_device_count",
-    "pb_index_create", "pb_index_destroy", "pb_index_size", "pb_index_dim", "pb_index_append", "pb_index_load",
+    "pb_index_create", "pb_index_create_metric", "pb_index_destroy", "pb_index_size", "pb_index_dim", "pb_index_append", "pb_index_load",
     "pb_index_search", "pb_index_search_device", "pb_index_search_packed", "pb_topk_merge_packed", "pb_topk_merge", "pb_index_read", "pb_index_fill_synthetic",
     "pb_index_set_option", "pb_index_get_stats",
     "pb_embed_create", "pb_embed_destroy", "pb_embed_info", "pb_embed_batch", "pb_embed_batch_device", "pb_mlhash",
@@ -67,6 +68,7 @@ def lib():
         L.pb_last_error.restype = C.c_char_p
         L.pb_device_count.argtypes = [C.POINTER(C.c_int)]
         L.pb_index_create.argtypes = [C.POINTER(vp), C.c_int, C.c_uint32, C.c_uint64]
+        L.pb_index_create_metric.argtypes = [C.POINTER(vp), C.c_int, C.c_uint32, C.c_uint64, C.c_int]
         L.pb_index_destroy.argtypes = [vp]
         L.pb_index_size.argtypes = [vp, u64p]
         L.pb_index_dim.argtypes = [vp, u32p]
@@ -148,11 +150,11 @@ def pack_results(ids: np.ndarray, dist: np.ndarray, cnt: np.ndarray) -> np.ndarr
 class Index:
     """Device-resident `semantic_hashes` table (reference: engine.rs:48,109,251-256,363-396)."""
 
-    def __init__(self, dim: int, capacity_rows: int, device: int = 0):
+    def __init__(self, dim: int, capacity_rows: int, device: int = 0, metric: int = 0):
         self._h = C.c_void_p()
         self.dim = dim
         self.device = device
-        _check(lib().pb_index_create(C.byref(self._h), device, dim, capacity_rows))
+        _check(lib().pb_index_create_metric(C.byref(self._h), device, dim, capacity_rows, metric))
 
     def close(self):
         if self._h:

@@ -37,6 +37,7 @@ bool fast_dim(uint32_t d) { return d >= 16 && d <= 1024 && (d & (d - 1)) == 0; }
 
 struct pb_index {
     int device = 0;
+    int metric = 0;  // PB_METRIC_*
     uint32_t dim = 0;
     uint64_t capacity = 0;
     uint64_t n_rows = 0;
@@ -291,9 +292,14 @@ int run_exact(pb_index *ix, uint32_t n_sel, uint32_t k) {
     const uint64_t want = (n_tiles + X_WAVES - 1) / X_WAVES;
     int n_lists = (int)std::max<uint64_t>(1, std::min<uint64_t>(want, X_MAX_WG));
     if (ix->opt_profile && ix->opt_path == 1) PB_HIP(hipEventRecord(ix->ev0, ix->stream));
-    hipLaunchKernelGGL(k_scan_exact, dim3(n_lists, n_sel), dim3(X_BLOCK), 0, ix->stream, ix->d_rows, ix->d_norms,
-                       ix->n_rows, (int)ix->dim, ix->d_queries, ix->d_qp, ix->d_qsel, ix->d_lut, ix->d_xlists[0],
-                       ix->d_xcounts[0], (uint32_t)PB_MAX_K);
+#define PB_X(MV)                                                                                                   \
+    hipLaunchKernelGGL((k_scan_exact<MV>), dim3(n_lists, n_sel), dim3(X_BLOCK), 0, ix->stream, ix->d_rows, ix->d_norms, \
+                       ix->n_rows, (int)ix->dim, ix->d_queries, ix->d_qp, ix->d_qsel, ix->d_lut, ix->d_xlists[0],  \
+                       ix->d_xcounts[0], (uint32_t)PB_MAX_K)
+    if (ix->metric == 1) PB_X(1);
+    else if (ix->metric == 2) PB_X(2);
+    else PB_X(0);
+#undef PB_X
     PB_HIP(hipGetLastError());
     if (ix->opt_profile && ix->opt_path == 1) PB_HIP(hipEventRecord(ix->ev1, ix->stream));
     int cur = 0;
@@ -372,7 +378,7 @@ int run_multi(pb_index *ix, uint32_t nq, uint32_t k, uint32_t base = 0) {
 }
 
 bool multi_eligible(const pb_index *ix, uint32_t nq) {
-    return fast_dim(ix->dim) && ix->dim == 256 && ix->n_rows >= 65536 &&
+    return ix->metric == 0 && fast_dim(ix->dim) && ix->dim == 256 && ix->n_rows >= 65536 &&
            (ix->opt_path == 3 || (ix->opt_path == 0 && nq >= (uint32_t)ix->opt_mq_min_queries));
 }
 
@@ -385,7 +391,7 @@ int search_chunk(pb_index *ix, uint32_t cq, uint32_t k, double max_dist) {
     uint8_t *hq = ix->h_stage;
     QParams *hp = reinterpret_cast<QParams *>(ix->h_stage + (size_t)Q_CHUNK * d);
     uint32_t *hsel = reinterpret_cast<uint32_t *>(ix->h_stage + (size_t)Q_CHUNK * (d + sizeof(QParams)));
-    const bool use_fast = (ix->opt_path == 0 || ix->opt_path == 2 || ix->opt_path == 3) && fast_dim(d);
+    const bool use_fast = ix->metric == 0 && (ix->opt_path == 0 || ix->opt_path == 2 || ix->opt_path == 3) && fast_dim(d);
     for (uint32_t q = 0; q < cq; ++q) make_qparams(ix, hq + (size_t)q * d, k, max_dist, &hp[q]);
     PB_HIP(hipMemcpyAsync(ix->d_queries, hq, (size_t)cq * d, hipMemcpyHostToDevice, ix->stream));
     PB_HIP(hipMemcpyAsync(ix->d_qp, hp, (size_t)cq * sizeof(QParams), hipMemcpyHostToDevice, ix->stream));
@@ -667,6 +673,14 @@ int pb_index_create(pb_index **out, int device, uint32_t dim, uint64_t capacity_
         return rc;
     }
     *out = ix;
+    return PB_OK;
+}
+
+int pb_index_create_metric(pb_index **out, int device, uint32_t dim, uint64_t capacity_rows, int metric) {
+    PB_CHECK(metric >= PB_METRIC_COSINE && metric <= PB_METRIC_HAMMING, PB_ERR_INVALID, "pb_index_create_metric: metric %d", metric);
+    int rc = pb_index_create(out, device, dim, capacity_rows);
+    if (rc) return rc;
+    (*out)->metric = metric;
     return PB_OK;
 }
 

@@ -596,6 +596,28 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
 // ------------------------------------------------------------------------------------------------
 // (2) exhaustive exact scan: one row per lane, every row re-scored with the reference arithmetic.
 // qsel[blockIdx.y] = index of the query to run (the host compacts the queries that need this pass).
+// METRIC 0: cosine_distance (engine.rs:572-588); 1: byte_distance (engine.rs:590-592); 2: hamming_distance
+// (engine.rs:594-604, including its `.sum::<u8>()` wrap-around).  The integer sums of 1 and 2 are exact in f32
+// (<= 255 * 1024 < 2^24), so only the final correctly rounded divide touches floating point.
+__device__ __forceinline__ float ref_byte_or_hamming(const uint8_t *__restrict__ row, const uint8_t *__restrict__ q,
+                                                      int d, int metric) {
+    uint32_t acc = 0;
+    int i = 0;
+    for (; i + 4 <= d; i += 4) {
+        uint32_t a, b;
+        __builtin_memcpy(&a, q + i, 4);
+        __builtin_memcpy(&b, row + i, 4);
+        acc = metric == 1 ? __builtin_amdgcn_sad_u8(a, b, acc) : acc + __popc(a ^ b);
+    }
+    for (; i < d; ++i) {
+        const uint32_t a = q[i], b = row[i];
+        acc += metric == 1 ? (a > b ? a - b : b - a) : __popc(a ^ b);
+    }
+    if (metric == 1) return (float)acc / (255.0f * (float)d);
+    return (float)(acc & 0xFFu) / (8.0f * (float)d);
+}
+
+template <int METRIC>
 __global__ __launch_bounds__(X_BLOCK) void k_scan_exact(
     const uint8_t *__restrict__ rows, const float *__restrict__ norms, uint64_t n_rows, int d,
     const uint8_t *__restrict__ queries, const QParams *__restrict__ qp, const uint32_t *__restrict__ qsel,
@@ -603,6 +625,7 @@ __global__ __launch_bounds__(X_BLOCK) void k_scan_exact(
     uint32_t list_stride) {
     __shared__ float s_lut[256];
     __shared__ float s_qf[1024];
+    __shared__ __attribute__((aligned(4))) uint8_t s_qb[1024];
     __shared__ uint64_t s_buf[X_WAVES][X_MAXE * WAVE];
     __shared__ int s_cnt[X_WAVES];
     const int q = (int)qsel[blockIdx.y];
@@ -611,7 +634,10 @@ __global__ __launch_bounds__(X_BLOCK) void k_scan_exact(
     const int wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < 256; i += X_BLOCK) s_lut[i] = lut[i];
     __syncthreads();
-    for (int i = threadIdx.x; i < d; i += X_BLOCK) s_qf[i] = s_lut[queries[(size_t)q * d + i]];
+    for (int i = threadIdx.x; i < d; i += X_BLOCK) {
+        s_qb[i] = queries[(size_t)q * d + i];
+        s_qf[i] = s_lut[s_qb[i]];
+    }
     __syncthreads();
     uint64_t *buf = s_buf[wave];
     const int K = (int)P.k;
@@ -623,9 +649,14 @@ __global__ __launch_bounds__(X_BLOCK) void k_scan_exact(
         const uint64_t r = t * WAVE + lane;
         uint64_t key = ~0ull;
         if (r < n_rows) {
-            const float dot = ref_fold_dot(rows + r * (uint64_t)d, s_qf, s_lut, d);
-            float cs;
-            const float dist = ref_distance(dot, P.sqrt_sa, norms[r], &cs);
+            float dist;
+            if constexpr (METRIC == 0) {
+                const float dot = ref_fold_dot(rows + r * (uint64_t)d, s_qf, s_lut, d);
+                float cs;
+                dist = ref_distance(dot, P.sqrt_sa, norms[r], &cs);
+            } else {
+                dist = ref_byte_or_hamming(rows + r * (uint64_t)d, s_qb, d, METRIC);
+            }
             if ((double)dist < P.max_dist) key = ((uint64_t)sortable_f32(dist) << 32) | (uint32_t)r;
         }
         const bool pass = key < thr_key;

@@ -461,3 +461,30 @@ def test_concurrent_callers_like_the_reference_threads():
     assert not errors, errors
     assert len(ix) == 20000
     check_against_oracle(ix, rows, ids, rows[[3, 15000]])
+
+
+# ---- the reference's other two blob distances over a phashes-like table -------------------
+@pytest.mark.parametrize("metric", [capi.PB_METRIC_BYTE, capi.PB_METRIC_HAMMING])
+@pytest.mark.parametrize("d", [32, 2, 33, 256])
+def test_byte_and_hamming_scans(metric, d):
+    rng = np.random.default_rng(90 + d + metric)
+    n = 30000
+    rows = rng.integers(0, 256, size=(n, d), dtype=np.uint8)
+    rows[100] = rows[20000]
+    q = np.stack([rows[20000], rng.integers(0, 256, size=d, dtype=np.uint8), 255 - rows[3]])
+    ids = np.arange(n, dtype=np.int64) * 3
+    ix = capi.Index(d, n, metric=metric)
+    ix.load(ids, rows)
+    got_ids, got_d, got_c = ix.search(q, 100, 0.45)
+    for qi in range(len(q)):
+        want_ids, want_d = oracle.scan_topk_metric(metric, q[qi], rows, ids, 100, 0.45)
+        c = int(got_c[qi])
+        assert c == len(want_ids)
+        assert np.array_equal(got_ids[qi, :c], want_ids)
+        assert np.array_equal(got_d[qi, :c].view(np.uint32), want_d.view(np.uint32))
+    # the reference's hamming KATs through the ABI (engine.rs:693-701)
+    if metric == capi.PB_METRIC_HAMMING and d == 2:
+        ix2 = capi.Index(2, 4, metric=metric)
+        ix2.load(np.arange(2), np.array([[0x0F, 0x0F], [0b01010101, 0b10101010]], dtype=np.uint8))
+        i2, d2 = ix2.search_one(np.array([0xFF, 0x0F], dtype=np.uint8), 100, 10.0)
+        assert i2.tolist() == [0, 1] and d2[0] == F32(0.25)
