@@ -60,12 +60,15 @@ struct pb_embedder {
     // workspace
     uint8_t *d_img = nullptr;
     float *buf_x[2] = {nullptr, nullptr};
-    float *buf_e = nullptr, *buf_dw = nullptr, *buf_part = nullptr, *buf_gate = nullptr, *buf_pool = nullptr;
+    float *buf_e = nullptr, *buf_dw = nullptr, *buf_gate = nullptr, *buf_pool = nullptr;
+    long long *buf_part = nullptr;  // SE pooling partial sums, 2^-24 fixed point
     float *d_out_f32 = nullptr;
     uint8_t *d_out_u8 = nullptr;
     int n_cu = 256;
     std::map<std::pair<const void *, long>, std::pair<int, int>> gemm_cfg;  // (layer weights, rows) -> (MR, NR), measured
-    std::map<std::pair<const void *, long>, DwGeom> dw_cfg;      // (layer weights, batch) -> depthwise form, measured
+    std::map<std::pair<const void *, long>, DwGeom> dw_cfg;
+    std::map<std::pair<const void *, long>, int> front_cfg;  // (block, batch) -> 0: expand GEMM + depthwise kernels, else fused with this chunk width
+    size_t part_floats_per_image = 0;      // (layer weights, batch) -> depthwise form, measured
     std::mutex mu;
 };
 
@@ -374,6 +377,100 @@ int launch_dw(pb_embedder *e, const Block &bl, const float *in, int B, int H, in
     return launch_dw_geom(e, bl, in, B, H, W, out, Ho, Wo, it->second);
 }
 
+// ---- fused MBConv front (expand + depthwise in one kernel, expanded tile in LDS) -------------------------------
+size_t front_lds_bytes(const Block &bl, int ec) {
+    const int R = 7 * bl.stride + bl.k, npos = R * R, mt = (npos + 15) / 16;
+    const size_t fl = (size_t)mt * 16 * bl.expand.Kpad + (size_t)npos * ec + (size_t)bl.expand.Kpad * (ec + 4) +
+                      (size_t)bl.k * bl.k * ec + 2 * (size_t)ec;
+    return fl * sizeof(float);
+}
+
+template <int KS, int S, int EC>
+int launch_front_t(pb_embedder *e, const Block &bl, const float *x, int B, int H, int W, float *out, int Ho, int Wo) {
+    const int tiles_x = (Wo + 7) / 8, tiles_y = (Ho + 7) / 8;
+    const size_t lds = front_lds_bytes(bl, EC);
+    auto kern = k_mbconv_front<KS, S, EC>;
+    if (lds > 48 * 1024)
+        PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(tiles_x * tiles_y, B, bl.e / EC), dim3(256), lds, e->stream, x, H, W, bl.cin, bl.expand.wt,
+                       bl.expand.Kpad, bl.expand.Npad, bl.expand.bias, bl.dw_w, bl.dw_b, bl.e, out, Ho, Wo, e->buf_part, tiles_x,
+                       tiles_x * tiles_y);
+    PB_HIP(hipGetLastError());
+    return PB_OK;
+}
+
+int launch_front(pb_embedder *e, const Block &bl, int ec, const float *x, int B, int H, int W, float *out, int Ho, int Wo) {
+#define PB_FR(KS, S)                                                                         \
+    (ec == 16   ? launch_front_t<KS, S, 16>(e, bl, x, B, H, W, out, Ho, Wo)                  \
+     : ec == 32 ? launch_front_t<KS, S, 32>(e, bl, x, B, H, W, out, Ho, Wo)                  \
+                : launch_front_t<KS, S, 48>(e, bl, x, B, H, W, out, Ho, Wo))
+    if (bl.k == 3 && bl.stride == 1) return PB_FR(3, 1);
+    if (bl.k == 3 && bl.stride == 2) return PB_FR(3, 2);
+    if (bl.k == 5 && bl.stride == 1) return PB_FR(5, 1);
+    return PB_FR(5, 2);
+#undef PB_FR
+}
+
+int launch_gemm(pb_embedder *e, const float *act, long M, const Gemm &g, const float *gate, int hw, const float *resid,
+                int do_silu, float *out);
+int launch_dw(pb_embedder *e, const Block &bl, const float *in, int B, int H, int W, float *out, int Ho, int Wo, DwGeom *used);
+
+// expand + depthwise of one block: the fused kernel (per channel-chunk width) and the two-kernel path are timed on
+// the real buffers at first use per (block, batch); returns the number of SE partial tiles written to buf_part
+int run_front(pb_embedder *e, const Block &bl, const float *x, int n, int H, int W, int Ho, int Wo, int *n_part_tiles) {
+    const std::pair<const void *, long> key(bl.expand.wt, (long)n);
+    auto separate = [&](int *tiles) -> int {
+        int rc = launch_gemm(e, x, (long)n * H * W, bl.expand, nullptr, 1, nullptr, 1, e->buf_e);
+        if (rc) return rc;
+        DwGeom g;
+        rc = launch_dw(e, bl, e->buf_e, n, H, W, e->buf_dw, Ho, Wo, &g);
+        *tiles = g.n_tiles;
+        return rc;
+    };
+    const int fused_tiles = ((Wo + 7) / 8) * ((Ho + 7) / 8);
+    auto it = e->front_cfg.find(key);
+    if (it == e->front_cfg.end()) {
+        int tiles = 0;
+        int rc = separate(&tiles);  // also warms the GEMM / depthwise selections
+        if (rc) return rc;
+        hipEvent_t e0, e1;
+        PB_HIP(hipEventCreate(&e0));
+        PB_HIP(hipEventCreate(&e1));
+        auto time_it = [&](int ec, float *ms) -> int {
+            PB_HIP(hipEventRecord(e0, e->stream));
+            for (int rep = 0; rep < 2; ++rep) {
+                int r2 = ec ? launch_front(e, bl, ec, x, n, H, W, e->buf_dw, Ho, Wo) : separate(&tiles);
+                if (r2) return r2;
+            }
+            PB_HIP(hipEventRecord(e1, e->stream));
+            PB_HIP(hipEventSynchronize(e1));
+            PB_HIP(hipEventElapsedTime(ms, e0, e1));
+            return PB_OK;
+        };
+        int best = 0;
+        float best_ms = 0.f;
+        if ((rc = time_it(0, &best_ms))) return rc;
+        for (int ec : {48, 32, 16}) {
+            if (bl.e % ec || front_lds_bytes(bl, ec) > 120 * 1024 || (size_t)fused_tiles * bl.e > e->part_floats_per_image) continue;
+            float ms = 0.f;
+            if ((rc = launch_front(e, bl, ec, x, n, H, W, e->buf_dw, Ho, Wo))) return rc;  // warm-up
+            if ((rc = time_it(ec, &ms))) return rc;
+            if (ms < best_ms) {
+                best_ms = ms;
+                best = ec;
+            }
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        it = e->front_cfg.emplace(key, best).first;
+    }
+    if (it->second) {
+        *n_part_tiles = fused_tiles;
+        return launch_front(e, bl, it->second, x, n, H, W, e->buf_dw, Ho, Wo);
+    }
+    return separate(n_part_tiles);
+}
+
 // forward for n images already on the device; results to device buffers
 int forward_device(pb_embedder *e, const uint8_t *d_rgb, int n, uint8_t *d_u8, float *d_f32) {
     int H = (int)e->H / 2, W = (int)e->W / 2;
@@ -387,16 +484,17 @@ int forward_device(pb_embedder *e, const uint8_t *d_rgb, int n, uint8_t *d_u8, f
     int cur = 0;
     for (const Block &bl : e->blocks) {
         const float *x = e->buf_x[cur];
-        const long M = (long)n * H * W;
-        const float *ein = x;
         int rc;
-        if (bl.has_expand) {
-            if ((rc = launch_gemm(e, x, M, bl.expand, nullptr, 1, nullptr, 1, e->buf_e))) return rc;
-            ein = e->buf_e;
-        }
         const int Ho = (H + bl.stride - 1) / bl.stride, Wo = (W + bl.stride - 1) / bl.stride;
-        DwGeom g;
-        if ((rc = launch_dw(e, bl, ein, n, H, W, e->buf_dw, Ho, Wo, &g))) return rc;
+        int part_tiles = 0;
+        if (bl.has_expand) {
+            if ((rc = run_front(e, bl, x, n, H, W, Ho, Wo, &part_tiles))) return rc;
+        } else {
+            DwGeom g0;
+            if ((rc = launch_dw(e, bl, x, n, H, W, e->buf_dw, Ho, Wo, &g0))) return rc;
+            part_tiles = g0.n_tiles;
+        }
+        struct { int n_tiles; } g{part_tiles};
 #define PB_SE(SPV)                                                                                                 \
     hipLaunchKernelGGL((k_se<SPV>), dim3(n), dim3(256), 0, e->stream, e->buf_part, g.n_tiles, bl.e, 1.0f / (float)(Ho * Wo), \
                        bl.se_w1, bl.se_b1, bl.se_w2t, bl.se_b2, e->buf_gate)
@@ -470,7 +568,8 @@ int pb_embed_create(pb_embedder **out, int device, const void *weights_blob, siz
             if (bl.has_expand) max_e = std::max(max_e, h * w * bl.e);
             max_dw = std::max(max_dw, ho * wo * bl.e);
             max_x = std::max(max_x, ho * wo * (size_t)bl.cout);
-            max_part = std::max(max_part, (size_t)32 * bl.e);  // both depthwise forms use at most 32 tiles / bands
+            // SE partials: the depthwise kernels use at most 32 tiles / bands, the fused front one per 8x8 output tile
+            max_part = std::max(max_part, std::max<size_t>(32, ((ho + 7) / 8) * ((wo + 7) / 8)) * bl.e);
             h = ho;
             w = wo;
         }
@@ -478,6 +577,7 @@ int pb_embed_create(pb_embedder **out, int device, const void *weights_blob, siz
         if ((rc = dalloc(e, &e->d_img, B * e->H * e->W * 3))) return rc;
         if ((rc = dalloc(e, &e->buf_x[0], B * max_x)) || (rc = dalloc(e, &e->buf_x[1], B * max_x))) return rc;
         if ((rc = dalloc(e, &e->buf_e, B * max_e)) || (rc = dalloc(e, &e->buf_dw, B * max_dw))) return rc;
+        e->part_floats_per_image = max_part;
         if ((rc = dalloc(e, &e->buf_part, B * max_part)) || (rc = dalloc(e, &e->buf_gate, B * std::max<size_t>(1152, e->D)))) return rc;
         if ((rc = dalloc(e, &e->buf_pool, B * 1280))) return rc;
         if ((rc = dalloc(e, &e->d_out_f32, B * e->D)) || (rc = dalloc(e, &e->d_out_u8, B * e->D))) return rc;

@@ -25,6 +25,23 @@ __device__ __forceinline__ float sigmoid_f(float x) {
 }
 __device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
 
+// Squeeze-excite pooling sums are accumulated in 64-bit fixed point (2^-24 resolution): integer addition is
+// associative, so the pooled mean -- and with it the whole embedding -- is bit-identical whatever the batch size,
+// tiling or kernel form that produced the partial sums.  (f32 partial sums made an image's hash depend, in the
+// last bit, on how many images shared its batch.)
+struct ll4 {
+    long long x, y, z, w;
+};
+__device__ __forceinline__ void se_acc(ll4 &s, const f32x4 &o) {
+    s.x += __float2ll_rn(o.x * 16777216.0f);
+    s.y += __float2ll_rn(o.y * 16777216.0f);
+    s.z += __float2ll_rn(o.z * 16777216.0f);
+    s.w += __float2ll_rn(o.w * 16777216.0f);
+}
+__device__ __forceinline__ void se_add(ll4 &s, const ll4 &o) {
+    s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+}
+
 // efficientnet.rs:39 -- 128u8.saturating_add_signed((f*128).max(-128).min(128) as i8), bit-exact
 __device__ __forceinline__ uint8_t quantize_u8(float f) {
     float t = f * 128.0f;
@@ -276,11 +293,11 @@ template <int KS, int S>
 __global__ __launch_bounds__(256) void k_dwconv(const float *__restrict__ in, int H, int W, int C,
                                                 const float *__restrict__ w, const float *__restrict__ bias,
                                                 float *__restrict__ out, int Ho, int Wo, int strips_per_tile,
-                                                float *__restrict__ part, int n_tiles, int cq_per_block) {
+                                                long long *__restrict__ part, int n_tiles, int cq_per_block) {
     constexpr int PAD = (KS - 1) / 2;
     constexpr int TX = 4;
     constexpr int NX = (TX - 1) * S + KS;
-    __shared__ f32x4 s_red[256];
+    __shared__ ll4 s_red[256];
     extern __shared__ f32x4 s_wt[];  // [KS*KS][cq_per_block]
     const int slots = blockDim.x / cq_per_block;
     const int cq_l = threadIdx.x % cq_per_block;
@@ -299,7 +316,7 @@ __global__ __launch_bounds__(256) void k_dwconv(const float *__restrict__ in, in
     float *ob = out + (size_t)b * Ho * Wo * C + c0;
     const int strips_x = (Wo + TX - 1) / TX;
     const int n_strips = Ho * strips_x;
-    f32x4 psum = {0.f, 0.f, 0.f, 0.f};
+    ll4 psum = {0, 0, 0, 0};
     const int st_begin = tile * strips_per_tile;
     const int st_end = (st_begin + strips_per_tile) < n_strips ? (st_begin + strips_per_tile) : n_strips;
     for (int st = st_begin + slot; st < st_end; st += slots) {
@@ -336,20 +353,16 @@ __global__ __launch_bounds__(256) void k_dwconv(const float *__restrict__ in, in
             if (x0 + t < Wo) {
                 f32x4 o = {silu_f(acc[t].x), silu_f(acc[t].y), silu_f(acc[t].z), silu_f(acc[t].w)};
                 *reinterpret_cast<f32x4 *>(ob + ((size_t)y * Wo + x0 + t) * C) = o;
-                psum.x = psum.x + o.x; psum.y = psum.y + o.y; psum.z = psum.z + o.z; psum.w = psum.w + o.w;
+                se_acc(psum, o);
             }
         }
     }
-    // reduce the strip slots in fixed order
     s_red[threadIdx.x] = psum;
     __syncthreads();
     if (slot == 0) {
-        f32x4 t = s_red[cq_l];
-        for (int sl = 1; sl < slots; ++sl) {
-            const f32x4 o = s_red[sl * cq_per_block + cq_l];
-            t.x = t.x + o.x; t.y = t.y + o.y; t.z = t.z + o.z; t.w = t.w + o.w;
-        }
-        *reinterpret_cast<f32x4 *>(part + ((size_t)b * n_tiles + tile) * C + c0) = t;
+        ll4 t = s_red[cq_l];
+        for (int sl = 1; sl < slots; ++sl) se_add(t, s_red[sl * cq_per_block + cq_l]);
+        *reinterpret_cast<ll4 *>(part + ((size_t)b * n_tiles + tile) * C + c0) = t;
     }
 }
 
@@ -363,10 +376,10 @@ template <int KS, int S, int TX>
 __global__ __launch_bounds__(256) void k_dwconv_roll(const float *__restrict__ in, int H, int W, int C,
                                                      const float *__restrict__ w, const float *__restrict__ bias,
                                                      float *__restrict__ out, int Ho, int Wo, int rows_per_band,
-                                                     float *__restrict__ part, int n_bands, int cq_per_block) {
+                                                     long long *__restrict__ part, int n_bands, int cq_per_block) {
     constexpr int PAD = (KS - 1) / 2;
     constexpr int NX = (TX - 1) * S + KS;
-    __shared__ f32x4 s_red[256];
+    __shared__ ll4 s_red[256];
     extern __shared__ f32x4 s_wt[];  // [KS*KS][cq_per_block]
     const int strips_x = blockDim.x / cq_per_block;
     const int cq_l = threadIdx.x % cq_per_block;
@@ -387,7 +400,7 @@ __global__ __launch_bounds__(256) void k_dwconv_roll(const float *__restrict__ i
     const int ix0 = x0 * S - PAD;
     const int y_begin = band * rows_per_band;
     const int y_end = (y_begin + rows_per_band) < Ho ? (y_begin + rows_per_band) : Ho;
-    f32x4 psum = {0.f, 0.f, 0.f, 0.f};
+    ll4 psum = {0, 0, 0, 0};
     f32x4 win[KS][NX];
     auto load_row = [&](int iy, f32x4 (&dst)[NX]) {
         const bool rv = iy >= 0 && iy < H;
@@ -424,7 +437,7 @@ __global__ __launch_bounds__(256) void k_dwconv_roll(const float *__restrict__ i
                 if (x0 + t < Wo) {
                     f32x4 o = {silu_f(acc[t].x), silu_f(acc[t].y), silu_f(acc[t].z), silu_f(acc[t].w)};
                     *reinterpret_cast<f32x4 *>(ob + ((size_t)y * Wo + x0 + t) * C) = o;
-                    psum.x = psum.x + o.x; psum.y = psum.y + o.y; psum.z = psum.z + o.z; psum.w = psum.w + o.w;
+                    se_acc(psum, o);
                 }
             }
             if (y + 1 < y_end) {  // slide the window down by S rows
@@ -440,12 +453,136 @@ __global__ __launch_bounds__(256) void k_dwconv_roll(const float *__restrict__ i
     s_red[threadIdx.x] = psum;
     __syncthreads();
     if (sx == 0) {
-        f32x4 t = s_red[cq_l];
-        for (int sl = 1; sl < strips_x; ++sl) {
-            const f32x4 o = s_red[sl * cq_per_block + cq_l];
-            t.x = t.x + o.x; t.y = t.y + o.y; t.z = t.z + o.z; t.w = t.w + o.w;
+        ll4 t = s_red[cq_l];
+        for (int sl = 1; sl < strips_x; ++sl) se_add(t, s_red[sl * cq_per_block + cq_l]);
+        *reinterpret_cast<ll4 *>(part + ((size_t)b * n_bands + band) * C + c0) = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused MBConv front: expand 1x1 (+bias+SiLU) -> depthwise KSxKS stride S (+bias+SiLU) -> SE partial sums, with
+// the 6x-expanded activation tile living only in LDS.  For the early blocks the expanded tensor is the largest
+// thing the network ever writes (64x64x96 f32 = 1.5 MB per image: 805 MB per 512-image batch, written by the
+// expand GEMM and read back by the depthwise kernel); here a block computes the expanded activation of the
+// (7*S+KS)^2 input window of its 8x8 output tile on the f32 matrix cores straight into LDS (halo recompute:
+// 13 % for 3x3 s2) and runs the depthwise filter from there.  Same MFMA operand maps and k order as k_gemm1x1 and
+// the same (ky, kx) accumulation order as k_dwconv, so the result differs from the unfused path only through the
+// order of the SE partial sums.  Out-of-image window positions hold zeros (the depthwise zero padding applies to
+// the EXPANDED activation).
+// grid = (tiles_y * tiles_x, B, E / EC); block = 256.  Dynamic LDS: x window + expanded window + weight slices.
+template <int KS, int S, int EC>
+__global__ __launch_bounds__(256) void k_mbconv_front(
+    const float *__restrict__ x, int H, int W, int Cin, const float *__restrict__ wt, int Kpad, int Epad,
+    const float *__restrict__ bias_e, const float *__restrict__ dw_w, const float *__restrict__ dw_b, int E,
+    float *__restrict__ out, int Ho, int Wo, long long *__restrict__ part, int tiles_x, int n_tiles) {
+    constexpr int TO = 8;
+    constexpr int R = (TO - 1) * S + KS;
+    constexpr int PAD = (KS - 1) / 2;
+    constexpr int NPOS = R * R;
+    constexpr int MT = (NPOS + 15) / 16;
+    constexpr int NC = EC / 16;
+    constexpr int LDW = EC + 4;
+    constexpr int CQ = EC / 4;
+    extern __shared__ __attribute__((aligned(16))) float s_all[];
+    float *s_x = s_all;                          // [MT*16][Kpad]
+    float *s_e = s_x + MT * 16 * Kpad;           // [NPOS][EC]
+    float *s_w = s_e + NPOS * EC;                // [Kpad][LDW]
+    float *s_dw = s_w + Kpad * LDW;              // [KS*KS][EC]
+    float *s_b = s_dw + KS * KS * EC;            // [EC] expand bias, [EC] dw bias
+    __shared__ ll4 s_red[256];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int b = blockIdx.y;
+    const int tile = blockIdx.x;
+    const int ty = tile / tiles_x, tx = tile % tiles_x;
+    const int e0 = blockIdx.z * EC;
+    const int oy0 = ty * TO, ox0 = tx * TO;
+    const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
+    const float *xb = x + (size_t)b * H * W * Cin;
+    // ---- stage the input window (zero outside the image / beyond Cin), the weight slices and biases
+    const int kq4 = Kpad / 4;
+    for (int i = tid; i < MT * 16 * kq4; i += 256) {
+        const int pos = i / kq4, k4 = i % kq4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (pos < NPOS && k4 * 4 < Cin) {
+            const int iy = iy0 + pos / R, ix = ix0 + pos % R;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = *reinterpret_cast<const f32x4 *>(xb + ((size_t)iy * W + ix) * Cin + k4 * 4);
         }
-        *reinterpret_cast<f32x4 *>(part + ((size_t)b * n_bands + band) * C + c0) = t;
+        *reinterpret_cast<f32x4 *>(s_x + pos * Kpad + k4 * 4) = v;
+    }
+    for (int i = tid; i < Kpad * (EC / 4); i += 256) {
+        const int kr = i / (EC / 4), c4 = i % (EC / 4);
+        *reinterpret_cast<f32x4 *>(s_w + kr * LDW + c4 * 4) = *reinterpret_cast<const f32x4 *>(wt + (size_t)kr * Epad + e0 + c4 * 4);
+    }
+    for (int i = tid; i < KS * KS * (EC / 4); i += 256) {
+        const int t = i / (EC / 4), c4 = i % (EC / 4);
+        *reinterpret_cast<f32x4 *>(s_dw + t * EC + c4 * 4) = *reinterpret_cast<const f32x4 *>(dw_w + (size_t)t * E + e0 + c4 * 4);
+    }
+    if (tid < EC) {
+        s_b[tid] = bias_e[e0 + tid];
+        s_b[EC + tid] = dw_b[e0 + tid];
+    }
+    __syncthreads();
+    // ---- expand on the matrix cores: positions x EC channels, K = Cin
+    for (int mt = wave; mt < MT; mt += 4) {
+        f32x4 acc[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int pos = mt * 16 + li;
+        for (int s = 0; s < Kpad; s += 16) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(s_x + pos * Kpad + s + 4 * kq);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float av = e == 0 ? a.x : (e == 1 ? a.y : (e == 2 ? a.z : a.w));
+                const float *wrow = s_w + (s + 4 * kq + e) * LDW + li;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wrow[c * 16], av, acc[c], 0, 0, 0);
+            }
+        }
+        if (pos < NPOS) {
+            const int iy = iy0 + pos / R, ix = ix0 + pos % R;
+            const bool inside = iy >= 0 && iy < H && ix >= 0 && ix < W;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int ch = 16 * c + 4 * kq;
+                f32x4 v = acc[c];
+                v.x = silu_f(v.x + s_b[ch]); v.y = silu_f(v.y + s_b[ch + 1]); v.z = silu_f(v.z + s_b[ch + 2]); v.w = silu_f(v.w + s_b[ch + 3]);
+                if (!inside) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4 *>(s_e + pos * EC + ch) = v;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- depthwise from LDS; a thread keeps one channel quad (256 % CQ == 0), so its SE partial is per quad
+    constexpr int SLOTS = 256 / CQ;  // pixel slots; threads beyond SLOTS * CQ idle in this phase (CQ = 12)
+    const int cq = tid % CQ;
+    const f32x4 bv = *reinterpret_cast<const f32x4 *>(s_b + EC + 4 * cq);
+    float *ob = out + (size_t)b * Ho * Wo * E + e0 + 4 * cq;
+    ll4 psum = {0, 0, 0, 0};
+    for (int p = tid < SLOTS * CQ ? tid / CQ : TO * TO; p < TO * TO; p += SLOTS) {
+        const int oy = p / TO, ox = p % TO;
+        if (oy0 + oy >= Ho || ox0 + ox >= Wo) continue;
+        f32x4 acc = bv;
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(s_e + ((oy * S + ky) * R + (ox * S + kx)) * EC + 4 * cq);
+                const f32x4 wv = *reinterpret_cast<const f32x4 *>(s_dw + (ky * KS + kx) * EC + 4 * cq);
+                const float p0 = v.x * wv.x, p1 = v.y * wv.y, p2 = v.z * wv.z, p3 = v.w * wv.w;
+                acc.x = acc.x + p0; acc.y = acc.y + p1; acc.z = acc.z + p2; acc.w = acc.w + p3;
+            }
+        f32x4 o = {silu_f(acc.x), silu_f(acc.y), silu_f(acc.z), silu_f(acc.w)};
+        *reinterpret_cast<f32x4 *>(ob + ((size_t)(oy0 + oy) * Wo + ox0 + ox) * E) = o;
+        se_acc(psum, o);
+    }
+    s_red[tid] = psum;
+    __syncthreads();
+    if (tid < CQ) {
+        ll4 t = s_red[tid];
+        for (int j = 1; j < SLOTS; ++j) se_add(t, s_red[j * CQ + tid]);
+        *reinterpret_cast<ll4 *>(part + ((size_t)b * n_tiles + tile) * E + e0 + 4 * tid) = t;
     }
 }
 
@@ -458,7 +595,7 @@ __global__ __launch_bounds__(256) void k_dwconv_roll(const float *__restrict__ i
 // conditional on a runtime value (a per-element runtime condition makes hipcc branch around every load and
 // wait for it: 48 serial L2 round trips).
 template <int SP>
-__global__ __launch_bounds__(256) void k_se(const float *__restrict__ part, int n_tiles, int E, float inv_hw,
+__global__ __launch_bounds__(256) void k_se(const long long *__restrict__ part, int n_tiles, int E, float inv_hw,
                                             const float *__restrict__ w1, const float *__restrict__ b1,
                                             const float *__restrict__ w2t, const float *__restrict__ b2,
                                             float *__restrict__ gate) {
@@ -470,9 +607,9 @@ __global__ __launch_bounds__(256) void k_se(const float *__restrict__ part, int 
 #pragma unroll
     for (int j = 0; j < SP; ++j) p[j] = 0.0f;
     for (int c = threadIdx.x; c < E; c += 256) {
-        float t = 0.0f;
-        for (int tl = 0; tl < n_tiles; ++tl) t = t + part[((size_t)b * n_tiles + tl) * E + c];
-        const float m = t * inv_hw;
+        long long t = 0;  // exact: fixed-point partial sums (see se_acc)
+        for (int tl = 0; tl < n_tiles; ++tl) t += part[((size_t)b * n_tiles + tl) * E + c];
+        const float m = (float)((double)t * (1.0 / 16777216.0) * (double)inv_hw);
         // issue every load of the column before the first use (hipcc otherwise pairs each load with a wait)
         float wv[SP];
 #pragma unroll

@@ -54,6 +54,23 @@ def test_batches_vs_oracle(n, max_batch):
     assert np.array_equal(f_b[::-1], f) and np.array_equal(u8_b[::-1], u8)
 
 
+def test_hash_is_bitwise_independent_of_batch_size():
+    # The reference hashes one image per call (efficientnet.rs:31-42), so an image has ONE hash.  Batching must
+    # not change it: the autotuned kernel forms differ per batch size (GEMM tile shapes, depthwise strip / rolling
+    # / fused-expand kernels, SE partial-sum tiling), and every one of them has to produce the same bits
+    # (fixed k-order in the GEMMs, fixed tap order in the depthwise convs, fixed-point SE pooling sums).
+    blob = W.synthetic_blob(synth.SEED_WEIGHTS, 128, 128, 256)
+    imgs = synth.synthetic_images(synth.SEED_IMAGES, 300, 192, 128, 128)
+    big = capi.Embedder(blob, max_batch=192)
+    u8, f = big.embed(imgs)
+    for mb in (1, 2, 7, 48):
+        emb = capi.Embedder(blob, max_batch=mb)
+        sub = imgs[: max(3 * mb + 1, 5)]
+        u8_s, f_s = emb.embed(sub)
+        assert np.array_equal(f_s.view(np.uint32), f[: len(sub)].view(np.uint32)), mb
+        assert np.array_equal(u8_s, u8[: len(sub)]), mb
+
+
 def test_mlhash_is_deterministic_like_the_reference_test():
     # efficientnet.rs:54-67: hamming_distance(mlhash(img), mlhash(img)) == 0
     blob = W.synthetic_blob(synth.SEED_WEIGHTS, 128, 128, 256)
