@@ -67,7 +67,7 @@ struct pb_embedder {
     int n_cu = 256;
     std::map<std::pair<const void *, long>, std::pair<int, int>> gemm_cfg;  // (layer weights, rows) -> (MR, NR), measured
     std::map<std::pair<const void *, long>, DwGeom> dw_cfg;
-    std::map<std::pair<const void *, long>, int> front_cfg;  // (block, batch) -> 0: expand GEMM + depthwise kernels, else fused with this chunk width
+    std::map<std::pair<const void *, long>, int> front_cfg;  // (block, batch) -> 0: expand GEMM + depthwise kernels, else fused kernel config 16 * bands + nc
     size_t part_floats_per_image = 0;      // (layer weights, batch) -> depthwise form, measured
     std::mutex mu;
 };
@@ -377,45 +377,51 @@ int launch_dw(pb_embedder *e, const Block &bl, const float *in, int B, int H, in
     return launch_dw_geom(e, bl, in, B, H, W, out, Ho, Wo, it->second);
 }
 
-// ---- fused MBConv front (expand + depthwise in one kernel, expanded tile in LDS) -------------------------------
-size_t front_lds_bytes(const Block &bl, int ec) {
-    const int R = 7 * bl.stride + bl.k, npos = R * R, mt = (npos + 15) / 16;
-    const size_t fl = (size_t)mt * 16 * bl.expand.Kpad + (size_t)npos * ec + (size_t)bl.expand.Kpad * (ec + 4) +
-                      (size_t)bl.k * bl.k * ec + 2 * (size_t)ec;
-    return fl * sizeof(float);
+// ---- fused MBConv front (expand + depthwise in one kernel, expanded rows in registers) -------------------------
+bool front_eligible(const Block &bl) {
+    const int kc = bl.expand.Kpad / 16;
+    if (!bl.has_expand || bl.e % 48 || bl.expand.Kpad % 16 || bl.cin % 4) return false;
+    return (bl.k == 3 && bl.stride == 2 && (kc == 1 || kc == 3)) || (bl.k == 3 && bl.stride == 1 && kc == 2) ||
+           (bl.k == 5 && bl.stride == 2 && kc == 2) || (bl.k == 5 && bl.stride == 1 && kc == 3);
 }
 
-template <int KS, int S, int EC>
-int launch_front_t(pb_embedder *e, const Block &bl, const float *x, int B, int H, int W, float *out, int Ho, int Wo) {
-    const int tiles_x = (Wo + 7) / 8, tiles_y = (Ho + 7) / 8;
-    const size_t lds = front_lds_bytes(bl, EC);
-    auto kern = k_mbconv_front<KS, S, EC>;
-    if (lds > 48 * 1024)
-        PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(tiles_x * tiles_y, B, bl.e / EC), dim3(256), lds, e->stream, x, H, W, bl.cin, bl.expand.wt,
-                       bl.expand.Kpad, bl.expand.Npad, bl.expand.bias, bl.dw_w, bl.dw_b, bl.e, out, Ho, Wo, e->buf_part, tiles_x,
-                       tiles_x * tiles_y);
+int front_strips(const Block &bl, int Wo) {
+    const int ow = (16 - bl.k) / bl.stride + 1;
+    return (Wo + ow - 1) / ow;
+}
+
+// cfg = 16 * n_bands + nc: n_bands row bands per strip, nc (1 or 3) 16-channel tiles per wave
+int launch_front(pb_embedder *e, const Block &bl, int cfg, const float *x, int B, int H, int W, float *out, int Ho, int Wo) {
+    const int n_bands = cfg >> 4, nc = cfg & 15;
+    const int n_strips = front_strips(bl, Wo);
+    const int rows_per_band = (Ho + n_bands - 1) / n_bands;
+    const dim3 grid((n_strips * n_bands + 3) / 4, B, bl.e / (16 * nc)), block(256);
+    const int kc = bl.expand.Kpad / 16;
+#define PB_FR1(KS, S, KC, NCV)                                                                                             \
+    hipLaunchKernelGGL((k_front_roll<KS, S, KC, NCV>), grid, block, 0, e->stream, x, H, W, bl.cin, bl.expand.wt, bl.expand.Npad, \
+                       bl.expand.bias, bl.dw_w, bl.dw_b, bl.e, out, Ho, Wo, e->buf_part, n_strips, n_bands, rows_per_band)
+#define PB_FR(KS, S, KC)             \
+    do {                             \
+        if (nc == 1) PB_FR1(KS, S, KC, 1); \
+        else PB_FR1(KS, S, KC, 3);   \
+    } while (0)
+    if (bl.k == 3 && bl.stride == 2 && kc == 1) PB_FR(3, 2, 1);
+    else if (bl.k == 3 && bl.stride == 2 && kc == 3) PB_FR(3, 2, 3);
+    else if (bl.k == 3 && bl.stride == 1 && kc == 2) PB_FR(3, 1, 2);
+    else if (bl.k == 5 && bl.stride == 2 && kc == 2) PB_FR(5, 2, 2);
+    else if (bl.k == 5 && bl.stride == 1 && kc == 3) PB_FR(5, 1, 3);
+    else PB_CHECK(false, PB_ERR_INVALID, "launch_front: no fused kernel for k%d s%d Kpad %d", bl.k, bl.stride, bl.expand.Kpad);
+#undef PB_FR
+#undef PB_FR1
     PB_HIP(hipGetLastError());
     return PB_OK;
-}
-
-int launch_front(pb_embedder *e, const Block &bl, int ec, const float *x, int B, int H, int W, float *out, int Ho, int Wo) {
-#define PB_FR(KS, S)                                                                         \
-    (ec == 16   ? launch_front_t<KS, S, 16>(e, bl, x, B, H, W, out, Ho, Wo)                  \
-     : ec == 32 ? launch_front_t<KS, S, 32>(e, bl, x, B, H, W, out, Ho, Wo)                  \
-                : launch_front_t<KS, S, 48>(e, bl, x, B, H, W, out, Ho, Wo))
-    if (bl.k == 3 && bl.stride == 1) return PB_FR(3, 1);
-    if (bl.k == 3 && bl.stride == 2) return PB_FR(3, 2);
-    if (bl.k == 5 && bl.stride == 1) return PB_FR(5, 1);
-    return PB_FR(5, 2);
-#undef PB_FR
 }
 
 int launch_gemm(pb_embedder *e, const float *act, long M, const Gemm &g, const float *gate, int hw, const float *resid,
                 int do_silu, float *out);
 int launch_dw(pb_embedder *e, const Block &bl, const float *in, int B, int H, int W, float *out, int Ho, int Wo, DwGeom *used);
 
-// expand + depthwise of one block: the fused kernel (per channel-chunk width) and the two-kernel path are timed on
+// expand + depthwise of one block: the fused kernel (per row-band count) and the two-kernel path are timed on
 // the real buffers at first use per (block, batch); returns the number of SE partial tiles written to buf_part
 int run_front(pb_embedder *e, const Block &bl, const float *x, int n, int H, int W, int Ho, int Wo, int *n_part_tiles) {
     const std::pair<const void *, long> key(bl.expand.wt, (long)n);
@@ -427,7 +433,8 @@ int run_front(pb_embedder *e, const Block &bl, const float *x, int n, int H, int
         *tiles = g.n_tiles;
         return rc;
     };
-    const int fused_tiles = ((Wo + 7) / 8) * ((Ho + 7) / 8);
+    const int n_strips = front_strips(bl, Wo);
+    auto bands_used = [&](int nb) { const int rpb = (Ho + nb - 1) / nb; return (Ho + rpb - 1) / rpb; };
     auto it = e->front_cfg.find(key);
     if (it == e->front_cfg.end()) {
         int tiles = 0;
@@ -436,10 +443,10 @@ int run_front(pb_embedder *e, const Block &bl, const float *x, int n, int H, int
         hipEvent_t e0, e1;
         PB_HIP(hipEventCreate(&e0));
         PB_HIP(hipEventCreate(&e1));
-        auto time_it = [&](int ec, float *ms) -> int {
+        auto time_it = [&](int nb, float *ms) -> int {
             PB_HIP(hipEventRecord(e0, e->stream));
             for (int rep = 0; rep < 2; ++rep) {
-                int r2 = ec ? launch_front(e, bl, ec, x, n, H, W, e->buf_dw, Ho, Wo) : separate(&tiles);
+                int r2 = nb ? launch_front(e, bl, nb, x, n, H, W, e->buf_dw, Ho, Wo) : separate(&tiles);
                 if (r2) return r2;
             }
             PB_HIP(hipEventRecord(e1, e->stream));
@@ -450,22 +457,28 @@ int run_front(pb_embedder *e, const Block &bl, const float *x, int n, int H, int
         int best = 0;
         float best_ms = 0.f;
         if ((rc = time_it(0, &best_ms))) return rc;
-        for (int ec : {48, 32, 16}) {
-            if (bl.e % ec || front_lds_bytes(bl, ec) > 120 * 1024 || (size_t)fused_tiles * bl.e > e->part_floats_per_image) continue;
-            float ms = 0.f;
-            if ((rc = launch_front(e, bl, ec, x, n, H, W, e->buf_dw, Ho, Wo))) return rc;  // warm-up
-            if ((rc = time_it(ec, &ms))) return rc;
-            if (ms < best_ms) {
-                best_ms = ms;
-                best = ec;
+        const float sep_ms = best_ms;
+        for (int nc : {3, 1})
+            for (int nb : {1, 2, 4, 8}) {
+                if (!front_eligible(bl) || bands_used(nb) != nb || (nb > 1 && Ho / nb < 4) ||
+                    (size_t)n_strips * nb * bl.e > e->part_floats_per_image)
+                    continue;
+                const int cfg = 16 * nb + nc;
+                float ms = 0.f;
+                if ((rc = launch_front(e, bl, cfg, x, n, H, W, e->buf_dw, Ho, Wo))) return rc;  // warm-up
+                if ((rc = time_it(cfg, &ms))) return rc;
+                if (getenv("PB_TRACE_TUNE")) fprintf(stderr, "front k%d s%d e%d n%d: bands %d nc %d %.1f us (separate %.1f)\n", bl.k, bl.stride, bl.e, n, nb, nc, ms * 500.f, sep_ms * 500.f);
+                if (ms < best_ms) {
+                    best_ms = ms;
+                    best = cfg;
+                }
             }
-        }
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
         it = e->front_cfg.emplace(key, best).first;
     }
     if (it->second) {
-        *n_part_tiles = fused_tiles;
+        *n_part_tiles = n_strips * (it->second >> 4);
         return launch_front(e, bl, it->second, x, n, H, W, e->buf_dw, Ho, Wo);
     }
     return separate(n_part_tiles);
@@ -568,8 +581,8 @@ int pb_embed_create(pb_embedder **out, int device, const void *weights_blob, siz
             if (bl.has_expand) max_e = std::max(max_e, h * w * bl.e);
             max_dw = std::max(max_dw, ho * wo * bl.e);
             max_x = std::max(max_x, ho * wo * (size_t)bl.cout);
-            // SE partials: the depthwise kernels use at most 32 tiles / bands, the fused front one per 8x8 output tile
-            max_part = std::max(max_part, std::max<size_t>(32, ((ho + 7) / 8) * ((wo + 7) / 8)) * bl.e);
+            // SE partials: the depthwise kernels use at most 32 tiles / bands, the fused front one per (strip, band)
+            max_part = std::max(max_part, std::max<size_t>(32, (size_t)front_strips(bl, (int)wo) * 8) * bl.e);
             h = ho;
             w = wo;
         }

@@ -33,10 +33,20 @@ struct ll4 {
     long long x, y, z, w;
 };
 __device__ __forceinline__ void se_acc(ll4 &s, const f32x4 &o) {
-    s.x += __float2ll_rn(o.x * 16777216.0f);
-    s.y += __float2ll_rn(o.y * 16777216.0f);
-    s.z += __float2ll_rn(o.z * 16777216.0f);
-    s.w += __float2ll_rn(o.w * 16777216.0f);
+    const float a = o.x * 16777216.0f, b = o.y * 16777216.0f, c = o.z * 16777216.0f, d = o.w * 16777216.0f;
+    // |o| < 128 (every activation seen in practice): the scaled value fits an i32, and rndne + cvt_i32 is a fifth
+    // of the instructions of the generic f32 -> i64 conversion; both give rint() exactly
+    if (fmaxf(fmaxf(fabsf(a), fabsf(b)), fmaxf(fabsf(c), fabsf(d))) < 2147483648.0f) {
+        s.x += (long long)__float2int_rn(a);
+        s.y += (long long)__float2int_rn(b);
+        s.z += (long long)__float2int_rn(c);
+        s.w += (long long)__float2int_rn(d);
+    } else {
+        s.x += __float2ll_rn(a);
+        s.y += __float2ll_rn(b);
+        s.z += __float2ll_rn(c);
+        s.w += __float2ll_rn(d);
+    }
 }
 __device__ __forceinline__ void se_add(ll4 &s, const ll4 &o) {
     s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
@@ -460,129 +470,206 @@ __global__ __launch_bounds__(256) void k_dwconv_roll(const float *__restrict__ i
 }
 
 // ------------------------------------------------------------------------------------------------
-// Fused MBConv front: expand 1x1 (+bias+SiLU) -> depthwise KSxKS stride S (+bias+SiLU) -> SE partial sums, with
-// the 6x-expanded activation tile living only in LDS.  For the early blocks the expanded tensor is the largest
-// thing the network ever writes (64x64x96 f32 = 1.5 MB per image: 805 MB per 512-image batch, written by the
-// expand GEMM and read back by the depthwise kernel); here a block computes the expanded activation of the
-// (7*S+KS)^2 input window of its 8x8 output tile on the f32 matrix cores straight into LDS (halo recompute:
-// 13 % for 3x3 s2) and runs the depthwise filter from there.  Same MFMA operand maps and k order as k_gemm1x1 and
-// the same (ky, kx) accumulation order as k_dwconv, so the result differs from the unfused path only through the
-// order of the SE partial sums.  Out-of-image window positions hold zeros (the depthwise zero padding applies to
-// the EXPANDED activation).
-// grid = (tiles_y * tiles_x, B, E / EC); block = 256.  Dynamic LDS: x window + expanded window + weight slices.
-template <int KS, int S, int EC>
-__global__ __launch_bounds__(256) void k_mbconv_front(
-    const float *__restrict__ x, int H, int W, int Cin, const float *__restrict__ wt, int Kpad, int Epad,
+// Rolling fused MBConv front: expand 1x1 (+bias+SiLU) -> depthwise KSxKS stride S (+bias+SiLU) -> SE partial sums
+// with the expanded activation living only in REGISTERS.
+// A wave owns a strip of 16 adjacent input columns and 16 NC expanded channels and walks down the rows of its band.
+// Per input row it runs the expand on the matrix cores with the 16 columns as the MFMA's column index, so lane
+// (li, kq) ends up holding channels 16c + 4kq .. +3 of column li -- exactly the operand map of k_gemm1x1, with the
+// weight fragments held in registers for the whole walk.  The last KS expanded rows stay in a register ring; the
+// depthwise filter takes its x-neighbours from the adjacent lanes of the 16-lane row with DPP row shifts (fused
+// into the multiplies: v_mul_f32_dpp) and its y-neighbours from the ring.  A strip yields
+// OW = (16 - KS) / S + 1 output columns (14 / 7 / 12 / 6 for 3x3 s1 / 3x3 s2 / 5x5 s1 / 5x5 s2); the x halo is
+// recomputed (MFMA work is not the limit here), the y halo only at band boundaries.  No LDS traffic apart from
+// the broadcast reads of the filter taps.  Same k order, tap order and roundings as the unfused kernels: the
+// outputs are bit-identical to k_gemm1x1 + k_dwconv.
+// grid = (ceil(n_strips * n_bands / 4), B, E / (16 NC)); block = 4 independent waves of one channel group.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+// the value held by lane li + d of the 16-lane row, 0 outside the row (d is a constant after unrolling)
+__device__ __forceinline__ float row_shift(float v, int d) {
+    switch (d) {
+        case -2: return dpp_f32<0x112>(v);  // row_shr:2
+        case -1: return dpp_f32<0x111>(v);  // row_shr:1
+        case 1: return dpp_f32<0x101>(v);   // row_shl:1
+        case 2: return dpp_f32<0x102>(v);   // row_shl:2
+        default: return v;
+    }
+}
+
+template <int KS, int S, int KC, int NC>
+__global__ __launch_bounds__(256, NC == 1 ? 4 : 2) void k_front_roll(
+    const float *__restrict__ x, int H, int W, int Cin, const float *__restrict__ wt, int Epad,
     const float *__restrict__ bias_e, const float *__restrict__ dw_w, const float *__restrict__ dw_b, int E,
-    float *__restrict__ out, int Ho, int Wo, long long *__restrict__ part, int tiles_x, int n_tiles) {
-    constexpr int TO = 8;
-    constexpr int R = (TO - 1) * S + KS;
+    float *__restrict__ out, int Ho, int Wo, long long *__restrict__ part, int n_strips, int n_bands, int rows_per_band) {
+    constexpr int EC = 16 * NC;
     constexpr int PAD = (KS - 1) / 2;
-    constexpr int NPOS = R * R;
-    constexpr int MT = (NPOS + 15) / 16;
-    constexpr int NC = EC / 16;
-    constexpr int LDW = EC + 4;
-    constexpr int CQ = EC / 4;
-    extern __shared__ __attribute__((aligned(16))) float s_all[];
-    float *s_x = s_all;                          // [MT*16][Kpad]
-    float *s_e = s_x + MT * 16 * Kpad;           // [NPOS][EC]
-    float *s_w = s_e + NPOS * EC;                // [Kpad][LDW]
-    float *s_dw = s_w + Kpad * LDW;              // [KS*KS][EC]
-    float *s_b = s_dw + KS * KS * EC;            // [EC] expand bias, [EC] dw bias
-    __shared__ ll4 s_red[256];
+    constexpr int OW = (16 - KS) / S + 1;
+    __shared__ __attribute__((aligned(16))) float s_dw[KS * KS * EC + 2 * EC];  // taps, then expand bias, depthwise bias
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
     const int b = blockIdx.y;
-    const int tile = blockIdx.x;
-    const int ty = tile / tiles_x, tx = tile % tiles_x;
     const int e0 = blockIdx.z * EC;
-    const int oy0 = ty * TO, ox0 = tx * TO;
-    const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
-    const float *xb = x + (size_t)b * H * W * Cin;
-    // ---- stage the input window (zero outside the image / beyond Cin), the weight slices and biases
-    const int kq4 = Kpad / 4;
-    for (int i = tid; i < MT * 16 * kq4; i += 256) {
-        const int pos = i / kq4, k4 = i % kq4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (pos < NPOS && k4 * 4 < Cin) {
-            const int iy = iy0 + pos / R, ix = ix0 + pos % R;
-            if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = *reinterpret_cast<const f32x4 *>(xb + ((size_t)iy * W + ix) * Cin + k4 * 4);
-        }
-        *reinterpret_cast<f32x4 *>(s_x + pos * Kpad + k4 * 4) = v;
-    }
-    for (int i = tid; i < Kpad * (EC / 4); i += 256) {
-        const int kr = i / (EC / 4), c4 = i % (EC / 4);
-        *reinterpret_cast<f32x4 *>(s_w + kr * LDW + c4 * 4) = *reinterpret_cast<const f32x4 *>(wt + (size_t)kr * Epad + e0 + c4 * 4);
-    }
     for (int i = tid; i < KS * KS * (EC / 4); i += 256) {
         const int t = i / (EC / 4), c4 = i % (EC / 4);
         *reinterpret_cast<f32x4 *>(s_dw + t * EC + c4 * 4) = *reinterpret_cast<const f32x4 *>(dw_w + (size_t)t * E + e0 + c4 * 4);
     }
     if (tid < EC) {
-        s_b[tid] = bias_e[e0 + tid];
-        s_b[EC + tid] = dw_b[e0 + tid];
+        s_dw[KS * KS * EC + tid] = bias_e[e0 + tid];
+        s_dw[KS * KS * EC + EC + tid] = dw_b[e0 + tid];
     }
     __syncthreads();
-    // ---- expand on the matrix cores: positions x EC channels, K = Cin
-    for (int mt = wave; mt < MT; mt += 4) {
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= n_strips * n_bands) return;
+    const int strip = item % n_strips, band = item / n_strips;
+    const int oy_b = band * rows_per_band;
+    const int oy_e = (oy_b + rows_per_band) < Ho ? (oy_b + rows_per_band) : Ho;
+    const int xpos = strip * OW * S - PAD + li;  // this lane's input column
+    const bool xok = xpos >= 0 && xpos < W;
+    const int jo = li - PAD;                     // output lanes sit on the centre tap of their window
+    const int ox = strip * OW + jo / S;
+    const bool is_out = jo >= 0 && (jo % S) == 0 && (jo / S) < OW && ox < Wo;
+    const float *xb = x + (size_t)b * H * W * Cin;
+
+    // weight fragments for the whole walk: A operand, lane (li, kq) holds wt[k = 16s + 4kq + e][e0 + 16c + li]
+    float wreg[KC][4][NC];
+#pragma unroll
+    for (int s2 = 0; s2 < KC; ++s2)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) wreg[s2][e][c] = wt[(size_t)(16 * s2 + 4 * kq + e) * Epad + e0 + 16 * c + li];
+
+    auto load_row = [&](int iy, f32x4 (&xa)[KC]) {
+        const bool ok = xok && iy >= 0 && iy < H;
+        const float *p = xb + ((size_t)(ok ? iy : 0) * W + (ok ? xpos : 0)) * Cin;
+#pragma unroll
+        for (int s2 = 0; s2 < KC; ++s2) {
+            const int k = 16 * s2 + 4 * kq;
+            // out-of-range lanes read a valid dummy address and are zeroed (no branch around the load)
+            f32x4 v = *reinterpret_cast<const f32x4 *>(p + (k < Cin ? k : 0));
+            if (!(ok && k < Cin)) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            xa[s2] = v;
+        }
+    };
+    auto expand_row = [&](int iy, const f32x4 (&xa)[KC], f32x4 (&ev)[NC]) {
         f32x4 acc[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const int pos = mt * 16 + li;
-        for (int s = 0; s < Kpad; s += 16) {
-            const f32x4 a = *reinterpret_cast<const f32x4 *>(s_x + pos * Kpad + s + 4 * kq);
+#pragma unroll
+        for (int s2 = 0; s2 < KC; ++s2)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float av = e == 0 ? a.x : (e == 1 ? a.y : (e == 2 ? a.z : a.w));
-                const float *wrow = s_w + (s + 4 * kq + e) * LDW + li;
+                const float av = e == 0 ? xa[s2].x : (e == 1 ? xa[s2].y : (e == 2 ? xa[s2].z : xa[s2].w));
 #pragma unroll
-                for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wrow[c * 16], av, acc[c], 0, 0, 0);
+                for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s2][e][c], av, acc[c], 0, 0, 0);
             }
-        }
-        if (pos < NPOS) {
-            const int iy = iy0 + pos / R, ix = ix0 + pos % R;
-            const bool inside = iy >= 0 && iy < H && ix >= 0 && ix < W;
+        const bool ok = xok && iy >= 0 && iy < H;  // the depthwise zero padding applies to the EXPANDED activation
+        int b_off = 4 * kq;  // biases are re-read from LDS (kept out of long-lived registers, see tap_off below)
+        asm volatile("" : "+v"(b_off));
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const int ch = 16 * c + 4 * kq;
-                f32x4 v = acc[c];
-                v.x = silu_f(v.x + s_b[ch]); v.y = silu_f(v.y + s_b[ch + 1]); v.z = silu_f(v.z + s_b[ch + 2]); v.w = silu_f(v.w + s_b[ch + 3]);
-                if (!inside) v = (f32x4){0.f, 0.f, 0.f, 0.f};
-                *reinterpret_cast<f32x4 *>(s_e + pos * EC + ch) = v;
-            }
+        for (int c = 0; c < NC; ++c) {
+            f32x4 v = acc[c];
+            const f32x4 bev = *reinterpret_cast<const f32x4 *>(s_dw + KS * KS * EC + 16 * c + b_off);
+            v.x = silu_f(v.x + bev.x); v.y = silu_f(v.y + bev.y); v.z = silu_f(v.z + bev.z); v.w = silu_f(v.w + bev.w);
+            if (!ok) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            ev[c] = v;
         }
+    };
+
+    f32x4 ring[KS][NC];
+    f32x4 xa[S][KC];
+    ll4 psum[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) psum[c] = (ll4){0, 0, 0, 0};
+    // prime: rows oy_b*S - PAD .. + (KS - S - 1) go to ring[S ..]; the loop shifts them down before use
+    const int iy_first = oy_b * S - PAD;
+#pragma unroll
+    for (int r = 0; r < KS - S; ++r) {
+        f32x4 xp[KC];
+        load_row(iy_first + r, xp);
+        expand_row(iy_first + r, xp, ring[S + r]);
     }
-    __syncthreads();
-    // ---- depthwise from LDS; a thread keeps one channel quad (256 % CQ == 0), so its SE partial is per quad
-    constexpr int SLOTS = 256 / CQ;  // pixel slots; threads beyond SLOTS * CQ idle in this phase (CQ = 12)
-    const int cq = tid % CQ;
-    const f32x4 bv = *reinterpret_cast<const f32x4 *>(s_b + EC + 4 * cq);
-    float *ob = out + (size_t)b * Ho * Wo * E + e0 + 4 * cq;
-    ll4 psum = {0, 0, 0, 0};
-    for (int p = tid < SLOTS * CQ ? tid / CQ : TO * TO; p < TO * TO; p += SLOTS) {
-        const int oy = p / TO, ox = p % TO;
-        if (oy0 + oy >= Ho || ox0 + ox >= Wo) continue;
-        f32x4 acc = bv;
+#pragma unroll
+    for (int j = 0; j < S; ++j) load_row(iy_first + KS - S + j, xa[j]);
+    for (int oy = oy_b; oy < oy_e; ++oy) {
+        const int iy_new = oy * S - PAD + KS - S;  // first of the S new input rows of this output row
+#pragma unroll
+        for (int r = 0; r < KS - S; ++r)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) ring[r][c] = ring[r + S][c];
+#pragma unroll
+        for (int j = 0; j < S; ++j) expand_row(iy_new + j, xa[j], ring[KS - S + j]);
+        if (oy + 1 < oy_e) {
+#pragma unroll
+            for (int j = 0; j < S; ++j) load_row(iy_new + S + j, xa[j]);  // next output row's inputs, in flight during the filter
+        }
+        // the taps are re-read from LDS every row (broadcast reads, 4 addresses per wave); the opaque offset keeps
+        // hipcc from hoisting all KS*KS*NC float4 out of the row loop into registers (and spilling)
+        int tap_off = 4 * kq;
+        asm volatile("" : "+v"(tap_off));
+        f32x4 o[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) o[c] = *reinterpret_cast<const f32x4 *>(s_dw + KS * KS * EC + EC + 16 * c + tap_off);
+        // fresh SSA names for the ring: otherwise hipcc recognises that a row's shifted copies were already
+        // computed for the previous output row and keeps all KS*(KS-1) of them alive across iterations
 #pragma unroll
         for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
-            for (int kx = 0; kx < KS; ++kx) {
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(s_e + ((oy * S + ky) * R + (ox * S + kx)) * EC + 4 * cq);
-                const f32x4 wv = *reinterpret_cast<const f32x4 *>(s_dw + (ky * KS + kx) * EC + 4 * cq);
-                const float p0 = v.x * wv.x, p1 = v.y * wv.y, p2 = v.z * wv.z, p3 = v.w * wv.w;
-                acc.x = acc.x + p0; acc.y = acc.y + p1; acc.z = acc.z + p2; acc.w = acc.w + p3;
+            for (int c = 0; c < NC; ++c)
+                asm volatile("" : "+v"(ring[ky][c].x), "+v"(ring[ky][c].y), "+v"(ring[ky][c].z), "+v"(ring[ky][c].w));
+        // tap t+1 is requested while tap t is applied; the scheduling barriers keep hipcc from issuing all
+        // KS*KS*NC reads up front (100+ live registers)
+        f32x4 wn[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) wn[c] = *reinterpret_cast<const f32x4 *>(s_dw + 16 * c + tap_off);
+#pragma unroll
+        for (int t = 0; t < KS * KS; ++t) {
+            const int ky = t / KS, kx = t % KS;
+            f32x4 wc[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) wc[c] = wn[c];
+            if (t + 1 < KS * KS) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) wn[c] = *reinterpret_cast<const f32x4 *>(s_dw + (t + 1) * EC + 16 * c + tap_off);
             }
-        f32x4 o = {silu_f(acc.x), silu_f(acc.y), silu_f(acc.z), silu_f(acc.w)};
-        *reinterpret_cast<f32x4 *>(ob + ((size_t)(oy0 + oy) * Wo + ox0 + ox) * E) = o;
-        se_acc(psum, o);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const f32x4 v = ring[ky][c];
+                const float p0 = row_shift(v.x, kx - PAD) * wc[c].x, p1 = row_shift(v.y, kx - PAD) * wc[c].y;
+                const float p2 = row_shift(v.z, kx - PAD) * wc[c].z, p3 = row_shift(v.w, kx - PAD) * wc[c].w;
+                o[c].x = o[c].x + p0; o[c].y = o[c].y + p1; o[c].z = o[c].z + p2; o[c].w = o[c].w + p3;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // pin the filter arithmetic here: hipcc otherwise sinks it into the is_out branch below while the DPP moves
+        // and tap reads (which cannot move into divergent control flow) stay outside with all their results live
+#pragma unroll
+        for (int c = 0; c < NC; ++c) asm volatile("" : "+v"(o[c].x), "+v"(o[c].y), "+v"(o[c].z), "+v"(o[c].w));
+        if (is_out) {
+            float *op = out + (((size_t)b * Ho + oy) * Wo + ox) * E + e0 + 4 * kq;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const f32x4 r = {silu_f(o[c].x), silu_f(o[c].y), silu_f(o[c].z), silu_f(o[c].w)};
+                *reinterpret_cast<f32x4 *>(op + 16 * c) = r;
+                se_acc(psum[c], r);
+            }
+        }
     }
-    s_red[tid] = psum;
-    __syncthreads();
-    if (tid < CQ) {
-        ll4 t = s_red[tid];
-        for (int j = 1; j < SLOTS; ++j) se_add(t, s_red[j * CQ + tid]);
-        *reinterpret_cast<ll4 *>(part + ((size_t)b * n_tiles + tile) * E + e0 + 4 * tid) = t;
+    // SE partial of this (strip, band): sum over the 16 columns of the row (exact integer adds)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) {
+            psum[c].x += __shfl_xor(psum[c].x, m, 64);
+            psum[c].y += __shfl_xor(psum[c].y, m, 64);
+            psum[c].z += __shfl_xor(psum[c].z, m, 64);
+            psum[c].w += __shfl_xor(psum[c].w, m, 64);
+        }
+        if (li == 0) *reinterpret_cast<ll4 *>(part + ((size_t)b * (n_strips * n_bands) + item) * E + e0 + 16 * c + 4 * kq) = psum[c];
     }
 }
 
