@@ -140,6 +140,8 @@ int pb_index_fill_synthetic(pb_index *idx, uint64_t seed, uint64_t first_row, ui
 #define PB_OPT_SCAN_GRID 7      /* explicit grid size (0 = workgroups per CU x CUs) */
 #define PB_OPT_SCAN_LAUNCH 8    /* 0 (default): one launch per query = one HBM pass each; 1: one launch for the chunk (queries share reads through the caches) */
 #define PB_OPT_MQ_WG_PER_CU 10  /* concurrent-query pass: workgroups per CU (default 2) */
+#define PB_OPT_MQ_PER_CHUNK 11  /* 1: bursts of > 64 queries run one 64-query pass at a time instead of sharing row tiles
+                                  among 512 queries per workgroup (default 0; for measurement) */
 int pb_index_set_option(pb_index *idx, int option, int64_t value);
 
 typedef struct pb_scan_stats {

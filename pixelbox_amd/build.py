@@ -41,6 +41,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         o = os.path.splitext(s)[0] + ".o"
         cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
                "-fno-fast-math", "-Wall", "-Wno-unused-function", "-c", s, "-o", o]
+        cmd[1:1] = os.environ.get("PB_EXTRA_HIPCC_FLAGS", "").split()  # kernel experiments (-D...), empty by default
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -18,6 +18,9 @@ PB_MAX_K = 256
 PB_OPT_SEARCH_PATH = 1
 PB_OPT_PROFILE = 2
 PB_OPT_STREAM = 3
+PB_OPT_MQ_MIN_QUERIES = 9
+PB_OPT_MQ_WG_PER_CU = 10
+PB_OPT_MQ_PER_CHUNK = 11
 PB_METRIC_COSINE, PB_METRIC_BYTE, PB_METRIC_HAMMING = 0, 1, 2
 
 # every symbol include/pixelbox_hip.h declares (tests/test_abi.py checks the header against this list

@@ -63,10 +63,10 @@ struct pb_index {
     uint64_t *d_xlists[2] = {nullptr, nullptr};  // exact pass ping-pong: Q_CHUNK * X_MAX_WG * PB_MAX_K
     uint32_t *d_xcounts[2] = {nullptr, nullptr};
     uint32_t *d_qsel = nullptr;     // Q_CHUNK
-    float *d_tau = nullptr;         // multi-query pass: per-query candidate threshold
-    uint64_t *d_cand = nullptr;     // Q_CHUNK * MQ_CAP
-    uint32_t *d_cand_cnt = nullptr; // Q_CHUNK
-    uint32_t *d_ghist = nullptr;    // Q_CHUNK * MQ_BINS
+    float *d_tau = nullptr;         // multi-query pass: per-query candidate threshold (PIPE_Q)
+    uint64_t *d_cand = nullptr;     // PIPE_Q * MQ_CAP
+    uint32_t *d_cand_cnt = nullptr; // PIPE_Q
+    uint32_t *d_ghist = nullptr;    // PIPE_Q * MQ_BINS
     int64_t *d_res_ids = nullptr;   // Q_CHUNK * PB_MAX_K
     float *d_res_dist = nullptr;
     ResultHdr *d_res_hdr = nullptr;
@@ -85,6 +85,7 @@ struct pb_index {
     int opt_mode = 0;       // 0 = one filter launch per query (independent HBM passes), 1 = one launch for the whole chunk
     int opt_mq_min_queries = 8;  // chunks with at least this many queries take the concurrent-query pass
     int opt_mq_wg_per_cu = 2;
+    int opt_mq_per_chunk = 0;  // 1: bursts run one 64-query pass at a time (the pre-workgroup-sharing form, for comparison)
     uint64_t stats_multi = 0;
     int opt_grid = 0;       // explicit filter-pass grid size (0: wg_per_cu * CUs)
     pb_scan_stats stats{};
@@ -105,10 +106,10 @@ int alloc_workspace(pb_index *ix) {
         PB_HIP(hipMalloc(&ix->d_xcounts[i], (size_t)Q_CHUNK * lists * sizeof(uint32_t)));
     }
     PB_HIP(hipMalloc(&ix->d_qsel, Q_CHUNK * sizeof(uint32_t)));
-    PB_HIP(hipMalloc(&ix->d_tau, Q_CHUNK * sizeof(float)));
-    PB_HIP(hipMalloc(&ix->d_cand, (size_t)Q_CHUNK * MQ_CAP * sizeof(uint64_t)));
-    PB_HIP(hipMalloc(&ix->d_cand_cnt, Q_CHUNK * sizeof(uint32_t)));
-    PB_HIP(hipMalloc(&ix->d_ghist, (size_t)Q_CHUNK * MQ_BINS * sizeof(uint32_t)));
+    PB_HIP(hipMalloc(&ix->d_tau, PIPE_Q * sizeof(float)));
+    PB_HIP(hipMalloc(&ix->d_cand, (size_t)PIPE_Q * MQ_CAP * sizeof(uint64_t)));
+    PB_HIP(hipMalloc(&ix->d_cand_cnt, PIPE_Q * sizeof(uint32_t)));
+    PB_HIP(hipMalloc(&ix->d_ghist, (size_t)PIPE_Q * MQ_BINS * sizeof(uint32_t)));
     PB_HIP(hipMalloc(&ix->d_res_ids, (size_t)PIPE_Q * PB_MAX_K * sizeof(int64_t)));
     PB_HIP(hipMalloc(&ix->d_res_dist, (size_t)PIPE_Q * PB_MAX_K * sizeof(float)));
     PB_HIP(hipMalloc(&ix->d_res_hdr, PIPE_Q * sizeof(ResultHdr)));
@@ -332,20 +333,23 @@ template <int QT>
 void launch_multi(pb_index *ix, bool hist, int grid, uint32_t base, uint32_t nq) {
     const uint8_t *dq = ix->d_queries + (size_t)base * ix->dim;
     const QParams *dp = ix->d_qp + base;
+    float *tau = ix->d_tau + base;
+    uint64_t *cand = ix->d_cand + (size_t)base * MQ_CAP;
+    uint32_t *cnt = ix->d_cand_cnt + base, *gh = ix->d_ghist + (size_t)base * MQ_BINS;
     if (hist)
         hipLaunchKernelGGL((k_scan_multi<QT, true>), dim3(grid), dim3(MQ_WAVES * 64), 0, ix->stream, ix->d_rows, ix->d_sumb,
-                           ix->d_denb, ix->n_rows, dq, dp, ix->d_tau, ix->d_cand, ix->d_cand_cnt, ix->d_ghist, (int)nq);
+                           ix->d_denb, ix->n_rows, dq, dp, tau, cand, cnt, gh, (int)nq);
     else
         hipLaunchKernelGGL((k_scan_multi<QT, false>), dim3(grid), dim3(MQ_WAVES * 64), 0, ix->stream, ix->d_rows, ix->d_sumb,
-                           ix->d_denb, ix->n_rows, dq, dp, ix->d_tau, ix->d_cand, ix->d_cand_cnt, ix->d_ghist, (int)nq);
+                           ix->d_denb, ix->n_rows, dq, dp, tau, cand, cnt, gh, (int)nq);
 }
 
 // queries [base, base + nq) of the staged device arrays; results to the same slots of d_res_*
 int run_multi(pb_index *ix, uint32_t nq, uint32_t k, uint32_t base = 0) {
     const int qt = (int)((nq + 15) / 16);
     const uint64_t n_tiles = (ix->n_rows + 15) / 16;
-    PB_HIP(hipMemsetAsync(ix->d_ghist, 0, (size_t)Q_CHUNK * MQ_BINS * sizeof(uint32_t), ix->stream));
-    PB_HIP(hipMemsetAsync(ix->d_cand_cnt, 0, Q_CHUNK * sizeof(uint32_t), ix->stream));
+    PB_HIP(hipMemsetAsync(ix->d_ghist + (size_t)base * MQ_BINS, 0, (size_t)nq * MQ_BINS * sizeof(uint32_t), ix->stream));
+    PB_HIP(hipMemsetAsync(ix->d_cand_cnt + base, 0, nq * sizeof(uint32_t), ix->stream));
     auto launch = [&](bool hist) {
         const uint64_t tiles = hist ? (n_tiles + MQ_SAMPLE - 1) / MQ_SAMPLE : n_tiles;
         const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((tiles + MQ_WAVES - 1) / MQ_WAVES,
@@ -362,17 +366,55 @@ int run_multi(pb_index *ix, uint32_t nq, uint32_t k, uint32_t base = 0) {
     // aim at ~max(3k, 384) candidates per query in the full table
     const uint32_t target_full = std::max<uint32_t>(3 * k, 384);
     const uint32_t target_sample = std::max<uint32_t>(2, (target_full + MQ_SAMPLE - 1) / MQ_SAMPLE);
-    hipLaunchKernelGGL(k_mq_pick_tau, dim3(nq), dim3(64), 0, ix->stream, ix->d_ghist, ix->d_qp + base, (int)nq, target_sample,
-                       ix->d_tau);
+    hipLaunchKernelGGL(k_mq_pick_tau, dim3(nq), dim3(64), 0, ix->stream, ix->d_ghist + (size_t)base * MQ_BINS, ix->d_qp + base,
+                       (int)nq, target_sample, ix->d_tau + base);
     PB_HIP(hipGetLastError());
     if (ix->opt_profile && base == 0) PB_HIP(hipEventRecord(ix->ev0, ix->stream));  // the first pass of a block is timed
     launch(false);
     PB_HIP(hipGetLastError());
     if (ix->opt_profile && base == 0) PB_HIP(hipEventRecord(ix->ev1, ix->stream));
     hipLaunchKernelGGL(k_mq_rescore, dim3(nq), dim3(1024), 0, ix->stream, ix->d_rows, ix->d_ids, ix->d_norms, (int)ix->dim,
-                       ix->d_queries + (size_t)base * ix->dim, ix->d_qp + base, ix->d_lut, ix->d_tau, ix->d_cand, ix->d_cand_cnt,
-                       ix->d_res_ids + (size_t)base * PB_MAX_K, ix->d_res_dist + (size_t)base * PB_MAX_K, ix->d_res_hdr + base,
-                       (uint32_t)PB_MAX_K);
+                       ix->d_queries + (size_t)base * ix->dim, ix->d_qp + base, ix->d_lut, ix->d_tau + base,
+                       ix->d_cand + (size_t)base * MQ_CAP, ix->d_cand_cnt + base, ix->d_res_ids + (size_t)base * PB_MAX_K,
+                       ix->d_res_dist + (size_t)base * PB_MAX_K, ix->d_res_hdr + base, (uint32_t)PB_MAX_K);
+    PB_HIP(hipGetLastError());
+    return PB_OK;
+}
+
+// A burst of nq <= PIPE_Q staged queries: the sample/threshold passes run per 64-query chunk (a sixteenth of the
+// table each), then ONE collect launch in which every workgroup shares its row tiles among 64 * MQ_WG_WAVES
+// queries, then the re-scoring of all nq candidate lists.
+constexpr int MQ_WG_WAVES = 8;
+int run_multi_block(pb_index *ix, uint32_t nq, uint32_t k) {
+    const uint64_t n_tiles = (ix->n_rows + 15) / 16;
+    PB_HIP(hipMemsetAsync(ix->d_ghist, 0, (size_t)nq * MQ_BINS * sizeof(uint32_t), ix->stream));
+    PB_HIP(hipMemsetAsync(ix->d_cand_cnt, 0, nq * sizeof(uint32_t), ix->stream));
+    const uint64_t tiles = (n_tiles + MQ_SAMPLE - 1) / MQ_SAMPLE;
+    // all 64-query chunks of the burst in one launch (grid.y = chunk).  Two workgroups per CU in total: every
+    // workgroup ends by adding its 64 x 256-bin LDS histogram to the global one, and with a full grid per chunk
+    // those tens of millions of global atomics, not the sampling, set the time of the pass
+    const uint32_t n_chunks = (nq + Q_CHUNK - 1) / Q_CHUNK;
+    const int hgrid = (int)std::max<uint64_t>(1, std::min<uint64_t>((tiles + MQ_WAVES - 1) / MQ_WAVES,
+                                                                      std::max<uint64_t>(16, 2ull * ix->n_cu / n_chunks)));
+    hipLaunchKernelGGL((k_scan_multi<4, true>), dim3(hgrid, n_chunks), dim3(MQ_WAVES * 64), 0, ix->stream,
+                       ix->d_rows, ix->d_sumb, ix->d_denb, ix->n_rows, ix->d_queries, ix->d_qp, ix->d_tau, ix->d_cand,
+                       ix->d_cand_cnt, ix->d_ghist, (int)nq);
+    PB_HIP(hipGetLastError());
+    const uint32_t target_full = std::max<uint32_t>(3 * k, 384);
+    const uint32_t target_sample = std::max<uint32_t>(2, (target_full + MQ_SAMPLE - 1) / MQ_SAMPLE);
+    hipLaunchKernelGGL(k_mq_pick_tau, dim3(nq), dim3(64), 0, ix->stream, ix->d_ghist, ix->d_qp, (int)nq, target_sample, ix->d_tau);
+    PB_HIP(hipGetLastError());
+    const uint64_t n_steps = (ix->n_rows + 16 * MQ_WG_WAVES - 1) / (16 * MQ_WG_WAVES);  // 16 NWQ rows per step
+    const uint32_t groups = (nq + 64 * MQ_WG_WAVES - 1) / (64 * MQ_WG_WAVES);
+    const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>(n_steps, (uint64_t)ix->n_cu * ix->opt_mq_wg_per_cu));
+    if (ix->opt_profile) PB_HIP(hipEventRecord(ix->ev0, ix->stream));
+    hipLaunchKernelGGL((k_scan_multi_wg<MQ_WG_WAVES>), dim3(grid, groups), dim3(MQ_WG_WAVES * 64), 0, ix->stream, ix->d_rows,
+                       ix->d_sumb, ix->d_denb, ix->n_rows, ix->d_queries, ix->d_qp, ix->d_tau, ix->d_cand, ix->d_cand_cnt, (int)nq);
+    PB_HIP(hipGetLastError());
+    if (ix->opt_profile) PB_HIP(hipEventRecord(ix->ev1, ix->stream));
+    hipLaunchKernelGGL(k_mq_rescore, dim3(nq), dim3(1024), 0, ix->stream, ix->d_rows, ix->d_ids, ix->d_norms, (int)ix->dim,
+                       ix->d_queries, ix->d_qp, ix->d_lut, ix->d_tau, ix->d_cand, ix->d_cand_cnt, ix->d_res_ids, ix->d_res_dist,
+                       ix->d_res_hdr, (uint32_t)PB_MAX_K);
     PB_HIP(hipGetLastError());
     return PB_OK;
 }
@@ -443,10 +485,14 @@ int search_block_multi(pb_index *ix, const uint8_t *queries, uint32_t nq, uint32
     for (uint32_t q = 0; q < nq; ++q) make_qparams(ix, hq + (size_t)q * d, k, max_dist, &hp[q]);
     PB_HIP(hipMemcpyAsync(ix->d_queries, hq, (size_t)nq * d, hipMemcpyHostToDevice, ix->stream));
     PB_HIP(hipMemcpyAsync(ix->d_qp, hp, (size_t)nq * sizeof(QParams), hipMemcpyHostToDevice, ix->stream));
-    uint32_t n_pass = 0;
-    for (uint32_t base = 0; base < nq; base += Q_CHUNK, ++n_pass) {
-        int rc = run_multi(ix, std::min(Q_CHUNK, nq - base), k, base);
+    if (nq > Q_CHUNK && !ix->opt_mq_per_chunk) {
+        int rc = run_multi_block(ix, nq, k);
         if (rc) return rc;
+    } else {
+        for (uint32_t base = 0; base < nq; base += Q_CHUNK) {
+            int rc = run_multi(ix, std::min(Q_CHUNK, nq - base), k, base);
+            if (rc) return rc;
+        }
     }
     PB_HIP(hipMemcpyAsync(ix->h_res_hdr, ix->d_res_hdr, nq * sizeof(ResultHdr), hipMemcpyDeviceToHost, ix->stream));
     PB_HIP(hipMemcpyAsync(ix->h_res_ids, ix->d_res_ids, (size_t)nq * PB_MAX_K * sizeof(int64_t), hipMemcpyDeviceToHost, ix->stream));
@@ -873,6 +919,10 @@ int pb_index_set_option(pb_index *ix, int option, int64_t value) {
         case PB_OPT_MQ_WG_PER_CU:
             PB_CHECK(value >= 1 && value <= 8, PB_ERR_INVALID, "1..8");
             ix->opt_mq_wg_per_cu = (int)value;
+            return PB_OK;
+        case PB_OPT_MQ_PER_CHUNK:
+            PB_CHECK(value == 0 || value == 1, PB_ERR_INVALID, "0 or 1");
+            ix->opt_mq_per_chunk = (int)value;
             return PB_OK;
         case PB_OPT_SCAN_LAUNCH:
             PB_CHECK(value == 0 || value == 1, PB_ERR_INVALID, "scan mode: 0 or 1");

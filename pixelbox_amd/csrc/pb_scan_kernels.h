@@ -766,6 +766,7 @@ constexpr int MQ_WAVES = 4;
 constexpr int MQ_BINS = 256;
 constexpr int MQ_CAP = 4096;
 constexpr int MQ_SAMPLE = 16;
+constexpr int MQ_HPITCH = 65;  // LDS histogram: [bin][query] with a 65-word pitch
 constexpr int MQ_LDROW = 272;  // 256 B row + 16 B pad: conflict-light ds_read_b128 in MFMA operand order
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -773,22 +774,33 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 template <int QT, bool HIST>
 __global__ __launch_bounds__(MQ_WAVES * WAVE) void k_scan_multi(
     const uint8_t *__restrict__ rows, const int32_t *__restrict__ sum_b, const int32_t *__restrict__ den_b,
-    uint64_t n_rows, const uint8_t *__restrict__ queries, const QParams *__restrict__ qp,
-    const float *__restrict__ tau, uint64_t *__restrict__ cand, uint32_t *__restrict__ cand_cnt,
-    uint32_t *__restrict__ ghist, int n_q) {
+    uint64_t n_rows, const uint8_t *queries, const QParams *qp, const float *tau, uint64_t *cand, uint32_t *cand_cnt,
+    uint32_t *ghist, int n_q) {
     constexpr int D = 256;
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[MQ_WAVES][16 * MQ_LDROW];
-    __shared__ uint32_t s_hist[HIST ? QT * 16 * MQ_BINS : 1];
+    __shared__ uint32_t s_hist[HIST ? MQ_BINS * MQ_HPITCH : 1];
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
     const int li = lane & 15, kq = lane >> 4;
+    // blockIdx.y selects a chunk of MQ_MAXQ queries (a burst's sample passes run as ONE launch); single-chunk
+    // launches have gridDim.y == 1
+    {
+        const int chunk0 = (int)blockIdx.y * MQ_MAXQ;
+        queries += (size_t)chunk0 * D;
+        qp += chunk0;
+        tau += chunk0;
+        cand += (size_t)chunk0 * MQ_CAP;
+        cand_cnt += chunk0;
+        ghist += (size_t)chunk0 * MQ_BINS;
+        n_q = (n_q - chunk0) < MQ_MAXQ ? (n_q - chunk0) : MQ_MAXQ;
+    }
     if constexpr (HIST) {
-        for (int i = threadIdx.x; i < QT * 16 * MQ_BINS; i += blockDim.x) s_hist[i] = 0;
+        for (int i = threadIdx.x; i < MQ_BINS * MQ_HPITCH; i += blockDim.x) s_hist[i] = 0;
         __syncthreads();
     }
     // query fragments (B operand): lane (j = li, kq) holds bytes [64 s + 16 kq, +16) of query 16 qt + j, as s8
     i32x4 bq[QT][4];
-    float den_a[QT], q_tau[QT], g_tau[QT];
+    float den_a[QT], q_tau[QT], g_tau[QT], rs_a[QT];
     int sum_a[QT], sa2[QT];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
@@ -805,6 +817,7 @@ __global__ __launch_bounds__(MQ_WAVES * WAVE) void k_scan_multi(
         q_tau[qt] = HIST ? qp[q].thr0 : tau[q];
         sa2[qt] = 2 * sum_a[qt];
         g_tau[qt] = q_tau[qt] * __builtin_amdgcn_sqrtf(den_a[qt]);  // tau > 0
+        rs_a[qt] = __builtin_amdgcn_rsqf(den_a[qt]);
     }
     uint8_t *tile = s_tile[wave];
     const uint64_t n_tiles = (n_rows + 15) / 16;
@@ -861,17 +874,27 @@ __global__ __launch_bounds__(MQ_WAVES * WAVE) void k_scan_multi(
         db.z = (rbase + 2 < n_rows) ? db.z : 1;
         db.w = (rbase + 3 < n_rows) ? db.w : 1;
         if constexpr (HIST) {
+            // the histogram only steers tau (efficiency, not correctness), so cos_filter is formed the cheap way:
+            // one multiply by the row's 1/sqrt(den_b) and one by the query's 1/sqrt(den_a); bins are laid out
+            // bin-major with a 65-word pitch so that the 16 query columns of a wave hit different LDS banks
+            float rsb[4];
+            int cr[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                rsb[r] = (rbase + r < n_rows) ? __builtin_amdgcn_rsqf((float)db[r]) : 0.0f;
+                cr[r] = 2 * sb[r] - 511 * D;
+            }
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
                 const int q = qt * 16 + li;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int num = 4 * acc[qt][r] + 2 * (sum_a[qt] + sb[r]) - 511 * D;
-                    const float cs = (float)num * __builtin_amdgcn_rsqf((float)db[r] * den_a[qt]);
-                    if ((rbase + r < n_rows) && (q < n_q) && cs >= q_tau[qt]) {
+                    const int num = 4 * acc[qt][r] + sa2[qt] + cr[r];
+                    const float cs = (float)num * rsb[r] * rs_a[qt];
+                    if (cs >= q_tau[qt] && q < n_q) {
                         int bin = (int)(cs * (float)MQ_BINS);
                         bin = bin < 0 ? 0 : (bin >= MQ_BINS ? MQ_BINS - 1 : bin);
-                        atomicAdd(&s_hist[(qt * 16 + li) * MQ_BINS + bin], 1u);
+                        atomicAdd(&s_hist[bin * MQ_HPITCH + q], 1u);
                     }
                 }
             }
@@ -905,10 +928,231 @@ __global__ __launch_bounds__(MQ_WAVES * WAVE) void k_scan_multi(
     if constexpr (HIST) {
         __syncthreads();
         for (int i = threadIdx.x; i < QT * 16 * MQ_BINS; i += blockDim.x) {
-            const uint32_t v = s_hist[i];
+            const int q = i / MQ_BINS, bin = i % MQ_BINS;  // ghist stays query-major
+            const uint32_t v = s_hist[bin * MQ_HPITCH + q];
             if (v) atomicAdd(&ghist[i], v);
         }
     }
+}
+
+// Collect pass for a large burst: a workgroup of NWQ waves walks the table ONCE for 64 * NWQ queries.  The row tile
+// (16 NWQ rows per step, four 16-byte loads per thread, s8-converted on the way) is staged in LDS, double-buffered
+// with one barrier per step and the global loads two steps ahead, and every wave multiplies it by ITS OWN 64
+// queries (4 x 4 query fragments resident in registers).  Table bytes per query drop from N*D/64 to N*D/(64 NWQ),
+// which moves the pass from the HBM roof to the i8-MFMA roof (at the clock the chip holds in an MFMA-dense loop).
+// Per (row, query) the survivor test is ONE v_fma_f32 plus a share of a max/compare:
+//     cos_filter >= tau  <=  num >= g W            with g = tau sqrt(den_a), W = sqrt(den_b) (1 - 1e-6)
+//                        <=  (4 acc' + cr) / W >= g - 1      acc' = acc + floor(2A/4),  cr = 2B - 511 D
+// * the per-query term rides in the accumulator: the MFMA chain starts from MAGIC + floor(2A[q] / 4);
+// * MAGIC = 0x4B400000 is the bit pattern of 1.5 * 2^23, so the i32 result READ AS A FLOAT is 12582912 + acc'
+//   (exact up to 2^24, an over-estimate beyond: still conservative), which makes the i32 -> f32 convert free;
+// * the per-row factors 4/W and (cr - 4 * 12582912)/W are computed once per step by the first threads (in f64,
+//   rounded once) and shared through LDS;
+// * the "- 1" covers the dropped remainder of 2A/4 (<= 2/W <= 0.125) and the f32 roundings (<= 0.6).
+// The rare survivors are re-tested exactly in integers and queued in LDS; the queue is drained with global atomics
+// between steps, so no wave waits for an atomic's return inside the MFMA stream.  The MFMAs of tile t+1 are issued
+// before the tests of tile t.  grid = (workgroups, ceil(n_q / (64 NWQ))).
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float max3_plain(float a, float b, float c) {
+    // v_max3_f32 without the quieting v_max x, x that fmaxf() puts in front of every operand (no NaNs here)
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ float fma_plain(float a, float b, float c) {
+    // one v_fma_f32: keeps hipcc from SLP-packing the tests into v_pk_fma_f32, which issues slower beside MFMAs
+    float d;
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+template <int NWQ>
+__global__ __launch_bounds__(NWQ * WAVE) void k_scan_multi_wg(
+    const uint8_t *__restrict__ rows, const int32_t *__restrict__ sum_b, const int32_t *__restrict__ den_b,
+    uint64_t n_rows, const uint8_t *__restrict__ queries, const QParams *__restrict__ qp,
+    const float *__restrict__ tau, uint64_t *__restrict__ cand, uint32_t *__restrict__ cand_cnt, int n_q) {
+    constexpr int D = 256;
+    constexpr int LPT = 4;             // 16-byte loads per thread per step
+    constexpr int TR = 4 * NWQ * LPT;  // rows per step
+    constexpr int NT = TR / 16;        // 16-row MFMA tiles per step
+    constexpr int QT = 4;
+    constexpr int MAGIC = 0x4B400000;  // bits of 12582912.0f
+    constexpr int QCAP = 512;          // survivor queue entries
+    static_assert(TR % 32 == 0 && TR <= NWQ * WAVE, "step shape");
+    __shared__ __attribute__((aligned(16))) uint8_t s_tile[2][TR * MQ_LDROW];
+    __shared__ __attribute__((aligned(16))) float s_iw[2][TR];  // 4 / W
+    __shared__ __attribute__((aligned(16))) float s_c2[2][TR];  // (cr - 4 * 12582912) / W
+    __shared__ i32x4 s_qacc[QCAP];  // survivor queue: accumulator quad, query, first row of the quad
+    __shared__ uint32_t s_qq[QCAP], s_qrow[QCAP];
+    __shared__ uint32_t s_qcnt;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int qbase = (int)blockIdx.y * (NWQ * 64) + wave * 64;
+    const bool active = qbase < n_q;  // a wave whose 64 queries lie past n_q only helps loading
+    if (tid == 0) s_qcnt = 0;
+    i32x4 bq[QT][4];
+    i32x4 cinit[QT];
+    float gthr[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        int q = qbase + qt * 16 + li;
+        q = q < n_q ? q : n_q - 1;  // padded columns repeat the last query (their results are never appended)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            i32x4 v = *reinterpret_cast<const i32x4 *>(queries + (size_t)q * D + 64 * s + 16 * kq);
+            v.x ^= 0x80808080; v.y ^= 0x80808080; v.z ^= 0x80808080; v.w ^= 0x80808080;
+            bq[qt][s] = v;
+        }
+        const int c0 = MAGIC + (2 * qp[q].sum_a) / 4;  // sum_a >= 0
+        cinit[qt] = (i32x4){c0, c0, c0, c0};
+        gthr[qt] = tau[q] * __builtin_amdgcn_sqrtf(qp[q].den_a) - 1.0f;  // tau > 0
+    }
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const uint64_t n_steps = (n_rows + TR - 1) / TR;
+    const int ld_row = tid >> 4, ld_col = (tid & 15) * 16;  // thread's first row of the step; the others are + 4 NWQ j
+    u32x4 ld[2][LPT];
+    int ld_sb[2] = {0, 0}, ld_db[2] = {1, 1};
+    auto issue = [&](uint64_t stp, u32x4 (&dst)[LPT], int &sb, int &db) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) {
+            uint64_t r = stp * TR + (uint64_t)(ld_row + j * 4 * NWQ);
+            r = r < n_rows ? r : n_rows - 1;
+            dst[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(rows + r * D + ld_col));
+        }
+        if (tid < TR) {
+            uint64_t rr = stp * TR + (uint64_t)tid;
+            rr = rr < n_rows ? rr : n_rows - 1;
+            sb = sum_b[rr];
+            db = den_b[rr];
+        }
+    };
+    auto stage = [&](uint64_t stp, int buf, const u32x4 (&src)[LPT], int sb, int db) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) {
+            u32x4 v = src[j];
+            v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u;
+            *reinterpret_cast<u32x4 *>(&s_tile[buf][(ld_row + j * 4 * NWQ) * MQ_LDROW + ld_col]) = v;
+        }
+        if (tid < TR) {
+            const bool ok = stp * TR + (uint64_t)tid < n_rows;  // rows past the end can never pass
+            const double w = (double)(__builtin_amdgcn_sqrtf((float)db) * (1.0f - 1e-6f));
+            s_iw[buf][tid] = ok ? (float)(4.0 / w) : 0.0f;
+            s_c2[buf][tid] = ok ? (float)(((double)(2 * sb - 511 * D) - 50331648.0) / w) : -3.0e38f;
+        }
+    };
+    // exact integer re-test of one queued (row, query) and append to the query's candidate list
+    auto retest_append = [&](int acc_bits, int q, uint32_t row) __attribute__((always_inline)) {
+        const int sa2 = 2 * qp[q].sum_a;
+        const int num = 4 * (acc_bits - MAGIC - sa2 / 4) + sa2 + 2 * sum_b[row] - 511 * D;
+        const float cs = (float)num * __builtin_amdgcn_rsqf((float)den_b[row] * qp[q].den_a);
+        if (cs >= tau[q]) {
+            const uint32_t idx = atomicAdd(&cand_cnt[q], 1u);
+            if (idx < MQ_CAP) cand[(size_t)q * MQ_CAP + idx] = filter_key(cs, row);
+        }
+    };
+    auto mfma_tile = [&](const uint8_t *tile, i32x4 (&acc)[QT]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const i32x4 a = *reinterpret_cast<const i32x4 *>(tile + li * MQ_LDROW + 64 * s + 16 * kq);
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt)
+                acc[qt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bq[qt][s], s == 0 ? cinit[qt] : acc[qt], 0, 0, 0);
+        }
+    };
+    auto test_tile = [&](const i32x4 (&acc)[QT], int buf, int tl, uint64_t stp) __attribute__((always_inline)) {
+        // lane holds rows rbase + r (r = 0..3) of query column li
+        const int rl = 16 * tl + 4 * kq;
+        const f32x4_t iw = *reinterpret_cast<const f32x4_t *>(&s_iw[buf][rl]);
+        const f32x4_t c2 = *reinterpret_cast<const f32x4_t *>(&s_c2[buf][rl]);
+        float t[QT][4], dq[QT];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t[qt][r] = fma_plain(__int_as_float(acc[qt][r]), iw[r], c2[r]);
+            dq[qt] = max3_plain(max3_plain(t[qt][0], t[qt][1], t[qt][2]), t[qt][3], -3.0e38f) - gthr[qt];
+        }
+        const float any = max3_plain(max3_plain(dq[0], dq[1], dq[2]), dq[3], -1.0f);
+        // ONE rarely-taken branch per tile.  It only QUEUES the lane's accumulator quad (4 rows of one query) in
+        // LDS, in a handful of instructions: with 8 waves meeting at a barrier every step, and some wave of a
+        // step's 64 wave-tiles nearly always holding a survivor, whatever this branch costs is paid by the whole
+        // workgroup on almost every step.  The exact re-test (which also discards the quad's non-survivors: it
+        // implies the test above) and the append to the candidate lists happen in drain().
+        if (any >= 0.0f) {
+            const uint32_t row0 = (uint32_t)(stp * TR) + (uint32_t)rl;
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                const int q = qbase + qt * 16 + li;
+                if (dq[qt] >= 0.0f && q < n_q) {
+                    const uint32_t slot = atomicAdd(&s_qcnt, 1u);
+                    if (slot < (uint32_t)QCAP) {
+                        s_qacc[slot] = acc[qt];
+                        s_qq[slot] = (uint32_t)q;
+                        s_qrow[slot] = row0;
+                    } else {
+                        // queue full: only a burst of (near-)duplicates of a query inside one 128-row step does
+                        // that.  Mark the list as overflowed; the query takes the exhaustive pass.
+                        atomicOr(&cand_cnt[q], 0x80000000u);
+                    }
+                }
+            }
+        }
+    };
+    // drain the survivor queue (called by all threads between two barriers)
+    auto drain = [&]() __attribute__((always_inline)) {
+        const uint32_t n = s_qcnt < (uint32_t)QCAP ? s_qcnt : (uint32_t)QCAP;
+        for (uint32_t i = tid; i < 4 * n; i += NWQ * WAVE) {
+            const uint32_t e = i >> 2, r = i & 3;
+            const uint32_t row = s_qrow[e] + r;
+            if ((uint64_t)row < n_rows) retest_append(reinterpret_cast<const int *>(&s_qacc[e])[r], (int)s_qq[e], row);
+        }
+        __syncthreads();
+        if (tid == 0) s_qcnt = 0;
+        __syncthreads();
+    };
+    // one step: loads for step + 2 go out, step is computed from LDS buffer `buf`, step + 1 (requested one step ago)
+    // is staged into the other buffer, barrier
+    auto step = [&](uint64_t stp, int buf, u32x4 (&ld_far)[LPT], int &sb_far, int &db_far, const u32x4 (&ld_near)[LPT], int sb_near,
+                    int db_near) __attribute__((always_inline)) {
+        const uint64_t s1 = stp + gridDim.x, s2 = s1 + gridDim.x;
+        if (active) {
+            i32x4 acc0[QT], acc1[QT];
+            mfma_tile(&s_tile[buf][0], acc0);
+            // ld_far's registers were staged one step ago: free again
+            if (s2 < n_steps) issue(s2, ld_far, sb_far, db_far);
+            // two tiles per trip and NOT unrolled further: with all NT tiles (and their rarely-taken re-test
+            // blocks) unrolled the loop body outgrows the instruction cache and every step refetches it
+#pragma nounroll
+            for (int tp = 0; tp < NT / 2; ++tp) {
+                mfma_tile(&s_tile[buf][(16 * (2 * tp + 1)) * MQ_LDROW], acc1);
+                test_tile(acc0, buf, 2 * tp, stp);
+                if (tp + 1 < NT / 2) mfma_tile(&s_tile[buf][(16 * (2 * tp + 2)) * MQ_LDROW], acc0);
+                test_tile(acc1, buf, 2 * tp + 1, stp);
+            }
+        } else if (s2 < n_steps) {
+            issue(s2, ld_far, sb_far, db_far);
+        }
+        if (s1 < n_steps) stage(s1, buf ^ 1, ld_near, sb_near, db_near);
+        __syncthreads();
+        if (s_qcnt >= (uint32_t)(QCAP / 2)) drain();  // uniform: read after the barrier
+    };
+    uint64_t st = blockIdx.x;
+    if (st < n_steps) {
+        issue(st, ld[0], ld_sb[0], ld_db[0]);
+        stage(st, 0, ld[0], ld_sb[0], ld_db[0]);
+        if (st + gridDim.x < n_steps) issue(st + gridDim.x, ld[1], ld_sb[1], ld_db[1]);
+    }
+    __syncthreads();
+    // step i computes from buffer i & 1; its "near" registers (step i + 1) are slot (i + 1) & 1, "far" slot i & 1
+    while (st < n_steps) {
+        step(st, 0, ld[0], ld_sb[0], ld_db[0], ld[1], ld_sb[1], ld_db[1]);
+        st += gridDim.x;
+        if (st >= n_steps) break;
+        step(st, 1, ld[1], ld_sb[1], ld_db[1], ld[0], ld_sb[0], ld_db[0]);
+        st += gridDim.x;
+    }
+    drain();
 }
 
 // per query: tau = lower edge of the highest histogram bin at which the sampled count reaches `target_sample`
@@ -955,8 +1199,9 @@ __global__ __launch_bounds__(1024) void k_mq_rescore(
     for (int i = tid; i < 256; i += 1024) s_lut[i] = lut[i];
     __syncthreads();
     for (int i = tid; i < d; i += 1024) s_qf[i] = s_lut[queries[(size_t)q * d + i]];
-    const uint32_t raw = cand_cnt[q];
-    const int cnt = raw < (uint32_t)MQ_CAP ? (int)raw : MQ_CAP;
+    const uint32_t raw = cand_cnt[q];  // bit 31: the collect pass dropped candidates (survivor queue overflow)
+    const uint32_t listed = raw & 0x7FFFFFFFu;
+    const int cnt = listed < (uint32_t)MQ_CAP ? (int)listed : MQ_CAP;
     int nsort = 64;
     while (nsort < cnt) nsort <<= 1;
     __syncthreads();

@@ -305,8 +305,9 @@ def test_packed_device_results_and_merge_roundtrip():
 
 
 # ---- concurrent-query pass (i8 MFMA, one pass over the table for up to 64 queries) ----------------------
-@pytest.mark.parametrize("nq", [1, 15, 16, 17, 33, 64, 100])
+@pytest.mark.parametrize("nq", [1, 15, 16, 17, 33, 64, 65, 100, 513, 600])
 def test_multi_query_pass_vs_oracle(nq):
+    # nq > 64: the burst form -- one collect launch whose workgroups share each row tile among 512 queries
     rng = np.random.default_rng(60 + nq)
     n = 70000
     rows = rng.integers(0, 256, size=(n, 256), dtype=np.uint8)
@@ -335,6 +336,22 @@ def test_multi_query_pass_tail_rows_and_auto_switch():
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
 
 
+def test_multi_query_burst_equals_per_chunk_passes_and_handles_tails():
+    rng = np.random.default_rng(63)
+    n = 65536 + 45  # 32-row steps: a partial last step, and its second 16-row tile entirely past the end
+    rows = rng.integers(0, 256, size=(n, 256), dtype=np.uint8)
+    ids = np.arange(n, dtype=np.int64) + 9
+    q = rng.integers(0, 256, size=(130, 256), dtype=np.uint8)
+    q[:4] = rows[[0, n - 1, n - 14, n - 33]]
+    a = make_index(rows, ids, path=MULTI)
+    b = make_index(rows, ids, path=MULTI)
+    b.set_option(capi.PB_OPT_MQ_PER_CHUNK, 1)
+    ra, rb = a.search(q, 100, 1e3), b.search(q, 100, 1e3)
+    assert all(np.array_equal(x, y) for x, y in zip(ra, rb))
+    check_against_oracle(a, rows, ids, q[:12])
+    check_against_oracle(a, rows, ids, q[100:], k=5, max_dist=3.5)
+
+
 def test_multi_query_pass_adversarial_falls_back():
     rng = np.random.default_rng(62)
     n = 80000
@@ -347,6 +364,8 @@ def test_multi_query_pass_adversarial_falls_back():
     check_against_oracle(ix, rows, ids, q)
     check_against_oracle(ix, rows, ids, q[3:6], max_dist=2e6)
     assert ix.stats().fallback >= 1
+    big = np.concatenate([q, rng.integers(0, 256, size=(70, 256), dtype=np.uint8)])  # the same through the burst form
+    check_against_oracle(ix, rows, ids, big)
     # clustered, embedding-like table
     centers = np.tanh(rng.standard_normal((30, 256)).astype(np.float32))
     which = rng.integers(0, 30, size=n)
