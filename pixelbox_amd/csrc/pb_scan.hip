@@ -168,6 +168,8 @@ int launch_norms(pb_index *ix, uint64_t first, uint64_t n) {
 
 // Per-query constants.  The f32 fold is the reference's (engine.rs:580-581, `hash_a` half); the
 // integer sums feed the filter pass.  Host arithmetic: this TU is compiled with -ffp-contract=off.
+void finish_qparams(const pb_index *ix, float acc, int64_t sum_a, int64_t sum_a2, uint32_t k, double max_dist, QParams *out);
+
 void make_qparams(const pb_index *ix, const uint8_t *q, uint32_t k, double max_dist, QParams *out) {
     const uint32_t d = ix->dim;
     float acc = 0.0f;
@@ -179,6 +181,42 @@ void make_qparams(const pb_index *ix, const uint8_t *q, uint32_t k, double max_d
         sum_a += q[i];
         sum_a2 += (int64_t)q[i] * q[i];
     }
+    finish_qparams(ix, acc, sum_a, sum_a2, k, max_dist, out);
+}
+
+// nq queries: the reference's left-to-right f32 fold is a dependent chain of d additions per query (~1 us at
+// d = 256 when done one query at a time: 0.4 ms of host time per 1024-query burst); eight chains are advanced
+// side by side, each in its own order, so the sums are bit-identical to make_qparams
+void make_qparams_batch(const pb_index *ix, const uint8_t *q, uint32_t nq, uint32_t k, double max_dist, QParams *out) {
+    const uint32_t d = ix->dim;
+    constexpr uint32_t W = 8;
+    uint32_t q0 = 0;
+    for (; q0 + W <= nq; q0 += W) {
+        float acc[W];
+        int64_t sa[W], sa2[W];
+        for (uint32_t j = 0; j < W; ++j) {
+            acc[j] = 0.0f;
+            sa[j] = 0;
+            sa2[j] = 0;
+        }
+        const uint8_t *base = q + (size_t)q0 * d;
+        for (uint32_t i = 0; i < d; ++i) {
+            for (uint32_t j = 0; j < W; ++j) {
+                const uint8_t v = base[(size_t)j * d + i];
+                const float x = ix->lut[v];
+                const float p = x * x;
+                acc[j] = acc[j] + p;
+                sa[j] += v;
+                sa2[j] += (int64_t)v * v;
+            }
+        }
+        for (uint32_t j = 0; j < W; ++j) finish_qparams(ix, acc[j], sa[j], sa2[j], k, max_dist, &out[q0 + j]);
+    }
+    for (; q0 < nq; ++q0) make_qparams(ix, q + (size_t)q0 * d, k, max_dist, &out[q0]);
+}
+
+void finish_qparams(const pb_index *ix, float acc, int64_t sum_a, int64_t sum_a2, uint32_t k, double max_dist, QParams *out) {
+    const uint32_t d = ix->dim;
     QParams P{};
     P.max_dist = max_dist;
     P.sqrt_sa = std::sqrt(acc);
@@ -363,8 +401,8 @@ int run_multi(pb_index *ix, uint32_t nq, uint32_t k, uint32_t base = 0) {
     };
     launch(true);
     PB_HIP(hipGetLastError());
-    // aim at ~max(3k, 384) candidates per query in the full table
-    const uint32_t target_full = std::max<uint32_t>(3 * k, 384);
+    // aim at ~max(4k, 512) candidates per query in the full table (1/32 sample: 16 sampled rows fix tau)
+    const uint32_t target_full = std::max<uint32_t>(4 * k, 512);
     const uint32_t target_sample = std::max<uint32_t>(2, (target_full + MQ_SAMPLE - 1) / MQ_SAMPLE);
     hipLaunchKernelGGL(k_mq_pick_tau, dim3(nq), dim3(64), 0, ix->stream, ix->d_ghist + (size_t)base * MQ_BINS, ix->d_qp + base,
                        (int)nq, target_sample, ix->d_tau + base);
@@ -390,17 +428,17 @@ int run_multi_block(pb_index *ix, uint32_t nq, uint32_t k) {
     PB_HIP(hipMemsetAsync(ix->d_ghist, 0, (size_t)nq * MQ_BINS * sizeof(uint32_t), ix->stream));
     PB_HIP(hipMemsetAsync(ix->d_cand_cnt, 0, nq * sizeof(uint32_t), ix->stream));
     const uint64_t tiles = (n_tiles + MQ_SAMPLE - 1) / MQ_SAMPLE;
-    // all 64-query chunks of the burst in one launch (grid.y = chunk).  Two workgroups per CU in total: every
+    // all 64-query chunks of the burst in one launch (grid.y = chunk).  Four workgroups per CU in total: every
     // workgroup ends by adding its 64 x 256-bin LDS histogram to the global one, and with a full grid per chunk
     // those tens of millions of global atomics, not the sampling, set the time of the pass
     const uint32_t n_chunks = (nq + Q_CHUNK - 1) / Q_CHUNK;
     const int hgrid = (int)std::max<uint64_t>(1, std::min<uint64_t>((tiles + MQ_WAVES - 1) / MQ_WAVES,
-                                                                      std::max<uint64_t>(16, 2ull * ix->n_cu / n_chunks)));
+                                                                      std::max<uint64_t>(16, 4ull * ix->n_cu / n_chunks)));
     hipLaunchKernelGGL((k_scan_multi<4, true>), dim3(hgrid, n_chunks), dim3(MQ_WAVES * 64), 0, ix->stream,
                        ix->d_rows, ix->d_sumb, ix->d_denb, ix->n_rows, ix->d_queries, ix->d_qp, ix->d_tau, ix->d_cand,
                        ix->d_cand_cnt, ix->d_ghist, (int)nq);
     PB_HIP(hipGetLastError());
-    const uint32_t target_full = std::max<uint32_t>(3 * k, 384);
+    const uint32_t target_full = std::max<uint32_t>(4 * k, 512);
     const uint32_t target_sample = std::max<uint32_t>(2, (target_full + MQ_SAMPLE - 1) / MQ_SAMPLE);
     hipLaunchKernelGGL(k_mq_pick_tau, dim3(nq), dim3(64), 0, ix->stream, ix->d_ghist, ix->d_qp, (int)nq, target_sample, ix->d_tau);
     PB_HIP(hipGetLastError());
@@ -434,7 +472,7 @@ int search_chunk(pb_index *ix, uint32_t cq, uint32_t k, double max_dist) {
     QParams *hp = reinterpret_cast<QParams *>(ix->h_stage + (size_t)Q_CHUNK * d);
     uint32_t *hsel = reinterpret_cast<uint32_t *>(ix->h_stage + (size_t)Q_CHUNK * (d + sizeof(QParams)));
     const bool use_fast = ix->metric == 0 && (ix->opt_path == 0 || ix->opt_path == 2 || ix->opt_path == 3) && fast_dim(d);
-    for (uint32_t q = 0; q < cq; ++q) make_qparams(ix, hq + (size_t)q * d, k, max_dist, &hp[q]);
+    make_qparams_batch(ix, hq, cq, k, max_dist, hp);
     PB_HIP(hipMemcpyAsync(ix->d_queries, hq, (size_t)cq * d, hipMemcpyHostToDevice, ix->stream));
     PB_HIP(hipMemcpyAsync(ix->d_qp, hp, (size_t)cq * sizeof(QParams), hipMemcpyHostToDevice, ix->stream));
     uint32_t n_sel = 0;
@@ -482,10 +520,14 @@ int search_block_multi(pb_index *ix, const uint8_t *queries, uint32_t nq, uint32
     uint8_t *hq = ix->h_pipe;
     QParams *hp = reinterpret_cast<QParams *>(ix->h_pipe + (size_t)PIPE_Q * d);
     memcpy(hq, queries, (size_t)nq * d);
-    for (uint32_t q = 0; q < nq; ++q) make_qparams(ix, hq + (size_t)q * d, k, max_dist, &hp[q]);
+    make_qparams_batch(ix, hq, nq, k, max_dist, hp);
     PB_HIP(hipMemcpyAsync(ix->d_queries, hq, (size_t)nq * d, hipMemcpyHostToDevice, ix->stream));
     PB_HIP(hipMemcpyAsync(ix->d_qp, hp, (size_t)nq * sizeof(QParams), hipMemcpyHostToDevice, ix->stream));
-    if (nq > Q_CHUNK && !ix->opt_mq_per_chunk) {
+    // the burst form queues survivors in LDS (1024 entries, drained between steps); a step of 128 rows x 512
+    // queries yields ~65536 * target / N of them, so small tables (where the ~max(4k, 512) wanted candidates are a
+    // large fraction of the rows) keep the per-chunk form
+    const uint64_t burst_min_rows = 512ull * std::max<uint32_t>(4 * k, 512);
+    if (nq > Q_CHUNK && !ix->opt_mq_per_chunk && ix->n_rows >= burst_min_rows) {
         int rc = run_multi_block(ix, nq, k);
         if (rc) return rc;
     } else {

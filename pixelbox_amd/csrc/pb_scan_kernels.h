@@ -765,8 +765,9 @@ constexpr int MQ_MAXQ = 64;
 constexpr int MQ_WAVES = 4;
 constexpr int MQ_BINS = 256;
 constexpr int MQ_CAP = 4096;
-constexpr int MQ_SAMPLE = 16;
-constexpr int MQ_HPITCH = 65;  // LDS histogram: [bin][query] with a 65-word pitch
+constexpr int MQ_SAMPLE = 32;
+constexpr int MQ_HPITCH = 65;  // LDS histogram: [bin pair][query] with a 65-word pitch, two 16-bit counters per word
+                               // (a workgroup samples far fewer than 65536 rows)
 constexpr int MQ_LDROW = 272;  // 256 B row + 16 B pad: conflict-light ds_read_b128 in MFMA operand order
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -778,7 +779,7 @@ __global__ __launch_bounds__(MQ_WAVES * WAVE) void k_scan_multi(
     uint32_t *ghist, int n_q) {
     constexpr int D = 256;
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[MQ_WAVES][16 * MQ_LDROW];
-    __shared__ uint32_t s_hist[HIST ? MQ_BINS * MQ_HPITCH : 1];
+    __shared__ uint32_t s_hist[HIST ? (MQ_BINS / 2) * MQ_HPITCH : 1];  // two 16-bit counters per word
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
     const int li = lane & 15, kq = lane >> 4;
@@ -795,7 +796,7 @@ __global__ __launch_bounds__(MQ_WAVES * WAVE) void k_scan_multi(
         n_q = (n_q - chunk0) < MQ_MAXQ ? (n_q - chunk0) : MQ_MAXQ;
     }
     if constexpr (HIST) {
-        for (int i = threadIdx.x; i < MQ_BINS * MQ_HPITCH; i += blockDim.x) s_hist[i] = 0;
+        for (int i = threadIdx.x; i < (MQ_BINS / 2) * MQ_HPITCH; i += blockDim.x) s_hist[i] = 0;
         __syncthreads();
     }
     // query fragments (B operand): lane (j = li, kq) holds bytes [64 s + 16 kq, +16) of query 16 qt + j, as s8
@@ -838,21 +839,21 @@ __global__ __launch_bounds__(MQ_WAVES * WAVE) void k_scan_multi(
         sbv = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(sum_b + r0 + 4 * (uint64_t)kq));
         dbv = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(den_b + r0 + 4 * (uint64_t)kq));
     };
-    u32x4 ld[4];
-    i32x4 sb_n = {0, 0, 0, 0}, db_n = {1, 1, 1, 1};
-    uint64_t t = (uint64_t)wave * gridDim.x + blockIdx.x;
-    if (t < n_tiles && tile_of(t) < n_tiles) issue(tile_of(t), ld, sb_n, db_n);
-    for (; t < n_tiles; t += stride) {
+    // two tiles in flight per wave (register slots 0 / 1): with one, a wave's next 4 KiB arrive later than it
+    // finishes the current tile and the pass runs at memory LATENCY
+    u32x4 ld[2][4];
+    i32x4 sb_n[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, db_n[2] = {{1, 1, 1, 1}, {1, 1, 1, 1}};
+    auto valid = [&](uint64_t tv) { return tv < n_tiles && tile_of(tv) < n_tiles; };
+    auto process = [&](uint64_t t, u32x4 (&lds)[4], i32x4 &sbn, i32x4 &dbn) __attribute__((always_inline)) {
         const uint64_t tt = tile_of(t);
-        if (tt >= n_tiles) break;
         const uint64_t row0 = tt * 16;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            *reinterpret_cast<u32x4 *>(tile + (4 * j + kq) * MQ_LDROW + li * 16) = ld[j];
-        i32x4 sb = sb_n, db = db_n;
+            *reinterpret_cast<u32x4 *>(tile + (4 * j + kq) * MQ_LDROW + li * 16) = lds[j];
+        i32x4 sb = sbn, db = dbn;
         {
-            const uint64_t tn = t + stride;
-            if (tn < n_tiles && tile_of(tn) < n_tiles) issue(tile_of(tn), ld, sb_n, db_n);
+            const uint64_t tn = t + 2 * stride;  // this slot's next tile
+            if (valid(tn)) issue(tile_of(tn), lds, sbn, dbn);
         }
         i32x4 acc[QT];
 #pragma unroll
@@ -894,7 +895,7 @@ __global__ __launch_bounds__(MQ_WAVES * WAVE) void k_scan_multi(
                     if (cs >= q_tau[qt] && q < n_q) {
                         int bin = (int)(cs * (float)MQ_BINS);
                         bin = bin < 0 ? 0 : (bin >= MQ_BINS ? MQ_BINS - 1 : bin);
-                        atomicAdd(&s_hist[bin * MQ_HPITCH + q], 1u);
+                        atomicAdd(&s_hist[(bin >> 1) * MQ_HPITCH + q], 1u << (16 * (bin & 1)));
                     }
                 }
             }
@@ -924,12 +925,22 @@ __global__ __launch_bounds__(MQ_WAVES * WAVE) void k_scan_multi(
                 }
             }
         }
+    };
+    uint64_t t = (uint64_t)wave * gridDim.x + blockIdx.x;
+    if (valid(t)) issue(tile_of(t), ld[0], sb_n[0], db_n[0]);
+    if (valid(t + stride)) issue(tile_of(t + stride), ld[1], sb_n[1], db_n[1]);
+    while (valid(t)) {
+        process(t, ld[0], sb_n[0], db_n[0]);
+        t += stride;
+        if (!valid(t)) break;
+        process(t, ld[1], sb_n[1], db_n[1]);
+        t += stride;
     }
     if constexpr (HIST) {
         __syncthreads();
         for (int i = threadIdx.x; i < QT * 16 * MQ_BINS; i += blockDim.x) {
             const int q = i / MQ_BINS, bin = i % MQ_BINS;  // ghist stays query-major
-            const uint32_t v = s_hist[bin * MQ_HPITCH + q];
+            const uint32_t v = (s_hist[(bin >> 1) * MQ_HPITCH + q] >> (16 * (bin & 1))) & 0xFFFFu;
             if (v) atomicAdd(&ghist[i], v);
         }
     }
@@ -978,7 +989,7 @@ __global__ __launch_bounds__(NWQ * WAVE) void k_scan_multi_wg(
     constexpr int NT = TR / 16;        // 16-row MFMA tiles per step
     constexpr int QT = 4;
     constexpr int MAGIC = 0x4B400000;  // bits of 12582912.0f
-    constexpr int QCAP = 512;          // survivor queue entries
+    constexpr int QCAP = 1024;         // survivor queue entries
     static_assert(TR % 32 == 0 && TR <= NWQ * WAVE, "step shape");
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[2][TR * MQ_LDROW];
     __shared__ __attribute__((aligned(16))) float s_iw[2][TR];  // 4 / W
