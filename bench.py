@@ -58,6 +58,11 @@ def parse():
 
 def main():
     args = parse()
+    # stdout must carry exactly ONE line, the JSON: native libraries (RCCL prints a version banner on some builds)
+    # write to fd 1 behind Python's back, so everything except the final line is sent to stderr
+    real_stdout = os.dup(1)
+    sys.stdout.flush()
+    os.dup2(2, 1)
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
@@ -208,7 +213,8 @@ def main():
         if last is not None:
             out["check"] = {"first_result_id": int(last[0][0][0]) if last[2][0] else None,
                             "first_result_dist": float(last[1][0][0]) if last[2][0] else None}
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if distributed:
         torch.distributed.destroy_process_group()
 

@@ -515,7 +515,8 @@ int search_chunk(pb_index *ix, uint32_t cq, uint32_t k, double max_dist) {
 // Concurrent-query path for a block of <= PIPE_Q queries: everything is staged and launched back to back, the
 // host waits ONCE, then re-runs the (rare) uncertified queries through the exhaustive pass.  Results land in
 // h_res_ids / h_res_dist / h_res_hdr slots [0, nq).
-int search_block_multi(pb_index *ix, const uint8_t *queries, uint32_t nq, uint32_t k, double max_dist) {
+int search_block_multi(pb_index *ix, const uint8_t *queries, uint32_t nq, uint32_t k, double max_dist,
+                       uint32_t *n_failed = nullptr) {
     const uint32_t d = ix->dim;
     uint8_t *hq = ix->h_pipe;
     QParams *hp = reinterpret_cast<QParams *>(ix->h_pipe + (size_t)PIPE_Q * d);
@@ -547,6 +548,7 @@ int search_block_multi(pb_index *ix, const uint8_t *queries, uint32_t nq, uint32
     std::vector<uint32_t> failed;
     for (uint32_t q = 0; q < nq; ++q)
         if (ix->h_res_hdr[q].status != 0) failed.push_back(q);
+    if (n_failed) *n_failed = (uint32_t)failed.size();
     ix->stats.queries += nq;
     ix->stats.fast_path += nq - failed.size();
     ix->stats_multi += nq - failed.size();
@@ -638,6 +640,26 @@ int search_packed_locked(pb_index *ix, const uint8_t *queries, uint32_t nq, uint
         return PB_OK;
     }
     PB_CHECK(ix->n_rows < (1ull << 32), PB_ERR_CAPACITY, "more than 2^32 rows per shard are not supported");
+    if (nq > Q_CHUNK && multi_eligible(ix, nq)) {
+        // a burst: the concurrent-query path a block at a time; queries that needed the exhaustive pass were
+        // patched in the host copies, so those blocks are written back before packing
+        for (uint32_t q0 = 0; q0 < nq; q0 += PIPE_Q) {
+            const uint32_t cq = std::min(PIPE_Q, nq - q0);
+            uint32_t n_failed = 0;
+            int rc = search_block_multi(ix, queries + (size_t)q0 * d, cq, k, max_dist, &n_failed);
+            if (rc) return rc;
+            if (n_failed) {
+                PB_HIP(hipMemcpyAsync(ix->d_res_ids, ix->h_res_ids, (size_t)cq * PB_MAX_K * sizeof(int64_t), hipMemcpyHostToDevice, ix->stream));
+                PB_HIP(hipMemcpyAsync(ix->d_res_dist, ix->h_res_dist, (size_t)cq * PB_MAX_K * sizeof(float), hipMemcpyHostToDevice, ix->stream));
+                PB_HIP(hipMemcpyAsync(ix->d_res_hdr, ix->h_res_hdr, cq * sizeof(ResultHdr), hipMemcpyHostToDevice, ix->stream));
+            }
+            hipLaunchKernelGGL(k_pack_results, dim3(cq), dim3(256), 0, ix->stream, ix->d_res_ids, ix->d_res_dist, ix->d_res_hdr,
+                               (uint32_t)PB_MAX_K, k, d_packed + (size_t)q0 * row);
+            PB_HIP(hipGetLastError());
+            PB_HIP(hipStreamSynchronize(ix->stream));  // the next block reuses the staging buffers
+        }
+        return PB_OK;
+    }
     for (uint32_t q0 = 0; q0 < nq; q0 += Q_CHUNK) {
         const uint32_t cq = std::min(Q_CHUNK, nq - q0);
         memcpy(ix->h_stage, queries + (size_t)q0 * d, (size_t)cq * d);

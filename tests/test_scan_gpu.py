@@ -304,6 +304,36 @@ def test_packed_device_results_and_merge_roundtrip():
         assert np.array_equal(g_d[qi, : g_c[qi]].view(np.uint32), want_d.view(np.uint32))
 
 
+def test_packed_burst_matches_host_results_including_fallback_queries():
+    # the all-gather message of a burst (> 64 queries) comes from the concurrent-query path; queries whose
+    # certificate failed are patched from the exhaustive pass before packing
+    import torch
+
+    rng = np.random.default_rng(51)
+    n = 262144 + 5
+    rows = rng.integers(0, 256, size=(n, 256), dtype=np.uint8)
+    v = rng.integers(0, 256, size=256, dtype=np.uint8)
+    rows[1000:7000] = v  # 6000 duplicates: that query's candidate list overflows -> exhaustive pass
+    ids = np.arange(n, dtype=np.int64) + 3
+    q = rng.integers(0, 256, size=(150, 256), dtype=np.uint8)
+    q[77] = v
+    k = 50
+    ix = make_index(rows, ids)
+    t = torch.zeros((len(q), 2 * k + 1), dtype=torch.int64, device="cuda")
+    ix.search_packed(q, k, 1e3, t.data_ptr())
+    torch.cuda.synchronize()
+    assert ix.stats().fallback >= 1
+    host = t.cpu().numpy()
+    ref = make_index(rows, ids, path=SINGLE)
+    l_ids, l_d, l_c = ref.search(q, k, 1e3)
+    assert np.array_equal(host[:, 2 * k], l_c)
+    for qi in range(len(q)):
+        c = int(l_c[qi])
+        assert np.array_equal(host[qi, :c], l_ids[qi, :c])
+        assert np.array_equal(host[qi, k : k + c].astype(np.uint32), l_d[qi, :c].view(np.uint32))
+    assert np.array_equal(host[77, :k], np.arange(1003, 1003 + k))
+
+
 # ---- concurrent-query pass (i8 MFMA, one pass over the table for up to 64 queries) ----------------------
 @pytest.mark.parametrize("nq", [1, 15, 16, 17, 33, 64, 65, 100])
 def test_multi_query_pass_vs_oracle(nq):
