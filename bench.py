@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--embed-batch", type=int, default=512)
     ap.add_argument("--embed-steps", type=int, default=10)
     ap.add_argument("--no-embed", action="store_true")
+    ap.add_argument("--e2e-images", type=int, default=131072,
+                    help="end-to-end leg (BASELINE configs[4]): embed + insert this many synthetic images, then serve "
+                         "1000 concurrent queries (0: skip; the configuration itself is 1000000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=2_000_000)
     ap.add_argument("--exact-path", action="store_true", help="force the exhaustive exact scan (diagnostic)")
@@ -188,6 +191,14 @@ def main():
         except capi.PixelboxError as e:
             embed = {"error": str(e)}
 
+    e2e = None
+    if args.e2e_images > 0 and not args.no_embed and not args.exact_path:
+        del sh  # free the 10M-row shard first
+        try:
+            e2e = bench_end_to_end(args, torch, rank, world, local_rank, distributed)
+        except capi.PixelboxError as e:
+            e2e = {"error": str(e)}
+
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, synth, qbytes[args.warmup][: 4])
@@ -210,6 +221,8 @@ def main():
             out["concurrent"] = concurrent
         if embed is not None:
             out["embed"] = embed
+        if e2e is not None:
+            out["end_to_end"] = e2e
         if last is not None:
             out["check"] = {"first_result_id": int(last[0][0][0]) if last[2][0] else None,
                             "first_result_dist": float(last[1][0][0]) if last[2][0] else None}
@@ -304,6 +317,88 @@ def bench_embed(args, torch, device, distributed):
                                "sample": f"{n} synthetic 128x128 images, batch-1 per call on 4 threads "
                                          "(PARALLEL_FILE_PROCESSORS = 4, engine.rs:22); naive f32 C port, not tract-onnx"}
     return res
+
+
+def bench_end_to_end(args, torch, rank, world, device, distributed):
+    """BASELINE configs[4] in one piece: embed N synthetic images (generated on the device), insert their hashes into
+    the row-sharded index (rank r embeds and stores images [r*N/G, (r+1)*N/G), ids = image number + 1), then serve
+    1000 concurrent similarity queries (the hashes of 1000 of the inserted images) through the all-gather merge."""
+    from pixelbox_amd import capi, synth, weights
+    from pixelbox_amd.sharded import ShardedIndex
+
+    n, nb, d = args.e2e_images, 512, 256
+    blob = weights.synthetic_blob(synth.SEED_WEIGHTS, 128, 128, d)
+    emb = capi.Embedder(blob, max_batch=nb, device=device)
+    sh = ShardedIndex(d, n, rank=rank, world=world, device=device,
+                      group=(torch.distributed.group.WORLD if distributed else None))
+    imgs = torch.empty((nb, 128, 128, 3), dtype=torch.uint8, device=f"cuda:{device}")
+    out = torch.empty((nb, d), dtype=torch.uint8, device=f"cuda:{device}")
+
+    def barrier():
+        if distributed:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    def hashes_of(first, count):
+        capi.fill_synthetic_images_device(device, synth.SEED_IMAGES, first, count, 128, 128, imgs.data_ptr())
+        emb.embed_device(imgs.data_ptr(), count, out.data_ptr())
+        torch.cuda.synchronize()
+        return out[:count].cpu().numpy()
+
+    hashes_of(0, nb)  # warm-up: kernel selection for the full batch
+    barrier()
+    t0 = time.perf_counter()
+    t_gen = 0.0
+    for first in range(sh.row_lo, sh.row_hi, nb):
+        count = min(nb, sh.row_hi - first)
+        tg = time.perf_counter()
+        capi.fill_synthetic_images_device(device, synth.SEED_IMAGES, first, count, 128, 128, imgs.data_ptr())
+        t_gen += time.perf_counter() - tg
+        emb.embed_device(imgs.data_ptr(), count, out.data_ptr())
+        torch.cuda.synchronize()
+        stored = sh.index.append(np.arange(first + 1, first + count + 1, dtype=np.int64), out[:count].cpu().numpy())
+        assert stored == count
+    barrier()
+    t_index = time.perf_counter() - t0
+    # 1000 query images, evenly spread over the collection; every rank recomputes their hashes (bit-identical on
+    # every GPU and for every batch size)
+    nq = 1000
+    pick = (np.arange(nq, dtype=np.int64) * n) // nq
+    qh = np.empty((nq, d), dtype=np.uint8)
+    for i, img in enumerate(pick):  # scattered image numbers: one image per generator call, batched embeds
+        capi.fill_synthetic_images_device(device, synth.SEED_IMAGES, int(img), 1, 128, 128, imgs[i % nb].data_ptr())
+        if (i + 1) % nb == 0 or i + 1 == nq:
+            cnt = i % nb + 1
+            emb.embed_device(imgs.data_ptr(), cnt, out.data_ptr())
+            torch.cuda.synchronize()
+            qh[i + 1 - cnt : i + 1] = out[:cnt].cpu().numpy()
+    sh.index.set_option(capi.PB_OPT_SEARCH_PATH, 0)
+    sh.search(qh[:128], args.k, args.max_dist)
+    sh.index.stats(reset=True)
+    barrier()
+    t1 = time.perf_counter()
+    ids, dist, cnt = sh.search(qh, args.k, args.max_dist)
+    barrier()
+    t_query = time.perf_counter() - t1
+    st = sh.index.stats()
+    if distributed:
+        t = torch.tensor([t_index, t_query], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        t_index, t_query = float(t[0].item()), float(t[1].item())
+    # every query image is in the collection: its own id (or an identical hash with a smaller id) comes first
+    self_found = int(np.sum((cnt > 0) & (dist[:, 0] <= 1e-6)))
+    exact_self = int(np.sum(ids[:, 0] == pick + 1))
+    return {"images": n, "index_phase_s": round(t_index, 3), "images_per_s": round(n / t_index, 1),
+            "of_which_image_generation_s": round(t_gen, 3),
+            "queries": nq, "query_phase_ms": round(t_query * 1e3, 3), "queries_per_s": round(nq / t_query, 1),
+            "queries_with_zero_distance_first_hit": self_found, "queries_whose_first_hit_is_their_own_id": exact_self,
+            "certified": int(st.fast_path), "exhaustive_fallback": int(st.fallback),
+            "note": "images generated on the GPU (pb_fill_synthetic_images), embedded in batches of 512, hashes inserted "
+                    "through pb_index_append (D2H + H2D of 128 KB per batch, per-row norms computed at insert); "
+                    "the configuration itself is 1000000 images (--e2e-images 1000000).  The random-init network maps "
+                    "the synthetic images onto few distinct hashes (~40 % exact duplicates, clusters of tens of "
+                    "thousands of rows within 4e-4 of a query's 100th cosine): for such queries no candidate list "
+                    "can certify the top-100 and they take the exhaustive pass (counted above)"}
 
 
 def cpu_baseline(args, synth, queries):

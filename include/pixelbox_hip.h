@@ -190,6 +190,13 @@ int pb_embed_set_option(pb_embedder *e, int option, int64_t value);
  * (definition in pixelbox_amd/synth.py).  byte_offset must be a multiple of 8. */
 int pb_fill_synthetic(int device, uint64_t seed, uint64_t byte_offset, uint64_t nbytes, uint8_t *d_out);
 
+/* Synthetic RGB8 images [start, start + n) of image stream `seed` on the device, d_out[n][h][w][3] -- the
+ * definition of pixelbox_amd/synth.py:synthetic_images (stream noise squeezed into a per-(image, channel)
+ * brightness window, integer arithmetic only).  h*w*3 must be a multiple of 8.  Lets the end-to-end
+ * configuration (BASELINE.json configs[4]: embed + insert 1M synthetic images) run without staging 49 GB of
+ * pixels through the host. */
+int pb_fill_synthetic_images(int device, uint64_t seed, uint64_t start, uint64_t n, uint32_t h, uint32_t w, uint8_t *d_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,7 +31,7 @@ SYMBOLS = [
     "pb_index_search", "pb_index_search_device", "pb_index_search_packed", "pb_topk_merge_packed", "pb_topk_merge", "pb_index_read", "pb_index_fill_synthetic",
     "pb_index_set_option", "pb_index_get_stats",
     "pb_embed_create", "pb_embed_destroy", "pb_embed_info", "pb_embed_batch", "pb_embed_batch_device", "pb_mlhash",
-    "pb_embed_set_option", "pb_fill_synthetic",
+    "pb_embed_set_option", "pb_fill_synthetic", "pb_fill_synthetic_images",
 ]
 
 
@@ -94,6 +94,7 @@ def lib():
         L.pb_mlhash.argtypes = [vp, u8p, u8p, C.c_size_t]
         L.pb_embed_set_option.argtypes = [vp, C.c_int, C.c_int64]
         L.pb_fill_synthetic.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, vp]
+        L.pb_fill_synthetic_images.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, vp]
         _lib = L
     return _lib
 
@@ -278,3 +279,8 @@ class Embedder:
 
 def fill_synthetic_device(device: int, seed: int, byte_offset: int, nbytes: int, d_ptr: int):
     _check(lib().pb_fill_synthetic(device, seed, byte_offset, nbytes, C.c_void_p(d_ptr)))
+
+
+def fill_synthetic_images_device(device: int, seed: int, start: int, n: int, h: int, w: int, d_ptr: int):
+    """Images [start, start + n) of synth.synthetic_images(seed, ...) written to device memory uint8[n][h][w][3]."""
+    _check(lib().pb_fill_synthetic_images(device, seed, start, n, h, w, C.c_void_p(d_ptr)))

@@ -46,6 +46,8 @@ struct pb_index {
     float *d_norms = nullptr;
     int32_t *d_sumb = nullptr;  // per-row integer sum of bytes, sum (2b-255)^2: side tables of the multi-query pass
     int32_t *d_denb = nullptr;
+    int32_t *d_min_den = nullptr;     // min over stored rows of sum (2b-255)^2 (device scalar, kept by k_row_norms)
+    int32_t min_den_b = 0x7FFFFFFF;   // host copy
     float *d_lut = nullptr;
     std::vector<int64_t> h_ids;  // ascending, mirrors d_ids
     float lut[256];
@@ -141,6 +143,7 @@ void free_all(pb_index *ix) {
     (void)hipFree(ix->d_ghist);
     (void)hipFree(ix->d_sumb);
     (void)hipFree(ix->d_denb);
+    (void)hipFree(ix->d_min_den);
     (void)hipFree(ix->d_res_ids);
     (void)hipFree(ix->d_res_dist);
     (void)hipFree(ix->d_res_hdr);
@@ -161,8 +164,11 @@ int launch_norms(pb_index *ix, uint64_t first, uint64_t n) {
     const uint64_t want = (n + block - 1) / block;
     const int grid = (int)std::min<uint64_t>(want, (uint64_t)ix->n_cu * 8);
     hipLaunchKernelGGL(k_row_norms, dim3(grid), dim3(block), 0, ix->stream, ix->d_rows, first, n, (int)ix->dim,
-                       ix->d_lut, ix->d_norms, ix->d_sumb, ix->d_denb);
+                       ix->d_lut, ix->d_norms, ix->d_sumb, ix->d_denb, ix->d_min_den);
     PB_HIP(hipGetLastError());
+    // the running minimum feeds the per-query error margin (finish_qparams); every caller synchronises next
+    PB_HIP(hipMemcpyAsync(&ix->min_den_b, ix->d_min_den, sizeof(int32_t), hipMemcpyDeviceToHost, ix->stream));
+    PB_HIP(hipStreamSynchronize(ix->stream));
     return PB_OK;
 }
 
@@ -229,8 +235,19 @@ void finish_qparams(const pb_index *ix, float acc, int64_t sum_a, int64_t sum_a2
     if (max_dist == max_dist && max_dist > -0.5 && max_dist < 9.0e5) {
         c_floor = (float)((1.0 / (max_dist + 1.0)) * (1.0 - 2e-6));
     }
-    const float thr_min = 2.0f * M_GLOB + 2e-6f;  // stay clear of the cos <= 1e-6 plateau (dist = 999999)
-    const float thr_filter = c_floor - 1.01f * M_GLOB;
+    // |cos_filter - cos_ref| <= m for this query against every stored row: de-quantisation LUT
+    // rounding 6u sqrt(n) (1/|X| + 1/|Y|) with |X| = sqrt(den_a)/255 and |Y| >= sqrt(min den_b)/255, the reference's
+    // fold/norm/divide roundings (2n+4)u, the filter's own f32 steps 1e-6; 25 % on top.  All-127/128 rows give the
+    // old fixed 4e-4-class margin; ordinary data ~3.5e-5, which is what lets clustered tables (many rows within a
+    // few 1e-4 of the k-th cosine) certify
+    const double u = 1.0 / 16777216.0, nn = (double)d;
+    const double den_q = (double)(4 * sum_a2 - 1020 * sum_a + 65025ll * d);
+    const double den_r = (double)std::max<int32_t>(1, ix->min_den_b);
+    double m = 1.25 * (6.0 * u * std::sqrt(nn) * 255.0 * (1.0 / std::sqrt(den_q) + 1.0 / std::sqrt(den_r)) + (2.0 * nn + 4.0) * u + 1e-6);
+    if (!(m < (double)M_GLOB)) m = (double)M_GLOB;  // never looser than the all-vectors worst case budgeted before
+    P.m = (float)m * (1.0f + 1e-6f);
+    const float thr_min = 2.0f * P.m + 2e-6f;  // stay clear of the cos <= 1e-6 plateau (dist = 999999)
+    const float thr_filter = c_floor - 1.01f * P.m;
     P.c_floor = c_floor;
     if (thr_filter >= thr_min) {
         P.thr0 = thr_filter;
@@ -490,7 +507,12 @@ int search_chunk(pb_index *ix, uint32_t cq, uint32_t k, double max_dist) {
             if (rc2) return rc2;
         }
         for (uint32_t q = 0; q < cq; ++q)
-            if (ix->h_res_hdr[q].status != 0) hsel[n_sel++] = q;
+            if (ix->h_res_hdr[q].status != 0) {
+                hsel[n_sel++] = q;
+                if (getenv("PB_TRACE_CERT"))
+                    fprintf(stderr, "cert fail (chunk path, multi=%d): q=%u count=%u n_cand=%u o_max=%.7f thr0=%.7f\n", (int)use_multi, q,
+                            ix->h_res_hdr[q].count, ix->h_res_hdr[q].n_cand, ix->h_res_hdr[q].o_max, hp[q].thr0);
+            }
         ix->stats.fast_path += cq - n_sel;
         if (use_multi) ix->stats_multi += cq - n_sel;
     } else {
@@ -547,7 +569,12 @@ int search_block_multi(pb_index *ix, const uint8_t *queries, uint32_t nq, uint32
     }
     std::vector<uint32_t> failed;
     for (uint32_t q = 0; q < nq; ++q)
-        if (ix->h_res_hdr[q].status != 0) failed.push_back(q);
+        if (ix->h_res_hdr[q].status != 0) {
+            failed.push_back(q);
+            if (getenv("PB_TRACE_CERT"))
+                fprintf(stderr, "cert fail (burst path): q=%u count=%u n_cand=%u o_max=%.7f thr0=%.7f\n", q, ix->h_res_hdr[q].count,
+                        ix->h_res_hdr[q].n_cand, ix->h_res_hdr[q].o_max, hp[q].thr0);
+        }
     if (n_failed) *n_failed = (uint32_t)failed.size();
     ix->stats.queries += nq;
     ix->stats.fast_path += nq - failed.size();
@@ -772,6 +799,8 @@ int pb_index_create(pb_index **out, int device, uint32_t dim, uint64_t capacity_
         PB_HIP(hipMalloc(&ix->d_denb, (capacity_rows + 32) * sizeof(int32_t)));
         PB_HIP(hipMemset(ix->d_sumb, 0, (capacity_rows + 32) * sizeof(int32_t)));
         PB_HIP(hipMemset(ix->d_denb, 0, (capacity_rows + 32) * sizeof(int32_t)));
+        PB_HIP(hipMalloc(&ix->d_min_den, sizeof(int32_t)));
+        PB_HIP(hipMemcpy(ix->d_min_den, &ix->min_den_b, sizeof(int32_t), hipMemcpyHostToDevice));
         PB_HIP(hipMalloc(&ix->d_lut, 256 * sizeof(float)));
         PB_HIP(hipMemcpy(ix->d_lut, ix->lut, 256 * sizeof(float), hipMemcpyHostToDevice));
         return alloc_workspace(ix);
@@ -1091,6 +1120,24 @@ int pb_fill_synthetic(int device, uint64_t seed, uint64_t byte_offset, uint64_t 
     const int block = 256;
     const int grid = (int)std::min<uint64_t>((n_words + block - 1) / block, 65536);
     hipLaunchKernelGGL(k_fill_synth, dim3(grid), dim3(block), 0, nullptr, seed, byte_offset / 8, n_words,
+                       reinterpret_cast<uint64_t *>(d_out));
+    PB_HIP(hipGetLastError());
+    PB_HIP(hipStreamSynchronize(nullptr));
+    return PB_OK;
+}
+
+int pb_fill_synthetic_images(int device, uint64_t seed, uint64_t start, uint64_t n, uint32_t h, uint32_t w, uint8_t *d_out) {
+    PB_CHECK(d_out || n == 0, PB_ERR_INVALID, "pb_fill_synthetic_images: null output");
+    const uint64_t per = (uint64_t)h * w * 3;
+    PB_CHECK(per > 0 && per % 8 == 0, PB_ERR_INVALID, "pb_fill_synthetic_images: h*w*3 = %llu must be a positive multiple of 8",
+             (unsigned long long)per);
+    if (n == 0) return PB_OK;
+    pb::DeviceGuard guard(device);
+    PB_CHECK(guard.ok, PB_ERR_HIP, "hipSetDevice(%d) failed", device);
+    const uint64_t n_words = n * per / 8;
+    const int block = 256;
+    const int grid = (int)std::min<uint64_t>((n_words + block - 1) / block, 65536);
+    hipLaunchKernelGGL(k_fill_synth_images, dim3(grid), dim3(block), 0, nullptr, seed, start, per, n_words,
                        reinterpret_cast<uint64_t *>(d_out));
     PB_HIP(hipGetLastError());
     PB_HIP(hipStreamSynchronize(nullptr));

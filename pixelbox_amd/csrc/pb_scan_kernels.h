@@ -45,7 +45,7 @@ constexpr int M_SORT = 4096;  // M_FANIN * PB_MAX_K
 // from the rounded de-quantisation table (|x| >= sqrt(n)/255), 1e-6 for the filter's own f32 steps.
 // n = 256: 3.1e-5 + 1.8e-4 + 1e-6.  The constant below is used for every n <= 1024 that the filter
 // pass accepts (gamma_n grows to 1.2e-4 at n = 1024, the table term does not depend on n).
-constexpr float M_GLOB = 4.0e-4f;
+constexpr float M_GLOB = 4.0e-4f;  // ceiling of the per-query margin QParams::m (worst case over all byte vectors)
 
 struct QParams {
     double max_dist;     // WHERE dist < ?
@@ -54,9 +54,9 @@ struct QParams {
     float thr0;          // filter pass: rows with cos_filter < thr0 are never collected
     float c_floor;       // every row with cos_ref < c_floor fails `dist < max_dist`
     int32_t sum_a;       // integer sum of query bytes
-    int32_t floor_is_filter;  // thr0 == c_floor - M_GLOB (rows below thr0 are provably filtered out)
+    int32_t floor_is_filter;  // thr0 == c_floor - m (rows below thr0 are provably filtered out)
     uint32_t k;
-    uint32_t pad;
+    float m;             // |cos_filter - cos_ref| <= m for this query against every stored row
 };
 
 struct ListHdr {
@@ -238,10 +238,11 @@ __device__ __forceinline__ float ref_distance(float dot, float sqrt_sa, float ro
 // sqrt(fold(x*x)) per row, row-per-lane (engine.rs:580-581, the `hash_b` half)
 __global__ void k_row_norms(const uint8_t *__restrict__ rows, uint64_t first, uint64_t n, int d,
                             const float *__restrict__ lut, float *__restrict__ norms,
-                            int32_t *__restrict__ sum_b, int32_t *__restrict__ den_b) {
+                            int32_t *__restrict__ sum_b, int32_t *__restrict__ den_b, int32_t *__restrict__ min_den) {
     __shared__ float s_lut[256];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_lut[i] = lut[i];
     __syncthreads();
+    int32_t my_min = 0x7FFFFFFF;  // smallest sum (2b-255)^2 seen: feeds the per-query error margin
     for (uint64_t r = first + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < first + n;
          r += (uint64_t)gridDim.x * blockDim.x) {
         const uint8_t *row = rows + r * (uint64_t)d;
@@ -257,8 +258,15 @@ __global__ void k_row_norms(const uint8_t *__restrict__ rows, uint64_t first, ui
         }
         norms[r] = sqrtf(acc);  // correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt default)
         sum_b[r] = sb;                                   // exact integers for the multi-query pass
-        den_b[r] = 4 * sb2 - 1020 * sb + 65025 * d;      // = sum (2b-255)^2
+        const int32_t den = 4 * sb2 - 1020 * sb + 65025 * d;  // = sum (2b-255)^2
+        den_b[r] = den;
+        my_min = den < my_min ? den : my_min;
     }
+    for (int off = 32; off >= 1; off >>= 1) {
+        const int32_t o = __shfl_xor(my_min, off);
+        my_min = o < my_min ? o : my_min;
+    }
+    if ((threadIdx.x & 63) == 0 && my_min != 0x7FFFFFFF) atomicMin(min_den, my_min);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -498,7 +506,7 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
         lb = P.thr0 + (float)found / scale - 2e-6f;
         lb = fmaxf(lb, P.thr0);
     }
-    const float cut = lb - 2.0f * M_GLOB;
+    const float cut = lb - 2.0f * P.m;
 
     // ---- candidates: every listed entry with cos_filter >= cut
     const int total_slots = n_lists * F_KWG;
@@ -576,7 +584,7 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
     if (tid == 0) {
         ck = 3.0f;
         for (int w = 0; w < SEL_BLOCK / WAVE; ++w) ck = fminf(ck, s_ck[w]);
-        const float o_max = fmaxf(fmaxf(cut, dmax), P.thr0) + M_GLOB;  // no unexamined row's exact cos reaches this
+        const float o_max = fmaxf(fmaxf(cut, dmax), P.thr0) + P.m;  // no unexamined row's exact cos reaches this
         bool ok = !overflow;
         if (n_out == P.k) {
             ok = ok && (o_max <= ck * (1.0f - 1e-6f));
@@ -1278,7 +1286,7 @@ __global__ __launch_bounds__(1024) void k_mq_rescore(
             ck = fminf(ck, s_red[w]);
             cfilt = fmaxf(cfilt, s_red2[w]);
         }
-        const float o_max = fmaxf(tau[q], P.thr0) + M_GLOB;  // no unlisted row's exact cosine reaches this
+        const float o_max = fmaxf(tau[q], P.thr0) + P.m;  // no unlisted row's exact cosine reaches this
         bool ok = raw <= (uint32_t)MQ_CAP;
         if (n_out == P.k) ok = ok && (o_max <= ck * (1.0f - 1e-6f));
         else ok = ok && ((P.floor_is_filter && o_max <= P.c_floor) || (o_max <= cfilt));
@@ -1318,6 +1326,29 @@ __global__ void k_fill_synth(uint64_t seed, uint64_t first_word, uint64_t n_word
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words;
          i += (uint64_t)gridDim.x * blockDim.x)
         out[i] = splitmix64_at(seed, first_word + i);
+}
+// synthetic RGB8 images (pixelbox_amd/synth.py:synthetic_images): word i of the output holds bytes 8i..8i+7 of the
+// pixel stream starting at image `start`; per = h*w*3 bytes per image
+__global__ void k_fill_synth_images(uint64_t seed, uint64_t start, uint64_t per, uint64_t n_words, uint64_t *__restrict__ out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t g0 = start * per + 8 * i;  // global byte index of this word's first byte
+        const uint64_t noise = splitmix64_at(seed, g0 >> 3);
+        uint64_t o = 0;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const uint64_t g = g0 + b;
+            const uint64_t img = g / per, c = g % 3;  // per % 3 == 0: channel = byte index mod 3
+            const uint64_t z = splitmix64_at(seed ^ 0xC0FFEEull, img * 3 + c);
+            const uint32_t lo = (uint32_t)(z & 0xFF) * 3 / 4;
+            const uint32_t span = (uint32_t)((z >> 8) & 0xFF) / 4 + 1;
+            const uint32_t nz = (uint32_t)(noise >> (8 * b)) & 0xFF;
+            uint32_t px = lo + ((nz * span) >> 8);
+            px = px > 255 ? 255 : px;
+            o |= (uint64_t)px << (8 * b);
+        }
+        out[i] = o;
+    }
 }
 __global__ void k_iota_ids(int64_t first_id, uint64_t n, int64_t *__restrict__ out) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;

@@ -112,6 +112,17 @@ def test_device_pointer_entry_point():
     assert np.array_equal(d_u8.cpu().numpy(), ref_u8) and np.array_equal(d_f.cpu().numpy(), ref_f)
 
 
+def test_device_image_generator_matches_the_host_definition():
+    import torch
+
+    for (h, w, start, n) in [(128, 128, 0, 3), (128, 128, 1000003, 5), (32, 40, 7, 9)]:
+        d = torch.zeros((n, h, w, 3), dtype=torch.uint8, device="cuda")
+        capi.fill_synthetic_images_device(0, synth.SEED_IMAGES, start, n, h, w, d.data_ptr())
+        assert np.array_equal(d.cpu().numpy(), synth.synthetic_images(synth.SEED_IMAGES, start, n, h, w))
+    with pytest.raises(capi.PixelboxError):
+        capi.fill_synthetic_images_device(0, 1, 0, 1, 3, 3, 1)  # 27 bytes per image: not a multiple of 8
+
+
 def test_bad_blobs_fail_loudly():
     blob = W.synthetic_blob(synth.SEED_WEIGHTS, 128, 128, 256)
     for bad in (blob[:-4], b"XXXX" + blob[4:], blob[:40]):
