@@ -1144,4 +1144,15 @@ int pb_fill_synthetic_images(int device, uint64_t seed, uint64_t start, uint64_t
     return PB_OK;
 }
 
+#ifdef PB_MQ_STAMP
+int pb_debug_mq_stamps(unsigned long long *out, int reset) {
+    PB_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mq_stamp), 8 * sizeof(unsigned long long)));
+    if (reset) {
+        unsigned long long z[8] = {0};
+        PB_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_mq_stamp), z, sizeof(z)));
+    }
+    return PB_OK;
+}
+#endif
+
 }  // extern "C"

@@ -986,6 +986,9 @@ __device__ __forceinline__ float fma_plain(float a, float b, float c) {
     return d;
 }
 
+#ifdef PB_MQ_STAMP
+__device__ unsigned long long g_mq_stamp[8];
+#endif
 template <int NWQ>
 __global__ __launch_bounds__(NWQ * WAVE) void k_scan_multi_wg(
     const uint8_t *__restrict__ rows, const int32_t *__restrict__ sum_b, const int32_t *__restrict__ den_b,
@@ -1130,11 +1133,17 @@ __global__ __launch_bounds__(NWQ * WAVE) void k_scan_multi_wg(
         if (tid == 0) s_qcnt = 0;
         __syncthreads();
     };
+#ifdef PB_MQ_STAMP
+    unsigned long long st_c = 0, st_s = 0, st_b = 0, st_n = 0;
+#endif
     // one step: loads for step + 2 go out, step is computed from LDS buffer `buf`, step + 1 (requested one step ago)
     // is staged into the other buffer, barrier
     auto step = [&](uint64_t stp, int buf, u32x4 (&ld_far)[LPT], int &sb_far, int &db_far, const u32x4 (&ld_near)[LPT], int sb_near,
                     int db_near) __attribute__((always_inline)) {
         const uint64_t s1 = stp + gridDim.x, s2 = s1 + gridDim.x;
+#ifdef PB_MQ_STAMP
+        const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#endif
         if (active) {
             i32x4 acc0[QT], acc1[QT];
             mfma_tile(&s_tile[buf][0], acc0);
@@ -1152,8 +1161,18 @@ __global__ __launch_bounds__(NWQ * WAVE) void k_scan_multi_wg(
         } else if (s2 < n_steps) {
             issue(s2, ld_far, sb_far, db_far);
         }
+#ifdef PB_MQ_STAMP
+        const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
+#endif
         if (s1 < n_steps) stage(s1, buf ^ 1, ld_near, sb_near, db_near);
+#ifdef PB_MQ_STAMP
+        const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
+#endif
         __syncthreads();
+#ifdef PB_MQ_STAMP
+        const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
+        st_c += ts1 - ts0; st_s += ts2 - ts1; st_b += ts3 - ts2; st_n += 1;
+#endif
         if (s_qcnt >= (uint32_t)(QCAP / 2)) drain();  // uniform: read after the barrier
     };
     uint64_t st = blockIdx.x;
@@ -1172,6 +1191,11 @@ __global__ __launch_bounds__(NWQ * WAVE) void k_scan_multi_wg(
         st += gridDim.x;
     }
     drain();
+#ifdef PB_MQ_STAMP
+    if (lane == 0 && active) {
+        atomicAdd(&g_mq_stamp[0], st_c); atomicAdd(&g_mq_stamp[1], st_s); atomicAdd(&g_mq_stamp[2], st_b); atomicAdd(&g_mq_stamp[3], st_n);
+    }
+#endif
 }
 
 // per query: tau = lower edge of the highest histogram bin at which the sampled count reaches `target_sample`
