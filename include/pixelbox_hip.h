@@ -180,6 +180,18 @@ int pb_embed_batch_device(pb_embedder *e, const uint8_t *d_rgb, uint32_t n, uint
 /* mlhash(img) -> Vec<u8> for one image: writes D bytes to out (out_len must be >= D). */
 int pb_mlhash(pb_embedder *e, const uint8_t *rgb, uint8_t *out, size_t out_len);
 
+/* The same for images of ANY size: efficientnet.rs:19-29 `image_to_tensor` in full -- the image crate's
+ * `resize_to_fill(W, H, FilterType::Triangle)` (scale to cover, separable triangle filter through an f32
+ * intermediate, centre crop; image 0.25.x semantics, restated -- the crate is not part of the reference tree, so
+ * this step is unpinned: oracle/pb_oracle_resize.c) runs on the GPU, then the forward pass.  rgb: width*height*3
+ * bytes, RGB8, row-major.  An image that already is W x H is passed through untouched, like the crate does. */
+int pb_mlhash_image(pb_embedder *e, const uint8_t *rgb, uint32_t width, uint32_t height, uint8_t *out, size_t out_len);
+/* n images of individual sizes: rgb[i] -> widths[i]*heights[i]*3 bytes; out_u8[n][D], out_f32[n][D] or NULL */
+int pb_embed_batch_images(pb_embedder *e, const uint8_t *const *rgb, const uint32_t *widths, const uint32_t *heights, uint32_t n,
+                          uint8_t *out_u8, float *out_f32);
+/* the pre-processed W x H RGB8 image itself (what the network sees before /255): out_rgb[H*W*3] */
+int pb_resize_to_fill(pb_embedder *e, const uint8_t *rgb, uint32_t width, uint32_t height, uint8_t *out_rgb);
+
 #define PB_OPT_EMBED_STREAM 3
 int pb_embed_set_option(pb_embedder *e, int option, int64_t value);
 

@@ -65,22 +65,27 @@ class Embedder {
 
 namespace image_hashes {
 // pub fn mlhash(img:&DynamicImage) -> Vec<u8>   (the model is an explicit handle instead of a lazy static)
+// Any image size: `resize_to_fill(W, H, Triangle)` of efficientnet.rs:20 runs on the GPU (pb_mlhash_image); an
+// image that already has the model's input size goes straight in, as in the image crate.
 inline std::vector<uint8_t> mlhash(const Embedder &model, const RgbImage &img) {
-    if (img.width != model.width() || img.height != model.height() || img.pixels.size() != (size_t)img.width * img.height * 3)
-        throw Error(PB_ERR_INVALID, "mlhash: image must be resized to the model input size first (efficientnet.rs:20)");
+    if (img.width == 0 || img.height == 0 || img.pixels.size() != (size_t)img.width * img.height * 3)
+        throw Error(PB_ERR_INVALID, "mlhash: empty image or pixel buffer of the wrong size");
     std::vector<uint8_t> out(model.dim());
-    check(pb_mlhash(model.raw(), img.pixels.data(), out.data(), out.size()));
+    check(pb_mlhash_image(model.raw(), img.pixels.data(), img.width, img.height, out.data(), out.size()));
     return out;
 }
 // batched form used by a re-built crawler stage
 inline std::vector<std::vector<uint8_t>> mlhash_batch(const Embedder &model, const std::vector<RgbImage> &imgs) {
-    const size_t per = (size_t)model.width() * model.height() * 3;
-    std::vector<uint8_t> in(imgs.size() * per), out(imgs.size() * model.dim());
+    std::vector<uint8_t> out(imgs.size() * model.dim());
+    std::vector<const uint8_t *> ptrs(imgs.size());
+    std::vector<uint32_t> ws(imgs.size()), hs(imgs.size());
     for (size_t i = 0; i < imgs.size(); ++i) {
-        if (imgs[i].pixels.size() != per) throw Error(PB_ERR_INVALID, "mlhash_batch: wrong image size");
-        std::copy(imgs[i].pixels.begin(), imgs[i].pixels.end(), in.begin() + i * per);
+        if (imgs[i].pixels.size() != (size_t)imgs[i].width * imgs[i].height * 3) throw Error(PB_ERR_INVALID, "mlhash_batch: wrong pixel buffer size");
+        ptrs[i] = imgs[i].pixels.data();
+        ws[i] = imgs[i].width;
+        hs[i] = imgs[i].height;
     }
-    check(pb_embed_batch(model.raw(), in.data(), (uint32_t)imgs.size(), out.data(), nullptr));
+    check(pb_embed_batch_images(model.raw(), ptrs.data(), ws.data(), hs.data(), (uint32_t)imgs.size(), out.data(), nullptr));
     std::vector<std::vector<uint8_t>> res(imgs.size());
     for (size_t i = 0; i < imgs.size(); ++i) res[i].assign(out.begin() + i * model.dim(), out.begin() + (i + 1) * model.dim());
     return res;

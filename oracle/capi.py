@@ -17,7 +17,7 @@ _lib = None
 
 
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(_HERE, f) for f in ("pb_oracle.c", "pb_oracle_effnet.c", "pb_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("pb_oracle.c", "pb_oracle_effnet.c", "pb_oracle_resize.c", "pb_oracle.h")]
     stale = not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-B", "libpb_oracle.so"], stdout=subprocess.DEVNULL)
@@ -50,6 +50,9 @@ def lib():
         L.pbo_effnet_forward.restype = C.c_int
         L.pbo_mlhash_batch.argtypes = [u8p, C.c_size_t, u8p, C.c_size_t, C.c_int, u8p, f32p]
         L.pbo_mlhash_batch.restype = C.c_int
+        L.pbo_resize_to_fill_rgb8.argtypes = [u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u8p]
+        L.pbo_resize_to_fill_rgb8.restype = C.c_int
+        L.pbo_resize_dimensions_fill.argtypes = [C.c_uint32] * 4 + [C.POINTER(C.c_uint32)] * 2
         _lib = L
     return _lib
 
@@ -165,3 +168,19 @@ def mlhash_batch(blob: bytes, imgs: np.ndarray, d: int, nthreads: int = 4, want_
     if rc:
         raise RuntimeError(f"pbo_mlhash_batch rc={rc}")
     return out, f
+
+
+def resize_to_fill(img: np.ndarray, nw: int, nh: int) -> np.ndarray:
+    """image 0.25.x `resize_to_fill(nw, nh, Triangle)` of an RGB8 image [h, w, 3] (restated, unpinned) -> [nh, nw, 3]."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape[:2]
+    out = np.empty((nh, nw, 3), dtype=np.uint8)
+    if lib().pbo_resize_to_fill_rgb8(_u8(img), w, h, nw, nh, _u8(out)):
+        raise RuntimeError("pbo_resize_to_fill_rgb8: empty image")
+    return out
+
+
+def resize_dimensions_fill(w: int, h: int, nw: int, nh: int) -> tuple[int, int]:
+    a, b = C.c_uint32(0), C.c_uint32(0)
+    lib().pbo_resize_dimensions_fill(w, h, nw, nh, C.byref(a), C.byref(b))
+    return a.value, b.value

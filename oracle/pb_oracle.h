@@ -80,6 +80,11 @@ int pbo_effnet_forward(const uint8_t *blob, size_t blob_len, const uint8_t *img,
 int pbo_mlhash_batch(const uint8_t *blob, size_t blob_len, const uint8_t *imgs, size_t n,
                      int nthreads, uint8_t *out_u8, float *out_f32);
 
+/* ---- pre-processing (pb_oracle_resize.c): efficientnet.rs:20 `resize_to_fill(W, H, Triangle).to_rgb8()` --------
+ * image 0.25.x's published algorithm restated for an RGB8 source.  PARITY UNPINNED (third-party crate, absent). */
+void pbo_resize_dimensions_fill(uint32_t w, uint32_t h, uint32_t nw, uint32_t nh, uint32_t *ow, uint32_t *oh);
+int pbo_resize_to_fill_rgb8(const uint8_t *src, uint32_t w, uint32_t h, uint32_t nw, uint32_t nh, uint8_t *out);
+
 #ifdef __cplusplus
 }
 #endif

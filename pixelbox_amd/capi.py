@@ -31,6 +31,7 @@ SYMBOLS = [
     "pb_index_search", "pb_index_search_device", "pb_index_search_packed", "pb_topk_merge_packed", "pb_topk_merge", "pb_index_read", "pb_index_fill_synthetic",
     "pb_index_set_option", "pb_index_get_stats",
     "pb_embed_create", "pb_embed_destroy", "pb_embed_info", "pb_embed_batch", "pb_embed_batch_device", "pb_mlhash",
+    "pb_mlhash_image", "pb_embed_batch_images", "pb_resize_to_fill",
     "pb_embed_set_option", "pb_fill_synthetic", "pb_fill_synthetic_images",
 ]
 
@@ -92,6 +93,9 @@ def lib():
         L.pb_embed_batch.argtypes = [vp, u8p, C.c_uint32, u8p, f32p]
         L.pb_embed_batch_device.argtypes = [vp, vp, C.c_uint32, vp, vp]
         L.pb_mlhash.argtypes = [vp, u8p, u8p, C.c_size_t]
+        L.pb_mlhash_image.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, u8p, C.c_size_t]
+        L.pb_embed_batch_images.argtypes = [vp, C.POINTER(u8p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint32, u8p, C.POINTER(C.c_float)]
+        L.pb_resize_to_fill.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, u8p]
         L.pb_embed_set_option.argtypes = [vp, C.c_int, C.c_int64]
         L.pb_fill_synthetic.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, vp]
         L.pb_fill_synthetic_images.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, vp]
@@ -271,6 +275,33 @@ class Embedder:
         rgb = np.ascontiguousarray(rgb, dtype=np.uint8).reshape(self.h, self.w, 3)
         out = np.empty(self.d, dtype=np.uint8)
         _check(lib().pb_mlhash(self._h, _p(rgb, C.c_uint8), _p(out, C.c_uint8), out.size))
+        return out
+
+    def mlhash_image(self, rgb: np.ndarray) -> np.ndarray:
+        """mlhash of an RGB8 image of ANY size [h, w, 3]: resize_to_fill(W, H, Triangle) on the GPU, then the network."""
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        h, w = rgb.shape[:2]
+        out = np.empty(self.d, dtype=np.uint8)
+        _check(lib().pb_mlhash_image(self._h, _p(rgb, C.c_uint8), w, h, _p(out, C.c_uint8), out.size))
+        return out
+
+    def embed_images(self, images, want_f32: bool = True):
+        """images: list of RGB8 arrays [h_i, w_i, 3] of individual sizes -> (u8 [n, D], f32 [n, D] or None)."""
+        imgs = [np.ascontiguousarray(im, dtype=np.uint8) for im in images]
+        n = len(imgs)
+        ptrs = (C.POINTER(C.c_uint8) * n)(*[_p(im, C.c_uint8) for im in imgs])
+        ws = (C.c_uint32 * n)(*[im.shape[1] for im in imgs])
+        hs = (C.c_uint32 * n)(*[im.shape[0] for im in imgs])
+        u8 = np.empty((n, self.d), dtype=np.uint8)
+        f = np.empty((n, self.d), dtype=np.float32) if want_f32 else None
+        _check(lib().pb_embed_batch_images(self._h, ptrs, ws, hs, n, _p(u8, C.c_uint8), _p(f, C.c_float) if want_f32 else None))
+        return u8, f
+
+    def resize_to_fill(self, rgb: np.ndarray) -> np.ndarray:
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        h, w = rgb.shape[:2]
+        out = np.empty((self.h, self.w, 3), dtype=np.uint8)
+        _check(lib().pb_resize_to_fill(self._h, _p(rgb, C.c_uint8), w, h, _p(out, C.c_uint8)))
         return out
 
     def set_option(self, option: int, value: int):

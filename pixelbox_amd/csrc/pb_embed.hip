@@ -69,6 +69,10 @@ struct pb_embedder {
     std::map<std::pair<const void *, long>, DwGeom> dw_cfg;
     std::map<std::pair<const void *, long>, int> front_cfg;  // (block, batch) -> 0: expand GEMM + depthwise kernels, else fused kernel config 16 * bands + nc
     size_t part_floats_per_image = 0;      // (layer weights, batch) -> depthwise form, measured
+    // pre-processing scratch (grow-only): source image bytes, vertical-pass f32 rows
+    uint8_t *d_src = nullptr;
+    float *d_tmp = nullptr;
+    size_t d_src_cap = 0, d_tmp_cap = 0;
     std::mutex mu;
 };
 
@@ -543,7 +547,55 @@ int forward_device(pb_embedder *e, const uint8_t *d_rgb, int n, uint8_t *d_u8, f
 
 void destroy(pb_embedder *e) {
     for (void *p : e->allocs) (void)hipFree(p);
+    (void)hipFree(e->d_src);
+    (void)hipFree(e->d_tmp);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+}
+
+// efficientnet.rs:20 on the device: resize_to_fill(W, H, Triangle) of one host RGB8 image into d_dst[H][W][3]
+// (image 0.25.x semantics; kernels in pb_embed_kernels.h; the tests compare with a CPU restatement bit for bit)
+int resize_to_slot(pb_embedder *e, const uint8_t *rgb, uint32_t w, uint32_t h, uint8_t *d_dst) {
+    PB_CHECK(rgb, PB_ERR_INVALID, "null image");
+    PB_CHECK(w >= 1 && h >= 1 && w <= 65535 && h <= 65535, PB_ERR_INVALID, "image size %ux%u outside 1..65535", w, h);
+    const uint32_t W = e->W, H = e->H;
+    // src/math/utils.rs resize_dimensions(.., fill = true)
+    const double wratio = (double)W / (double)w, hratio = (double)H / (double)h;
+    const double ratio = wratio > hratio ? wratio : hratio;
+    const double a = std::round((double)w * ratio), b = std::round((double)h * ratio);
+    const uint32_t w2 = a < 1.0 ? 1u : (uint32_t)a, h2 = b < 1.0 ? 1u : (uint32_t)b;
+    PB_CHECK(w2 >= W && h2 >= H, PB_ERR_INVALID, "resize_to_fill: %ux%u does not cover %ux%u", w2, h2, W, H);
+    // src/dynimage.rs resize_to_fill: centre crop along the dimension that overshoots
+    uint32_t cx = 0, cy = 0;
+    if ((uint64_t)W * h2 > (uint64_t)w2 * H) cy = (h2 - H) / 2;
+    else cx = (w2 - W) / 2;
+    const size_t src_bytes = (size_t)w * h * 3;
+    if (src_bytes > e->d_src_cap) {
+        (void)hipFree(e->d_src);
+        e->d_src = nullptr;
+        e->d_src_cap = 0;
+        PB_HIP(hipMalloc(&e->d_src, src_bytes));
+        e->d_src_cap = src_bytes;
+    }
+    PB_HIP(hipMemcpyAsync(e->d_src, rgb, src_bytes, hipMemcpyHostToDevice, e->stream));
+    const uint32_t n_out = W * H;
+    if (w2 == w && h2 == h) {  // imageops::resize: same dimensions -> copy
+        hipLaunchKernelGGL(k_crop_rgb8, dim3((n_out + 255) / 256), dim3(256), 0, e->stream, e->d_src, w, cx, cy, W, H, d_dst);
+        PB_HIP(hipGetLastError());
+        return PB_OK;
+    }
+    const size_t tmp_floats = (size_t)H * w * 3;
+    if (tmp_floats > e->d_tmp_cap) {
+        (void)hipFree(e->d_tmp);
+        e->d_tmp = nullptr;
+        e->d_tmp_cap = 0;
+        PB_HIP(hipMalloc(&e->d_tmp, tmp_floats * sizeof(float)));
+        e->d_tmp_cap = tmp_floats;
+    }
+    hipLaunchKernelGGL(k_resize_v, dim3((w + 255) / 256, H), dim3(256), 0, e->stream, e->d_src, w, h, h2, cy, e->d_tmp);
+    PB_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_resize_h, dim3((n_out + 255) / 256), dim3(256), 0, e->stream, e->d_tmp, w, w2, cx, W, H, d_dst);
+    PB_HIP(hipGetLastError());
+    return PB_OK;
 }
 
 }  // namespace
@@ -660,6 +712,50 @@ int pb_mlhash(pb_embedder *e, const uint8_t *rgb, uint8_t *out, size_t out_len) 
     PB_CHECK(e, PB_ERR_INVALID, "pb_mlhash: null embedder");
     PB_CHECK(out_len >= e->D, PB_ERR_INVALID, "pb_mlhash: out_len %zu < D = %u", out_len, e->D);
     return pb_embed_batch(e, rgb, 1, out, nullptr);
+}
+
+int pb_embed_batch_images(pb_embedder *e, const uint8_t *const *rgb, const uint32_t *widths, const uint32_t *heights, uint32_t n,
+                          uint8_t *out_u8, float *out_f32) {
+    PB_CHECK(e, PB_ERR_INVALID, "pb_embed_batch_images: null embedder");
+    PB_CHECK(n == 0 || (rgb && widths && heights && out_u8), PB_ERR_INVALID, "pb_embed_batch_images: null buffer");
+    std::lock_guard<std::mutex> lock(e->mu);
+    pb::DeviceGuard guard(e->device);
+    const size_t img_bytes = (size_t)e->H * e->W * 3;
+    for (uint32_t i0 = 0; i0 < n; i0 += e->max_batch) {
+        const uint32_t c = std::min(e->max_batch, n - i0);
+        for (uint32_t i = 0; i < c; ++i) {
+            int rc = resize_to_slot(e, rgb[i0 + i], widths[i0 + i], heights[i0 + i], e->d_img + (size_t)i * img_bytes);
+            if (rc) return rc;
+            // the source scratch is reused by the next image: its copy must have been consumed
+            PB_HIP(hipStreamSynchronize(e->stream));
+        }
+        int rc = forward_device(e, e->d_img, (int)c, e->d_out_u8, e->d_out_f32);
+        if (rc) return rc;
+        PB_HIP(hipMemcpyAsync(out_u8 + (size_t)i0 * e->D, e->d_out_u8, (size_t)c * e->D, hipMemcpyDeviceToHost, e->stream));
+        if (out_f32)
+            PB_HIP(hipMemcpyAsync(out_f32 + (size_t)i0 * e->D, e->d_out_f32, (size_t)c * e->D * sizeof(float),
+                                  hipMemcpyDeviceToHost, e->stream));
+        PB_HIP(hipStreamSynchronize(e->stream));
+    }
+    return PB_OK;
+}
+
+int pb_mlhash_image(pb_embedder *e, const uint8_t *rgb, uint32_t width, uint32_t height, uint8_t *out, size_t out_len) {
+    PB_CHECK(e, PB_ERR_INVALID, "pb_mlhash_image: null embedder");
+    PB_CHECK(out_len >= e->D, PB_ERR_INVALID, "pb_mlhash_image: out_len %zu < D = %u", out_len, e->D);
+    return pb_embed_batch_images(e, &rgb, &width, &height, 1, out, nullptr);
+}
+
+int pb_resize_to_fill(pb_embedder *e, const uint8_t *rgb, uint32_t width, uint32_t height, uint8_t *out_rgb) {
+    PB_CHECK(e, PB_ERR_INVALID, "pb_resize_to_fill: null embedder");
+    PB_CHECK(out_rgb, PB_ERR_INVALID, "pb_resize_to_fill: null output");
+    std::lock_guard<std::mutex> lock(e->mu);
+    pb::DeviceGuard guard(e->device);
+    int rc = resize_to_slot(e, rgb, width, height, e->d_img);
+    if (rc) return rc;
+    PB_HIP(hipMemcpyAsync(out_rgb, e->d_img, (size_t)e->H * e->W * 3, hipMemcpyDeviceToHost, e->stream));
+    PB_HIP(hipStreamSynchronize(e->stream));
+    return PB_OK;
 }
 
 int pb_embed_set_option(pb_embedder *e, int option, int64_t value) {

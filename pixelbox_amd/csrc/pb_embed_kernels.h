@@ -741,6 +741,89 @@ __global__ void k_avgpool(const float *__restrict__ feat, int hw, int C, float i
     pooled[(size_t)b * C + c] = t * inv_hw;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Pre-processing of an arbitrary-size RGB8 image (efficientnet.rs:20): `resize_to_fill(W, H, Triangle)` of the
+// image crate 0.25.x -- scale to cover, separable triangle filter (vertical pass into f32, horizontal pass back to
+// u8), centre crop.  Restated from the crate's published algorithm (src/imageops/sample.rs vertical_sample /
+// horizontal_sample, src/math/utils.rs resize_dimensions); the tests hold a CPU restatement of the same text and the
+// two agree bit for bit (same f32 operations in the same order).  Only the rows / columns that survive the crop
+// are computed.
+__device__ __forceinline__ float triangle_kernel(float x) {
+    const float a = fabsf(x);
+    return a < 1.0f ? 1.0f - a : 0.0f;
+}
+// tap window of output sample o when in_size samples become out_size: [left, right), centre `input`, scale sratio
+__device__ __forceinline__ void resize_window(uint32_t o, uint32_t in_size, uint32_t out_size, int &left, int &right,
+                                              float &input, float &sratio) {
+    const float ratio = (float)in_size / (float)out_size;
+    sratio = ratio < 1.0f ? 1.0f : ratio;
+    const float src_support = 1.0f * sratio;
+    float in0 = ((float)o + 0.5f) * ratio;
+    long long l = (long long)floorf(in0 - src_support);
+    l = l < 0 ? 0 : (l > (long long)in_size - 1 ? (long long)in_size - 1 : l);
+    long long r = (long long)ceilf(in0 + src_support);
+    r = r < l + 1 ? l + 1 : (r > (long long)in_size ? (long long)in_size : r);
+    left = (int)l;
+    right = (int)r;
+    input = in0 - 0.5f;
+}
+// vertical pass: src u8 [h][w][3] -> tmp f32 [rows][w][3] for output rows oy0 .. oy0 + rows - 1 of the h2-row image
+__global__ __launch_bounds__(256) void k_resize_v(const uint8_t *__restrict__ src, uint32_t w, uint32_t h, uint32_t h2,
+                                                  uint32_t oy0, float *__restrict__ tmp) {
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t row = blockIdx.y;
+    if (x >= w) return;
+    int left, right;
+    float input, sratio;
+    resize_window(oy0 + row, h, h2, left, right, input, sratio);
+    float sum = 0.0f;
+    for (int i = left; i < right; ++i) sum = sum + triangle_kernel(((float)i - input) / sratio);
+    float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;
+    for (int i = left; i < right; ++i) {
+        const float wgt = triangle_kernel(((float)i - input) / sratio) / sum;
+        const uint8_t *p = src + ((size_t)i * w + x) * 3;
+        const float m0 = (float)p[0] * wgt, m1 = (float)p[1] * wgt, m2 = (float)p[2] * wgt;
+        t0 = t0 + m0; t1 = t1 + m1; t2 = t2 + m2;
+    }
+    float *o = tmp + ((size_t)row * w + x) * 3;
+    o[0] = t0; o[1] = t1; o[2] = t2;
+}
+// horizontal pass + crop: tmp f32 [H][w][3] -> dst u8 [H][W][3], output columns ox0 .. ox0 + W - 1 of the w2-column image
+__global__ __launch_bounds__(256) void k_resize_h(const float *__restrict__ tmp, uint32_t w, uint32_t w2, uint32_t ox0,
+                                                  uint32_t W, uint32_t H, uint8_t *__restrict__ dst) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= W * H) return;
+    const uint32_t y = i / W, xo = i % W;
+    int left, right;
+    float input, sratio;
+    resize_window(ox0 + xo, w, w2, left, right, input, sratio);
+    float sum = 0.0f;
+    for (int k = left; k < right; ++k) sum = sum + triangle_kernel(((float)k - input) / sratio);
+    float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;
+    for (int k = left; k < right; ++k) {
+        const float wgt = triangle_kernel(((float)k - input) / sratio) / sum;
+        const float *p = tmp + ((size_t)y * w + k) * 3;
+        const float m0 = p[0] * wgt, m1 = p[1] * wgt, m2 = p[2] * wgt;
+        t0 = t0 + m0; t1 = t1 + m1; t2 = t2 + m2;
+    }
+    auto to_u8 = [](float t) -> uint8_t {
+        t = t < 0.0f ? 0.0f : (t > 255.0f ? 255.0f : t);
+        return (uint8_t)roundf(t);  // f32::round: half away from zero
+    };
+    uint8_t *o = dst + (size_t)i * 3;
+    o[0] = to_u8(t0); o[1] = to_u8(t1); o[2] = to_u8(t2);
+}
+// same-size source (imageops::resize copies instead of resampling): crop only
+__global__ __launch_bounds__(256) void k_crop_rgb8(const uint8_t *__restrict__ src, uint32_t w, uint32_t cx, uint32_t cy,
+                                                   uint32_t W, uint32_t H, uint8_t *__restrict__ dst) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= W * H) return;
+    const uint32_t y = i / W, x = i % W;
+    const uint8_t *p = src + ((size_t)(cy + y) * w + cx + x) * 3;
+    uint8_t *o = dst + (size_t)i * 3;
+    o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
+}
+
 // tanh + u8 quantiser (efficientnet.rs:39) on the Linear(1280, D) outputs (computed by k_gemm1x1, bias included)
 __global__ void k_tanh_quant(const float *__restrict__ pre, long n, float *__restrict__ out_f32,
                              uint8_t *__restrict__ out_u8) {
