@@ -151,7 +151,9 @@ typedef struct pb_scan_stats {
     uint64_t profiled_launches; /* scan-kernel launches bracketed by events (PB_OPT_PROFILE) */
     double profiled_ms;       /* their summed duration */
     uint64_t profiled_bytes;  /* algorithmic bytes those launches streamed (rows * dim per query) */
-} pb_scan_stats;
+    uint64_t second_chance;   /* no certificate at first, answered exactly by the second-chance pass: every row within
+                                 the error margin of the first attempt's k-th cosine listed and re-scored */
+} pb_scan_stats;                /* queries = fast_path + second_chance + fallback */
 int pb_index_get_stats(pb_index *idx, pb_scan_stats *out, int reset);
 
 /* ======================================================================================

@@ -44,7 +44,8 @@ class PixelboxError(RuntimeError):
 
 class ScanStats(C.Structure):
     _fields_ = [("queries", C.c_uint64), ("fast_path", C.c_uint64), ("fallback", C.c_uint64),
-                ("profiled_launches", C.c_uint64), ("profiled_ms", C.c_double), ("profiled_bytes", C.c_uint64)]
+                ("profiled_launches", C.c_uint64), ("profiled_ms", C.c_double), ("profiled_bytes", C.c_uint64),
+                ("second_chance", C.c_uint64)]
 
 
 _lib = None

@@ -69,6 +69,13 @@ struct pb_index {
     uint64_t *d_cand = nullptr;     // PIPE_Q * MQ_CAP
     uint32_t *d_cand_cnt = nullptr; // PIPE_Q
     uint32_t *d_ghist = nullptr;    // PIPE_Q * MQ_BINS
+    // second chance (k_mq_rescore_big): compacted queries / params / thresholds / big candidate lists of one chunk
+    uint8_t *d_queries2 = nullptr;  // Q_CHUNK * dim
+    QParams *d_qp2 = nullptr;       // Q_CHUNK
+    float *d_tau2 = nullptr;        // Q_CHUNK
+    uint64_t *d_cand2 = nullptr;    // Q_CHUNK * MQ_CAP2
+    uint32_t *d_cand_cnt2 = nullptr;  // Q_CHUNK
+    uint32_t *d_qsel2 = nullptr;    // Q_CHUNK
     int64_t *d_res_ids = nullptr;   // Q_CHUNK * PB_MAX_K
     float *d_res_dist = nullptr;
     ResultHdr *d_res_hdr = nullptr;
@@ -112,6 +119,12 @@ int alloc_workspace(pb_index *ix) {
     PB_HIP(hipMalloc(&ix->d_cand, (size_t)PIPE_Q * MQ_CAP * sizeof(uint64_t)));
     PB_HIP(hipMalloc(&ix->d_cand_cnt, PIPE_Q * sizeof(uint32_t)));
     PB_HIP(hipMalloc(&ix->d_ghist, (size_t)PIPE_Q * MQ_BINS * sizeof(uint32_t)));
+    PB_HIP(hipMalloc(&ix->d_queries2, (size_t)Q_CHUNK * d));
+    PB_HIP(hipMalloc(&ix->d_qp2, Q_CHUNK * sizeof(QParams)));
+    PB_HIP(hipMalloc(&ix->d_tau2, Q_CHUNK * sizeof(float)));
+    PB_HIP(hipMalloc(&ix->d_cand2, (size_t)Q_CHUNK * MQ_CAP2 * sizeof(uint64_t)));
+    PB_HIP(hipMalloc(&ix->d_cand_cnt2, Q_CHUNK * sizeof(uint32_t)));
+    PB_HIP(hipMalloc(&ix->d_qsel2, Q_CHUNK * sizeof(uint32_t)));
     PB_HIP(hipMalloc(&ix->d_res_ids, (size_t)PIPE_Q * PB_MAX_K * sizeof(int64_t)));
     PB_HIP(hipMalloc(&ix->d_res_dist, (size_t)PIPE_Q * PB_MAX_K * sizeof(float)));
     PB_HIP(hipMalloc(&ix->d_res_hdr, PIPE_Q * sizeof(ResultHdr)));
@@ -141,6 +154,12 @@ void free_all(pb_index *ix) {
     (void)hipFree(ix->d_cand);
     (void)hipFree(ix->d_cand_cnt);
     (void)hipFree(ix->d_ghist);
+    (void)hipFree(ix->d_queries2);
+    (void)hipFree(ix->d_qp2);
+    (void)hipFree(ix->d_tau2);
+    (void)hipFree(ix->d_cand2);
+    (void)hipFree(ix->d_cand_cnt2);
+    (void)hipFree(ix->d_qsel2);
     (void)hipFree(ix->d_sumb);
     (void)hipFree(ix->d_denb);
     (void)hipFree(ix->d_min_den);
@@ -393,10 +412,10 @@ void launch_multi(pb_index *ix, bool hist, int grid, uint32_t base, uint32_t nq)
     uint32_t *cnt = ix->d_cand_cnt + base, *gh = ix->d_ghist + (size_t)base * MQ_BINS;
     if (hist)
         hipLaunchKernelGGL((k_scan_multi<QT, true>), dim3(grid), dim3(MQ_WAVES * 64), 0, ix->stream, ix->d_rows, ix->d_sumb,
-                           ix->d_denb, ix->n_rows, dq, dp, tau, cand, cnt, gh, (int)nq);
+                           ix->d_denb, ix->n_rows, dq, dp, tau, cand, cnt, gh, (int)nq, (uint32_t)MQ_CAP, 0);
     else
         hipLaunchKernelGGL((k_scan_multi<QT, false>), dim3(grid), dim3(MQ_WAVES * 64), 0, ix->stream, ix->d_rows, ix->d_sumb,
-                           ix->d_denb, ix->n_rows, dq, dp, tau, cand, cnt, gh, (int)nq);
+                           ix->d_denb, ix->n_rows, dq, dp, tau, cand, cnt, gh, (int)nq, (uint32_t)MQ_CAP, 0);
 }
 
 // queries [base, base + nq) of the staged device arrays; results to the same slots of d_res_*
@@ -453,7 +472,7 @@ int run_multi_block(pb_index *ix, uint32_t nq, uint32_t k) {
                                                                       std::max<uint64_t>(16, 4ull * ix->n_cu / n_chunks)));
     hipLaunchKernelGGL((k_scan_multi<4, true>), dim3(hgrid, n_chunks), dim3(MQ_WAVES * 64), 0, ix->stream,
                        ix->d_rows, ix->d_sumb, ix->d_denb, ix->n_rows, ix->d_queries, ix->d_qp, ix->d_tau, ix->d_cand,
-                       ix->d_cand_cnt, ix->d_ghist, (int)nq);
+                       ix->d_cand_cnt, ix->d_ghist, (int)nq, (uint32_t)MQ_CAP, 0);
     PB_HIP(hipGetLastError());
     const uint32_t target_full = std::max<uint32_t>(4 * k, 512);
     const uint32_t target_sample = std::max<uint32_t>(2, (target_full + MQ_SAMPLE - 1) / MQ_SAMPLE);
@@ -474,6 +493,57 @@ int run_multi_block(pb_index *ix, uint32_t nq, uint32_t k) {
     return PB_OK;
 }
 
+// Second chance (pb_scan_kernels.h (4)): queries d_qsel2[0..n_sel) of the staged chunk, thresholds d_tau2[0..n_sel).
+// One shared sweep with 64 Ki-entry lists, then exact scoring of every listed row.  Results and headers land in the
+// queries' own slots; status 1 = list overflow or fewer than k results (-> exhaustive pass).
+bool second_chance_eligible(const pb_index *ix) {
+    return ix->metric == 0 && ix->dim == 256 && ix->n_rows >= 4096 && ix->opt_path != 1 && !getenv("PB_NO_SECOND_CHANCE");
+}
+
+int run_second_chance(pb_index *ix, uint32_t n_sel) {
+    hipLaunchKernelGGL(k_gather_queries, dim3(n_sel), dim3(256), 0, ix->stream, ix->d_queries, ix->d_qp, ix->d_qsel2, (int)ix->dim,
+                       ix->d_queries2, ix->d_qp2);
+    PB_HIP(hipGetLastError());
+    PB_HIP(hipMemsetAsync(ix->d_cand_cnt2, 0, n_sel * sizeof(uint32_t), ix->stream));
+    const uint64_t n_tiles = (ix->n_rows + 15) / 16;
+    const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((n_tiles + MQ_WAVES - 1) / MQ_WAVES,
+                                                                     (uint64_t)ix->n_cu * ix->opt_mq_wg_per_cu));
+    // Would the rows above tau2 fit the 64 Ki-entry lists?  A 1/32 sample answers for the price of a thirty-second
+    // of a sweep (bin 0 of the histogram buffer = sampled rows with cos_filter >= tau2).  A query whose estimate is
+    // past the list gets an unreachable threshold: its sweep costs nothing and its (empty, "fewer than k") result
+    // sends it to the exhaustive pass.  Without this a table with ~1e5 near-ties per query spends its time on
+    // global atomics for lists that overflow anyway.
+    if (n_tiles >= 4096) {
+        PB_HIP(hipMemsetAsync(ix->d_ghist, 0, (size_t)n_sel * MQ_BINS * sizeof(uint32_t), ix->stream));
+        const uint64_t stiles = (n_tiles + MQ_SAMPLE - 1) / MQ_SAMPLE;
+        const int hgrid = (int)std::max<uint64_t>(1, std::min<uint64_t>((stiles + MQ_WAVES - 1) / MQ_WAVES, (uint64_t)ix->n_cu));
+        hipLaunchKernelGGL((k_scan_multi<4, true>), dim3(hgrid), dim3(MQ_WAVES * 64), 0, ix->stream, ix->d_rows, ix->d_sumb, ix->d_denb,
+                           ix->n_rows, ix->d_queries2, ix->d_qp2, ix->d_tau2, ix->d_cand2, ix->d_cand_cnt2, ix->d_ghist, (int)n_sel,
+                           (uint32_t)MQ_CAP2, 1);
+        PB_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_sc_gate, dim3(1), dim3(64), 0, ix->stream, ix->d_ghist, (int)n_sel, (uint32_t)(MQ_CAP2 / MQ_SAMPLE * 3 / 4),
+                           ix->d_tau2);
+        PB_HIP(hipGetLastError());
+    }
+#define PB_SC(QTV)                                                                                                        \
+    hipLaunchKernelGGL((k_scan_multi<QTV, false>), dim3(grid), dim3(MQ_WAVES * 64), 0, ix->stream, ix->d_rows, ix->d_sumb,  \
+                       ix->d_denb, ix->n_rows, ix->d_queries2, ix->d_qp2, ix->d_tau2, ix->d_cand2, ix->d_cand_cnt2,       \
+                       (uint32_t *)nullptr, (int)n_sel, (uint32_t)MQ_CAP2, 0)
+    switch ((n_sel + 15) / 16) {
+        case 1: PB_SC(1); break;
+        case 2: PB_SC(2); break;
+        case 3: PB_SC(3); break;
+        default: PB_SC(4); break;
+    }
+#undef PB_SC
+    PB_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_mq_rescore_big, dim3(n_sel), dim3(1024), 0, ix->stream, ix->d_rows, ix->d_ids, ix->d_norms, (int)ix->dim,
+                       ix->d_queries2, ix->d_qp2, ix->d_lut, ix->d_cand2, ix->d_cand_cnt2, (uint32_t)MQ_CAP2, ix->d_qsel2,
+                       ix->d_res_ids, ix->d_res_dist, ix->d_res_hdr, (uint32_t)PB_MAX_K);
+    PB_HIP(hipGetLastError());
+    return PB_OK;
+}
+
 bool multi_eligible(const pb_index *ix, uint32_t nq) {
     return ix->metric == 0 && fast_dim(ix->dim) && ix->dim == 256 && ix->n_rows >= 65536 &&
            (ix->opt_path == 3 || (ix->opt_path == 0 && nq >= (uint32_t)ix->opt_mq_min_queries));
@@ -483,7 +553,8 @@ bool multi_eligible(const pb_index *ix, uint32_t nq) {
 // host (D2H of the 16-byte headers only), re-run uncertified queries through the exhaustive pass.
 // On return d_res_ids / d_res_dist / d_res_hdr hold the final results of the chunk and h_res_hdr mirrors
 // the headers.
-int search_chunk(pb_index *ix, uint32_t cq, uint32_t k, double max_dist) {
+int search_chunk(pb_index *ix, uint32_t cq, uint32_t k, double max_dist, const float *ck_hint = nullptr,
+                 const uint32_t *hint_ncand = nullptr, const float *hint_omax = nullptr) {
     const uint32_t d = ix->dim;
     uint8_t *hq = ix->h_stage;
     QParams *hp = reinterpret_cast<QParams *>(ix->h_stage + (size_t)Q_CHUNK * d);
@@ -517,6 +588,52 @@ int search_chunk(pb_index *ix, uint32_t cq, uint32_t k, double max_dist) {
         if (use_multi) ix->stats_multi += cq - n_sel;
     } else {
         for (uint32_t q = 0; q < cq; ++q) hsel[n_sel++] = q;
+    }
+    // second chance: a query that HAS k results (ck = their smallest exact cosine, from the attempt above or handed
+    // in by the burst path) but no certificate gets every row with cos_filter >= ck (1 - 1e-6) - 1.01 m scored exactly
+    if (n_sel && (ck_hint || use_fast) && (ck_hint ? ix->metric == 0 && ix->dim == 256 && ix->n_rows >= 4096 && !getenv("PB_NO_SECOND_CHANCE")
+                                                    : second_chance_eligible(ix))) {
+        uint32_t sc_sel[Q_CHUNK], rest[Q_CHUNK];
+        float sc_tau[Q_CHUNK];
+        uint32_t n_sc = 0, n_rest = 0;
+        for (uint32_t i = 0; i < n_sel; ++i) {
+            const uint32_t q = hsel[i];
+            const float ck = ck_hint ? ck_hint[q] : ix->h_res_hdr[q].ck;
+            const float tau2 = ck * (1.0f - 1e-6f) - 1.01f * hp[q].m - 1e-7f;
+            // a concurrent-query attempt reports how many rows reached ITS threshold (o_max - m): if that threshold
+            // was no lower than tau2 and the count already exceeds the second chance's list, it cannot fit either
+            const ResultHdr &h1 = ck_hint ? ResultHdr{0, 1, hint_ncand ? hint_ncand[q] : 0u, hint_omax ? hint_omax[q] : 0.0f, ck}
+                                          : ix->h_res_hdr[q];
+            const bool hopeless = (ck_hint ? hint_ncand != nullptr : use_multi) && (h1.n_cand & 0x7FFFFFFFu) > (uint32_t)MQ_CAP2 &&
+                                  (h1.o_max - hp[q].m) >= tau2;
+            if (ck > 0.0f && tau2 > hp[q].thr0 && tau2 > 0.0f && !hopeless) {
+                sc_sel[n_sc] = q;
+                sc_tau[n_sc++] = tau2;
+            } else {
+                rest[n_rest++] = q;
+            }
+        }
+        if (n_sc) {
+            PB_HIP(hipMemcpyAsync(ix->d_qsel2, sc_sel, n_sc * sizeof(uint32_t), hipMemcpyHostToDevice, ix->stream));
+            PB_HIP(hipMemcpyAsync(ix->d_tau2, sc_tau, n_sc * sizeof(float), hipMemcpyHostToDevice, ix->stream));
+            int rc = run_second_chance(ix, n_sc);
+            if (rc) return rc;
+            PB_HIP(hipMemcpyAsync(ix->h_res_hdr, ix->d_res_hdr, cq * sizeof(ResultHdr), hipMemcpyDeviceToHost, ix->stream));
+            PB_HIP(hipStreamSynchronize(ix->stream));
+            for (uint32_t i = 0; i < n_sc; ++i) {
+                if (ix->h_res_hdr[sc_sel[i]].status != 0) {
+                    rest[n_rest++] = sc_sel[i];
+                    if (getenv("PB_TRACE_CERT"))
+                        fprintf(stderr, "second chance failed: q=%u listed=%u (cap %d) tau2=%.7f\n", sc_sel[i], ix->h_res_hdr[sc_sel[i]].n_cand,
+                                MQ_CAP2, sc_tau[i]);
+                } else {
+                    ++ix->stats.second_chance;
+                }
+            }
+            std::sort(rest, rest + n_rest);
+            n_sel = n_rest;
+            for (uint32_t i = 0; i < n_rest; ++i) hsel[i] = rest[i];
+        }
     }
     if (n_sel) {
         PB_HIP(hipMemcpyAsync(ix->d_qsel, hsel, n_sel * sizeof(uint32_t), hipMemcpyHostToDevice, ix->stream));
@@ -594,7 +711,14 @@ int search_block_multi(pb_index *ix, const uint8_t *queries, uint32_t nq, uint32
         const int saved = ix->opt_path;
         ix->opt_path = 1;
         const uint64_t q_before = ix->stats.queries;
-        int rc = search_chunk(ix, cq, k, max_dist);
+        float ck_hint[Q_CHUNK], omax_hint[Q_CHUNK];  // the burst attempt's k-th exact cosines: the second chance starts from them
+        uint32_t ncand_hint[Q_CHUNK];
+        for (uint32_t i = 0; i < cq; ++i) {
+            ck_hint[i] = keep_hdr[failed[f0 + i]].ck;
+            omax_hint[i] = keep_hdr[failed[f0 + i]].o_max;
+            ncand_hint[i] = keep_hdr[failed[f0 + i]].n_cand;
+        }
+        int rc = search_chunk(ix, cq, k, max_dist, ck_hint, ncand_hint, omax_hint);
         ix->opt_path = saved;
         ix->stats.queries = q_before;  // already counted above
         if (rc) return rc;

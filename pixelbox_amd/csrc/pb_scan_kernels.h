@@ -69,6 +69,7 @@ struct ResultHdr {
     uint32_t status;  // 0 = certified, 1 = needs the exhaustive pass
     uint32_t n_cand;
     float o_max;
+    float ck;  // smallest exact cosine among the count results when count == k (a lower bound of the true k-th), else -1
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -597,6 +598,7 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
         h.status = ok ? 0u : 1u;
         h.n_cand = n_cand_raw;
         h.o_max = o_max;
+        h.ck = n_out == P.k ? ck : -1.0f;
         out_hdr[q] = h;
     }
 }
@@ -754,6 +756,7 @@ __global__ __launch_bounds__(M_BLOCK) void k_merge_lists(
             h.status = 0;
             h.n_cand = 0;
             h.o_max = 0.0f;
+            h.ck = -1.0f;
             out_hdr[q] = h;
         }
     }
@@ -784,7 +787,9 @@ template <int QT, bool HIST>
 __global__ __launch_bounds__(MQ_WAVES * WAVE) void k_scan_multi(
     const uint8_t *__restrict__ rows, const int32_t *__restrict__ sum_b, const int32_t *__restrict__ den_b,
     uint64_t n_rows, const uint8_t *queries, const QParams *qp, const float *tau, uint64_t *cand, uint32_t *cand_cnt,
-    uint32_t *ghist, int n_q) {
+    uint32_t *ghist, int n_q, uint32_t cap, int count_mode) {
+    // count_mode (HIST only): instead of a histogram, count the sampled rows with cos_filter >= tau[q] into bin 0
+    // (the second chance asks "would the rows above tau2 fit the list?" before paying for a full sweep)
     constexpr int D = 256;
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[MQ_WAVES][16 * MQ_LDROW];
     __shared__ uint32_t s_hist[HIST ? (MQ_BINS / 2) * MQ_HPITCH : 1];  // two 16-bit counters per word
@@ -798,7 +803,7 @@ __global__ __launch_bounds__(MQ_WAVES * WAVE) void k_scan_multi(
         queries += (size_t)chunk0 * D;
         qp += chunk0;
         tau += chunk0;
-        cand += (size_t)chunk0 * MQ_CAP;
+        cand += (size_t)chunk0 * cap;
         cand_cnt += chunk0;
         ghist += (size_t)chunk0 * MQ_BINS;
         n_q = (n_q - chunk0) < MQ_MAXQ ? (n_q - chunk0) : MQ_MAXQ;
@@ -823,7 +828,7 @@ __global__ __launch_bounds__(MQ_WAVES * WAVE) void k_scan_multi(
         }
         den_a[qt] = qp[q].den_a;
         sum_a[qt] = qp[q].sum_a;
-        q_tau[qt] = HIST ? qp[q].thr0 : tau[q];
+        q_tau[qt] = (HIST && !count_mode) ? qp[q].thr0 : tau[q];
         sa2[qt] = 2 * sum_a[qt];
         g_tau[qt] = q_tau[qt] * __builtin_amdgcn_sqrtf(den_a[qt]);  // tau > 0
         rs_a[qt] = __builtin_amdgcn_rsqf(den_a[qt]);
@@ -901,7 +906,7 @@ __global__ __launch_bounds__(MQ_WAVES * WAVE) void k_scan_multi(
                     const int num = 4 * acc[qt][r] + sa2[qt] + cr[r];
                     const float cs = (float)num * rsb[r] * rs_a[qt];
                     if (cs >= q_tau[qt] && q < n_q) {
-                        int bin = (int)(cs * (float)MQ_BINS);
+                        int bin = count_mode ? 0 : (int)(cs * (float)MQ_BINS);
                         bin = bin < 0 ? 0 : (bin >= MQ_BINS ? MQ_BINS - 1 : bin);
                         atomicAdd(&s_hist[(bin >> 1) * MQ_HPITCH + q], 1u << (16 * (bin & 1)));
                     }
@@ -927,7 +932,7 @@ __global__ __launch_bounds__(MQ_WAVES * WAVE) void k_scan_multi(
                         const float cs = (float)num * __builtin_amdgcn_rsqf((float)db[r] * den_a[qt]);
                         if (cs >= q_tau[qt] && q < n_q) {
                             const uint32_t idx = atomicAdd(&cand_cnt[q], 1u);
-                            if (idx < MQ_CAP) cand[(size_t)q * MQ_CAP + idx] = filter_key(cs, (uint32_t)(rbase + r));
+                            if (idx < cap) cand[(size_t)q * cap + idx] = filter_key(cs, (uint32_t)(rbase + r));
                         }
                     }
                 }
@@ -1319,7 +1324,114 @@ __global__ __launch_bounds__(1024) void k_mq_rescore(
         h.status = ok ? 0u : 1u;
         h.n_cand = raw;
         h.o_max = o_max;
+        h.ck = n_out == P.k ? ck : -1.0f;
         out_hdr[q] = h;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// (4) second chance for a query whose first attempt FOUND k results but could not certify them (clustered
+// tables: more rows within the margin of the k-th cosine than the candidate lists hold).  Let ck1 be the smallest
+// exact cosine among those k results.  The true k-th cosine is >= ck1, so every row of the true top-k has
+// cos_ref >= ck1, hence cos_filter >= ck1 - m.  The collect pass (k_scan_multi, HIST = false) is re-run with
+// tau2 = ck1 (1 - 1e-6) - 1.01 m and a 64 Ki-entry list per query, and k_mq_rescore_big scores EVERY listed row with
+// the reference arithmetic and selects the k smallest (dist, id): every unlisted row has
+// cos_ref < tau2 + m < ck1 (1 - 1e-6) <= c_k (1 - 1e-6), i.e. a strictly larger distance than the k-th result (same
+// argument as the certificate) -- the result is exact without a certificate, provided the list did
+// not overflow (then: exhaustive pass).  Cost: one sweep of the table shared by up to 64 such queries plus the
+// re-scoring of the listed rows, instead of an exhaustive exact sweep per query.
+constexpr int MQ_CAP2 = 65536;
+
+// queries[sel[i]], qp[sel[i]] -> contiguous copies (the collect kernel wants its queries in one block)
+__global__ void k_gather_queries(const uint8_t *__restrict__ queries, const QParams *__restrict__ qp,
+                                 const uint32_t *__restrict__ sel, int d, uint8_t *__restrict__ out_q,
+                                 QParams *__restrict__ out_qp) {
+    const int i = blockIdx.x;
+    const uint32_t s = sel[i];
+    for (int j = threadIdx.x; j < d; j += blockDim.x) out_q[(size_t)i * d + j] = queries[(size_t)s * d + j];
+    if (threadIdx.x == 0) out_qp[i] = qp[s];
+}
+
+// second-chance gate: queries whose sampled count of rows above tau2 (bin 0) predicts a list overflow get a
+// threshold no row reaches
+__global__ void k_sc_gate(const uint32_t *__restrict__ ghist, int n_q, uint32_t max_sampled, float *__restrict__ tau2) {
+    for (int q = threadIdx.x; q < n_q; q += blockDim.x)
+        if (ghist[(size_t)q * MQ_BINS] > max_sampled) tau2[q] = 2.0f;
+}
+
+// one block per (compacted) query i; results go to slot sel[i]
+__global__ __launch_bounds__(1024) void k_mq_rescore_big(
+    const uint8_t *__restrict__ rows, const int64_t *__restrict__ ids, const float *__restrict__ norms, int d,
+    const uint8_t *__restrict__ queries, const QParams *__restrict__ qp, const float *__restrict__ lut,
+    const uint64_t *__restrict__ cand, const uint32_t *__restrict__ cand_cnt, uint32_t cap,
+    const uint32_t *__restrict__ sel, int64_t *__restrict__ out_ids, float *__restrict__ out_dist,
+    ResultHdr *__restrict__ out_hdr, uint32_t out_stride) {
+    constexpr int CH = 4096, PER = CH / 1024;
+    __shared__ float s_lut[256];
+    __shared__ float s_qf[256];  // dim 256 only (as the collect pass)
+    __shared__ uint64_t s_sort[CH];
+    __shared__ uint64_t s_best[2 * (int)PB_MAX_K];
+    __shared__ uint32_t s_nvalid;
+    const int q = blockIdx.x;
+    const uint32_t oq = sel[q];
+    const int tid = threadIdx.x;
+    const QParams P = qp[q];
+    for (int i = tid; i < 256; i += 1024) s_lut[i] = lut[i];
+    for (int i = tid; i < 2 * PB_MAX_K; i += 1024) s_best[i] = ~0ull;
+    if (tid == 0) s_nvalid = 0;
+    __syncthreads();
+    for (int i = tid; i < d; i += 1024) s_qf[i] = s_lut[queries[(size_t)q * d + i]];
+    const uint32_t raw = cand_cnt[q];
+    if (raw > cap) {  // list overflow: nothing to gain from scoring a truncated list (uniform branch)
+        if (tid == 0) {
+            ResultHdr h;
+            h.count = 0;
+            h.status = 1u;
+            h.n_cand = raw;
+            h.o_max = 0.0f;
+            h.ck = -1.0f;
+            out_hdr[oq] = h;
+        }
+        return;
+    }
+    const uint32_t cnt = raw;
+    __syncthreads();
+    for (uint32_t base = 0; base < cnt; base += CH) {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const uint32_t i = tid + j * 1024;
+            uint64_t key = ~0ull;
+            if (base + i < cnt) {
+                const uint32_t r = (uint32_t)cand[(size_t)q * cap + base + i];
+                const float dot = ref_fold_dot(rows + (uint64_t)r * d, s_qf, s_lut, d);
+                float cs;
+                const float dist = ref_distance(dot, P.sqrt_sa, norms[r], &cs);
+                if ((double)dist < P.max_dist) key = ((uint64_t)sortable_f32(dist) << 32) | r;
+            }
+            s_sort[i] = key;
+        }
+        block_bitonic_sort(s_sort, CH);
+        // the chunk's best PB_MAX_K join the running best PB_MAX_K
+        if (tid < PB_MAX_K) s_best[PB_MAX_K + tid] = s_sort[tid];
+        block_bitonic_sort(s_best, 2 * PB_MAX_K);
+    }
+    if (tid < PB_MAX_K && s_best[tid] != ~0ull) atomicAdd(&s_nvalid, 1u);
+    __syncthreads();
+    const uint32_t n_valid = s_nvalid;
+    const uint32_t n_out = n_valid < P.k ? n_valid : P.k;
+    if (tid < (int)n_out) {
+        const uint64_t key = s_best[tid];
+        out_ids[(size_t)oq * out_stride + tid] = ids[(uint32_t)key];
+        out_dist[(size_t)oq * out_stride + tid] = unsortable_f32((uint32_t)(key >> 32));
+    }
+    if (tid == 0) {
+        ResultHdr h;
+        h.count = n_out;
+        h.status = (raw <= cap && n_out == P.k) ? 0u : 1u;  // fewer than k: leave it to the exhaustive pass
+        h.n_cand = raw;
+        h.o_max = 0.0f;
+        h.ck = -1.0f;
+        out_hdr[oq] = h;
     }
 }
 

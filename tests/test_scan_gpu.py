@@ -322,7 +322,8 @@ def test_packed_burst_matches_host_results_including_fallback_queries():
     t = torch.zeros((len(q), 2 * k + 1), dtype=torch.int64, device="cuda")
     ix.search_packed(q, k, 1e3, t.data_ptr())
     torch.cuda.synchronize()
-    assert ix.stats().fallback >= 1
+    st = ix.stats()
+    assert st.fallback + st.second_chance >= 1  # the duplicates' query did not certify at first
     host = t.cpu().numpy()
     ref = make_index(rows, ids, path=SINGLE)
     l_ids, l_d, l_c = ref.search(q, k, 1e3)
@@ -403,6 +404,65 @@ def test_multi_query_burst_equals_per_chunk_passes_and_handles_tails():
     check_against_oracle(a, rows, ids, q[124:], k=5, max_dist=3.5)
 
 
+def _tight_cluster_table(rng, n, n_cluster):
+    """n uniform rows plus n_cluster rows that differ from one centre vector in a handful of bytes by +-1: thousands
+    of rows whose cosines to the centre (and to each other) agree to ~1e-5 -- more near-ties around the 100th
+    neighbour than any candidate list holds."""
+    rows = rng.integers(0, 256, size=(n, 256), dtype=np.uint8)
+    centre = rng.integers(20, 236, size=256, dtype=np.uint8)
+    where = rng.choice(n, size=n_cluster, replace=False)
+    c = np.repeat(centre[None, :], n_cluster, axis=0).astype(np.int16)
+    for i in range(n_cluster):
+        idx = rng.choice(256, size=rng.integers(0, 4), replace=False)
+        c[i, idx] += rng.choice([-1, 1], size=len(idx))
+    rows[where] = c.astype(np.uint8)
+    return rows, centre, where
+
+
+@pytest.mark.parametrize("path", [SINGLE, MULTI])
+def test_second_chance_answers_tight_clusters_exactly(path):
+    # the first attempt finds 100 results but cannot certify them (9000 rows within ~1e-5 of the 100th cosine);
+    # the second chance lists every row within the margin of that cosine and re-scores all of them
+    rng = np.random.default_rng(70 + path)
+    n = 120000
+    rows, centre, where = _tight_cluster_table(rng, n, 9000)
+    ids = np.arange(n, dtype=np.int64) * 2 + 1
+    q = np.concatenate([centre[None, :], rows[where[:5]], rng.integers(0, 256, size=(6, 256), dtype=np.uint8)])
+    ix = make_index(rows, ids, path=path)
+    check_against_oracle(ix, rows, ids, q)
+    st = ix.stats()
+    assert st.second_chance >= 3 and st.queries == st.fast_path + st.second_chance + st.fallback
+    # and with the second chance disabled the same queries take the exhaustive pass (same answers)
+    os.environ["PB_NO_SECOND_CHANCE"] = "1"
+    try:
+        ix2 = make_index(rows, ids, path=path)
+        check_against_oracle(ix2, rows, ids, q[:3])
+        assert ix2.stats().second_chance == 0 and ix2.stats().fallback >= 2
+    finally:
+        del os.environ["PB_NO_SECOND_CHANCE"]
+
+
+def test_second_chance_in_a_burst_and_list_overflow():
+    rng = np.random.default_rng(73)
+    n = 262144 + 3
+    rows, centre, where = _tight_cluster_table(rng, n, 9000)
+    v = rng.integers(0, 256, size=256, dtype=np.uint8)
+    dup = rng.choice(np.setdiff1d(np.arange(n), where), size=70000, replace=False)
+    rows[dup] = v  # 70000 exact duplicates: more than the second chance's 65536-entry list -> exhaustive pass
+    ids = np.arange(n, dtype=np.int64) + 1
+    q = rng.integers(0, 256, size=(90, 256), dtype=np.uint8)
+    q[3], q[40], q[41], q[77] = centre, rows[where[0]], rows[where[1]], v
+    ix = make_index(rows, ids, path=MULTI)
+    check_against_oracle(ix, rows, ids, q[[3, 40, 41, 77, 0, 89]])
+    ix.stats(reset=True)
+    got = ix.search(q, 100, 1e3)
+    st = ix.stats()
+    assert st.second_chance >= 3 and st.fallback >= 1
+    ref = make_index(rows, ids, path=EXACT)
+    want = ref.search(q, 100, 1e3)
+    assert all(np.array_equal(x, y) for x, y in zip(got, want))
+
+
 def test_multi_query_burst_survivor_queue_overflow():
     # forty identical queries and 3000 consecutive exact duplicates of them: a 128-row step then holds 1280 survivor
     # quads, more than the burst kernel's LDS queue; the affected lists are flagged and those queries re-run
@@ -417,7 +477,8 @@ def test_multi_query_burst_survivor_queue_overflow():
     q[:40] = v
     ix = make_index(rows, ids, path=MULTI)
     got_ids, got_d, got_c = ix.search(q, 100, 1e3)
-    assert ix.stats().fallback >= 1
+    st = ix.stats()
+    assert st.fallback + st.second_chance >= 1  # flagged lists do not certify; the duplicates fit the second chance
     assert all(np.array_equal(got_ids[i, :100], np.arange(5001, 5101)) for i in range(40))
     check_against_oracle(ix, rows, ids, q[[0, 39, 40, 41, 60, 79]])
 
@@ -433,7 +494,8 @@ def test_multi_query_pass_adversarial_falls_back():
     ix = make_index(rows, ids, path=MULTI)
     check_against_oracle(ix, rows, ids, q)
     check_against_oracle(ix, rows, ids, q[3:6], max_dist=2e6)
-    assert ix.stats().fallback >= 1
+    st = ix.stats()
+    assert st.fallback + st.second_chance >= 1
     big = np.concatenate([q, rng.integers(0, 256, size=(70, 256), dtype=np.uint8)])  # the same through the burst form
     check_against_oracle(ix, rows, ids, big)
     # clustered, embedding-like table
