@@ -674,59 +674,123 @@ __global__ __launch_bounds__(256, NC == 1 ? 4 : 2) void k_front_roll(
 }
 
 // ------------------------------------------------------------------------------------------------
-// squeeze-excite gates for one image per block: mean over pixels (sum of the tile partials in order),
+// squeeze-excite gates for one image per block: mean over pixels (exact integer sum of the tile partials),
 // FC(E->S)+SiLU, FC(S->E)+sigmoid.  w1: [S][E]; w2t: [S][E] (transposed se_expand); gate: [B][E].
-// FC1 is organised so that every global load is independent (thread t owns channels t, t+256, ... and keeps
-// S partial sums in registers), then reduced across the block in a fixed order: no latency-serial chains.
-// SP = S rounded up to 8/16/32/48; w1, b1 and w2t are zero-padded to SP rows on the host, so no load is
-// conditional on a runtime value (a per-element runtime condition makes hipcc branch around every load and
-// wait for it: 48 serial L2 round trips).
-template <int SP>
-__global__ __launch_bounds__(256) void k_se(const long long *__restrict__ part, int n_tiles, int E, float inv_hw,
-                                            const float *__restrict__ w1, const float *__restrict__ b1,
-                                            const float *__restrict__ w2t, const float *__restrict__ b2,
-                                            float *__restrict__ gate) {
-    __shared__ float s_part[4][SP];
-    __shared__ float s_s[SP];
-    const int b = blockIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float p[SP];
+// The kernel is a chain of three dependent global-memory round trips (partials, w1, w2t) and nothing else, so it is
+// laid out to make each of them ONE trip: a thread owns a channel QUAD and a group of JG squeeze units
+// (blockDim = QP * G with QP = quads rounded up to a wave multiple and G = SP / JG groups), issues its JG 16-byte
+// weight loads back to back and only then uses them.  Reductions run in a fixed order (shuffles inside a wave,
+// then the waves of a group in index order; FC2's G partial sums in group order): deterministic and independent
+// of the batch.  SP = S rounded up to 8/16/32/48; w1, b1 and w2t are zero-padded to SP rows on the host, so no
+// load is conditional on a runtime value.
+// IMG images per block share every weight load (the kernel moves 2 * SP * E * 4 bytes of weights per block from
+// L2: at 512 blocks of one image that is 226 MB for the widest layers and sets the time); each image's arithmetic
+// and its order are the same for every IMG, so the gates do not depend on it.
+template <int SP, int IMG>
+__global__ __launch_bounds__(1024) void k_se(const long long *__restrict__ part, int n_tiles, int E, float inv_hw,
+                                             const float *__restrict__ w1, const float *__restrict__ b1,
+                                             const float *__restrict__ w2t, const float *__restrict__ b2,
+                                             float *__restrict__ gate, int QP, int n_img) {
+    constexpr int JG = SP < 16 ? SP : 16;  // squeeze units per thread
+    constexpr int G = SP / JG;             // thread groups
+    __shared__ float s_part[IMG][16][JG];  // [image][wave][j of the wave's group]
+    __shared__ float s_s[IMG][SP];
+    __shared__ f32x4 s_t[IMG][G > 1 ? G - 1 : 1][320];  // FC2 partial sums of groups 1.. (QP <= 320)
+    const int b0 = blockIdx.x * IMG;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int g = tid / QP, cq = tid - g * QP;  // QP is a multiple of 64: a wave never straddles two groups
+    const int n_quads = E >> 2;
+    const bool on = cq < n_quads;
+    const int c = on ? 4 * cq : 0;
+    const int j0 = g * JG;
+    // ---- squeeze: mean of the quad (every group recomputes it: n_tiles 32-byte loads per image)
+    f32x4 m[IMG];
 #pragma unroll
-    for (int j = 0; j < SP; ++j) p[j] = 0.0f;
-    for (int c = threadIdx.x; c < E; c += 256) {
-        long long t = 0;  // exact: fixed-point partial sums (see se_acc)
-        for (int tl = 0; tl < n_tiles; ++tl) t += part[((size_t)b * n_tiles + tl) * E + c];
-        const float m = (float)((double)t * (1.0 / 16777216.0) * (double)inv_hw);
-        // issue every load of the column before the first use (hipcc otherwise pairs each load with a wait)
-        float wv[SP];
+    for (int i = 0; i < IMG; ++i) {
+        const int b = (b0 + i) < n_img ? (b0 + i) : (n_img - 1);  // a padded slot repeats the last image
+        ll4 t = {0, 0, 0, 0};  // exact: fixed-point partial sums (see se_acc)
+        for (int tl = 0; tl < n_tiles; ++tl) se_add(t, *reinterpret_cast<const ll4 *>(part + ((size_t)b * n_tiles + tl) * E + c));
+        const double sc = (1.0 / 16777216.0) * (double)inv_hw;
+        m[i] = (f32x4){(float)((double)t.x * sc), (float)((double)t.y * sc), (float)((double)t.z * sc), (float)((double)t.w * sc)};
+        if (!on) m[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    // ---- FC1 partial sums over this thread's quad for its JG units
+    float p[IMG][JG];
+    {
+        f32x4 wv[JG];
 #pragma unroll
-        for (int j = 0; j < SP; ++j) wv[j] = w1[(size_t)j * E + c];
+        for (int j = 0; j < JG; ++j) wv[j] = *reinterpret_cast<const f32x4 *>(w1 + (size_t)(j0 + j) * E + c);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < SP; ++j) p[j] = p[j] + m * wv[j];
+        for (int i = 0; i < IMG; ++i)
+#pragma unroll
+            for (int j = 0; j < JG; ++j) {
+                float a = m[i].x * wv[j].x;
+                a = a + m[i].y * wv[j].y; a = a + m[i].z * wv[j].z; a = a + m[i].w * wv[j].w;
+                p[i][j] = a;
+            }
     }
 #pragma unroll
-    for (int j = 0; j < SP; ++j) {
-        float t = p[j];
-        for (int off = 32; off >= 1; off >>= 1) t = t + __shfl_xor(t, off);
-        if (lane == 0) s_part[wave][j] = t;
-    }
-    __syncthreads();
-    if (threadIdx.x < SP) {
-        const int j = threadIdx.x;
-        const float t = ((s_part[0][j] + s_part[1][j]) + s_part[2][j]) + s_part[3][j];
-        s_s[j] = silu_f(t + b1[j]);  // padded rows: silu(0 + 0) = 0
-    }
-    __syncthreads();
-    for (int c = threadIdx.x; c < E; c += 256) {
-        float t = b2[c];
-        float wv[SP];
+    for (int i = 0; i < IMG; ++i)
 #pragma unroll
-        for (int j = 0; j < SP; ++j) wv[j] = w2t[(size_t)j * E + c];
+        for (int j = 0; j < JG; ++j) {
+            float v = p[i][j];
+            for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_xor(v, off);
+            if (lane == 0) s_part[i][wave][j] = v;
+        }
+    __syncthreads();
+    if (tid < SP * IMG) {
+        const int i = tid / SP, jj = tid - i * SP;
+        const int gg = jj / JG, j = jj - gg * JG;
+        const int w0 = gg * (QP >> 6), w1n = w0 + (QP >> 6);  // the waves of group gg, in order
+        float v = s_part[i][w0][j];
+        for (int w = w0 + 1; w < w1n; ++w) v = v + s_part[i][w][j];
+        s_s[i][jj] = silu_f(v + b1[jj]);  // padded rows: silu(0 + 0) = 0
+    }
+    __syncthreads();
+    // ---- FC2: partial sum of this thread's JG units for its quad; group 0 adds the others in order
+    f32x4 acc[IMG];
+    {
+        f32x4 wv[JG];
+#pragma unroll
+        for (int j = 0; j < JG; ++j) wv[j] = *reinterpret_cast<const f32x4 *>(w2t + (size_t)(j0 + j) * E + c);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < SP; ++j) t = t + s_s[j] * wv[j];
-        gate[(size_t)b * E + c] = sigmoid_f(t);
+        for (int i = 0; i < IMG; ++i) {
+            acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < JG; ++j) {
+                const float sj = s_s[i][j0 + j];
+                acc[i].x = acc[i].x + sj * wv[j].x; acc[i].y = acc[i].y + sj * wv[j].y;
+                acc[i].z = acc[i].z + sj * wv[j].z; acc[i].w = acc[i].w + sj * wv[j].w;
+            }
+        }
+    }
+    if constexpr (G > 1) {
+        if (g > 0) {
+#pragma unroll
+            for (int i = 0; i < IMG; ++i) s_t[i][g - 1][cq] = acc[i];
+        }
+        __syncthreads();
+    }
+    if (g == 0 && on) {
+        const f32x4 bv = *reinterpret_cast<const f32x4 *>(b2 + c);
+#pragma unroll
+        for (int i = 0; i < IMG; ++i) {
+            if (b0 + i >= n_img) break;
+            f32x4 v = bv;
+            v.x = v.x + acc[i].x; v.y = v.y + acc[i].y; v.z = v.z + acc[i].z; v.w = v.w + acc[i].w;
+            if constexpr (G > 1) {
+#pragma unroll
+                for (int gg = 1; gg < G; ++gg) {
+                    const f32x4 o = s_t[i][gg - 1][cq];
+                    v.x = v.x + o.x; v.y = v.y + o.y; v.z = v.z + o.z; v.w = v.w + o.w;
+                }
+            }
+            const f32x4 r = {sigmoid_f(v.x), sigmoid_f(v.y), sigmoid_f(v.z), sigmoid_f(v.w)};
+            *reinterpret_cast<f32x4 *>(gate + (size_t)(b0 + i) * E + c) = r;
+        }
     }
 }
 
