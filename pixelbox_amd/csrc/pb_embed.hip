@@ -42,7 +42,7 @@ struct Block {
 };
 
 struct DwGeom {
-    int roll;  // 0: strip kernel (k_dwconv), 1: rolling-window kernel (k_dwconv_roll)
+    int roll;  // 0: strip kernel (k_dwconv), 1: rolling-window kernel (k_dwconv_roll), 2: whole map in LDS (k_dwconv_lds)
     int zsplit, cqpb, slots, n_tiles, strips_per_tile;  // for roll: slots = strips_x, strips_per_tile = rows per band
 };
 
@@ -317,9 +317,42 @@ DwGeom dw_geom_roll(int C, int k, int ho, int wo, int batch, int n_cu) {
     return g;
 }
 
+// whole-map-in-LDS geometry for small maps; returns roll = 0 (strip geometry) when it does not apply
+DwGeom dw_geom_lds(int C, int k, int h, int w, int ho, int wo, int batch, int n_cu) {
+    DwGeom g = dw_geom(C, ho, wo, batch, n_cu);
+    if (h > 16 || w > 16) return g;
+    const int pad = (k - 1) / 2, cq = C / 4;
+    const size_t per_quad = ((size_t)(h + 2 * pad) * (w + 2 * pad) + (size_t)k * k) * 16;
+    int cqb = 0;
+    for (int dv = 1; dv <= 32 && dv <= cq; ++dv)
+        if (cq % dv == 0 && dv * per_quad <= 40 * 1024) cqb = dv;
+    if (!cqb) return g;
+    g.roll = 2;
+    g.cqpb = cqb;
+    g.zsplit = cq / cqb;
+    g.slots = std::max(1, std::min(256 / cqb, ho * wo));
+    g.n_tiles = 1;
+    g.strips_per_tile = 0;
+    return g;
+}
+
 int launch_dw_geom(pb_embedder *e, const Block &bl, const float *in, int B, int H, int W, float *out, int Ho, int Wo,
                    const DwGeom &g) {
     dim3 grid(g.n_tiles, B, g.zsplit), block(g.cqpb * g.slots);
+    if (g.roll == 2) {
+        const int pad = (bl.k - 1) / 2;
+        const size_t lds2 = ((size_t)(H + 2 * pad) * (W + 2 * pad) + (size_t)bl.k * bl.k) * g.cqpb * 16;
+#define PB_DWL(KS, S)                                                                                                \
+    hipLaunchKernelGGL((k_dwconv_lds<KS, S>), grid, block, lds2, e->stream, in, H, W, bl.e, bl.dw_w, bl.dw_b, out, Ho, Wo, \
+                       e->buf_part, g.cqpb)
+        if (bl.k == 3 && bl.stride == 1) PB_DWL(3, 1);
+        else if (bl.k == 3 && bl.stride == 2) PB_DWL(3, 2);
+        else if (bl.k == 5 && bl.stride == 1) PB_DWL(5, 1);
+        else PB_DWL(5, 2);
+#undef PB_DWL
+        PB_HIP(hipGetLastError());
+        return PB_OK;
+    }
     const size_t lds = (size_t)bl.k * bl.k * g.cqpb * 16;  // filter taps of this block's channel quads
     if (!g.roll) {
 #define PB_DW(KS, S)                                                                                            \
@@ -350,14 +383,16 @@ int launch_dw(pb_embedder *e, const Block &bl, const float *in, int B, int H, in
     const std::pair<const void *, long> key(bl.dw_w, (long)B);
     auto it = e->dw_cfg.find(key);
     if (it == e->dw_cfg.end()) {
-        DwGeom cands[2] = {dw_geom(bl.e, Ho, Wo, B, e->n_cu), dw_geom_roll(bl.e, bl.k, Ho, Wo, B, e->n_cu)};
+        DwGeom cands[3] = {dw_geom(bl.e, Ho, Wo, B, e->n_cu), dw_geom_roll(bl.e, bl.k, Ho, Wo, B, e->n_cu),
+                           dw_geom_lds(bl.e, bl.k, H, W, Ho, Wo, B, e->n_cu)};
         int best = 0;
-        if (cands[1].roll) {
+        if (cands[1].roll || cands[2].roll) {
             float best_ms = 1e30f;
             hipEvent_t e0, e1;
             PB_HIP(hipEventCreate(&e0));
             PB_HIP(hipEventCreate(&e1));
-            for (int c = 0; c < 2; ++c) {
+            for (int c = 0; c < 3; ++c) {
+                if (c > 0 && !cands[c].roll) continue;  // form not applicable to this layer
                 int rc = launch_dw_geom(e, bl, in, B, H, W, out, Ho, Wo, cands[c]);
                 if (rc) return rc;
                 PB_HIP(hipEventRecord(e0, e->stream));

@@ -470,6 +470,67 @@ __global__ __launch_bounds__(256) void k_dwconv_roll(const float *__restrict__ i
 }
 
 // ------------------------------------------------------------------------------------------------
+// Depthwise conv for SMALL maps (<= 16 x 16 input): one block stages the whole zero-padded map of its channel
+// quads in LDS -- every input element is read from global memory exactly once, coalesced -- and all KS*KS taps of
+// every output come from LDS.  (The strip kernel re-reads each input ~10x through L1/L2, which is what bounds the
+// 8x8 and 4x4 layers.)  Same bias-first (ky, kx) accumulation with separately rounded products as k_dwconv, zero
+// taps outside the image (acc + 0*w == acc): bit-identical.  The block sees all pixels of its channels, so the SE
+// partial sum is the whole sum (n_tiles = 1).
+// grid = (1, B, C/4/cqb); blockDim = cqb * slots; dynamic LDS = ((H+2P)(W+2P) + KS*KS) * cqb * 16 bytes.
+template <int KS, int S>
+__global__ __launch_bounds__(256) void k_dwconv_lds(const float *__restrict__ in, int H, int W, int C,
+                                                    const float *__restrict__ w, const float *__restrict__ bias,
+                                                    float *__restrict__ out, int Ho, int Wo,
+                                                    long long *__restrict__ part, int cqb) {
+    constexpr int PAD = (KS - 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) f32x4 s_lds_dw[];
+    __shared__ ll4 s_red[256];
+    const int Hp = H + 2 * PAD, Wp = W + 2 * PAD;
+    f32x4 *s_in = s_lds_dw;                    // [Hp * Wp][cqb]
+    f32x4 *s_w = s_lds_dw + Hp * Wp * cqb;     // [KS * KS][cqb]
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int cq_l = tid % cqb, slot = tid / cqb, slots = blockDim.x / cqb;
+    const int c0 = 4 * (blockIdx.z * cqb + cq_l);
+    const float *ib = in + (size_t)b * H * W * C + c0;
+    for (int p = slot; p < Hp * Wp; p += slots) {
+        const int y = p / Wp - PAD, x = p % Wp - PAD;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (y >= 0 && y < H && x >= 0 && x < W) v = *reinterpret_cast<const f32x4 *>(ib + ((size_t)y * W + x) * C);
+        s_in[p * cqb + cq_l] = v;
+    }
+    for (int t = slot; t < KS * KS; t += slots) s_w[t * cqb + cq_l] = *reinterpret_cast<const f32x4 *>(w + (size_t)t * C + c0);
+    __syncthreads();
+    const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + c0);
+    float *ob = out + (size_t)b * Ho * Wo * C + c0;
+    ll4 psum = {0, 0, 0, 0};
+    for (int o = slot; o < Ho * Wo; o += slots) {
+        const int oy = o / Wo, ox = o % Wo;
+        f32x4 acc = bv;
+        const f32x4 *ip = s_in + ((oy * S) * Wp + ox * S) * cqb + cq_l;
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) {
+                const f32x4 v = ip[(ky * Wp + kx) * cqb];
+                const f32x4 wv = s_w[(ky * KS + kx) * cqb + cq_l];
+                const float p0 = v.x * wv.x, p1 = v.y * wv.y, p2 = v.z * wv.z, p3 = v.w * wv.w;
+                acc.x = acc.x + p0; acc.y = acc.y + p1; acc.z = acc.z + p2; acc.w = acc.w + p3;
+            }
+        const f32x4 r = {silu_f(acc.x), silu_f(acc.y), silu_f(acc.z), silu_f(acc.w)};
+        *reinterpret_cast<f32x4 *>(ob + (size_t)o * C) = r;
+        se_acc(psum, r);
+    }
+    s_red[tid] = psum;
+    __syncthreads();
+    if (slot == 0) {
+        ll4 t = s_red[cq_l];
+        for (int sl = 1; sl < slots; ++sl) se_add(t, s_red[sl * cqb + cq_l]);
+        *reinterpret_cast<ll4 *>(part + (size_t)b * C + c0) = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Rolling fused MBConv front: expand 1x1 (+bias+SiLU) -> depthwise KSxKS stride S (+bias+SiLU) -> SE partial sums
 // with the expanded activation living only in REGISTERS.
 // A wave owns a strip of 16 adjacent input columns and 16 NC expanded channels and walks down the rows of its band.
