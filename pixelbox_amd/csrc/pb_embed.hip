@@ -65,7 +65,7 @@ struct pb_embedder {
     float *d_out_f32 = nullptr;
     uint8_t *d_out_u8 = nullptr;
     int n_cu = 256;
-    std::map<std::pair<const void *, long>, std::pair<int, int>> gemm_cfg;  // (layer weights, rows) -> (MR, NR), measured
+    std::map<std::pair<const void *, long>, std::pair<int, int>> gemm_cfg;  // (layer weights, rows) -> (MR, NR), measured; MR < 0: eight-wave form
     std::map<std::pair<const void *, long>, DwGeom> dw_cfg;
     std::map<std::pair<const void *, long>, int> front_cfg;  // (block, batch) -> 0: expand GEMM + depthwise kernels, else fused kernel config 16 * bands + nc
     size_t part_floats_per_image = 0;      // (layer weights, batch) -> depthwise form, measured
@@ -196,12 +196,12 @@ int load_weights(pb_embedder *e, const uint8_t *blob, size_t len) {
     return PB_OK;
 }
 
-template <int MR, bool GATE>
+template <int MR, bool GATE, int NW = 4>
 void launch_gemm_mr(int nr, dim3 grid, hipStream_t st, const float *act, int M, const Gemm &g, const float *gate, int hw,
                     const float *resid, int do_silu, float *out) {
 #define PB_G(NRV)                                                                                                    \
     case NRV:                                                                                                        \
-        hipLaunchKernelGGL((k_gemm1x1<MR, NRV, GATE>), grid, dim3(256), 0, st, act, M, g.K, g.wt, g.Kpad, g.Npad, g.bias, \
+        hipLaunchKernelGGL((k_gemm1x1<MR, NRV, GATE, NW>), grid, dim3(64 * NW), 0, st, act, M, g.K, g.wt, g.Kpad, g.Npad, g.bias, \
                            g.N, gate, hw, resid, do_silu, out);                                                      \
         break;
     switch (nr) {
@@ -216,15 +216,20 @@ void launch_gemm_mr(int nr, dim3 grid, hipStream_t st, const float *act, int M, 
 // times every candidate on the real buffers (HIP events, 1 warm-up + 2 timed launches each; the outputs are
 // simply overwritten with identical values) and the winner is cached per (layer, M).
 struct GemmCfg {
-    int mr, nr;
+    int mr, nr, nw;  // nw = 8: eight waves per block (MR = 1 only), else four
 };
 
 void launch_gemm_cfg(pb_embedder *e, GemmCfg c, const float *act, long M, const Gemm &g, const float *gate, int hw,
                      const float *resid, int do_silu, float *out) {
     const int tiles = g.Npad / 16;
-    const long rows_per_block = 64L * c.mr;
+    const long rows_per_block = 16L * c.nw * c.mr;
     dim3 grid((unsigned)((M + rows_per_block - 1) / rows_per_block), (unsigned)(tiles / c.nr));
     const int nr = c.nr;
+    if (c.nw == 8) {
+        if (gate) launch_gemm_mr<1, true, 8>(nr, grid, e->stream, act, (int)M, g, gate, hw, resid, do_silu, out);
+        else launch_gemm_mr<1, false, 8>(nr, grid, e->stream, act, (int)M, g, gate, hw, resid, do_silu, out);
+        return;
+    }
 #define PB_L(MRV)                                                                                                    \
     (gate ? launch_gemm_mr<MRV, true>(nr, grid, e->stream, act, (int)M, g, gate, hw, resid, do_silu, out)            \
           : launch_gemm_mr<MRV, false>(nr, grid, e->stream, act, (int)M, g, gate, hw, resid, do_silu, out))
@@ -240,16 +245,17 @@ int launch_gemm(pb_embedder *e, const float *act, long M, const Gemm &g, const f
     const std::pair<const void *, long> key(g.wt, M);
     auto it = e->gemm_cfg.find(key);
     if (it == e->gemm_cfg.end()) {
-        GemmCfg best{1, 1};
+        GemmCfg best{1, 1, 4};
         float best_ms = 1e30f;
         hipEvent_t e0, e1;
         PB_HIP(hipEventCreate(&e0));
         PB_HIP(hipEventCreate(&e1));
         for (int nr = 8; nr >= 1; --nr) {
             if (tiles % nr) continue;
-            for (int mr : {4, 2, 1}) {
+            for (int mr : {4, 2, 1, 0}) {  // 0: the eight-wave form of MR = 1
                 if (mr > 1 && M <= 64L * (mr / 2)) continue;  // tile taller than the problem
-                const GemmCfg c{mr, nr};
+                if (mr == 0 && M <= 64) continue;
+                const GemmCfg c{mr ? mr : 1, nr, mr ? 4 : 8};
                 launch_gemm_cfg(e, c, act, M, g, gate, hw, resid, do_silu, out);
                 PB_HIP(hipEventRecord(e0, e->stream));
                 launch_gemm_cfg(e, c, act, M, g, gate, hw, resid, do_silu, out);
@@ -267,9 +273,10 @@ int launch_gemm(pb_embedder *e, const float *act, long M, const Gemm &g, const f
         }
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
-        it = e->gemm_cfg.emplace(key, std::make_pair(best.mr, best.nr)).first;
+        it = e->gemm_cfg.emplace(key, std::make_pair(best.mr * (best.nw == 8 ? -1 : 1), best.nr)).first;
     }
-    launch_gemm_cfg(e, GemmCfg{it->second.first, it->second.second}, act, M, g, gate, hw, resid, do_silu, out);
+    launch_gemm_cfg(e, GemmCfg{std::abs(it->second.first), it->second.second, it->second.first < 0 ? 8 : 4}, act, M, g, gate, hw,
+                    resid, do_silu, out);
     PB_HIP(hipGetLastError());
     return PB_OK;
 }

@@ -139,8 +139,8 @@ constexpr int G_KC = 64;  // K chunk staged in LDS (double-buffered: one barrier
 // written to the other LDS buffer afterwards (one barrier per chunk); (b) the activation operand of k-step
 // t+PD is requested before the MFMAs of k-step t (register ring), so the global-load latency of the streamed
 // operand hides behind 4*MR*NR MFMAs per step times PD steps.
-template <int MR, int NR, bool GATE>
-__global__ __launch_bounds__(256) void k_gemm1x1(const float *__restrict__ act, int M, int K,
+template <int MR, int NR, bool GATE, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void k_gemm1x1(const float *__restrict__ act, int M, int K,
                                                  const float *__restrict__ wt, int Kpad, int Npad,
                                                  const float *__restrict__ bias, int N,
                                                  const float *__restrict__ gate, int hw,
@@ -149,14 +149,16 @@ __global__ __launch_bounds__(256) void k_gemm1x1(const float *__restrict__ act, 
     constexpr int NT = 16 * NR;
     constexpr int LDW = NT + 4;  // +4: rows k and k+4 land 16 banks apart (conflict-free ds_read_b32)
     constexpr int PD = MR == 4 ? 2 : 4;  // activation prefetch distance in k-steps; must divide G_KC/16 = 4 (ring slot = step % PD)
-    constexpr int WREGS = (G_KC * (NT / 4) + 255) / 256;  // float4 per thread per weight chunk
+    constexpr int NTHR = 64 * NW;  // NW = 8: the same 16*MR rows per wave, twice the waves per block (the late layers have
+                                   // few row tiles: more waves per CU hide the operand latency without changing the k order)
+    constexpr int WREGS = (G_KC * (NT / 4) + NTHR - 1) / NTHR;  // float4 per thread per weight chunk
     __shared__ __attribute__((aligned(16))) float s_w[2][G_KC * LDW];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int li = lane & 15;   // pixel within a tile (activation operand) / channel within a tile (weight operand)
     const int kk = lane >> 4;   // k slot
     const int n0 = blockIdx.y * NT;
-    const long m_block = (long)blockIdx.x * (64 * MR);
+    const long m_block = (long)blockIdx.x * (16 * NW * MR);
     long mrow[MR];
     bool mval[MR];
     const float *arow[MR];
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(256) void k_gemm1x1(const float *__restrict__ act, 
         const int k0 = chunk * G_KC;
 #pragma unroll
         for (int j = 0; j < WREGS; ++j) {
-            const int i = threadIdx.x + j * 256;
+            const int i = threadIdx.x + j * NTHR;
             const int kr = i / (NT / 4), c4 = i % (NT / 4);
             const int krc = (k0 + kr) < Kpad ? (k0 + kr) : (Kpad - 1);  // clamp: rows beyond Kpad are never used
             wreg[j] = *reinterpret_cast<const f32x4 *>(wt + (size_t)krc * Npad + n0 + c4 * 4);
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(256) void k_gemm1x1(const float *__restrict__ act, 
     auto store_w = [&](int buf) {
 #pragma unroll
         for (int j = 0; j < WREGS; ++j) {
-            const int i = threadIdx.x + j * 256;
+            const int i = threadIdx.x + j * NTHR;
             const int kr = i / (NT / 4), c4 = i % (NT / 4);
             if (kr < G_KC) *reinterpret_cast<f32x4 *>(&s_w[buf][kr * LDW + c4 * 4]) = wreg[j];
         }
