@@ -534,10 +534,10 @@ int run_front(pb_embedder *e, const Block &bl, const float *x, int n, int H, int
 int forward_device(pb_embedder *e, const uint8_t *d_rgb, int n, uint8_t *d_u8, float *d_f32) {
     int H = (int)e->H / 2, W = (int)e->W / 2;
     {
-        const long total = (long)n * H * W * 4;
-        const int grid = (int)std::min<long>((total + 255) / 256, (long)e->n_cu * 16);
-        hipLaunchKernelGGL(k_stem, dim3(grid), dim3(256), 0, e->stream, d_rgb, n, (int)e->H, (int)e->W, e->stem_w, e->stem_b,
-                           e->buf_x[0]);
+        // one block per output row, taps from LDS-staged input rows (W is a multiple of 32 and <= 1024: 37 KB at most)
+        const int grid = (int)std::min<long>((long)n * H, (long)e->n_cu * 16);
+        hipLaunchKernelGGL(k_stem, dim3(grid), dim3(256), (size_t)3 * (e->W + 1) * 3 * sizeof(float), e->stream, d_rgb, n,
+                           (int)e->H, (int)e->W, e->stem_w, e->stem_b, e->buf_x[0]);
         PB_HIP(hipGetLastError());
     }
     int cur = 0;

@@ -67,57 +67,79 @@ __device__ __forceinline__ uint8_t quantize_u8(float f) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// stem: u8 NHWC [B,H,W,3] -> f32 NHWC [B,H/2,W/2,32]; 3x3 stride 2 pad 1, + bias, SiLU.
-// The px/255 conversion of efficientnet.rs:27 is fused here (correctly rounded divide).
-// One thread = one output pixel x 8 channels (4 threads per pixel).  w: [27][32] (tap-major: ky,kx,ci).
+// stem: u8 NHWC [B,H,W,3] -> f32 NHWC [B,H/2,W/2,32]; 3x3 stride 2 pad 1, + bias, SiLU, as an im2col GEMM on the
+// f32 matrix cores: K = 27 taps (padded to 32), N = 32 channels, M = output pixels.  A block owns one output row
+// (b, y): its three input rows are loaded as dwords (coalesced), converted through the v/255 table (the px/255 of
+// efficientnet.rs:27, correctly rounded, tabulated once per block) and laid out as floats behind one zero pixel
+// (the left border; rows above the image are zeros).  A wave takes 16 consecutive output pixels per trip: lane
+// (li, kq) reads the 8 taps k = 16s + 4kq + e of pixel li from LDS (one ds_read_b32 each), the weights
+// [32 channels][32 taps] sit in 16 registers per lane for the whole kernel, 16 MFMAs produce 16 pixels x 32
+// channels, and each lane ends up with 4 consecutive channels of its pixel (float4 store, 128 contiguous bytes
+// per pixel).  Input sizes are multiples of 32 (checked at load), so rows are whole dwords and whole MFMA tiles.
+// w: [27][32] (tap-major: ky, kx, ci).
 __global__ __launch_bounds__(256) void k_stem(const uint8_t *__restrict__ img, int B, int H, int W,
-                                              const float *__restrict__ w, const float *__restrict__ bias,
-                                              float *__restrict__ out) {
-    __shared__ float s_w[27 * 32];
-    __shared__ float s_b[32];
-    __shared__ float s_px[256];  // v as f32 / 255.0 (efficientnet.rs:27), correctly rounded, tabulated once
-    for (int i = threadIdx.x; i < 27 * 32; i += blockDim.x) s_w[i] = w[i];
-    if (threadIdx.x < 32) s_b[threadIdx.x] = bias[threadIdx.x];
+                                                   const float *__restrict__ w, const float *__restrict__ bias,
+                                                   float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float s_rows[];  // [3][(W + 1) * 3] floats, pixel -1 first
+    __shared__ float s_px[256];
     s_px[threadIdx.x & 255] = (float)(threadIdx.x & 255) / 255.0f;
-    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, kq = lane >> 4;
     const int Ho = H / 2, Wo = W / 2;
-    const long total = (long)B * Ho * Wo * 4;
-    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-        const int cg = (int)(t & 3);
-        const long p = t >> 2;
-        const int x = (int)(p % Wo);
-        const int y = (int)((p / Wo) % Ho);
-        const int b = (int)(p / ((long)Wo * Ho));
-        float acc[8];
+    const int RS = (W + 1) * 3;  // floats per staged row
+    int toff[8];
+    bool t_on[8];
+    float wreg[2][8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) acc[c] = s_b[cg * 8 + c];
-        const uint8_t *ib = img + (size_t)b * H * W * 3;
+    for (int j = 0; j < 8; ++j) {
+        const int k = 16 * (j >> 2) + 4 * kq + (j & 3);
+        const int ky = k / 9, kx = (k % 9) / 3, ci = k % 3;
+        t_on[j] = k < 27;
+        toff[j] = t_on[j] ? ky * RS + kx * 3 + ci : 0;  // relative to staged pixel (2x - 1) of row 0
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int iy = y * 2 + ky - 1;
-            if (iy < 0 || iy >= H) continue;
+        for (int c = 0; c < 2; ++c) wreg[c][j] = t_on[j] ? w[k * 32 + 16 * c + li] : 0.0f;
+    }
+    f32x4 bv[2];
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int ix = x * 2 + kx - 1;
-                if (ix < 0 || ix >= W) continue;
-                const uint8_t *px = ib + ((size_t)iy * W + ix) * 3;
-#pragma unroll
-                for (int ci = 0; ci < 3; ++ci) {
-                    const float a = s_px[px[ci]];
-                    const float *wr = s_w + ((ky * 3 + kx) * 3 + ci) * 32 + cg * 8;
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        const float pr = a * wr[c];
-                        acc[c] = acc[c] + pr;
-                    }
-                }
+    for (int c = 0; c < 2; ++c) bv[c] = *reinterpret_cast<const f32x4 *>(bias + 16 * c + 4 * kq);
+    __syncthreads();
+    const int row_dwords = W * 3 / 4;
+    for (int ry = blockIdx.x; ry < B * Ho; ry += gridDim.x) {
+        const int b = ry / Ho, y = ry - b * Ho;
+        // stage input rows 2y - 1, 2y, 2y + 1
+        for (int i = threadIdx.x; i < 3 * row_dwords; i += 256) {
+            const int r = i / row_dwords, dq = i - r * row_dwords;
+            const int iy = 2 * y - 1 + r;
+            float *dst = s_rows + r * RS + 3 + 4 * dq;
+            if (iy >= 0) {
+                const uint32_t u = *reinterpret_cast<const uint32_t *>(img + ((size_t)b * H + iy) * W * 3 + 4 * dq);
+                dst[0] = s_px[u & 0xFF]; dst[1] = s_px[(u >> 8) & 0xFF]; dst[2] = s_px[(u >> 16) & 0xFF]; dst[3] = s_px[u >> 24];
+            } else {
+                dst[0] = 0.f; dst[1] = 0.f; dst[2] = 0.f; dst[3] = 0.f;
             }
         }
-        float *o = out + p * 32 + cg * 8;
-        f32x4 v0 = {silu_f(acc[0]), silu_f(acc[1]), silu_f(acc[2]), silu_f(acc[3])};
-        f32x4 v1 = {silu_f(acc[4]), silu_f(acc[5]), silu_f(acc[6]), silu_f(acc[7])};
-        *reinterpret_cast<f32x4 *>(o) = v0;
-        *reinterpret_cast<f32x4 *>(o + 4) = v1;
+        if (threadIdx.x < 9) s_rows[(threadIdx.x / 3) * RS + threadIdx.x % 3] = 0.0f;  // pixel -1 of each row
+        __syncthreads();
+        for (int tx = wave; tx < Wo / 16; tx += 4) {
+            const int x = tx * 16 + li;
+            const float *base = s_rows + 2 * x * 3;  // staged pixel index 2x <-> image column 2x - 1
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = t_on[j] ? base[toff[j]] : 0.0f;
+            f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[c][j], v[j], acc[c], 0, 0, 0);
+            float *o = out + ((size_t)ry * Wo + x) * 32;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                f32x4 r = acc[c];
+                r.x = silu_f(r.x + bv[c].x); r.y = silu_f(r.y + bv[c].y); r.z = silu_f(r.z + bv[c].z); r.w = silu_f(r.w + bv[c].w);
+                *reinterpret_cast<f32x4 *>(o + 16 * c + 4 * kq) = r;
+            }
+        }
+        __syncthreads();
     }
 }
 
