@@ -358,8 +358,7 @@ def bench_end_to_end(args, torch, rank, world, device, distributed):
         t_gen += time.perf_counter() - tg
         emb.embed_device(imgs.data_ptr(), count, out.data_ptr())
         torch.cuda.synchronize()
-        stored = sh.index.append(np.arange(first + 1, first + count + 1, dtype=np.int64), out[:count].cpu().numpy())
-        assert stored == count
+        sh.index.append_device(np.arange(first + 1, first + count + 1, dtype=np.int64), out.data_ptr())
     barrier()
     t_index = time.perf_counter() - t0
     # 1000 query images, evenly spread over the collection; every rank recomputes their hashes (bit-identical on
@@ -396,7 +395,7 @@ def bench_end_to_end(args, torch, rank, world, device, distributed):
             "queries_with_zero_distance_first_hit": self_found, "queries_whose_first_hit_is_their_own_id": exact_self,
             "certified": int(st.fast_path), "second_chance": int(st.second_chance), "exhaustive_fallback": int(st.fallback),
             "note": "images generated on the GPU (pb_fill_synthetic_images), embedded in batches of 512, hashes inserted "
-                    "through pb_index_append (D2H + H2D of 128 KB per batch, per-row norms computed at insert); "
+                    "device-to-device through pb_index_append_device (per-row norms computed at insert); "
                     "the configuration itself is 1000000 images (--e2e-images 1000000).  The random-init network maps "
                     "the synthetic images onto few distinct hashes (~40 % exact duplicates, clusters of tens of "
                     "thousands of rows within 4e-4 of a query's 100th cosine): for such queries no candidate list "

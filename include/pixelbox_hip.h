@@ -77,6 +77,12 @@ int pb_index_dim(const pb_index *idx, uint32_t *dim);
 int pb_index_append(pb_index *idx, const int64_t *image_ids, const uint8_t *rows, uint64_t n,
                     uint64_t *n_inserted);
 
+/* The same for rows that are already in DEVICE memory (the hashes pb_embed_batch_device just wrote): the crawler ->
+ * embed -> insert pipeline without a host round trip for the rows.  image_ids stay a HOST array; they must be
+ * strictly ascending and greater than every stored id (fresh `last_insert_rowid()` values, engine.rs:249) -- updates
+ * and out-of-order ids go through pb_index_append. */
+int pb_index_append_device(pb_index *idx, const int64_t *image_ids, const uint8_t *d_rows, uint64_t n);
+
 /* Bulk (re)load at Engine::open (engine.rs:117-145) from
  * `SELECT image_id, hash FROM semantic_hashes ORDER BY image_id`: replaces the index content.
  * image_ids must be strictly increasing. */

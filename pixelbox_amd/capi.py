@@ -27,7 +27,7 @@ PB_METRIC_COSINE, PB_METRIC_BYTE, PB_METRIC_HAMMING = 0, 1, 2
 # and the built library against both)
 SYMBOLS = [
     "pb_last_error", "pb_version", "pb_device_count",
-    "pb_index_create", "pb_index_create_metric", "pb_index_destroy", "pb_index_size", "pb_index_dim", "pb_index_append", "pb_index_load",
+    "pb_index_create", "pb_index_create_metric", "pb_index_destroy", "pb_index_size", "pb_index_dim", "pb_index_append", "pb_index_append_device", "pb_index_load",
     "pb_index_search", "pb_index_search_device", "pb_index_search_packed", "pb_topk_merge_packed", "pb_topk_merge", "pb_index_read", "pb_index_fill_synthetic",
     "pb_index_set_option", "pb_index_get_stats",
     "pb_embed_create", "pb_embed_destroy", "pb_embed_info", "pb_embed_batch", "pb_embed_batch_device", "pb_mlhash",
@@ -78,6 +78,7 @@ def lib():
         L.pb_index_size.argtypes = [vp, u64p]
         L.pb_index_dim.argtypes = [vp, u32p]
         L.pb_index_append.argtypes = [vp, i64p, u8p, C.c_uint64, u64p]
+        L.pb_index_append_device.argtypes = [vp, i64p, vp, C.c_uint64]
         L.pb_index_load.argtypes = [vp, i64p, u8p, C.c_uint64]
         L.pb_index_search.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, C.c_double, i64p, f32p, u32p]
         L.pb_index_search_device.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, C.c_double, vp, vp, vp]
@@ -188,6 +189,11 @@ class Index:
         stored = C.c_uint64(0)
         _check(lib().pb_index_append(self._h, _p(ids, C.c_int64), _p(rows, C.c_uint8), ids.shape[0], C.byref(stored)))
         return stored.value
+
+    def append_device(self, image_ids, d_rows_ptr: int):
+        """Rows already on the device (uint8[n][dim] at d_rows_ptr); ids: host array, ascending and beyond every stored id."""
+        ids = np.ascontiguousarray(image_ids, dtype=np.int64)
+        _check(lib().pb_index_append_device(self._h, _p(ids, C.c_int64), C.c_void_p(d_rows_ptr), ids.shape[0]))
 
     def load(self, image_ids, rows):
         ids = np.ascontiguousarray(image_ids, dtype=np.int64)

@@ -1010,6 +1010,23 @@ int pb_index_append(pb_index *ix, const int64_t *image_ids, const uint8_t *rows,
     return PB_OK;
 }
 
+int pb_index_append_device(pb_index *ix, const int64_t *image_ids, const uint8_t *d_rows, uint64_t n) {
+    PB_CHECK(ix, PB_ERR_INVALID, "pb_index_append_device: null index");
+    PB_CHECK(n == 0 || (image_ids && d_rows), PB_ERR_INVALID, "pb_index_append_device: null ids/rows");
+    if (n == 0) return PB_OK;
+    std::lock_guard<std::mutex> lock(ix->mu);
+    pb::DeviceGuard guard(ix->device);
+    // the embed stage hands over fresh images: ids strictly ascending and beyond everything stored (anything else
+    // -- an update, an out-of-order id -- goes through pb_index_append, which implements INSERT OR IGNORE)
+    int64_t prev = ix->h_ids.empty() ? std::numeric_limits<int64_t>::min() : ix->h_ids.back();
+    for (uint64_t i = 0; i < n; ++i) {
+        PB_CHECK(image_ids[i] > prev, PB_ERR_INVALID, "pb_index_append_device: image_ids must be strictly ascending and greater than "
+                 "every stored id (id %lld at position %llu)", (long long)image_ids[i], (unsigned long long)i);
+        prev = image_ids[i];
+    }
+    return append_tail(ix, image_ids, d_rows, n, hipMemcpyDeviceToDevice);
+}
+
 int pb_index_load(pb_index *ix, const int64_t *image_ids, const uint8_t *rows, uint64_t n) {
     PB_CHECK(ix, PB_ERR_INVALID, "pb_index_load: null index");
     PB_CHECK(n == 0 || (image_ids && rows), PB_ERR_INVALID, "pb_index_load: null ids/rows");

@@ -271,6 +271,28 @@ def test_bad_arguments_fail_loudly():
         ix.load(np.array([3, 2], dtype=np.int64), np.zeros((2, 256), dtype=np.uint8))
 
 
+def test_append_device_rows():
+    import torch
+
+    rng = np.random.default_rng(52)
+    rows = rng.integers(0, 256, size=(3000, 256), dtype=np.uint8)
+    ids = np.arange(3000, dtype=np.int64) * 3 + 7
+    ix = capi.Index(256, 4000)
+    ix.append(ids[:1000], rows[:1000])
+    d = torch.from_numpy(rows[1000:]).cuda()
+    ix.append_device(ids[1000:2500], d.data_ptr())
+    ix.append_device(ids[2500:], d[1500:].data_ptr())
+    assert len(ix) == 3000
+    got_ids, got_rows = ix.read(0, 3000)
+    assert np.array_equal(got_ids, ids) and np.array_equal(got_rows, rows)
+    check_against_oracle(ix, rows, ids, rows[[5, 1500, 2999]])
+    with pytest.raises(capi.PixelboxError):
+        ix.append_device(ids[10:12], d.data_ptr())  # not beyond the stored ids
+    with pytest.raises(capi.PixelboxError):
+        ix.append_device(np.array([20000, 19999], dtype=np.int64), d.data_ptr())  # not ascending
+    assert len(ix) == 3000
+
+
 def test_packed_device_results_and_merge_roundtrip():
     import torch
 
