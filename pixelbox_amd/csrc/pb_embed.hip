@@ -271,6 +271,9 @@ int launch_gemm(pb_embedder *e, const float *act, long M, const Gemm &g, const f
                 }
             }
         }
+        if (getenv("PB_TRACE_TUNE"))
+            fprintf(stderr, "gemm M%ld K%d N%d%s: best MR%d NR%d NW%d %.1f us = %.1f TFLOP/s\n", M, g.K, g.N, gate ? " gated" : "", best.mr,
+                    best.nr, best.nw, best_ms * 500.f, 2.0 * (double)M * g.K * g.N / (best_ms * 0.5e-3) / 1e12);
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
         it = e->gemm_cfg.emplace(key, std::make_pair(best.mr * (best.nw == 8 ? -1 : 1), best.nr)).first;

@@ -62,6 +62,7 @@ struct pb_index {
     QParams *d_qp = nullptr;        // Q_CHUNK
     uint64_t *d_lists = nullptr;    // filter lists: Q_CHUNK * F_MAX_WG * F_KWG ; exact lists reuse
     ListHdr *d_hdrs = nullptr;      // Q_CHUNK * F_MAX_WG
+    uint64_t *d_dropkeys = nullptr; // Q_CHUNK * F_MAX_WG (byte / hamming pass: smallest key each workgroup dropped)
     uint64_t *d_xlists[2] = {nullptr, nullptr};  // exact pass ping-pong: Q_CHUNK * X_MAX_WG * PB_MAX_K
     uint32_t *d_xcounts[2] = {nullptr, nullptr};
     uint32_t *d_qsel = nullptr;     // Q_CHUNK
@@ -109,6 +110,7 @@ int alloc_workspace(pb_index *ix) {
     PB_HIP(hipMalloc(&ix->d_qp, PIPE_Q * sizeof(QParams)));
     PB_HIP(hipMalloc(&ix->d_lists, (size_t)Q_CHUNK * F_MAX_WG * F_KWG * sizeof(uint64_t)));
     PB_HIP(hipMalloc(&ix->d_hdrs, (size_t)Q_CHUNK * F_MAX_WG * sizeof(ListHdr)));
+    PB_HIP(hipMalloc(&ix->d_dropkeys, (size_t)Q_CHUNK * F_MAX_WG * sizeof(uint64_t)));
     for (int i = 0; i < 2; ++i) {
         const size_t lists = i == 0 ? X_MAX_WG : (X_MAX_WG + M_FANIN - 1) / M_FANIN;
         PB_HIP(hipMalloc(&ix->d_xlists[i], (size_t)Q_CHUNK * lists * PB_MAX_K * sizeof(uint64_t)));
@@ -154,6 +156,7 @@ void free_all(pb_index *ix) {
     (void)hipFree(ix->d_cand);
     (void)hipFree(ix->d_cand_cnt);
     (void)hipFree(ix->d_ghist);
+    (void)hipFree(ix->d_dropkeys);
     (void)hipFree(ix->d_queries2);
     (void)hipFree(ix->d_qp2);
     (void)hipFree(ix->d_tau2);
@@ -361,6 +364,41 @@ int run_fast(pb_index *ix, uint32_t nq) {
     return PB_OK;
 }
 
+// byte_distance / hamming_distance: coalesced exact-key pass (one launch per query, like the cosine filter) + merge
+template <int METRIC>
+int launch_dist(pb_index *ix, int n_wg, uint32_t q) {
+#define PB_D(LPRV)                                                                                                   \
+    hipLaunchKernelGGL((k_scan_dist<LPRV, METRIC>), dim3(n_wg, 1), dim3(F_WAVES * 64), 0, ix->stream, ix->d_rows, ix->n_rows, \
+                       ix->d_queries, ix->d_qp, ix->d_lists, ix->d_hdrs, ix->d_dropkeys, (int)q)
+    switch (ix->dim / 16) {
+        case 1: PB_D(1); break;
+        case 2: PB_D(2); break;
+        case 4: PB_D(4); break;
+        case 8: PB_D(8); break;
+        case 16: PB_D(16); break;
+        case 32: PB_D(32); break;
+        case 64: PB_D(64); break;
+        default: return pb::fail(PB_ERR_INTERNAL, "distance pass: unsupported dim %u", ix->dim);
+    }
+#undef PB_D
+    PB_HIP(hipGetLastError());
+    return PB_OK;
+}
+
+int run_fast_dist(pb_index *ix, uint32_t nq) {
+    const int n_wg = std::min(filter_grid(ix), (int)F_MAX_WG / 2);  // k_select_keys sorts 8192 keys: <= 256 lists
+    if (ix->opt_profile) PB_HIP(hipEventRecord(ix->ev0, ix->stream));
+    for (uint32_t q = 0; q < nq; ++q) {
+        int rc = ix->metric == 1 ? launch_dist<1>(ix, n_wg, q) : launch_dist<2>(ix, n_wg, q);
+        if (rc) return rc;
+    }
+    if (ix->opt_profile) PB_HIP(hipEventRecord(ix->ev1, ix->stream));
+    hipLaunchKernelGGL(k_select_keys, dim3(nq), dim3(SEL_BLOCK), 0, ix->stream, ix->d_ids, ix->d_qp, ix->d_lists, ix->d_hdrs,
+                       ix->d_dropkeys, n_wg, ix->d_res_ids, ix->d_res_dist, ix->d_res_hdr, (uint32_t)PB_MAX_K);
+    PB_HIP(hipGetLastError());
+    return PB_OK;
+}
+
 // exhaustive exact pass for the n_sel queries listed in d_qsel
 int run_exact(pb_index *ix, uint32_t n_sel, uint32_t k) {
     const uint64_t n_tiles = (ix->n_rows + WAVE - 1) / WAVE;
@@ -559,7 +597,9 @@ int search_chunk(pb_index *ix, uint32_t cq, uint32_t k, double max_dist, const f
     uint8_t *hq = ix->h_stage;
     QParams *hp = reinterpret_cast<QParams *>(ix->h_stage + (size_t)Q_CHUNK * d);
     uint32_t *hsel = reinterpret_cast<uint32_t *>(ix->h_stage + (size_t)Q_CHUNK * (d + sizeof(QParams)));
-    const bool use_fast = ix->metric == 0 && (ix->opt_path == 0 || ix->opt_path == 2 || ix->opt_path == 3) && fast_dim(d);
+    // cosine: filter pass + certificate; byte / hamming: coalesced exact-key pass + drop-bound check
+    const bool use_dist = ix->metric != 0 && ix->opt_path != 1 && fast_dim(d);
+    const bool use_fast = use_dist || (ix->metric == 0 && (ix->opt_path == 0 || ix->opt_path == 2 || ix->opt_path == 3) && fast_dim(d));
     make_qparams_batch(ix, hq, cq, k, max_dist, hp);
     PB_HIP(hipMemcpyAsync(ix->d_queries, hq, (size_t)cq * d, hipMemcpyHostToDevice, ix->stream));
     PB_HIP(hipMemcpyAsync(ix->d_qp, hp, (size_t)cq * sizeof(QParams), hipMemcpyHostToDevice, ix->stream));
@@ -569,7 +609,7 @@ int search_chunk(pb_index *ix, uint32_t cq, uint32_t k, double max_dist, const f
     // the packed/device entry point and small calls)
     const bool use_multi = use_fast && multi_eligible(ix, cq);
     if (use_fast) {
-        int rc = use_multi ? run_multi(ix, cq, k) : run_fast(ix, cq);
+        int rc = use_dist ? run_fast_dist(ix, cq) : (use_multi ? run_multi(ix, cq, k) : run_fast(ix, cq));
         if (rc) return rc;
         PB_HIP(hipMemcpyAsync(ix->h_res_hdr, ix->d_res_hdr, cq * sizeof(ResultHdr), hipMemcpyDeviceToHost, ix->stream));
         PB_HIP(hipStreamSynchronize(ix->stream));
@@ -591,7 +631,7 @@ int search_chunk(pb_index *ix, uint32_t cq, uint32_t k, double max_dist, const f
     }
     // second chance: a query that HAS k results (ck = their smallest exact cosine, from the attempt above or handed
     // in by the burst path) but no certificate gets every row with cos_filter >= ck (1 - 1e-6) - 1.01 m scored exactly
-    if (n_sel && (ck_hint || use_fast) && (ck_hint ? ix->metric == 0 && ix->dim == 256 && ix->n_rows >= 4096 && !getenv("PB_NO_SECOND_CHANCE")
+    if (n_sel && !use_dist && (ck_hint || use_fast) && (ck_hint ? ix->metric == 0 && ix->dim == 256 && ix->n_rows >= 4096 && !getenv("PB_NO_SECOND_CHANCE")
                                                     : second_chance_eligible(ix))) {
         uint32_t sc_sel[Q_CHUNK], rest[Q_CHUNK];
         float sc_tau[Q_CHUNK];

@@ -404,6 +404,134 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
 }
 
 // ------------------------------------------------------------------------------------------------
+// (1c) byte_distance / hamming_distance (engine.rs:590-604) as a coalesced, HBM-bound pass over a `phashes`-like
+// table: the same streaming skeleton as k_scan_filter (LPR lanes share a row, 16 B each, U loads in flight), with
+// v_sad_u8 / popcount as the inner op.  These distances are EXACT in the integer domain (a sum below 2^24 and one
+// correctly rounded divide -- the u8 wrap of hamming included), so the keys (dist bits, row) are final: no
+// re-scoring.  A wave keeps its F_KW best keys and the best key it dropped; k_select_keys merges the workgroup
+// lists and the result is the reference's iff its k-th key is smaller than every dropped key (else: exhaustive).
+template <int LPR, int METRIC, int U = 8, int NW = F_WAVES>
+__global__ __launch_bounds__(NW * WAVE) void k_scan_dist(const uint8_t *__restrict__ rows, uint64_t n_rows,
+                                                       const uint8_t *__restrict__ queries,
+                                                       const QParams *__restrict__ qp, uint64_t *__restrict__ lists,
+                                                       ListHdr *__restrict__ hdrs, uint64_t *__restrict__ drop_keys,
+                                                       int q_base) {
+    constexpr int D = LPR * 16;
+    constexpr int RPT = WAVE / LPR;
+    constexpr int ROWS_IT = U * RPT;
+    constexpr int ROUNDS = (U + LPR - 1) / LPR;
+    __shared__ uint64_t s_buf[NW][F_CAPW];
+    __shared__ int s_cnt[NW];
+    __shared__ uint64_t s_drop[NW];
+    const int q = q_base + blockIdx.y;
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+    const int sub = lane % LPR;
+    const int g = lane / LPR;
+    const QParams P = qp[q];
+    const uint4 qv = *reinterpret_cast<const uint4 *>(queries + (size_t)q * D + sub * 16);
+    uint64_t *buf = s_buf[wave];
+    uint64_t thr_key = ~0ull;  // keep keys < thr_key
+    uint64_t dropped = ~0ull;  // smallest key this wave dropped
+    int cnt = 0;
+    const float denom = METRIC == 1 ? 255.0f * (float)D : 8.0f * (float)D;
+    const uint64_t n_super = (n_rows + ROWS_IT - 1) / ROWS_IT;
+    const uint64_t stride = (uint64_t)gridDim.x * NW;
+    for (uint64_t s = (uint64_t)wave * gridDim.x + blockIdx.x; s < n_super; s += stride) {
+        const uint64_t row0 = s * ROWS_IT;
+        uint4 b[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            uint64_t r = row0 + (uint64_t)(u * RPT + g);
+            r = r < n_rows ? r : n_rows - 1;
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(rows + r * D + sub * 16));
+            b[u] = make_uint4(t.x, t.y, t.z, t.w);
+        }
+        int sv[ROUNDS];
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; ++rd) sv[rd] = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            uint32_t a;
+            if constexpr (METRIC == 1) {
+                a = __builtin_amdgcn_sad_u8(qv.x, b[u].x, 0u);
+                a = __builtin_amdgcn_sad_u8(qv.y, b[u].y, a);
+                a = __builtin_amdgcn_sad_u8(qv.z, b[u].z, a);
+                a = __builtin_amdgcn_sad_u8(qv.w, b[u].w, a);
+            } else {
+                a = __popc(qv.x ^ b[u].x) + __popc(qv.y ^ b[u].y) + __popc(qv.z ^ b[u].z) + __popc(qv.w ^ b[u].w);
+            }
+            const int tot = group_sum<LPR>((int)a);
+            sv[u / LPR] = ((u % LPR) == sub) ? tot : sv[u / LPR];
+        }
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; ++rd) {
+            const int u = rd * LPR + sub;
+            const uint64_t r = row0 + (uint64_t)(u * RPT + g);
+            const bool valid = (u < U) && (r < n_rows);
+            const uint32_t acc = (uint32_t)sv[rd];
+            const float dist = METRIC == 1 ? (float)acc / denom : (float)(acc & 0xFFu) / denom;  // engine.rs:592 / :603
+            uint64_t key = ~0ull;
+            if (valid && (double)dist < P.max_dist) key = ((uint64_t)sortable_f32(dist) << 32) | (uint32_t)r;
+            const bool pass = key < thr_key;
+            const uint64_t m = __ballot(pass);
+            if (m) {
+                if (pass) buf[cnt + mbcnt(m)] = key;
+                cnt += __popcll(m);
+                if (cnt > F_CAPW - WAVE) {
+                    thr_key = wave_keep_smallest<F_CAPW / WAVE>(buf, cnt, F_KW);  // = the largest key kept
+                    cnt = F_KW;
+                    dropped = thr_key + 1 < dropped ? thr_key + 1 : dropped;  // everything dropped is > thr_key
+                    thr_key = thr_key + 1;                                      // keep only keys <= the kept maximum
+                }
+            }
+        }
+    }
+    if (cnt > F_KW) {
+        const uint64_t kth = wave_keep_smallest<F_CAPW / WAVE>(buf, cnt, F_KW);
+        cnt = F_KW;
+        dropped = kth + 1 < dropped ? kth + 1 : dropped;
+    }
+    if (lane == 0) {
+        s_cnt[wave] = cnt;
+        s_drop[wave] = dropped;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    constexpr int ME = NW * F_KW / WAVE;
+    __shared__ uint64_t s_merge[NW * F_KW];
+    int total = 0;
+    uint64_t drop = ~0ull;
+    for (int w = 0; w < NW; ++w) {
+        const int c = s_cnt[w];
+        if (lane < c) s_merge[total + lane] = s_buf[w][lane];
+        total += c;
+        drop = s_drop[w] < drop ? s_drop[w] : drop;
+    }
+    if (total > F_KWG) {
+        const uint64_t kth = wave_keep_smallest<ME>(s_merge, total, F_KWG);
+        total = F_KWG;
+        drop = kth + 1 < drop ? kth + 1 : drop;
+    }
+    const uint64_t mykey = lane < total ? s_merge[lane] : ~0ull;
+    int rank = 0;
+    for (int j = 0; j < total; ++j) {
+        const uint64_t o = __shfl((unsigned long long)mykey, j);
+        rank += o < mykey ? 1 : 0;
+    }
+    uint64_t *out = lists + ((size_t)q * gridDim.x + blockIdx.x) * F_KWG;
+    if (lane < total) out[rank] = mykey;
+    if (lane == 0) {
+        ListHdr h;
+        h.count = (uint32_t)total;
+        h.dropped = 0.0f;
+        hdrs[(size_t)q * gridDim.x + blockIdx.x] = h;
+        drop_keys[(size_t)q * gridDim.x + blockIdx.x] = drop;  // every key this workgroup saw and did not list is >= drop
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // in-LDS bitonic sort of n (power of two) u64 keys, ascending; all threads of the block participate
 __device__ __forceinline__ void block_bitonic_sort(uint64_t *s, int n) {
     for (int k = 2; k <= n; k <<= 1) {
@@ -599,6 +727,64 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
         h.n_cand = n_cand_raw;
         h.o_max = o_max;
         h.ck = n_out == P.k ? ck : -1.0f;
+        out_hdr[q] = h;
+    }
+}
+
+// (1d) merge of the k_scan_dist workgroup lists: sort all listed keys, take the first k; exact iff the k-th key is
+// below every workgroup's `drop` bound (fewer than k results: iff nothing was dropped at all).  One block per query.
+__global__ __launch_bounds__(SEL_BLOCK) void k_select_keys(const int64_t *__restrict__ ids, const QParams *__restrict__ qp,
+                                                           const uint64_t *__restrict__ lists, const ListHdr *__restrict__ hdrs,
+                                                           const uint64_t *__restrict__ drop_keys, int n_lists,
+                                                           int64_t *__restrict__ out_ids, float *__restrict__ out_dist,
+                                                           ResultHdr *__restrict__ out_hdr, uint32_t out_stride) {
+    constexpr int CAP = F_MAX_WG * F_KWG / 2;  // 8192 keys: 256 workgroup lists
+    __shared__ uint64_t s_key[CAP];
+    __shared__ uint64_t s_min[SEL_BLOCK / WAVE];
+    __shared__ uint32_t s_n;
+    const int q = blockIdx.x;
+    const int tid = threadIdx.x;
+    const QParams P = qp[q];
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    uint64_t dmin = ~0ull;
+    const bool too_many = n_lists * F_KWG > CAP;
+    for (int l = tid; l < n_lists; l += SEL_BLOCK) {
+        const uint64_t dk = drop_keys[(size_t)q * n_lists + l];
+        dmin = dk < dmin ? dk : dmin;
+    }
+    for (int i = tid; i < CAP; i += SEL_BLOCK) {
+        const int l = i / F_KWG, j = i % F_KWG;
+        uint64_t key = ~0ull;
+        if (l < n_lists && j < (int)hdrs[(size_t)q * n_lists + l].count) key = lists[((size_t)q * n_lists + l) * F_KWG + j];
+        s_key[i] = key;
+        if (key != ~0ull) atomicAdd(&s_n, 1u);
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        const uint64_t o = __shfl_xor((unsigned long long)dmin, off);
+        dmin = o < dmin ? o : dmin;
+    }
+    if ((tid & 63) == 0) s_min[tid >> 6] = dmin;
+    block_bitonic_sort(s_key, CAP);
+    const uint32_t n_valid = s_n;
+    const uint32_t n_out = n_valid < P.k ? n_valid : P.k;
+    if (tid < (int)n_out) {
+        const uint64_t key = s_key[tid];
+        out_ids[(size_t)q * out_stride + tid] = ids[(uint32_t)key];
+        out_dist[(size_t)q * out_stride + tid] = unsortable_f32((uint32_t)(key >> 32));
+    }
+    if (tid == 0) {
+        uint64_t dm = ~0ull;
+        for (int w = 0; w < SEL_BLOCK / WAVE; ++w) dm = s_min[w] < dm ? s_min[w] : dm;
+        bool ok = !too_many;
+        if (n_out == P.k) ok = ok && s_key[n_out - 1] < dm;
+        else ok = ok && dm == ~0ull;
+        ResultHdr h;
+        h.count = n_out;
+        h.status = ok ? 0u : 1u;
+        h.n_cand = n_valid;
+        h.o_max = 0.0f;
+        h.ck = -1.0f;
         out_hdr[q] = h;
     }
 }

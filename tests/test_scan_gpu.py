@@ -661,3 +661,34 @@ def test_byte_and_hamming_scans(metric, d):
         ix2.load(np.arange(2), np.array([[0x0F, 0x0F], [0b01010101, 0b10101010]], dtype=np.uint8))
         i2, d2 = ix2.search_one(np.array([0xFF, 0x0F], dtype=np.uint8), 100, 10.0)
         assert i2.tolist() == [0, 1] and d2[0] == F32(0.25)
+
+
+@pytest.mark.parametrize("metric", [capi.PB_METRIC_BYTE, capi.PB_METRIC_HAMMING])
+def test_byte_and_hamming_coalesced_pass_and_its_fallback(metric):
+    # dims the streaming skeleton accepts (powers of two, 16..1024) take the coalesced exact-key pass; its result
+    # stands when the k-th key lies below every key a workgroup dropped, else the exhaustive pass answers
+    rng = np.random.default_rng(95 + metric)
+    n = 200000
+    rows = rng.integers(0, 256, size=(n, 256), dtype=np.uint8)
+    rows[150000] = rows[7]
+    ids = np.arange(n, dtype=np.int64) * 2 + 1
+    q = np.stack([rows[7], rng.integers(0, 256, size=256, dtype=np.uint8), rows[199999]])
+    ix = capi.Index(256, n, metric=metric)
+    ix.load(ids, rows)
+    for k, md in ((100, 0.6), (7, 0.3), (256, 10.0)):
+        got_ids, got_d, got_c = ix.search(q, k, md)
+        for qi in range(len(q)):
+            want_ids, want_d = oracle.scan_topk_metric(metric, q[qi], rows, ids, k, md)
+            c = int(got_c[qi])
+            assert c == len(want_ids) and np.array_equal(got_ids[qi, :c], want_ids)
+            assert np.array_equal(got_d[qi, :c].view(np.uint32), want_d.view(np.uint32))
+    st = ix.stats()
+    assert st.fast_path >= 6 and st.queries == st.fast_path + st.fallback
+    # 5000 identical rows in one id range: far more ties than a workgroup lists -> drop bound fails -> exhaustive
+    rows2 = rows.copy()
+    rows2[40000:45000] = rows2[40000]
+    ix2 = capi.Index(256, n, metric=metric)
+    ix2.load(ids, rows2)
+    g_ids, g_d, g_c = ix2.search(rows2[40000][None, :], 100, 0.6)
+    w_ids, w_d = oracle.scan_topk_metric(metric, rows2[40000], rows2, ids, 100, 0.6)
+    assert np.array_equal(g_ids[0, : g_c[0]], w_ids) and np.array_equal(g_d[0, : g_c[0]].view(np.uint32), w_d.view(np.uint32))
