@@ -717,8 +717,11 @@ int search_block_multi(pb_index *ix, const uint8_t *queries, uint32_t nq, uint32
         }
     }
     PB_HIP(hipMemcpyAsync(ix->h_res_hdr, ix->d_res_hdr, nq * sizeof(ResultHdr), hipMemcpyDeviceToHost, ix->stream));
-    PB_HIP(hipMemcpyAsync(ix->h_res_ids, ix->d_res_ids, (size_t)nq * PB_MAX_K * sizeof(int64_t), hipMemcpyDeviceToHost, ix->stream));
-    PB_HIP(hipMemcpyAsync(ix->h_res_dist, ix->d_res_dist, (size_t)nq * PB_MAX_K * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
+    // only the first k of the PB_MAX_K result slots of each query travel (1.2 MB instead of 3 MB per 1024 queries)
+    PB_HIP(hipMemcpy2DAsync(ix->h_res_ids, PB_MAX_K * sizeof(int64_t), ix->d_res_ids, PB_MAX_K * sizeof(int64_t), k * sizeof(int64_t), nq,
+                            hipMemcpyDeviceToHost, ix->stream));
+    PB_HIP(hipMemcpy2DAsync(ix->h_res_dist, PB_MAX_K * sizeof(float), ix->d_res_dist, PB_MAX_K * sizeof(float), k * sizeof(float), nq,
+                            hipMemcpyDeviceToHost, ix->stream));
     PB_HIP(hipStreamSynchronize(ix->stream));
     if (ix->opt_profile) {
         int rc2 = account_profile(ix, 1, 1);
