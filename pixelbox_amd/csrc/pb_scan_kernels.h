@@ -1563,7 +1563,7 @@ __global__ __launch_bounds__(1024) void k_mq_rescore_big(
     const int tid = threadIdx.x;
     const QParams P = qp[q];
     for (int i = tid; i < 256; i += 1024) s_lut[i] = lut[i];
-    for (int i = tid; i < 2 * PB_MAX_K; i += 1024) s_best[i] = ~0ull;
+    for (int i = tid; i < 2 * (int)PB_MAX_K; i += 1024) s_best[i] = ~0ull;
     if (tid == 0) s_nvalid = 0;
     __syncthreads();
     for (int i = tid; i < d; i += 1024) s_qf[i] = s_lut[queries[(size_t)q * d + i]];
@@ -1598,10 +1598,10 @@ __global__ __launch_bounds__(1024) void k_mq_rescore_big(
         }
         block_bitonic_sort(s_sort, CH);
         // the chunk's best PB_MAX_K join the running best PB_MAX_K
-        if (tid < PB_MAX_K) s_best[PB_MAX_K + tid] = s_sort[tid];
+        if (tid < (int)PB_MAX_K) s_best[PB_MAX_K + tid] = s_sort[tid];
         block_bitonic_sort(s_best, 2 * PB_MAX_K);
     }
-    if (tid < PB_MAX_K && s_best[tid] != ~0ull) atomicAdd(&s_nvalid, 1u);
+    if (tid < (int)PB_MAX_K && s_best[tid] != ~0ull) atomicAdd(&s_nvalid, 1u);
     __syncthreads();
     const uint32_t n_valid = s_nvalid;
     const uint32_t n_out = n_valid < P.k ? n_valid : P.k;
