@@ -536,7 +536,24 @@ int run_front(pb_embedder *e, const Block &bl, const float *x, int n, int H, int
 // forward for n images already on the device; results to device buffers
 int forward_device(pb_embedder *e, const uint8_t *d_rgb, int n, uint8_t *d_u8, float *d_f32) {
     int H = (int)e->H / 2, W = (int)e->W / 2;
-    {
+    // the first block (no expansion, 3x3 stride 1, 32 channels, no residual) takes its depthwise conv fused into the
+    // stem when the 3-row LDS ring fits (input width <= 320); identical bits either way
+    const Block &b0 = e->blocks.front();
+    // bands of 16 output rows (2 stem rows of halo each), fewer rows per band for small batches (<= 32 partial tiles)
+    int rpb = 16;
+    while (rpb > 4 && (long)n * ((H + rpb - 1) / rpb) < 2L * e->n_cu && (H + rpb / 2 - 1) / (rpb / 2) <= 32) rpb /= 2;
+    const size_t fused_lds = (size_t)3 * (W + 2) * 36 * sizeof(float) + (size_t)(2 * rpb + 5) * (e->W * 3 + 4);
+    const bool fuse_stem = !b0.has_expand && b0.k == 3 && b0.stride == 1 && b0.e == 32 && fused_lds <= 60 * 1024 &&
+                           (H + rpb - 1) / rpb <= 32 && !getenv("PB_NO_STEM_FUSION");
+    int stem_bands = 0;
+    if (fuse_stem) {
+        stem_bands = (H + rpb - 1) / rpb;
+        if (fused_lds > 48 * 1024)
+            PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stem_dw), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds));
+        hipLaunchKernelGGL(k_stem_dw, dim3(stem_bands, n), dim3(256), fused_lds, e->stream, d_rgb, n, (int)e->H, (int)e->W, e->stem_w,
+                           e->stem_b, b0.dw_w, b0.dw_b, e->buf_dw, e->buf_part, stem_bands, rpb);
+        PB_HIP(hipGetLastError());
+    } else {
         // one block per output row, taps from LDS-staged input rows (W is a multiple of 32 and <= 1024: 37 KB at most)
         const int grid = (int)std::min<long>((long)n * H, (long)e->n_cu * 16);
         hipLaunchKernelGGL(k_stem, dim3(grid), dim3(256), (size_t)3 * (e->W + 1) * 3 * sizeof(float), e->stream, d_rgb, n,
@@ -549,7 +566,9 @@ int forward_device(pb_embedder *e, const uint8_t *d_rgb, int n, uint8_t *d_u8, f
         int rc;
         const int Ho = (H + bl.stride - 1) / bl.stride, Wo = (W + bl.stride - 1) / bl.stride;
         int part_tiles = 0;
-        if (bl.has_expand) {
+        if (fuse_stem && &bl == &b0) {
+            part_tiles = stem_bands;  // depthwise output and SE partials are already in buf_dw / buf_part
+        } else if (bl.has_expand) {
             if ((rc = run_front(e, bl, x, n, H, W, Ho, Wo, &part_tiles))) return rc;
         } else {
             DwGeom g0;

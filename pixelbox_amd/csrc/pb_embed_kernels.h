@@ -144,6 +144,135 @@ __global__ __launch_bounds__(256) void k_stem(const uint8_t *__restrict__ img, i
 }
 
 // ------------------------------------------------------------------------------------------------
+// stem + the first block's depthwise 3x3 (stride 1) in one kernel: the stem's output (64 x 64 x 32 f32 per image,
+// 268 MB per 512-image batch, written once and read once by nothing but that depthwise conv -- the first block has
+// no expansion and no residual) never leaves the CU.  A block owns a band of output rows.  It first loads ALL the
+// input rows the band needs (2 rows per stem row + 1, as raw bytes, coalesced dwords, one memory round trip for the
+// whole band) into LDS; then, per stem row, the MFMA stem of k_stem with its taps gathered from those bytes through
+// the v/255 table, the activated row written into a 3-row LDS ring ([pixel + 1][36 floats]: 4 floats of padding
+// per pixel keep the MFMA-layout float4 writes conflict-free; one zero pixel on each side and zero rows outside the
+// image are the depthwise zero padding), and once three rows are in the ring the depthwise filter of the middle
+// row from LDS (a thread = one pixel x channel quad, bias-first (ky, kx) accumulation with separately rounded
+// products, as k_dwconv), + SiLU, store, SE partial sums.  Stem rows at band edges are recomputed by the
+// neighbouring band.  Identical arithmetic to k_stem + k_dwconv: same bits.
+// grid = (n_bands, B); dynamic LDS = (2 rows_per_band + 5) * RSB bytes + 3 * (W / 2 + 2) * 36 floats.
+__global__ __launch_bounds__(256) void k_stem_dw(const uint8_t *__restrict__ img, int B, int H, int W,
+                                                 const float *__restrict__ w, const float *__restrict__ bias,
+                                                 const float *__restrict__ dw_w, const float *__restrict__ dw_b,
+                                                 float *__restrict__ out, long long *__restrict__ part, int n_bands,
+                                                 int rows_per_band) {
+    extern __shared__ __attribute__((aligned(16))) float s_sd[];
+    __shared__ float s_px[256];
+    __shared__ f32x4 s_dww[9 * 8];
+    __shared__ f32x4 s_dwb[8];
+    __shared__ ll4 s_red[256];
+    const int Ho = H / 2, Wo = W / 2;
+    const int RSB = W * 3 + 4;     // bytes per staged input row: 4 pad bytes (bytes 1..3 = pixel -1 = 0), then the row
+    const int RP = (Wo + 2) * 36;  // floats per ring row
+    float *s_ring = s_sd;
+    uint8_t *s_in = reinterpret_cast<uint8_t *>(s_sd + 3 * RP);
+    const int tid = threadIdx.x;
+    s_px[tid & 255] = (float)(tid & 255) / 255.0f;
+    if (tid < 72) s_dww[tid] = *reinterpret_cast<const f32x4 *>(dw_w + (tid >> 3) * 32 + (tid & 7) * 4);
+    if (tid < 8) s_dwb[tid] = *reinterpret_cast<const f32x4 *>(dw_b + tid * 4);
+    for (int i = tid; i < 3 * 2 * 36; i += 256) {  // the ring's border pixels (columns -1 and Wo) stay zero
+        const int r = i / 72, side = (i % 72) / 36, f = i % 36;
+        s_ring[r * RP + (side ? (Wo + 1) * 36 : 0) + f] = 0.0f;
+    }
+    const int b = blockIdx.y, band = blockIdx.x;
+    const int y0 = band * rows_per_band;
+    const int y1 = (y0 + rows_per_band) < Ho ? (y0 + rows_per_band) : Ho;
+    // input rows 2 (y0 - 1) - 1 .. 2 y1 + 1 -> staged rows 0 .. ; rows outside the image are zero bytes (v/255 = 0)
+    const int iy0 = 2 * (y0 - 1) - 1;
+    const int n_in = 2 * (y1 - y0 + 2) + 1;
+    const int row_dwords = W * 3 / 4;
+    for (int i = tid; i < n_in * (row_dwords + 1); i += 256) {
+        const int r = i / (row_dwords + 1), dq = i - r * (row_dwords + 1);  // dq = 0: the pad dword
+        const int iy = iy0 + r;
+        uint32_t u = 0;
+        if (dq > 0 && iy >= 0 && iy < H) u = *reinterpret_cast<const uint32_t *>(img + ((size_t)b * H + iy) * W * 3 + 4 * (dq - 1));
+        *reinterpret_cast<uint32_t *>(s_in + (size_t)r * RSB + 4 * dq) = u;
+    }
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    int toff[8];
+    bool t_on[8];
+    float wreg[2][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 16 * (j >> 2) + 4 * kq + (j & 3);
+        const int ky = k / 9, kx = (k % 9) / 3, ci = k % 3;
+        t_on[j] = k < 27;
+        toff[j] = t_on[j] ? ky * RSB + kx * 3 + ci : 0;  // bytes, relative to staged pixel (2x - 1) of the stem row's first input row
+#pragma unroll
+        for (int c = 0; c < 2; ++c) wreg[c][j] = t_on[j] ? w[k * 32 + 16 * c + li] : 0.0f;
+    }
+    f32x4 bv[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) bv[c] = *reinterpret_cast<const f32x4 *>(bias + 16 * c + 4 * kq);
+    const int quad = tid & 7;
+    ll4 psum = {0, 0, 0, 0};
+    __syncthreads();
+    for (int sy = y0 - 1; sy <= y1; ++sy) {
+        float *ring = s_ring + ((sy + 3) % 3) * RP;
+        if (sy >= 0 && sy < Ho) {
+            const uint8_t *rows0 = s_in + (size_t)(2 * (sy - y0 + 1)) * RSB + 1;  // staged pixel 0 (= column -1) of input row 2 sy - 1
+            for (int tx = wave; tx < Wo / 16; tx += 4) {
+                const int x = tx * 16 + li;
+                const uint8_t *base = rows0 + 6 * x;
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = t_on[j] ? s_px[base[toff[j]]] : 0.0f;
+                f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[c][j], v[j], acc[c], 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    f32x4 r = acc[c];
+                    r.x = silu_f(r.x + bv[c].x); r.y = silu_f(r.y + bv[c].y); r.z = silu_f(r.z + bv[c].z); r.w = silu_f(r.w + bv[c].w);
+                    *reinterpret_cast<f32x4 *>(ring + (x + 1) * 36 + 16 * c + 4 * kq) = r;
+                }
+            }
+        } else {
+            for (int i = tid; i < Wo * 8; i += 256)
+                *reinterpret_cast<f32x4 *>(ring + ((i >> 3) + 1) * 36 + 4 * (i & 7)) = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();
+        const int oy = sy - 1;
+        if (oy >= y0 && oy < y1) {
+            const float *r0 = s_ring + ((oy - 1 + 3) % 3) * RP, *r1 = s_ring + ((oy + 3) % 3) * RP, *r2 = s_ring + ((oy + 1 + 3) % 3) * RP;
+            for (int px = tid >> 3; px < Wo; px += 32) {
+                f32x4 acc = s_dwb[quad];
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const float *rr = ky == 0 ? r0 : (ky == 1 ? r1 : r2);
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const f32x4 v = *reinterpret_cast<const f32x4 *>(rr + (px + kx) * 36 + 4 * quad);
+                        const f32x4 wv = s_dww[(ky * 3 + kx) * 8 + quad];
+                        const float p0 = v.x * wv.x, p1 = v.y * wv.y, p2 = v.z * wv.z, p3 = v.w * wv.w;
+                        acc.x = acc.x + p0; acc.y = acc.y + p1; acc.z = acc.z + p2; acc.w = acc.w + p3;
+                    }
+                }
+                const f32x4 r = {silu_f(acc.x), silu_f(acc.y), silu_f(acc.z), silu_f(acc.w)};
+                *reinterpret_cast<f32x4 *>(out + (((size_t)b * Ho + oy) * Wo + px) * 32 + 4 * quad) = r;
+                se_acc(psum, r);
+            }
+        }
+        __syncthreads();  // the next stem row overwrites the ring slot the filter just read
+    }
+    s_red[tid] = psum;
+    __syncthreads();
+    if (tid < 8) {
+        ll4 t = s_red[tid];
+        for (int j = 1; j < 32; ++j) se_add(t, s_red[j * 8 + tid]);
+        *reinterpret_cast<ll4 *>(part + ((size_t)b * n_bands + band) * 32 + 4 * tid) = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // 1x1 convolution as GEMM on f32 MFMA:  out[m][n] = epi( sum_k act'[m][k] * wt[k][n] + bias[n] )
 //   act'[m][k] = act[m][k] * gate[m / hw][k]   (squeeze-excite scale fused on the operand; gate may be null)
 //   epi: optional SiLU, optional residual add.
