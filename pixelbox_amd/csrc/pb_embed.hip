@@ -466,25 +466,27 @@ int launch_front(pb_embedder *e, const Block &bl, int cfg, const float *x, int B
     return PB_OK;
 }
 
-// ---- fused MBConv front for small maps (k_mbconv_small): cfg = 0x1000 + 16 * nr + log2(groups per workgroup) ------
-bool small_eligible(const Block &bl, int H, int W, int nr) {
+// ---- fused MBConv front for small maps (k_mbconv_small): cfg = 0x1000 + 256 * mr + 16 * nr + log2(groups per workgroup)
+bool small_eligible(const Block &bl, int H, int W, int nr, int mr) {
     const int P = H * W;
-    if (!bl.has_expand || (P != 64 && P != 16) || H != W || bl.e % (16 * nr) || bl.expand.Kpad % 16 || bl.cin % 4) return false;
+    if (!bl.has_expand || H != W || bl.e % (16 * nr) || bl.expand.Kpad % 16 || bl.cin % 4) return false;
+    if (!((P == 256 && mr == 4) || (P == 64 && mr == 1) || (P == 16 && mr == 1))) return false;  // two row tiles per wave never won
+    if (P == 256) return (bl.k == 5 && bl.stride == 1) || (bl.k == 3 && bl.stride == 2);
     return (bl.k == 3 && bl.stride == 1) || (bl.k == 5 && bl.stride == 1) || (bl.k == 5 && bl.stride == 2);
 }
 
-size_t small_lds_bytes(const Block &bl, int H, int W, int nr) {
-    const int nt = 16 * nr, pad = (bl.k - 1) / 2, g = 64 / (H * W);
+size_t small_lds_bytes(const Block &bl, int H, int W, int nr, int mr) {
+    const int nt = 16 * nr, pad = (bl.k - 1) / 2, g = 64 * mr / (H * W);
     return ((size_t)bl.expand.Kpad * (nt + 4) + (size_t)g * (H + 2 * pad) * (W + 2 * pad) * nt + (size_t)bl.k * bl.k * nt + 2 * nt) * sizeof(float);
 }
 
-template <int KS, int S, int NR>
+template <int KS, int S, int NR, int MR>
 int launch_small_t(pb_embedder *e, const Block &bl, int gpw, const float *x, int B, int H, int W, float *out, int Ho, int Wo) {
-    const size_t lds = small_lds_bytes(bl, H, W, NR);
-    auto kern = k_mbconv_small<KS, S, NR>;
+    const size_t lds = small_lds_bytes(bl, H, W, NR, MR);
+    auto kern = k_mbconv_small<KS, S, NR, MR>;
     if (lds > 48 * 1024)
         PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int G = 64 / (H * W), n_groups = (B + G - 1) / G;
+    const int G = 64 * MR / (H * W), n_groups = (B + G - 1) / G;
     hipLaunchKernelGGL(kern, dim3((n_groups + gpw - 1) / gpw, 1, bl.e / (16 * NR)), dim3(256), lds, e->stream, x, H, W, bl.cin, bl.expand.wt,
                        bl.expand.Kpad, bl.expand.Npad, bl.expand.bias, bl.dw_w, bl.dw_b, bl.e, out, Ho, Wo, e->buf_part, B, gpw);
     PB_HIP(hipGetLastError());
@@ -492,12 +494,15 @@ int launch_small_t(pb_embedder *e, const Block &bl, int gpw, const float *x, int
 }
 
 int launch_small(pb_embedder *e, const Block &bl, int cfg, const float *x, int B, int H, int W, float *out, int Ho, int Wo) {
-    const int nr = (cfg >> 4) & 15, gpw = 1 << (cfg & 15);
-#define PB_SM(KS, S) (nr == 2 ? launch_small_t<KS, S, 2>(e, bl, gpw, x, B, H, W, out, Ho, Wo) : launch_small_t<KS, S, 3>(e, bl, gpw, x, B, H, W, out, Ho, Wo))
+    const int mr = (cfg >> 8) & 15, nr = (cfg >> 4) & 15, gpw = 1 << (cfg & 15);
+#define PB_SM2(KS, S, MRV) (nr == 2 ? launch_small_t<KS, S, 2, MRV>(e, bl, gpw, x, B, H, W, out, Ho, Wo) : launch_small_t<KS, S, 3, MRV>(e, bl, gpw, x, B, H, W, out, Ho, Wo))
+#define PB_SM(KS, S) PB_SM2(KS, S, 1)
+    if (mr == 4) return (bl.k == 5) ? PB_SM2(5, 1, 4) : PB_SM2(3, 2, 4);
     if (bl.k == 3 && bl.stride == 1) return PB_SM(3, 1);
     if (bl.k == 5 && bl.stride == 1) return PB_SM(5, 1);
     return PB_SM(5, 2);
 #undef PB_SM
+#undef PB_SM2
 }
 
 int launch_gemm(pb_embedder *e, const float *act, long M, const Gemm &g, const float *gate, int hw, const float *resid,
@@ -556,24 +561,27 @@ int run_front(pb_embedder *e, const Block &bl, const float *x, int n, int H, int
                     best = cfg;
                 }
             }
-        for (int nr : {3, 2})
-            for (int lg : {0, 1, 2}) {
-                if (!small_eligible(bl, H, W, nr) || small_lds_bytes(bl, H, W, nr) > 100 * 1024) continue;
-                const int cfg = 0x1000 + 16 * nr + lg;
-                float ms = 0.f;
-                if ((rc = launch_small(e, bl, cfg, x, n, H, W, e->buf_dw, Ho, Wo))) return rc;  // warm-up
-                PB_HIP(hipEventRecord(e0, e->stream));
-                for (int rep = 0; rep < 2; ++rep)
-                    if ((rc = launch_small(e, bl, cfg, x, n, H, W, e->buf_dw, Ho, Wo))) return rc;
-                PB_HIP(hipEventRecord(e1, e->stream));
-                PB_HIP(hipEventSynchronize(e1));
-                PB_HIP(hipEventElapsedTime(&ms, e0, e1));
-                if (getenv("PB_TRACE_TUNE")) fprintf(stderr, "front k%d s%d e%d n%d: small-map fused nr %d groups/wg %d %.1f us (separate %.1f)\n", bl.k, bl.stride, bl.e, n, nr, 1 << lg, ms * 500.f, sep_ms * 500.f);
-                if (ms < best_ms) {
-                    best_ms = ms;
-                    best = cfg;
+        for (int mr : {1, 4})
+            for (int nr : {3, 2})
+                for (int lg : {0, 1, 2}) {
+                    if (!small_eligible(bl, H, W, nr, mr) || small_lds_bytes(bl, H, W, nr, mr) > 100 * 1024) continue;
+                    const int cfg = 0x1000 + 256 * mr + 16 * nr + lg;
+                    float ms = 0.f;
+                    if ((rc = launch_small(e, bl, cfg, x, n, H, W, e->buf_dw, Ho, Wo))) return rc;  // warm-up
+                    PB_HIP(hipEventRecord(e0, e->stream));
+                    for (int rep = 0; rep < 2; ++rep)
+                        if ((rc = launch_small(e, bl, cfg, x, n, H, W, e->buf_dw, Ho, Wo))) return rc;
+                    PB_HIP(hipEventRecord(e1, e->stream));
+                    PB_HIP(hipEventSynchronize(e1));
+                    PB_HIP(hipEventElapsedTime(&ms, e0, e1));
+                    if (getenv("PB_TRACE_TUNE"))
+                        fprintf(stderr, "front k%d s%d e%d n%d: small-map fused mr %d nr %d groups/wg %d %.1f us (separate %.1f)\n", bl.k, bl.stride, bl.e, n,
+                                mr, nr, 1 << lg, ms * 500.f, sep_ms * 500.f);
+                    if (ms < best_ms) {
+                        best_ms = ms;
+                        best = cfg;
+                    }
                 }
-            }
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
         it = e->front_cfg.emplace(key, best).first;

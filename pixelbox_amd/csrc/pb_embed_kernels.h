@@ -888,28 +888,30 @@ __global__ __launch_bounds__(256, NC == 1 ? 4 : 2) void k_front_roll(
 }
 
 // ------------------------------------------------------------------------------------------------
-// Fused MBConv front for SMALL maps (8 x 8 and 4 x 4 inputs: the eleven late blocks).  There the 6x-expanded
+// Fused MBConv front for SMALL maps (16 x 16, 8 x 8 and 4 x 4 inputs: the twelve late blocks).  There the 6x-expanded
 // activation of one image is small (64 px x 48 channels = 12 KB per channel group), so a workgroup computes it
 // whole -- expand 1x1 on the f32 MFMA with the SAME operand maps and k order as k_gemm1x1 (weights of the channel
 // group resident in LDS for the workgroup's whole life, activations streamed from global as float4) -- keeps it in
 // LDS inside a zero ring (the depthwise padding), and runs the depthwise filter + SiLU + SE sums from there (tap
 // order and roundings of k_dwconv).  The expanded tensor's HBM round trip and the depthwise launch disappear.
-// A group = 64 pixel rows = one 8 x 8 image or four 4 x 4 images; wave w owns rows 16w .. 16w + 15.  A workgroup
+// A group = 64 MR pixel rows = one 16 x 16 image (MR = 4), one or two 8 x 8 images, four or eight 4 x 4 images; wave w
+// owns MR row tiles of 16.  A workgroup
 // walks `groups_per_wg` consecutive groups with its weights staged once.  SE sums: int64 LDS atomics (integer
 // adds: order-free), complete per image, so n_tiles = 1.  Outputs are bit-identical to k_gemm1x1 + k_dwconv.
 // grid = (ceil(n_groups / groups_per_wg), 1, E / (16 NR)); block = 256.
 // dynamic LDS (floats): Kpad * (NT + 4) weights | G * (H+2P) * (W+2P) * NT expanded window | KS*KS*NT taps | 2 NT biases
-template <int KS, int S, int NR>
+template <int KS, int S, int NR, int MR>
 __global__ __launch_bounds__(256) void k_mbconv_small(
     const float *__restrict__ x, int H, int W, int Cin, const float *__restrict__ wt, int Kpad, int Epad,
     const float *__restrict__ bias_e, const float *__restrict__ dw_w, const float *__restrict__ dw_b, int E,
     float *__restrict__ out, int Ho, int Wo, long long *__restrict__ part, int n_img, int groups_per_wg) {
     constexpr int NT = 16 * NR, LDW = NT + 4, CQ = NT / 4;
     constexpr int PAD = (KS - 1) / 2;
+    constexpr int ROWS = 64 * MR;  // pixel rows per group: MR row tiles per wave (the weight fragments of a k-step serve all MR)
     extern __shared__ __attribute__((aligned(16))) float s_ms[];
-    __shared__ unsigned long long s_se[4][NT];  // [image of the group][channel]: 2^-24 fixed-point sums (se_acc)
-    const int P = H * W;       // 64 or 16
-    const int G = 64 / P;      // images per group
+    __shared__ unsigned long long s_se[8][NT];  // [image of the group][channel]: 2^-24 fixed-point sums (se_acc)
+    const int P = H * W;       // 256, 64 or 16
+    const int G = ROWS / P;    // images per group (1 .. 8)
     const int Hp = H + 2 * PAD, Wp = W + 2 * PAD;
     float *s_w = s_ms;                          // [Kpad][LDW]
     float *s_e = s_w + Kpad * LDW;              // [G][Hp * Wp][NT]
@@ -933,33 +935,48 @@ __global__ __launch_bounds__(256) void k_mbconv_small(
         s_b[NT + tid] = dw_b[e0 + tid];
     }
     for (int i = tid; i < G * Hp * Wp * (NT / 4); i += 256) *reinterpret_cast<f32x4 *>(s_e + 4 * i) = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int i = tid; i < 4 * NT; i += 256) s_se[i / NT][i % NT] = 0ull;
+    for (int i = tid; i < 8 * NT; i += 256) s_se[i / NT][i % NT] = 0ull;
     __syncthreads();
     const int n_groups = (n_img + G - 1) / G;
     const int g_first = blockIdx.x * groups_per_wg;
     const int n_steps = Kpad / 16;
-    // this lane's pixel row of the group: row = 16 wave + li -> image g_img of the group, pixel p
-    const int row = 16 * wave + li;
-    const int g_img = row / P, pix = row % P;
-    const int py = pix / W, px = pix % W;
-    float *e_dst = s_e + (g_img * Hp * Wp + (py + PAD) * Wp + (px + PAD)) * NT;
-    for (int gi = g_first; gi < g_first + groups_per_wg && gi < n_groups; ++gi) {
-        const int img = gi * G + g_img;
-        const bool iv = img < n_img;
-        // ---- expand: 16 pixel rows x NT channels per wave, K = Cin
-        {
-            const float *arow = x + ((size_t)(iv ? img : 0) * P + pix) * Cin;
-            f32x4 acc[NR];
+    // this lane's MR pixel rows of the group: row = 16 (MR wave + r) + li -> image g_img of the group, pixel pix
+    int g_img[MR], pix[MR];
+    float *e_dst[MR];
 #pragma unroll
-            for (int c = 0; c < NR; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            f32x4 a_nxt = *reinterpret_cast<const f32x4 *>(arow + (4 * kq < Cin ? 4 * kq : 0));
+    for (int r = 0; r < MR; ++r) {
+        const int row = 16 * (MR * wave + r) + li;
+        g_img[r] = row / P;
+        pix[r] = row % P;
+        e_dst[r] = s_e + (g_img[r] * Hp * Wp + (pix[r] / W + PAD) * Wp + (pix[r] % W + PAD)) * NT;
+    }
+    for (int gi = g_first; gi < g_first + groups_per_wg && gi < n_groups; ++gi) {
+        // ---- expand: MR x 16 pixel rows x NT channels per wave, K = Cin
+        {
+            bool iv[MR];
+            const float *arow[MR];
+            f32x4 a_nxt[MR];
+            f32x4 acc[MR][NR];
+#pragma unroll
+            for (int r = 0; r < MR; ++r) {
+                const int img = gi * G + g_img[r];
+                iv[r] = img < n_img;
+                arow[r] = x + ((size_t)(iv[r] ? img : 0) * P + pix[r]) * Cin;
+                a_nxt[r] = *reinterpret_cast<const f32x4 *>(arow[r] + (4 * kq < Cin ? 4 * kq : 0));
+#pragma unroll
+                for (int c = 0; c < NR; ++c) acc[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
             for (int s = 0; s < n_steps; ++s) {
                 const int kbase = 16 * s + 4 * kq;
-                f32x4 a = a_nxt;
-                if (!(iv && kbase < Cin)) a = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (s + 1 < n_steps) {
-                    const int kn = kbase + 16;
-                    a_nxt = *reinterpret_cast<const f32x4 *>(arow + (kn < Cin ? kn : 0));
+                f32x4 a[MR];
+#pragma unroll
+                for (int r = 0; r < MR; ++r) {
+                    a[r] = a_nxt[r];
+                    if (!(iv[r] && kbase < Cin)) a[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (s + 1 < n_steps) {
+                        const int kn = kbase + 16;
+                        a_nxt[r] = *reinterpret_cast<const f32x4 *>(arow[r] + (kn < Cin ? kn : 0));
+                    }
                 }
                 const float *wbase = s_w + kbase * LDW + li;
                 float wv[4][NR];
@@ -969,20 +986,24 @@ __global__ __launch_bounds__(256) void k_mbconv_small(
                     for (int c = 0; c < NR; ++c) wv[e][c] = wbase[e * LDW + c * 16];
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float av = e == 0 ? a.x : (e == 1 ? a.y : (e == 2 ? a.z : a.w));
+                for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int c = 0; c < NR; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[e][c], av, acc[c], 0, 0, 0);
-                }
+                    for (int r = 0; r < MR; ++r) {
+                        const float av = e == 0 ? a[r].x : (e == 1 ? a[r].y : (e == 2 ? a[r].z : a[r].w));
+#pragma unroll
+                        for (int c = 0; c < NR; ++c) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[e][c], av, acc[r][c], 0, 0, 0);
+                    }
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
-            for (int c = 0; c < NR; ++c) {
-                const f32x4 bev = *reinterpret_cast<const f32x4 *>(s_b + 16 * c + 4 * kq);
-                f32x4 v = acc[c];
-                v.x = silu_f(v.x + bev.x); v.y = silu_f(v.y + bev.y); v.z = silu_f(v.z + bev.z); v.w = silu_f(v.w + bev.w);
-                *reinterpret_cast<f32x4 *>(e_dst + 16 * c + 4 * kq) = v;
-            }
+            for (int r = 0; r < MR; ++r)
+#pragma unroll
+                for (int c = 0; c < NR; ++c) {
+                    const f32x4 bev = *reinterpret_cast<const f32x4 *>(s_b + 16 * c + 4 * kq);
+                    f32x4 v = acc[r][c];
+                    v.x = silu_f(v.x + bev.x); v.y = silu_f(v.y + bev.y); v.z = silu_f(v.z + bev.z); v.w = silu_f(v.w + bev.w);
+                    *reinterpret_cast<f32x4 *>(e_dst[r] + 16 * c + 4 * kq) = v;
+                }
         }
         __syncthreads();
         // ---- depthwise from LDS: items = (image of the group, output pixel, channel quad)
@@ -1003,10 +1024,10 @@ __global__ __launch_bounds__(256) void k_mbconv_small(
                     const float p0 = v.x * wv.x, p1 = v.y * wv.y, p2 = v.z * wv.z, p3 = v.w * wv.w;
                     acc.x = acc.x + p0; acc.y = acc.y + p1; acc.z = acc.z + p2; acc.w = acc.w + p3;
                 }
-            const f32x4 r = {silu_f(acc.x), silu_f(acc.y), silu_f(acc.z), silu_f(acc.w)};
-            *reinterpret_cast<f32x4 *>(out + ((size_t)img2 * HoWo + o) * E + e0 + 4 * cq) = r;
+            const f32x4 r4 = {silu_f(acc.x), silu_f(acc.y), silu_f(acc.z), silu_f(acc.w)};
+            *reinterpret_cast<f32x4 *>(out + ((size_t)img2 * HoWo + o) * E + e0 + 4 * cq) = r4;
             ll4 q4 = {0, 0, 0, 0};
-            se_acc(q4, r);
+            se_acc(q4, r4);
             atomicAdd(&s_se[g2][4 * cq + 0], (unsigned long long)q4.x);
             atomicAdd(&s_se[g2][4 * cq + 1], (unsigned long long)q4.y);
             atomicAdd(&s_se[g2][4 * cq + 2], (unsigned long long)q4.z);
