@@ -202,7 +202,7 @@ def main():
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args, synth, qbytes[args.warmup][: 4])
+        cpu = cpu_baseline(args, synth, qbytes[args.warmup][:16])
 
     if rank == 0:
         out = {
@@ -310,7 +310,7 @@ def bench_embed(args, torch, device, distributed):
     if int(os.environ.get("RANK", "0")) == 0 and not args.no_cpu_baseline:
         from oracle import capi as oracle
 
-        n = 24
+        n = 2048
         sample = synth.fill_synthetic(synth.SEED_IMAGES, 0, n * 128 * 128 * 3).reshape(n, 128, 128, 3)
         t0 = time.perf_counter()
         oracle.mlhash_batch(blob, sample, 256, nthreads=4, want_f32=False)
