@@ -148,3 +148,20 @@ def test_embed_then_search_end_to_end():
     want_ids, want_d = oracle.scan_topk(u8[0], u8, ids, 100, 1e3)
     assert np.array_equal(got_ids, want_ids) and np.array_equal(got_d.view(np.uint32), want_d.view(np.uint32))
     assert got_ids[0] == 1 and got_d[0] <= 1e-6
+
+
+@pytest.mark.parametrize("h,w,d,n", [(32, 64, 8, 5), (96, 32, 64, 3), (160, 128, 16, 2), (64, 64, 1024, 4), (256, 256, 32, 1)])
+def test_other_input_sizes_and_latent_dims_vs_oracle(h, w, d, n):
+    # map sizes from 128 x 128 down to 1 x 2: every kernel form's eligibility rules get exercised (rolling fused
+    # front, small-map fused front on 16x16 / 8x8 / 4x4, strip / rolling / LDS depthwise, stem fusion)
+    blob = W.synthetic_blob(synth.SEED_WEIGHTS, h, w, d)
+    imgs = synth.synthetic_images(synth.SEED_IMAGES, 900, n, h, w)
+    emb = capi.Embedder(blob, max_batch=4)
+    u8, f = emb.embed(imgs)
+    ref_u8, ref_f = oracle.mlhash_batch(blob, imgs, d, nthreads=8)
+    assert_embeddings_close(f, ref_f)
+    assert np.array_equal(u8, no.quantize(f))
+    assert_bytes_match(u8, ref_u8, ref_f)
+    big = capi.Embedder(blob, max_batch=64)
+    u8b, fb = big.embed(np.concatenate([imgs] * 16))
+    assert np.array_equal(fb[:n].view(np.uint32), f.view(np.uint32)) and np.array_equal(fb[-n:].view(np.uint32), f.view(np.uint32))

@@ -692,3 +692,64 @@ def test_byte_and_hamming_coalesced_pass_and_its_fallback(metric):
     g_ids, g_d, g_c = ix2.search(rows2[40000][None, :], 100, 0.6)
     w_ids, w_d = oracle.scan_topk_metric(metric, rows2[40000], rows2, ids, 100, 0.6)
     assert np.array_equal(g_ids[0, : g_c[0]], w_ids) and np.array_equal(g_d[0, : g_c[0]].view(np.uint32), w_d.view(np.uint32))
+
+
+# ---- randomized sweep: table shapes, data shapes, k, max_dist, paths -----------------------------------------
+def _random_table(rng, n, d, kind):
+    if kind == "uniform":
+        return rng.integers(0, 256, size=(n, d), dtype=np.uint8)
+    if kind == "narrow":  # bytes around 128: tiny norms, the filter's worst case
+        return rng.integers(120, 137, size=(n, d), dtype=np.uint8)
+    if kind == "binary":  # saturated hashes: many exact ties
+        return (rng.integers(0, 2, size=(n, d), dtype=np.uint8) * 255).astype(np.uint8)
+    if kind == "clustered":
+        centers = rng.integers(0, 256, size=(8, d), dtype=np.int16)
+        which = rng.integers(0, 8, size=n)
+        return np.clip(centers[which] + rng.integers(-3, 4, size=(n, d)), 0, 255).astype(np.uint8)
+    if kind == "dups":
+        base = rng.integers(0, 256, size=(max(1, n // 50), d), dtype=np.uint8)
+        return base[rng.integers(0, len(base), size=n)]
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PB_SWEEP_SEEDS", "24"))))
+def test_randomized_sweep_against_oracle(seed):
+    rng = np.random.default_rng(1000 + seed)
+    d = int(rng.choice([16, 32, 64, 128, 256, 256, 256, 512, 1024, 48, 100]))  # the last two: no filter pass for that width
+    n = int(rng.choice([1, 2, 63, 64, 65, 1000, 4097, 20000, 70000]))
+    kind = str(rng.choice(["uniform", "narrow", "binary", "clustered", "dups"]))
+    k = int(rng.choice([1, 7, 100, 255, 256]))
+    max_dist = float(rng.choice([1e3, 1e3, 0.5, 3.0, 2e6, 1e-7]))
+    path = int(rng.choice([AUTO, AUTO, SINGLE, MULTI, EXACT]))
+    rows = _random_table(rng, n, d, kind)
+    ids = np.sort(rng.choice(np.arange(10 * n + 10, dtype=np.int64), size=n, replace=False)) - 5 * n  # negative ids too
+    nq = int(rng.choice([1, 3, 9, 70]))
+    q = _random_table(rng, nq, d, kind)
+    q[0] = rows[rng.integers(0, n)]
+    ix = make_index(rows, ids, path=path)
+    check_against_oracle(ix, rows, ids, q, k=k, max_dist=max_dist)
+    st = ix.stats()
+    assert st.queries == nq == st.fast_path + st.second_chance + st.fallback
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PB_SWEEP_SEEDS", "16"))))
+def test_randomized_sweep_byte_and_hamming(seed):
+    rng = np.random.default_rng(2000 + seed)
+    metric = int(rng.choice([capi.PB_METRIC_BYTE, capi.PB_METRIC_HAMMING]))
+    d = int(rng.choice([2, 16, 32, 33, 64, 256, 256, 1024]))
+    n = int(rng.choice([1, 64, 1000, 30000, 120000]))
+    kind = str(rng.choice(["uniform", "binary", "clustered", "dups"]))
+    k = int(rng.choice([1, 100, 256]))
+    max_dist = float(rng.choice([10.0, 0.45, 0.3, 1e-9]))
+    rows = _random_table(rng, n, d, kind)
+    ids = np.arange(n, dtype=np.int64) * 2 - n
+    q = _random_table(rng, 3, d, kind)
+    q[0] = rows[rng.integers(0, n)]
+    ix = capi.Index(d, n, metric=metric)
+    ix.load(ids, rows)
+    got_ids, got_d, got_c = ix.search(q, k, max_dist)
+    for qi in range(3):
+        want_ids, want_d = oracle.scan_topk_metric(metric, q[qi], rows, ids, k, max_dist)
+        c = int(got_c[qi])
+        assert c == len(want_ids) and np.array_equal(got_ids[qi, :c], want_ids)
+        assert np.array_equal(got_d[qi, :c].view(np.uint32), want_d.view(np.uint32))
