@@ -466,7 +466,7 @@ int launch_front(pb_embedder *e, const Block &bl, int cfg, const float *x, int B
     return PB_OK;
 }
 
-// ---- fused MBConv front for small maps (k_mbconv_small): cfg = 0x1000 + 256 * mr + 16 * nr + log2(groups per workgroup)
+// ---- fused MBConv front for small maps (k_mbconv_small): cfg = 0x1000 + 256 * mr + 16 * nr + 8 * regs + log2(groups per workgroup)
 bool small_eligible(const Block &bl, int H, int W, int nr, int mr) {
     const int P = H * W;
     if (!bl.has_expand || H != W || bl.e % (16 * nr) || bl.expand.Kpad % 16 || bl.cin % 4) return false;
@@ -475,15 +475,21 @@ bool small_eligible(const Block &bl, int H, int W, int nr, int mr) {
     return (bl.k == 3 && bl.stride == 1) || (bl.k == 5 && bl.stride == 1) || (bl.k == 5 && bl.stride == 2);
 }
 
+// the k-step counts the operands-in-registers form is instantiated for (EfficientNet-B0 widths 40 / 80 / 112 / 192)
+bool small_regs_form(const Block &bl, int mr) {
+    const int ns = bl.expand.Kpad / 16;
+    return mr == 4 ? ns == 3 : (ns == 5 || ns == 7 || ns == 12);
+}
+
 size_t small_lds_bytes(const Block &bl, int H, int W, int nr, int mr) {
     const int nt = 16 * nr, pad = (bl.k - 1) / 2, g = 64 * mr / (H * W);
     return ((size_t)bl.expand.Kpad * (nt + 4) + (size_t)g * (H + 2 * pad) * (W + 2 * pad) * nt + (size_t)bl.k * bl.k * nt + 2 * nt) * sizeof(float);
 }
 
-template <int KS, int S, int NR, int MR>
+template <int KS, int S, int NR, int MR, int NS>
 int launch_small_t(pb_embedder *e, const Block &bl, int gpw, const float *x, int B, int H, int W, float *out, int Ho, int Wo) {
     const size_t lds = small_lds_bytes(bl, H, W, NR, MR);
-    auto kern = k_mbconv_small<KS, S, NR, MR>;
+    auto kern = k_mbconv_small<KS, S, NR, MR, NS>;
     if (lds > 48 * 1024)
         PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int G = 64 * MR / (H * W), n_groups = (B + G - 1) / G;
@@ -493,9 +499,26 @@ int launch_small_t(pb_embedder *e, const Block &bl, int gpw, const float *x, int
     return PB_OK;
 }
 
+// NS = k-steps held in registers (Kpad / 16 for the EfficientNet-B0 widths 40 / 80 / 112 / 192), 0 = streaming form
+template <int KS, int S, int NR, int MR>
+int launch_small_ns(pb_embedder *e, const Block &bl, int gpw, bool regs, const float *x, int B, int H, int W, float *out, int Ho, int Wo) {
+    const int ns = regs ? bl.expand.Kpad / 16 : 0;
+#define PB_SMN(NSV) launch_small_t<KS, S, NR, MR, NSV>(e, bl, gpw, x, B, H, W, out, Ho, Wo)
+    if constexpr (MR == 4) {
+        if (ns == 3) return PB_SMN(3);
+    } else {
+        if (ns == 5) return PB_SMN(5);
+        if (ns == 7) return PB_SMN(7);
+        if (ns == 12) return PB_SMN(12);
+    }
+    return PB_SMN(0);
+#undef PB_SMN
+}
+
 int launch_small(pb_embedder *e, const Block &bl, int cfg, const float *x, int B, int H, int W, float *out, int Ho, int Wo) {
-    const int mr = (cfg >> 8) & 15, nr = (cfg >> 4) & 15, gpw = 1 << (cfg & 15);
-#define PB_SM2(KS, S, MRV) (nr == 2 ? launch_small_t<KS, S, 2, MRV>(e, bl, gpw, x, B, H, W, out, Ho, Wo) : launch_small_t<KS, S, 3, MRV>(e, bl, gpw, x, B, H, W, out, Ho, Wo))
+    const int mr = (cfg >> 8) & 15, nr = (cfg >> 4) & 15, gpw = 1 << (cfg & 7);
+    const bool regs = cfg & 8;  // activation operands of a group held in registers (NS > 0) instead of streamed
+#define PB_SM2(KS, S, MRV) (nr == 2 ? launch_small_ns<KS, S, 2, MRV>(e, bl, gpw, regs, x, B, H, W, out, Ho, Wo) : launch_small_ns<KS, S, 3, MRV>(e, bl, gpw, regs, x, B, H, W, out, Ho, Wo))
 #define PB_SM(KS, S) PB_SM2(KS, S, 1)
     if (mr == 4) return (bl.k == 5) ? PB_SM2(5, 1, 4) : PB_SM2(3, 2, 4);
     if (bl.k == 3 && bl.stride == 1) return PB_SM(3, 1);
@@ -563,8 +586,9 @@ int run_front(pb_embedder *e, const Block &bl, const float *x, int n, int H, int
             }
         for (int mr : {1, 4})
             for (int nr : {3, 2})
-                for (int lg : {0, 1, 2}) {
+                for (int lg : {0, 1, 2, 9, 10}) {  // 8 + lg: operands-in-registers form (needs >= 2 groups per workgroup to pay)
                     if (!small_eligible(bl, H, W, nr, mr) || small_lds_bytes(bl, H, W, nr, mr) > 100 * 1024) continue;
+                    if ((lg & 8) && !small_regs_form(bl, mr)) continue;
                     const int cfg = 0x1000 + 256 * mr + 16 * nr + lg;
                     float ms = 0.f;
                     if ((rc = launch_small(e, bl, cfg, x, n, H, W, e->buf_dw, Ho, Wo))) return rc;  // warm-up
@@ -575,8 +599,8 @@ int run_front(pb_embedder *e, const Block &bl, const float *x, int n, int H, int
                     PB_HIP(hipEventSynchronize(e1));
                     PB_HIP(hipEventElapsedTime(&ms, e0, e1));
                     if (getenv("PB_TRACE_TUNE"))
-                        fprintf(stderr, "front k%d s%d e%d n%d: small-map fused mr %d nr %d groups/wg %d %.1f us (separate %.1f)\n", bl.k, bl.stride, bl.e, n,
-                                mr, nr, 1 << lg, ms * 500.f, sep_ms * 500.f);
+                        fprintf(stderr, "front k%d s%d e%d n%d: small-map fused mr %d nr %d groups/wg %d%s %.1f us (separate %.1f)\n", bl.k, bl.stride, bl.e, n,
+                                mr, nr, 1 << (lg & 7), (lg & 8) ? " regs" : "", ms * 500.f, sep_ms * 500.f);
                     if (ms < best_ms) {
                         best_ms = ms;
                         best = cfg;
@@ -902,5 +926,18 @@ int pb_embed_set_option(pb_embedder *e, int option, int64_t value) {
     }
     return pb::fail(PB_ERR_INVALID, "pb_embed_set_option: unknown option %d", option);
 }
+
+#ifdef PB_SM_STAMP_E
+int pb_debug_small_stamps(unsigned long long *out, int reset) {  // out: 65536 * 10
+    PB_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sm_stamp), 65536 * 10 * sizeof(unsigned long long)));
+    if (reset) {
+        void *p = nullptr;
+        PB_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(g_sm_stamp)));
+        PB_HIP(hipMemset(p, 0, 65536 * 10 * sizeof(unsigned long long)));
+        PB_HIP(hipDeviceSynchronize());
+    }
+    return PB_OK;
+}
+#endif
 
 }  // extern "C"

@@ -52,6 +52,22 @@ __device__ __forceinline__ void se_add(ll4 &s, const ll4 &o) {
     s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
 }
 
+// One depthwise filter tap on a channel quad: acc += v * w, as ONE fused multiply-add per channel (v_fma_f32 /
+// v_pk_fma_f32 / v_fmac_f32_dpp) in EVERY depthwise form (strip, rolling, LDS, fused fronts, stem), so that all forms
+// still give identical bits.  The unfused mul + add of the CPU restatement costs twice the VALU issue slots, and the
+// depthwise phases are VALU-issue-bound; the fused form differs from it by at most half an ulp of the sum per tap
+// (it is the more accurate of the two) -- far inside the 1e-5 bar the parity tests hold the embedding to.
+// -DPB_DW_UNFUSED restores the two-instruction form for comparison.
+__device__ __forceinline__ void dw_tap(f32x4 &acc, const f32x4 &v, const f32x4 &w) {
+#ifdef PB_DW_UNFUSED
+    const float p0 = v.x * w.x, p1 = v.y * w.y, p2 = v.z * w.z, p3 = v.w * w.w;
+    acc.x = acc.x + p0; acc.y = acc.y + p1; acc.z = acc.z + p2; acc.w = acc.w + p3;
+#else
+    acc.x = __builtin_fmaf(v.x, w.x, acc.x); acc.y = __builtin_fmaf(v.y, w.y, acc.y);
+    acc.z = __builtin_fmaf(v.z, w.z, acc.z); acc.w = __builtin_fmaf(v.w, w.w, acc.w);
+#endif
+}
+
 // efficientnet.rs:39 -- 128u8.saturating_add_signed((f*128).max(-128).min(128) as i8), bit-exact
 __device__ __forceinline__ uint8_t quantize_u8(float f) {
     float t = f * 128.0f;
@@ -83,7 +99,7 @@ __global__ __launch_bounds__(256) void k_stem(const uint8_t *__restrict__ img, i
     extern __shared__ __attribute__((aligned(16))) float s_rows[];  // [3][(W + 1) * 3] floats, pixel -1 first
     __shared__ float s_px[256];
     s_px[threadIdx.x & 255] = (float)(threadIdx.x & 255) / 255.0f;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 15, kq = lane >> 4;
     const int Ho = H / 2, Wo = W / 2;
     const int RS = (W + 1) * 3;  // floats per staged row
@@ -193,7 +209,7 @@ __global__ __launch_bounds__(256) void k_stem_dw(const uint8_t *__restrict__ img
         if (dq > 0 && iy >= 0 && iy < H) u = *reinterpret_cast<const uint32_t *>(img + ((size_t)b * H + iy) * W * 3 + 4 * (dq - 1));
         *reinterpret_cast<uint32_t *>(s_in + (size_t)r * RSB + 4 * dq) = u;
     }
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: what it indexes stays in SGPRs
     const int li = lane & 15, kq = lane >> 4;
     int toff[8];
     bool t_on[8];
@@ -252,8 +268,7 @@ __global__ __launch_bounds__(256) void k_stem_dw(const uint8_t *__restrict__ img
                     for (int kx = 0; kx < 3; ++kx) {
                         const f32x4 v = *reinterpret_cast<const f32x4 *>(rr + (px + kx) * 36 + 4 * quad);
                         const f32x4 wv = s_dww[(ky * 3 + kx) * 8 + quad];
-                        const float p0 = v.x * wv.x, p1 = v.y * wv.y, p2 = v.z * wv.z, p3 = v.w * wv.w;
-                        acc.x = acc.x + p0; acc.y = acc.y + p1; acc.z = acc.z + p2; acc.w = acc.w + p3;
+                        dw_tap(acc, v, wv);
                     }
                 }
                 const f32x4 r = {silu_f(acc.x), silu_f(acc.y), silu_f(acc.z), silu_f(acc.w)};
@@ -305,7 +320,7 @@ __global__ __launch_bounds__(64 * NW) void k_gemm1x1(const float *__restrict__ a
     constexpr int WREGS = (G_KC * (NT / 4) + NTHR - 1) / NTHR;  // float4 per thread per weight chunk
     __shared__ __attribute__((aligned(16))) float s_w[2][G_KC * LDW];
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: what it indexes stays in SGPRs
     const int li = lane & 15;   // pixel within a tile (activation operand) / channel within a tile (weight operand)
     const int kk = lane >> 4;   // k slot
     const int n0 = blockIdx.y * NT;
@@ -506,8 +521,7 @@ __global__ __launch_bounds__(256) void k_dwconv(const float *__restrict__ in, in
                 for (int t = 0; t < TX; ++t) {
                     // out-of-range taps hold zeros: acc + 0*w == acc, the same value the oracle's skip gives
                     const f32x4 v = seg[t * S + kx];
-                    const float p0 = v.x * wv.x, p1 = v.y * wv.y, p2 = v.z * wv.z, p3 = v.w * wv.w;
-                    acc[t].x = acc[t].x + p0; acc[t].y = acc[t].y + p1; acc[t].z = acc[t].z + p2; acc[t].w = acc[t].w + p3;
+                    dw_tap(acc[t], v, wv);
                 }
             }
         }
@@ -590,8 +604,7 @@ __global__ __launch_bounds__(256) void k_dwconv_roll(const float *__restrict__ i
 #pragma unroll
                     for (int t = 0; t < TX; ++t) {
                         const f32x4 v = win[ky][t * S + kx];
-                        const float p0 = v.x * wv.x, p1 = v.y * wv.y, p2 = v.z * wv.z, p3 = v.w * wv.w;
-                        acc[t].x = acc[t].x + p0; acc[t].y = acc[t].y + p1; acc[t].z = acc[t].z + p2; acc[t].w = acc[t].w + p3;
+                        dw_tap(acc[t], v, wv);
                     }
                 }
             }
@@ -667,8 +680,7 @@ __global__ __launch_bounds__(256) void k_dwconv_lds(const float *__restrict__ in
             for (int kx = 0; kx < KS; ++kx) {
                 const f32x4 v = ip[(ky * Wp + kx) * cqb];
                 const f32x4 wv = s_w[(ky * KS + kx) * cqb + cq_l];
-                const float p0 = v.x * wv.x, p1 = v.y * wv.y, p2 = v.z * wv.z, p3 = v.w * wv.w;
-                acc.x = acc.x + p0; acc.y = acc.y + p1; acc.z = acc.z + p2; acc.w = acc.w + p3;
+                dw_tap(acc, v, wv);
             }
         const f32x4 r = {silu_f(acc.x), silu_f(acc.y), silu_f(acc.z), silu_f(acc.w)};
         *reinterpret_cast<f32x4 *>(ob + (size_t)o * C) = r;
@@ -712,6 +724,27 @@ __device__ __forceinline__ float row_shift(float v, int d) {
     }
 }
 
+// acc += (value of x in lane li + d of the 16-lane row, 0 outside the row) * w as ONE instruction: v_fmac_f32 with the
+// DPP row shift on its first source.  hipcc folds update_dpp into v_mul_f32 but not into the tied-operand v_fmac, and
+// a v_mov_b32_dpp per shifted tap doubles the filter's issue slots.  The DPP source must not have been written by
+// the two VALU instructions before (hardware does not interlock that; hipcc inserts the wait states for its own DPP
+// moves but cannot see inside asm): every use below reads a ring row that an earlier phase of the row iteration
+// produced.  Same value as dw_tap on row_shift(x, d).
+__device__ __forceinline__ float fmac_shift(float acc, float x, float w, int d) {
+#ifdef PB_DW_UNFUSED
+    return acc + row_shift(x, d) * w;
+#else
+    switch (d) {
+        case -2: asm("v_fmac_f32_dpp %0, %1, %2 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(x), "v"(w)); break;
+        case -1: asm("v_fmac_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(x), "v"(w)); break;
+        case 1: asm("v_fmac_f32_dpp %0, %1, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(x), "v"(w)); break;
+        case 2: asm("v_fmac_f32_dpp %0, %1, %2 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(x), "v"(w)); break;
+        default: acc = __builtin_fmaf(x, w, acc); break;
+    }
+    return acc;
+#endif
+}
+
 template <int KS, int S, int KC, int NC>
 __global__ __launch_bounds__(256, NC == 1 ? 4 : 2) void k_front_roll(
     const float *__restrict__ x, int H, int W, int Cin, const float *__restrict__ wt, int Epad,
@@ -722,7 +755,7 @@ __global__ __launch_bounds__(256, NC == 1 ? 4 : 2) void k_front_roll(
     constexpr int OW = (16 - KS) / S + 1;
     __shared__ __attribute__((aligned(16))) float s_dw[KS * KS * EC + 2 * EC];  // taps, then expand bias, depthwise bias
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: what it indexes stays in SGPRs
     const int li = lane & 15, kq = lane >> 4;
     const int b = blockIdx.y;
     const int e0 = blockIdx.z * EC;
@@ -793,6 +826,16 @@ __global__ __launch_bounds__(256, NC == 1 ? 4 : 2) void k_front_roll(
         }
     };
 
+    // a 3x3 filter of one channel group is 36 registers: kept for the whole walk (the kernel has them to spare);
+    // the larger ones are re-read from LDS every row, see tap_off below
+    constexpr bool TAPS_IN_REGS = KS * KS * NC <= 9;
+    f32x4 wtap[TAPS_IN_REGS ? KS * KS : 1][NC];
+    if constexpr (TAPS_IN_REGS) {
+#pragma unroll
+        for (int t = 0; t < KS * KS; ++t)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) wtap[t][c] = *reinterpret_cast<const f32x4 *>(s_dw + t * EC + 16 * c + 4 * kq);
+    }
     f32x4 ring[KS][NC];
     f32x4 xa[S][KC];
     ll4 psum[NC];
@@ -837,25 +880,31 @@ __global__ __launch_bounds__(256, NC == 1 ? 4 : 2) void k_front_roll(
         // tap t+1 is requested while tap t is applied; the scheduling barriers keep hipcc from issuing all
         // KS*KS*NC reads up front (100+ live registers)
         f32x4 wn[NC];
+        if constexpr (!TAPS_IN_REGS) {
 #pragma unroll
-        for (int c = 0; c < NC; ++c) wn[c] = *reinterpret_cast<const f32x4 *>(s_dw + 16 * c + tap_off);
+            for (int c = 0; c < NC; ++c) wn[c] = *reinterpret_cast<const f32x4 *>(s_dw + 16 * c + tap_off);
+        }
 #pragma unroll
         for (int t = 0; t < KS * KS; ++t) {
             const int ky = t / KS, kx = t % KS;
             f32x4 wc[NC];
+            if constexpr (TAPS_IN_REGS) {
 #pragma unroll
-            for (int c = 0; c < NC; ++c) wc[c] = wn[c];
-            if (t + 1 < KS * KS) {
+                for (int c = 0; c < NC; ++c) wc[c] = wtap[t][c];
+            } else {
 #pragma unroll
-                for (int c = 0; c < NC; ++c) wn[c] = *reinterpret_cast<const f32x4 *>(s_dw + (t + 1) * EC + 16 * c + tap_off);
+                for (int c = 0; c < NC; ++c) wc[c] = wn[c];
+                if (t + 1 < KS * KS) {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) wn[c] = *reinterpret_cast<const f32x4 *>(s_dw + (t + 1) * EC + 16 * c + tap_off);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const f32x4 v = ring[ky][c];
-                const float p0 = row_shift(v.x, kx - PAD) * wc[c].x, p1 = row_shift(v.y, kx - PAD) * wc[c].y;
-                const float p2 = row_shift(v.z, kx - PAD) * wc[c].z, p3 = row_shift(v.w, kx - PAD) * wc[c].w;
-                o[c].x = o[c].x + p0; o[c].y = o[c].y + p1; o[c].z = o[c].z + p2; o[c].w = o[c].w + p3;
+                o[c].x = fmac_shift(o[c].x, v.x, wc[c].x, kx - PAD); o[c].y = fmac_shift(o[c].y, v.y, wc[c].y, kx - PAD);
+                o[c].z = fmac_shift(o[c].z, v.z, wc[c].z, kx - PAD); o[c].w = fmac_shift(o[c].w, v.w, wc[c].w, kx - PAD);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -900,7 +949,13 @@ __global__ __launch_bounds__(256, NC == 1 ? 4 : 2) void k_front_roll(
 // adds: order-free), complete per image, so n_tiles = 1.  Outputs are bit-identical to k_gemm1x1 + k_dwconv.
 // grid = (ceil(n_groups / groups_per_wg), 1, E / (16 NR)); block = 256.
 // dynamic LDS (floats): Kpad * (NT + 4) weights | G * (H+2P) * (W+2P) * NT expanded window | KS*KS*NT taps | 2 NT biases
-template <int KS, int S, int NR, int MR>
+#ifdef PB_SM_STAMP_E
+__device__ unsigned long long g_sm_stamp[65536 * 10];  // [workgroup * 4 + wave][slot]
+#define PB_ST(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_[i] += t_ - st_t; st_t = t_; } while (0)
+#else
+#define PB_ST(i) do {} while (0)
+#endif
+template <int KS, int S, int NR, int MR, int NS>
 __global__ __launch_bounds__(256) void k_mbconv_small(
     const float *__restrict__ x, int H, int W, int Cin, const float *__restrict__ wt, int Kpad, int Epad,
     const float *__restrict__ bias_e, const float *__restrict__ dw_w, const float *__restrict__ dw_b, int E,
@@ -918,9 +973,49 @@ __global__ __launch_bounds__(256) void k_mbconv_small(
     float *s_dw = s_e + G * Hp * Wp * NT;       // [KS * KS][NT]
     float *s_b = s_dw + KS * KS * NT;           // [NT] expand bias, [NT] depthwise bias
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: what it indexes stays in SGPRs
     const int li = lane & 15, kq = lane >> 4;
     const int e0 = blockIdx.z * NT;
+#ifdef PB_SM_STAMP_E
+    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_t = __builtin_amdgcn_s_memtime();
+    const unsigned long long st_t0 = st_t;
+#endif
+    const int n_groups = (n_img + G - 1) / G;
+    const int g_first = blockIdx.x * groups_per_wg;
+    const int n_steps = Kpad / 16;
+    // this lane's MR pixel rows of the group: row = 16 (MR wave + r) + li -> image g_img of the group, pixel pix
+    int g_img[MR], pix[MR];
+    float *e_dst[MR];
+#pragma unroll
+    for (int r = 0; r < MR; ++r) {
+        const int row = 16 * (MR * wave + r) + li;
+        g_img[r] = row / P;
+        pix[r] = row % P;
+        e_dst[r] = s_e + (g_img[r] * Hp * Wp + (pix[r] / W + PAD) * Wp + (pix[r] % W + PAD)) * NT;
+    }
+    // NS > 0 (= Kpad / 16): the lane's activation operands of a whole group (MR rows x NS float4) are loaded in ONE
+    // burst and held in registers -- requested for the first group before the weight staging, for every next group
+    // right after the current group's last MFMA, so that the round trip runs under the depthwise phase.  The
+    // streaming form (NS = 0: one k-step ahead, 8 MFMAs = 256 cycles of cover per load) left the MFMA pipe waiting
+    // for L2 at every step: the expand phase alone ran at 45 % of the MFMA rate.  Loaded values are masked (image
+    // past the batch, k past Cin) at use, not at load: a select after the load would wait for it on the spot.
+    f32x4 a_all[MR][NS > 0 ? NS : 1];
+    auto load_group = [&](int gi2) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < MR; ++r) {
+            const int img = gi2 * G + g_img[r];
+            const float *arow = x + ((size_t)(img < n_img ? img : 0) * P + pix[r]) * Cin;
+#pragma unroll
+            for (int s2 = 0; s2 < NS; ++s2) {
+                const int kb = 16 * s2 + 4 * kq;
+                a_all[r][s2] = *reinterpret_cast<const f32x4 *>(arow + (kb < Cin ? kb : 0));
+            }
+        }
+    };
+    if constexpr (NS > 0) {
+        if (g_first < n_groups) load_group(g_first);
+    }
     // ---- once per workgroup: weights of this channel group, taps, biases, zero ring
     for (int i = tid; i < Kpad * (NT / 4); i += 256) {
         const int kr = i / (NT / 4), c4 = i % (NT / 4);
@@ -937,22 +1032,57 @@ __global__ __launch_bounds__(256) void k_mbconv_small(
     for (int i = tid; i < G * Hp * Wp * (NT / 4); i += 256) *reinterpret_cast<f32x4 *>(s_e + 4 * i) = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int i = tid; i < 8 * NT; i += 256) s_se[i / NT][i % NT] = 0ull;
     __syncthreads();
-    const int n_groups = (n_img + G - 1) / G;
-    const int g_first = blockIdx.x * groups_per_wg;
-    const int n_steps = Kpad / 16;
-    // this lane's MR pixel rows of the group: row = 16 (MR wave + r) + li -> image g_img of the group, pixel pix
-    int g_img[MR], pix[MR];
-    float *e_dst[MR];
-#pragma unroll
-    for (int r = 0; r < MR; ++r) {
-        const int row = 16 * (MR * wave + r) + li;
-        g_img[r] = row / P;
-        pix[r] = row % P;
-        e_dst[r] = s_e + (g_img[r] * Hp * Wp + (pix[r] / W + PAD) * Wp + (pix[r] % W + PAD)) * NT;
-    }
+    PB_ST(0);
     for (int gi = g_first; gi < g_first + groups_per_wg && gi < n_groups; ++gi) {
         // ---- expand: MR x 16 pixel rows x NT channels per wave, K = Cin
-        {
+        if constexpr (NS > 0) {
+            f32x4 acc[MR][NR];
+            bool iv[MR];
+#pragma unroll
+            for (int r = 0; r < MR; ++r) {
+                iv[r] = gi * G + g_img[r] < n_img;
+#pragma unroll
+                for (int c = 0; c < NR; ++c) acc[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int kbase = 16 * s + 4 * kq;
+                f32x4 a[MR];
+#pragma unroll
+                for (int r = 0; r < MR; ++r) {
+                    a[r] = a_all[r][s];
+                    if (!(iv[r] && kbase < Cin)) a[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+                const float *wbase = s_w + kbase * LDW + li;
+                float wv[4][NR];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int c = 0; c < NR; ++c) wv[e][c] = wbase[e * LDW + c * 16];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int r = 0; r < MR; ++r) {
+                        const float av = e == 0 ? a[r].x : (e == 1 ? a[r].y : (e == 2 ? a[r].z : a[r].w));
+#pragma unroll
+                        for (int c = 0; c < NR; ++c) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[e][c], av, acc[r][c], 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            PB_ST(1);
+            if (gi + 1 < g_first + groups_per_wg && gi + 1 < n_groups) load_group(gi + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < MR; ++r)
+#pragma unroll
+                for (int c = 0; c < NR; ++c) {
+                    const f32x4 bev = *reinterpret_cast<const f32x4 *>(s_b + 16 * c + 4 * kq);
+                    f32x4 v = acc[r][c];
+                    v.x = silu_f(v.x + bev.x); v.y = silu_f(v.y + bev.y); v.z = silu_f(v.z + bev.z); v.w = silu_f(v.w + bev.w);
+                    *reinterpret_cast<f32x4 *>(e_dst[r] + 16 * c + 4 * kq) = v;
+                }
+        } else {
             bool iv[MR];
             const float *arow[MR];
             f32x4 a_nxt[MR];
@@ -995,6 +1125,7 @@ __global__ __launch_bounds__(256) void k_mbconv_small(
                     }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            PB_ST(1);
 #pragma unroll
             for (int r = 0; r < MR; ++r)
 #pragma unroll
@@ -1005,14 +1136,18 @@ __global__ __launch_bounds__(256) void k_mbconv_small(
                     *reinterpret_cast<f32x4 *>(e_dst[r] + 16 * c + 4 * kq) = v;
                 }
         }
+        PB_ST(2);
         __syncthreads();
+        PB_ST(3);
         // ---- depthwise from LDS: items = (image of the group, output pixel, channel quad)
         const int HoWo = Ho * Wo;
+        const int lg_wo = 31 - __builtin_clz(Wo), lg_howo = 31 - __builtin_clz(HoWo);
         for (int it = tid; it < G * HoWo * CQ; it += 256) {
-            const int cq = it % CQ, o = (it / CQ) % HoWo, g2 = it / (CQ * HoWo);
+            // Ho, Wo are powers of two (small_eligible: square 16 / 8 / 4 maps): shifts, not runtime divisions
+            const int cq = it % CQ, po = it / CQ, o = po & (HoWo - 1), g2 = po >> lg_howo;
             const int img2 = gi * G + g2;
             if (img2 >= n_img) continue;
-            const int oy = o / Wo, ox = o % Wo;
+            const int oy = o >> lg_wo, ox = o & (Wo - 1);
             const float *ip = s_e + (g2 * Hp * Wp + (oy * S) * Wp + ox * S) * NT + 4 * cq;
             f32x4 acc = *reinterpret_cast<const f32x4 *>(s_b + NT + 4 * cq);
 #pragma unroll
@@ -1021,8 +1156,7 @@ __global__ __launch_bounds__(256) void k_mbconv_small(
                 for (int kx = 0; kx < KS; ++kx) {
                     const f32x4 v = *reinterpret_cast<const f32x4 *>(ip + (ky * Wp + kx) * NT);
                     const f32x4 wv = *reinterpret_cast<const f32x4 *>(s_dw + (ky * KS + kx) * NT + 4 * cq);
-                    const float p0 = v.x * wv.x, p1 = v.y * wv.y, p2 = v.z * wv.z, p3 = v.w * wv.w;
-                    acc.x = acc.x + p0; acc.y = acc.y + p1; acc.z = acc.z + p2; acc.w = acc.w + p3;
+                    dw_tap(acc, v, wv);
                 }
             const f32x4 r4 = {silu_f(acc.x), silu_f(acc.y), silu_f(acc.z), silu_f(acc.w)};
             *reinterpret_cast<f32x4 *>(out + ((size_t)img2 * HoWo + o) * E + e0 + 4 * cq) = r4;
@@ -1033,7 +1167,9 @@ __global__ __launch_bounds__(256) void k_mbconv_small(
             atomicAdd(&s_se[g2][4 * cq + 2], (unsigned long long)q4.z);
             atomicAdd(&s_se[g2][4 * cq + 3], (unsigned long long)q4.w);
         }
+        PB_ST(4);
         __syncthreads();
+        PB_ST(5);
         for (int i = tid; i < G * NT; i += 256) {
             const int g2 = i / NT, ch = i % NT;
             const int img2 = gi * G + g2;
@@ -1041,7 +1177,19 @@ __global__ __launch_bounds__(256) void k_mbconv_small(
             s_se[g2][ch] = 0ull;
         }
         __syncthreads();  // the next group overwrites the expanded window
+        PB_ST(6);
+#ifdef PB_SM_STAMP_E
+        st_[7] += 1;
+#endif
     }
+#ifdef PB_SM_STAMP_E
+    if (lane == 0 && E == PB_SM_STAMP_E && KS == PB_SM_STAMP_KS && S == 1) {
+        const size_t w_ = ((size_t)(blockIdx.z * gridDim.x + blockIdx.x) * 4 + wave) & 65535;
+        for (int i = 0; i < 8; ++i) g_sm_stamp[w_ * 10 + i] = st_[i];
+        g_sm_stamp[w_ * 10 + 8] = __builtin_amdgcn_s_memtime() - st_t0;
+        g_sm_stamp[w_ * 10 + 9] = 1ull;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1069,7 +1217,7 @@ __global__ __launch_bounds__(1024) void k_se(const long long *__restrict__ part,
     __shared__ f32x4 s_t[IMG][G > 1 ? G - 1 : 1][320];  // FC2 partial sums of groups 1.. (QP <= 320)
     const int b0 = blockIdx.x * IMG;
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: what it indexes stays in SGPRs
     const int g = tid / QP, cq = tid - g * QP;  // QP is a multiple of 64: a wave never straddles two groups
     const int n_quads = E >> 2;
     const bool on = cq < n_quads;

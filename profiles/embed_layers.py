@@ -7,6 +7,8 @@ import sys
 def main(path):
     rows = list(csv.DictReader(open(path)))
     idx = [i for i, r in enumerate(rows) if "k_stem" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    idx = [i for i, r in enumerate(rows) if "k_stem" in r["Kernel_Name"]]
     big = max(int(rows[i]["Grid_Size_X"]) for i in idx)
     s = [i for i in idx if int(rows[i]["Grid_Size_X"]) == big][-1]  # last forward of the largest batch
     tot, by = 0.0, {}
@@ -20,7 +22,7 @@ def main(path):
         fam = short.split("<")[0]
         by[fam] = by.get(fam, 0.0) + dur
         print(f"{short:26s} grid={r['Grid_Size_X']:>9s}x{r['Grid_Size_Y']:>4s}x{r['Grid_Size_Z']:>2s} wg={r['Workgroup_Size_X']:>4s} vgpr={r['VGPR_Count']:>4s} {dur:8.1f} us")
-        if "k_fc_tanh" in n:
+        if "k_tanh_quant" in n:
             break
     print("total us", round(tot, 1), {k: round(v, 1) for k, v in by.items()})
 

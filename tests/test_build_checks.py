@@ -1,0 +1,49 @@
+"""Build-time checks on the generated gfx950 code (no GPU needed: hipcc cross-compiles here).
+
+`fmac_shift` (pb_embed_kernels.h) issues `v_fmac_f32_dpp` through inline asm.  CDNA needs two wait states between a
+VALU write of a VGPR and a DPP read of it, and five after a VALU write of EXEC; hipcc inserts them for the DPP moves
+it generates itself but cannot see inside asm, so the kernels are written to keep the producers far away -- and this
+test reads the device assembly to make sure the scheduler did not move one next to a consumer.
+"""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _written_vgprs(instr: str):
+    m = re.match(r"(\S+)\s+(v\[(\d+):(\d+)\]|v(\d+))\b", instr)
+    if not m or not m.group(1).startswith("v_"):
+        return set()
+    if m.group(3):
+        return set(range(int(m.group(3)), int(m.group(4)) + 1))
+    return {int(m.group(5))}
+
+
+@pytest.mark.timeout(600)
+def test_inline_asm_dpp_reads_keep_their_wait_states(tmp_path):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    out = tmp_path / "pb_embed.s"
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+                           "--cuda-device-only", "-S", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "pixelbox_amd", "csrc", "pb_embed.hip"), "-o", str(out)],
+                          stderr=subprocess.DEVNULL)
+    ins = [l.strip() for l in open(out) if re.match(r"^\s+[a-z]", l)]
+    n = 0
+    for k, t in enumerate(ins):
+        m = re.match(r"v_fmac_f32_dpp v\d+, v(\d+), v\d+", t)
+        if not m:
+            continue
+        n += 1
+        src = int(m.group(1))
+        for back in (1, 2):
+            assert src not in _written_vgprs(ins[k - back]), f"DPP source v{src} written {back} instruction(s) before: {ins[k - back]} -> {t}"
+        for back in range(1, 6):
+            assert not ins[k - back].startswith("v_cmpx"), f"VALU write of EXEC {back} instruction(s) before a DPP read: {t}"
+    assert n > 0, "fmac_shift no longer compiles to v_fmac_f32_dpp"
