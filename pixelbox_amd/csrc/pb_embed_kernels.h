@@ -8,6 +8,7 @@
 // (bit-for-bit an fmaf chain), the only MFMA dtype that keeps the embedding within 1e-5 of an f32 CPU
 // implementation.  Depthwise convolutions, squeeze-excite and the head are HBM/latency-bound VALU kernels.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -387,56 +388,68 @@ __global__ __launch_bounds__(64 * NW) void k_gemm1x1(const float *__restrict__ a
     store_w(0);
     __syncthreads();
 
-    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+    // The full chunks run in a loop of their own and the tail chunk (Kpad % 64 != 0) after it: with both forms in ONE
+    // loop body the ring slots are phis of two paths and hipcc copies all of them at the back edge behind vmcnt(0).
+    auto do_chunk = [&](int chunk, auto full) __attribute__((always_inline)) {
         const int k0 = chunk * G_KC;
         const int kc = (Kpad - k0) < G_KC ? (Kpad - k0) : G_KC;
         if (chunk + 1 < n_chunks) load_w(chunk + 1);
         const float *sw = s_w[chunk & 1] + li;
-        for (int s0 = 0; s0 < kc; s0 += 16 * PD) {
+        // one k-step: operands of step t from ring slot u, request of step t + PD into the same slot, 4 NR LDS reads,
+        // 4 MR NR MFMAs.  The request is UNCONDITIONAL (past the last step it re-reads the last one, never used): a
+        // load under `if (t + PD < n_steps)` makes the slot a phi of (loaded, kept), which hipcc resolves by loading
+        // into a temporary and copying it into the slot after the step's MFMAs -- behind s_waitcnt vmcnt(0), i.e. every
+        // step waited for the load it had issued 4 MR NR MFMAs earlier and the ring hid one step of latency, not PD.
+        auto k_step = [&](int s, int u) __attribute__((always_inline)) {
+            const int t = (k0 + s) / 16;  // global k-step; t % PD == u because PD divides the 4 steps of a chunk
+            const int kbase = t * 16 + 4 * kk;
+            f32x4 a[MR];
 #pragma unroll
-            for (int u = 0; u < PD; ++u) {
-                const int s = s0 + 16 * u;
-                if (s < kc) {
-                    const int t = (k0 + s) / 16;  // global k-step; t % PD == u because PD divides the 4 steps of a chunk
-                    const int kbase = t * 16 + 4 * kk;
-                    f32x4 a[MR];
+            for (int r = 0; r < MR; ++r) {
+                a[r] = aring[u][r];
+                if constexpr (GATE) {
+                    const f32x4 g = gring[u][r];
+                    a[r].x = a[r].x * g.x; a[r].y = a[r].y * g.y; a[r].z = a[r].z * g.z; a[r].w = a[r].w * g.w;
+                }
+                if (!(mval[r] && kbase < K)) a[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            load_act((t + PD < n_steps) ? (t + PD) : (n_steps - 1), u);
+            // weight fragments of the whole k-step: all 4*NR LDS reads are issued before the first MFMA
+            // (sched_barrier keeps hipcc from sinking each read next to its use, which exposes the LDS
+            // latency between every pair of MFMAs)
+            float wv[4][NR];
+            const float *wbase = sw + (s + 4 * kk) * LDW;
 #pragma unroll
-                    for (int r = 0; r < MR; ++r) {
-                        a[r] = aring[u][r];
-                        if constexpr (GATE) {
-                            const f32x4 g = gring[u][r];
-                            a[r].x = a[r].x * g.x; a[r].y = a[r].y * g.y; a[r].z = a[r].z * g.z; a[r].w = a[r].w * g.w;
-                        }
-                        if (!(mval[r] && kbase < K)) a[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    }
-                    if (t + PD < n_steps) load_act(t + PD, u);
-                    // weight fragments of the whole k-step: all 4*NR LDS reads are issued before the first MFMA
-                    // (sched_barrier keeps hipcc from sinking each read next to its use, which exposes the LDS
-                    // latency between every pair of MFMAs)
-                    float wv[4][NR];
-                    const float *wbase = sw + (s + 4 * kk) * LDW;
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
+                for (int c = 0; c < NR; ++c) wv[e][c] = wbase[e * LDW + c * 16];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int c = 0; c < NR; ++c) wv[e][c] = wbase[e * LDW + c * 16];
-                    __builtin_amdgcn_sched_barrier(0);
+            for (int e = 0; e < 4; ++e) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
+                for (int r = 0; r < MR; ++r) {
+                    const float av = e == 0 ? a[r].x : (e == 1 ? a[r].y : (e == 2 ? a[r].z : a[r].w));
 #pragma unroll
-                        for (int r = 0; r < MR; ++r) {
-                            const float av = e == 0 ? a[r].x : (e == 1 ? a[r].y : (e == 2 ? a[r].z : a[r].w));
-#pragma unroll
-                            for (int c = 0; c < NR; ++c)
-                                acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[e][c], av, acc[r][c], 0, 0, 0);
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
+                    for (int c = 0; c < NR; ++c)
+                        acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[e][c], av, acc[r][c], 0, 0, 0);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if constexpr (decltype(full)::value) {  // four unguarded steps
+#pragma unroll
+            for (int q = 0; q < G_KC / 16; ++q) k_step(16 * q, q % PD);
+        } else {  // tail chunk, once per kernel
+#pragma unroll
+            for (int q = 0; q < G_KC / 16; ++q)
+                if (16 * q < kc) k_step(16 * q, q % PD);
         }
         if (chunk + 1 < n_chunks) store_w((chunk + 1) & 1);
         __syncthreads();
-    }
+    };
+    const int n_full = Kpad / G_KC;
+    for (int chunk = 0; chunk < n_full; ++chunk) do_chunk(chunk, std::true_type{});
+    if (n_full < n_chunks) do_chunk(n_full, std::false_type{});
     // epilogue: lane holds channels n0 + 16c + 4kk .. +3 of pixel mrow[r]
 #pragma unroll
     for (int r = 0; r < MR; ++r) {
