@@ -483,7 +483,7 @@ bool small_regs_form(const Block &bl, int mr) {
 
 size_t small_lds_bytes(const Block &bl, int H, int W, int nr, int mr) {
     const int nt = 16 * nr, pad = (bl.k - 1) / 2, g = 64 * mr / (H * W);
-    return ((size_t)bl.expand.Kpad * (nt + 4) + (size_t)g * (H + 2 * pad) * (W + 2 * pad) * nt + (size_t)bl.k * bl.k * nt + 2 * nt) * sizeof(float);
+    return ((size_t)bl.expand.Kpad * (nt + 4) + (size_t)g * (H + 2 * pad) * ((W + 2 * pad) | 1) * nt + (size_t)bl.k * bl.k * nt + 2 * nt) * sizeof(float);
 }
 
 template <int KS, int S, int NR, int MR, int NS>

@@ -961,7 +961,7 @@ __global__ __launch_bounds__(256, NC == 1 ? 4 : 2) void k_front_roll(
 // walks `groups_per_wg` consecutive groups with its weights staged once.  SE sums: int64 LDS atomics (integer
 // adds: order-free), complete per image, so n_tiles = 1.  Outputs are bit-identical to k_gemm1x1 + k_dwconv.
 // grid = (ceil(n_groups / groups_per_wg), 1, E / (16 NR)); block = 256.
-// dynamic LDS (floats): Kpad * (NT + 4) weights | G * (H+2P) * (W+2P) * NT expanded window | KS*KS*NT taps | 2 NT biases
+// dynamic LDS (floats): Kpad * (NT + 4) weights | G * (H+2P) * ((W+2P) | 1) * NT expanded window | KS*KS*NT taps | 2 NT biases
 #ifdef PB_SM_STAMP_E
 __device__ unsigned long long g_sm_stamp[65536 * 10];  // [workgroup * 4 + wave][slot]
 #define PB_ST(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_[i] += t_ - st_t; st_t = t_; } while (0)
@@ -980,7 +980,7 @@ __global__ __launch_bounds__(256) void k_mbconv_small(
     __shared__ unsigned long long s_se[8][NT];  // [image of the group][channel]: 2^-24 fixed-point sums (se_acc)
     const int P = H * W;       // 256, 64 or 16
     const int G = ROWS / P;    // images per group (1 .. 8)
-    const int Hp = H + 2 * PAD, Wp = W + 2 * PAD;
+    const int Hp = H + 2 * PAD, Wp = (W + 2 * PAD) | 1;  // odd row pitch: see the depthwise phase
     float *s_w = s_ms;                          // [Kpad][LDW]
     float *s_e = s_w + Kpad * LDW;              // [G][Hp * Wp][NT]
     float *s_dw = s_e + G * Hp * Wp * NT;       // [KS * KS][NT]
@@ -1152,29 +1152,58 @@ __global__ __launch_bounds__(256) void k_mbconv_small(
         PB_ST(2);
         __syncthreads();
         PB_ST(3);
-        // ---- depthwise from LDS: items = (image of the group, output pixel, channel quad)
+        // ---- depthwise from LDS: items = (image of the group, pair of adjacent outputs of a row, channel quad) for
+        // stride 1, single outputs for stride 2.  Per filter row a thread reads the pair's KS + 1 window values and the
+        // KS taps once (16-byte LDS reads) and applies them to both outputs from registers: 11 reads per 10 tap
+        // applications (5x5) where one output per thread took 20 -- with fused taps the LDS reads were half of the
+        // phase's issue slots.  Wider strips leave waves without work (an 8 x 8 map x 8 channel quads is 256 pairs:
+        // one per thread) and ran slower.  Per output the taps are still applied ky-major, kx-minor.  Lanes run
+        // over the channel quads first, then over output rows: with the odd row pitch the rows a 16-lane read
+        // group touches alternate between the two halves of the 256-byte bank row.
         const int HoWo = Ho * Wo;
-        const int lg_wo = 31 - __builtin_clz(Wo), lg_howo = 31 - __builtin_clz(HoWo);
-        for (int it = tid; it < G * HoWo * CQ; it += 256) {
-            // Ho, Wo are powers of two (small_eligible: square 16 / 8 / 4 maps): shifts, not runtime divisions
-            const int cq = it % CQ, po = it / CQ, o = po & (HoWo - 1), g2 = po >> lg_howo;
+        constexpr int TX = S == 1 ? 2 : 1;
+        constexpr int NIN = (TX - 1) * S + KS;
+        const int lg_ho = 31 - __builtin_clz(Ho);
+        const int n_sx = Wo / TX, lg_sx = 31 - __builtin_clz(n_sx);  // Ho, Wo: powers of two (small_eligible)
+        for (int it = tid; it < G * n_sx * Ho * CQ; it += 256) {
+            const int cq = it % CQ, po = it / CQ, oy = po & (Ho - 1), sx = (po >> lg_ho) & (n_sx - 1), g2 = po >> (lg_ho + lg_sx);
             const int img2 = gi * G + g2;
             if (img2 >= n_img) continue;
-            const int oy = o >> lg_wo, ox = o & (Wo - 1);
-            const float *ip = s_e + (g2 * Hp * Wp + (oy * S) * Wp + ox * S) * NT + 4 * cq;
-            f32x4 acc = *reinterpret_cast<const f32x4 *>(s_b + NT + 4 * cq);
+            const int ox0 = sx * TX;
+            const float *ip = s_e + (g2 * Hp * Wp + (oy * S) * Wp + ox0 * S) * NT + 4 * cq;
+            f32x4 acc[TX];
+            {
+                const f32x4 bv = *reinterpret_cast<const f32x4 *>(s_b + NT + 4 * cq);
 #pragma unroll
-            for (int ky = 0; ky < KS; ++ky)
+                for (int j = 0; j < TX; ++j) acc[j] = bv;
+            }
 #pragma unroll
-                for (int kx = 0; kx < KS; ++kx) {
-                    const f32x4 v = *reinterpret_cast<const f32x4 *>(ip + (ky * Wp + kx) * NT);
-                    const f32x4 wv = *reinterpret_cast<const f32x4 *>(s_dw + (ky * KS + kx) * NT + 4 * cq);
-                    dw_tap(acc, v, wv);
+            for (int ky = 0; ky < KS; ++ky) {
+                f32x4 v[NIN], wv[KS];
+#pragma unroll
+                for (int i = 0; i < NIN; ++i) v[i] = *reinterpret_cast<const f32x4 *>(ip + (ky * Wp + i) * NT);
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx) wv[kx] = *reinterpret_cast<const f32x4 *>(s_dw + (ky * KS + kx) * NT + 4 * cq);
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+                    for (int j = 0; j < TX; ++j) dw_tap(acc[j], v[j * S + kx], wv[kx]);
+                // one filter row at a time (hipcc otherwise interleaves the rows and keeps every read live): the pins
+                // close the row's arithmetic, the barrier keeps the next row's reads behind it
+                if constexpr (TX > 1) {
+#pragma unroll
+                    for (int j = 0; j < TX; ++j) asm volatile("" : "+v"(acc[j].x), "+v"(acc[j].y), "+v"(acc[j].z), "+v"(acc[j].w));
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-            const f32x4 r4 = {silu_f(acc.x), silu_f(acc.y), silu_f(acc.z), silu_f(acc.w)};
-            *reinterpret_cast<f32x4 *>(out + ((size_t)img2 * HoWo + o) * E + e0 + 4 * cq) = r4;
+            }
             ll4 q4 = {0, 0, 0, 0};
-            se_acc(q4, r4);
+            float *op = out + ((size_t)img2 * HoWo + oy * Wo + ox0) * E + e0 + 4 * cq;
+#pragma unroll
+            for (int j = 0; j < TX; ++j) {
+                const f32x4 r4 = {silu_f(acc[j].x), silu_f(acc[j].y), silu_f(acc[j].z), silu_f(acc[j].w)};
+                *reinterpret_cast<f32x4 *>(op + (size_t)j * E) = r4;
+                se_acc(q4, r4);
+            }
             atomicAdd(&s_se[g2][4 * cq + 0], (unsigned long long)q4.x);
             atomicAdd(&s_se[g2][4 * cq + 1], (unsigned long long)q4.y);
             atomicAdd(&s_se[g2][4 * cq + 2], (unsigned long long)q4.z);
