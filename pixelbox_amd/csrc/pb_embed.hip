@@ -928,12 +928,12 @@ int pb_embed_set_option(pb_embedder *e, int option, int64_t value) {
 }
 
 #ifdef PB_SM_STAMP_E
-int pb_debug_small_stamps(unsigned long long *out, int reset) {  // out: 65536 * 10
-    PB_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sm_stamp), 65536 * 10 * sizeof(unsigned long long)));
+int pb_debug_small_stamps(unsigned long long *out, int reset) {  // out: 65536 * 12
+    PB_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sm_stamp), 65536 * 12 * sizeof(unsigned long long)));
     if (reset) {
         void *p = nullptr;
         PB_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(g_sm_stamp)));
-        PB_HIP(hipMemset(p, 0, 65536 * 10 * sizeof(unsigned long long)));
+        PB_HIP(hipMemset(p, 0, 65536 * 12 * sizeof(unsigned long long)));
         PB_HIP(hipDeviceSynchronize());
     }
     return PB_OK;

@@ -963,7 +963,7 @@ __global__ __launch_bounds__(256, NC == 1 ? 4 : 2) void k_front_roll(
 // grid = (ceil(n_groups / groups_per_wg), 1, E / (16 NR)); block = 256.
 // dynamic LDS (floats): Kpad * (NT + 4) weights | G * (H+2P) * ((W+2P) | 1) * NT expanded window | KS*KS*NT taps | 2 NT biases
 #ifdef PB_SM_STAMP_E
-__device__ unsigned long long g_sm_stamp[65536 * 10];  // [workgroup * 4 + wave][slot]
+__device__ unsigned long long g_sm_stamp[65536 * 12];  // [workgroup * 4 + wave][slot]
 #define PB_ST(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_[i] += t_ - st_t; st_t = t_; } while (0)
 #else
 #define PB_ST(i) do {} while (0)
@@ -977,7 +977,7 @@ __global__ __launch_bounds__(256) void k_mbconv_small(
     constexpr int PAD = (KS - 1) / 2;
     constexpr int ROWS = 64 * MR;  // pixel rows per group: MR row tiles per wave (the weight fragments of a k-step serve all MR)
     extern __shared__ __attribute__((aligned(16))) float s_ms[];
-    __shared__ unsigned long long s_se[8][NT];  // [image of the group][channel]: 2^-24 fixed-point sums (se_acc)
+    __shared__ unsigned long long s_se[2][8][NT];  // [group parity][image of the group][channel]: 2^-24 fixed-point sums (se_acc)
     const int P = H * W;       // 256, 64 or 16
     const int G = ROWS / P;    // images per group (1 .. 8)
     const int Hp = H + 2 * PAD, Wp = (W + 2 * PAD) | 1;  // odd row pitch: see the depthwise phase
@@ -990,7 +990,7 @@ __global__ __launch_bounds__(256) void k_mbconv_small(
     const int li = lane & 15, kq = lane >> 4;
     const int e0 = blockIdx.z * NT;
 #ifdef PB_SM_STAMP_E
-    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_t = __builtin_amdgcn_s_memtime();
     const unsigned long long st_t0 = st_t;
 #endif
@@ -1030,23 +1030,66 @@ __global__ __launch_bounds__(256) void k_mbconv_small(
         if (g_first < n_groups) load_group(g_first);
     }
     // ---- once per workgroup: weights of this channel group, taps, biases, zero ring
-    for (int i = tid; i < Kpad * (NT / 4); i += 256) {
-        const int kr = i / (NT / 4), c4 = i % (NT / 4);
-        *reinterpret_cast<f32x4 *>(s_w + kr * LDW + c4 * 4) = *reinterpret_cast<const f32x4 *>(wt + (size_t)kr * Epad + e0 + c4 * 4);
+    // (every global load of the staging is requested before the first LDS store -- the first four weight quads per
+    // thread, the taps, the biases: one round trip to L2 instead of one per loop turn and per array)
+    {
+        constexpr int NTAP4 = KS * KS * (NT / 4);  // <= 300 float4
+        constexpr int NTJ = (NTAP4 + 255) / 256;
+        const int n_w4 = Kpad * (NT / 4);
+        f32x4 w4[4], t4[NTJ];
+        float be = 0.f, bd = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = tid + 256 * j;
+            const int ic = i < n_w4 ? i : 0;
+            w4[j] = *reinterpret_cast<const f32x4 *>(wt + (size_t)(ic / (NT / 4)) * Epad + e0 + (ic % (NT / 4)) * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < NTJ; ++j) {
+            const int i = tid + 256 * j;
+            const int ic = i < NTAP4 ? i : 0;
+            t4[j] = *reinterpret_cast<const f32x4 *>(dw_w + (size_t)(ic / (NT / 4)) * E + e0 + (ic % (NT / 4)) * 4);
+        }
+        if (tid < NT) {
+            be = bias_e[e0 + tid];
+            bd = dw_b[e0 + tid];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = tid + 256 * j;
+            if (i < n_w4) *reinterpret_cast<f32x4 *>(s_w + (i / (NT / 4)) * LDW + (i % (NT / 4)) * 4) = w4[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NTJ; ++j) {
+            const int i = tid + 256 * j;
+            if (i < NTAP4) *reinterpret_cast<f32x4 *>(s_dw + (i / (NT / 4)) * NT + (i % (NT / 4)) * 4) = t4[j];
+        }
+        if (tid < NT) {
+            s_b[tid] = be;
+            s_b[NT + tid] = bd;
+        }
+        for (int i0 = tid + 4 * 256; i0 < n_w4; i0 += 4 * 256) {  // weight slices beyond 16 KB (K > 128 or 48 channels)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = i0 + 256 * j;
+                const int ic = i < n_w4 ? i : 0;
+                w4[j] = *reinterpret_cast<const f32x4 *>(wt + (size_t)(ic / (NT / 4)) * Epad + e0 + (ic % (NT / 4)) * 4);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = i0 + 256 * j;
+                if (i < n_w4) *reinterpret_cast<f32x4 *>(s_w + (i / (NT / 4)) * LDW + (i % (NT / 4)) * 4) = w4[j];
+            }
+        }
     }
-    for (int i = tid; i < KS * KS * (NT / 4); i += 256) {
-        const int t = i / (NT / 4), c4 = i % (NT / 4);
-        *reinterpret_cast<f32x4 *>(s_dw + t * NT + c4 * 4) = *reinterpret_cast<const f32x4 *>(dw_w + (size_t)t * E + e0 + c4 * 4);
-    }
-    if (tid < NT) {
-        s_b[tid] = bias_e[e0 + tid];
-        s_b[NT + tid] = dw_b[e0 + tid];
-    }
+    PB_ST(10);
     for (int i = tid; i < G * Hp * Wp * (NT / 4); i += 256) *reinterpret_cast<f32x4 *>(s_e + 4 * i) = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int i = tid; i < 8 * NT; i += 256) s_se[i / NT][i % NT] = 0ull;
+    for (int i = tid; i < 2 * 8 * NT; i += 256) (&s_se[0][0][0])[i] = 0ull;
+    PB_ST(11);
     __syncthreads();
     PB_ST(0);
     for (int gi = g_first; gi < g_first + groups_per_wg && gi < n_groups; ++gi) {
+        const int sp = (gi - g_first) & 1;
         // ---- expand: MR x 16 pixel rows x NT channels per wave, K = Cin
         if constexpr (NS > 0) {
             f32x4 acc[MR][NR];
@@ -1204,10 +1247,10 @@ __global__ __launch_bounds__(256) void k_mbconv_small(
                 *reinterpret_cast<f32x4 *>(op + (size_t)j * E) = r4;
                 se_acc(q4, r4);
             }
-            atomicAdd(&s_se[g2][4 * cq + 0], (unsigned long long)q4.x);
-            atomicAdd(&s_se[g2][4 * cq + 1], (unsigned long long)q4.y);
-            atomicAdd(&s_se[g2][4 * cq + 2], (unsigned long long)q4.z);
-            atomicAdd(&s_se[g2][4 * cq + 3], (unsigned long long)q4.w);
+            atomicAdd(&s_se[sp][g2][4 * cq + 0], (unsigned long long)q4.x);
+            atomicAdd(&s_se[sp][g2][4 * cq + 1], (unsigned long long)q4.y);
+            atomicAdd(&s_se[sp][g2][4 * cq + 2], (unsigned long long)q4.z);
+            atomicAdd(&s_se[sp][g2][4 * cq + 3], (unsigned long long)q4.w);
         }
         PB_ST(4);
         __syncthreads();
@@ -1215,10 +1258,11 @@ __global__ __launch_bounds__(256) void k_mbconv_small(
         for (int i = tid; i < G * NT; i += 256) {
             const int g2 = i / NT, ch = i % NT;
             const int img2 = gi * G + g2;
-            if (img2 < n_img) part[(size_t)img2 * E + e0 + ch] = (long long)s_se[g2][ch];
-            s_se[g2][ch] = 0ull;
+            if (img2 < n_img) part[(size_t)img2 * E + e0 + ch] = (long long)s_se[sp][g2][ch];
+            s_se[sp][g2][ch] = 0ull;
         }
-        __syncthreads();  // the next group overwrites the expanded window
+        // no barrier here: the next group's sums go to the other s_se buffer (this one is added to again two barriers
+        // from now), and its expand phase overwrites a window that every wave has finished reading (barrier above)
         PB_ST(6);
 #ifdef PB_SM_STAMP_E
         st_[7] += 1;
@@ -1227,9 +1271,11 @@ __global__ __launch_bounds__(256) void k_mbconv_small(
 #ifdef PB_SM_STAMP_E
     if (lane == 0 && E == PB_SM_STAMP_E && KS == PB_SM_STAMP_KS && S == 1) {
         const size_t w_ = ((size_t)(blockIdx.z * gridDim.x + blockIdx.x) * 4 + wave) & 65535;
-        for (int i = 0; i < 8; ++i) g_sm_stamp[w_ * 10 + i] = st_[i];
-        g_sm_stamp[w_ * 10 + 8] = __builtin_amdgcn_s_memtime() - st_t0;
-        g_sm_stamp[w_ * 10 + 9] = 1ull;
+        for (int i = 0; i < 8; ++i) g_sm_stamp[w_ * 12 + i] = st_[i];
+        g_sm_stamp[w_ * 12 + 10] = st_[10];
+        g_sm_stamp[w_ * 12 + 11] = st_[11];
+        g_sm_stamp[w_ * 12 + 8] = __builtin_amdgcn_s_memtime() - st_t0;
+        g_sm_stamp[w_ * 12 + 9] = 1ull;
     }
 #endif
 }

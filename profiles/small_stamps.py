@@ -19,7 +19,7 @@ for _ in range(3):
     emb.embed_device(imgs.data_ptr(), batch, out.data_ptr())
 torch.cuda.synchronize()
 L = capi.lib()
-buf = (C.c_ulonglong * (65536 * 10))()
+buf = (C.c_ulonglong * (65536 * 12))()
 rc = L.pb_debug_small_stamps(buf, 1)
 print('rc', rc, L.pb_last_error())
 emb.embed_device(imgs.data_ptr(), batch, out.data_ptr())
@@ -27,10 +27,12 @@ torch.cuda.synchronize()
 rc = L.pb_debug_small_stamps(buf, 0)
 print('rc', rc, L.pb_last_error())
 import numpy as np
-v = np.ctypeslib.as_array(buf).reshape(65536, 10).astype(np.float64).sum(axis=0).tolist()
+v = np.ctypeslib.as_array(buf).reshape(65536, 12).astype(np.float64).sum(axis=0).tolist()
 names = ["staging", "expand mfma", "expand epilogue", "barrier 1", "depthwise", "barrier 2", "part + barrier 3"]
 waves, groups = v[9], v[7]
 print(f"waves {waves}, wave-groups {groups}, lifetime per wave {v[8] / max(waves, 1):.0f} cycles")
-print(f"  {'staging':18s} {v[0] / max(waves, 1):8.0f} per wave")
+print(f"  {'weights -> LDS':18s} {v[10] / max(waves, 1):8.0f} per wave")
+print(f"  {'taps, zero ring':18s} {v[11] / max(waves, 1):8.0f} per wave")
+print(f"  {'first barrier':18s} {v[0] / max(waves, 1):8.0f} per wave")
 for i in range(1, 7):
     print(f"  {names[i]:18s} {v[i] / max(groups, 1):8.0f} per wave and group")
