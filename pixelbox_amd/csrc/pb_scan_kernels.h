@@ -289,7 +289,7 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
 
     const int q = q_base + blockIdx.y;
     const int lane = lane_id();
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: loop bounds and LDS bases stay in SGPRs
     const int sub = lane % LPR;
     const int g = lane / LPR;
     const QParams P = qp[q];
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_dist(const uint8_t *__restri
     __shared__ uint64_t s_drop[NW];
     const int q = q_base + blockIdx.y;
     const int lane = lane_id();
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: loop bounds and LDS bases stay in SGPRs
     const int sub = lane % LPR;
     const int g = lane / LPR;
     const QParams P = qp[q];
@@ -827,7 +827,7 @@ __global__ __launch_bounds__(X_BLOCK) void k_scan_exact(
     const int q = (int)qsel[blockIdx.y];
     const QParams P = qp[q];
     const int lane = lane_id();
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: loop bounds and LDS bases stay in SGPRs
     for (int i = threadIdx.x; i < 256; i += X_BLOCK) s_lut[i] = lut[i];
     __syncthreads();
     for (int i = threadIdx.x; i < d; i += X_BLOCK) {
@@ -980,7 +980,7 @@ __global__ __launch_bounds__(MQ_WAVES * WAVE) void k_scan_multi(
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[MQ_WAVES][16 * MQ_LDROW];
     __shared__ uint32_t s_hist[HIST ? (MQ_BINS / 2) * MQ_HPITCH : 1];  // two 16-bit counters per word
     const int lane = lane_id();
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: loop bounds and LDS bases stay in SGPRs
     const int li = lane & 15, kq = lane >> 4;
     // blockIdx.y selects a chunk of MQ_MAXQ queries (a burst's sample passes run as ONE launch); single-chunk
     // launches have gridDim.y == 1
@@ -1200,7 +1200,7 @@ __global__ __launch_bounds__(NWQ * WAVE) void k_scan_multi_wg(
     __shared__ uint32_t s_qq[QCAP], s_qrow[QCAP];
     __shared__ uint32_t s_qcnt;
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, kq = lane >> 4;
     const int qbase = (int)blockIdx.y * (NWQ * 64) + wave * 64;
     const bool active = qbase < n_q;  // a wave whose 64 queries lie past n_q only helps loading
