@@ -1316,8 +1316,21 @@ __global__ __launch_bounds__(1024) void k_se(const long long *__restrict__ part,
 #pragma unroll
     for (int i = 0; i < IMG; ++i) {
         const int b = (b0 + i) < n_img ? (b0 + i) : (n_img - 1);  // a padded slot repeats the last image
-        ll4 t = {0, 0, 0, 0};  // exact: fixed-point partial sums (see se_acc)
-        for (int tl = 0; tl < n_tiles; ++tl) se_add(t, *reinterpret_cast<const ll4 *>(part + ((size_t)b * n_tiles + tl) * E + c));
+        ll4 t = {0, 0, 0, 0};  // exact: fixed-point partial sums (see se_acc); integer adds, any order
+        {
+            // eight tiles per trip, all their loads requested before the first add: one tile per trip made a small batch's
+            // SE kernel a chain of up to 32 dependent round trips (14 us at batch 1)
+            const long long *pp = part + (size_t)b * n_tiles * E + c;
+            int tl = 0;
+            for (; tl + 8 <= n_tiles; tl += 8) {
+                ll4 u[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) u[j] = *reinterpret_cast<const ll4 *>(pp + (size_t)(tl + j) * E);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) se_add(t, u[j]);
+            }
+            for (; tl < n_tiles; ++tl) se_add(t, *reinterpret_cast<const ll4 *>(pp + (size_t)tl * E));
+        }
         const double sc = (1.0 / 16777216.0) * (double)inv_hw;
         m[i] = (f32x4){(float)((double)t.x * sc), (float)((double)t.y * sc), (float)((double)t.z * sc), (float)((double)t.w * sc)};
         if (!on) m[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
