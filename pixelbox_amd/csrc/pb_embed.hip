@@ -225,6 +225,14 @@ void launch_gemm_cfg(pb_embedder *e, GemmCfg c, const float *act, long M, const 
     const long rows_per_block = 16L * c.nw * c.mr;
     dim3 grid((unsigned)((M + rows_per_block - 1) / rows_per_block), (unsigned)(tiles / c.nr));
     const int nr = c.nr;
+    if (c.nw == 1) {  // one wave per 16 x 16 tile, weights from global (a few pixel rows: small batches of the late layers)
+        const dim3 tg((unsigned)((M + 15) / 16), (unsigned)tiles);
+        if (gate)
+            hipLaunchKernelGGL((k_gemm_thin<true>), tg, dim3(64), 0, e->stream, act, (int)M, g.K, g.wt, g.Kpad, g.Npad, g.bias, g.N, gate, hw, resid, do_silu, out);
+        else
+            hipLaunchKernelGGL((k_gemm_thin<false>), tg, dim3(64), 0, e->stream, act, (int)M, g.K, g.wt, g.Kpad, g.Npad, g.bias, g.N, gate, hw, resid, do_silu, out);
+        return;
+    }
     if (c.nw == 8) {
         if (gate) launch_gemm_mr<1, true, 8>(nr, grid, e->stream, act, (int)M, g, gate, hw, resid, do_silu, out);
         else launch_gemm_mr<1, false, 8>(nr, grid, e->stream, act, (int)M, g, gate, hw, resid, do_silu, out);
@@ -252,10 +260,11 @@ int launch_gemm(pb_embedder *e, const float *act, long M, const Gemm &g, const f
         PB_HIP(hipEventCreate(&e1));
         for (int nr = 8; nr >= 1; --nr) {
             if (tiles % nr) continue;
-            for (int mr : {4, 2, 1, 0}) {  // 0: the eight-wave form of MR = 1
+            for (int mr : {4, 2, 1, 0, -1}) {  // 0: the eight-wave form of MR = 1; -1: the one-wave form (k_gemm_thin)
                 if (mr > 1 && M <= 64L * (mr / 2)) continue;  // tile taller than the problem
                 if (mr == 0 && M <= 64) continue;
-                const GemmCfg c{mr ? mr : 1, nr, mr ? 4 : 8};
+                if (mr == -1 && (nr != 1 || M > 1024)) continue;
+                const GemmCfg c{mr > 0 ? mr : 1, nr, mr > 0 ? 4 : (mr == 0 ? 8 : 1)};
                 launch_gemm_cfg(e, c, act, M, g, gate, hw, resid, do_silu, out);
                 PB_HIP(hipEventRecord(e0, e->stream));
                 launch_gemm_cfg(e, c, act, M, g, gate, hw, resid, do_silu, out);
@@ -276,9 +285,10 @@ int launch_gemm(pb_embedder *e, const float *act, long M, const Gemm &g, const f
                     best.nr, best.nw, best_ms * 500.f, 2.0 * (double)M * g.K * g.N / (best_ms * 0.5e-3) / 1e12);
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
-        it = e->gemm_cfg.emplace(key, std::make_pair(best.mr * (best.nw == 8 ? -1 : 1), best.nr)).first;
+        it = e->gemm_cfg.emplace(key, std::make_pair(best.nw == 1 ? 100 : best.mr * (best.nw == 8 ? -1 : 1), best.nr)).first;
     }
-    launch_gemm_cfg(e, GemmCfg{std::abs(it->second.first), it->second.second, it->second.first < 0 ? 8 : 4}, act, M, g, gate, hw,
+    const int enc = it->second.first;  // 100: one-wave form; negative: eight-wave form
+    launch_gemm_cfg(e, GemmCfg{enc == 100 ? 1 : std::abs(enc), it->second.second, enc == 100 ? 1 : (enc < 0 ? 8 : 4)}, act, M, g, gate, hw,
                     resid, do_silu, out);
     PB_HIP(hipGetLastError());
     return PB_OK;

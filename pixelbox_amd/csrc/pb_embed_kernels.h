@@ -472,6 +472,80 @@ __global__ __launch_bounds__(64 * NW) void k_gemm1x1(const float *__restrict__ a
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same 1x1 convolution for a handful of pixel rows (one image: M = 16 .. 256): one wave per workgroup owns one
+// 16-row x 16-channel tile and reads its weight operand straight from global memory (4 dwords per k-step, 64-byte
+// segments across the 16 channel lanes), PD k-steps ahead, with no LDS staging and no barriers.  k_gemm1x1 on such a
+// problem is a latency chain -- per 64-deep chunk a weight fetch, an LDS store and a workgroup barrier for ONE busy
+// wave (15 us for K = 1152 at M = 16); here the chain is the K / 4 dependent MFMAs themselves.  Operand maps, k order,
+// gate-then-mask and epilogue are those of k_gemm1x1: the outputs are bit-identical.
+// grid = (ceil(M / 16), Npad / 16); block = 64.
+template <bool GATE>
+__global__ __launch_bounds__(64) void k_gemm_thin(const float *__restrict__ act, int M, int K, const float *__restrict__ wt,
+                                                  int Kpad, int Npad, const float *__restrict__ bias, int N,
+                                                  const float *__restrict__ gate, int hw, const float *__restrict__ resid,
+                                                  int do_silu, float *__restrict__ out) {
+    constexpr int PD = 16;  // k-steps in flight: at batch 1 the weights come from HBM / Infinity Cache (each byte is used once per forward)
+    const int lane = threadIdx.x & 63, li = lane & 15, kk = lane >> 4;
+    const int n0 = blockIdx.y * 16;
+    const long mrow = (long)blockIdx.x * 16 + li;
+    const bool mval = mrow < M;
+    const long mc = mval ? mrow : 0;
+    const float *arow = act + mc * K;
+    const float *grow = GATE ? gate + (mc / hw) * K : nullptr;
+    const float *wcol = wt + n0 + li;
+    const int n_steps = Kpad / 16;
+    f32x4 ar[PD], gr[GATE ? PD : 1];
+    float wr[PD][4];
+    auto load_step = [&](int t, int slot) __attribute__((always_inline)) {
+        const int kbase = t * 16 + 4 * kk;
+        const int kb = (mval && kbase < K) ? kbase : 0;
+        ar[slot] = *reinterpret_cast<const f32x4 *>(arow + kb);
+        if constexpr (GATE) gr[slot] = *reinterpret_cast<const f32x4 *>(grow + kb);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wr[slot][e] = wcol[(size_t)(kbase + e) * Npad];
+    };
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    auto k_step = [&](int t, int slot) __attribute__((always_inline)) {
+        const int kbase = t * 16 + 4 * kk;
+        f32x4 a = ar[slot];
+        if constexpr (GATE) {
+            const f32x4 g = gr[slot];
+            a.x = a.x * g.x; a.y = a.y * g.y; a.z = a.z * g.z; a.w = a.w * g.w;
+        }
+        if (!(mval && kbase < K)) a = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float w4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w4[e] = wr[slot][e];
+        load_step((t + PD < n_steps) ? (t + PD) : (n_steps - 1), slot);  // unconditional: see k_gemm1x1
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[0], a.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[1], a.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[2], a.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[3], a.w, acc, 0, 0, 0);
+    };
+#pragma unroll
+    for (int t = 0; t < PD; ++t) load_step(t < n_steps ? t : n_steps - 1, t);
+    int t0 = 0;
+    for (; t0 + PD <= n_steps; t0 += PD) {
+#pragma unroll
+        for (int u = 0; u < PD; ++u) k_step(t0 + u, u);
+    }
+#pragma unroll
+    for (int u = 0; u < PD; ++u)
+        if (t0 + u < n_steps) k_step(t0 + u, u);
+    const int n = n0 + kk * 4;
+    if (!mval || n >= N) return;  // N % 4 == 0
+    const f32x4 b = *reinterpret_cast<const f32x4 *>(bias + n);
+    f32x4 v = acc;
+    v.x = v.x + b.x; v.y = v.y + b.y; v.z = v.z + b.z; v.w = v.w + b.w;
+    if (do_silu) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+    if (resid) {
+        const f32x4 rv = *reinterpret_cast<const f32x4 *>(resid + mrow * N + n);
+        v.x = rv.x + v.x; v.y = rv.y + v.y; v.z = rv.z + v.z; v.w = rv.w + v.w;
+    }
+    *reinterpret_cast<f32x4 *>(out + mrow * N + n) = v;
+}
+
+// ------------------------------------------------------------------------------------------------
 // depthwise KSxKS conv, stride S, pad (KS-1)/2, + bias + SiLU, NHWC, with the squeeze-excite pooling
 // partial sums fused: part[b][tile][c] = sum of the outputs of this block's pixels (fixed order ->
 // deterministic).  Register tiling: a thread owns a strip of TX = 4 adjacent output pixels of one row for one
