@@ -1200,7 +1200,7 @@ __global__ __launch_bounds__(NWQ * WAVE) void k_scan_multi_wg(
     __shared__ uint32_t s_qq[QCAP], s_qrow[QCAP];
     __shared__ uint32_t s_qcnt;
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, wave = tid >> 6;  // (a scalar wave index measured 2.5 % slower here: 2.82 vs 2.75 ms)
     const int li = lane & 15, kq = lane >> 4;
     const int qbase = (int)blockIdx.y * (NWQ * 64) + wave * 64;
     const bool active = qbase < n_q;  // a wave whose 64 queries lie past n_q only helps loading
