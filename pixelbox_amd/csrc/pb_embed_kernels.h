@@ -393,7 +393,10 @@ __global__ __launch_bounds__(64 * NW) void k_gemm1x1(const float *__restrict__ a
     auto do_chunk = [&](int chunk, auto full) __attribute__((always_inline)) {
         const int k0 = chunk * G_KC;
         const int kc = (Kpad - k0) < G_KC ? (Kpad - k0) : G_KC;
-        if (chunk + 1 < n_chunks) load_w(chunk + 1);
+        // full chunks fetch and stage the next weight chunk unconditionally (after the last one: the same chunk again, into
+        // the buffer nobody reads): under a condition hipcc's wait-count pass must assume the path "fetched but not
+        // stored" and drains every outstanding load (vmcnt(0)) at the top of each chunk, operand ring included
+        if constexpr (decltype(full)::value) load_w(chunk + 1 < n_chunks ? chunk + 1 : n_chunks - 1);
         const float *sw = s_w[chunk & 1] + li;
         // one k-step: operands of step t from ring slot u, request of step t + PD into the same slot, 4 NR LDS reads,
         // 4 MR NR MFMAs.  The request is UNCONDITIONAL (past the last step it re-reads the last one, never used): a
@@ -444,7 +447,7 @@ __global__ __launch_bounds__(64 * NW) void k_gemm1x1(const float *__restrict__ a
             for (int q = 0; q < G_KC / 16; ++q)
                 if (16 * q < kc) k_step(16 * q, q % PD);
         }
-        if (chunk + 1 < n_chunks) store_w((chunk + 1) & 1);
+        if constexpr (decltype(full)::value) store_w((chunk + 1) & 1);
         __syncthreads();
     };
     const int n_full = Kpad / G_KC;
