@@ -274,6 +274,8 @@ int launch_gemm(pb_embedder *e, const float *act, long M, const Gemm &g, const f
                 PB_HIP(hipGetLastError());
                 float ms = 0.f;
                 PB_HIP(hipEventElapsedTime(&ms, e0, e1));
+                if (getenv("PB_TRACE_TUNE") && getenv("PB_TRACE_TUNE")[0] == '2')
+                    fprintf(stderr, "  gemm M%ld K%d N%d: MR%d NR%d NW%d %.1f us\n", M, g.K, g.N, c.mr, c.nr, c.nw, ms * 500.f);
                 if (ms < best_ms) {
                     best_ms = ms;
                     best = c;
