@@ -30,6 +30,7 @@ struct Gemm {  // 1x1 conv as GEMM
     int K = 0, N = 0, Kpad = 0, Npad = 0;
     float *wt = nullptr;    // [Kpad][Npad]
     float *bias = nullptr;  // [Npad]
+    uint2 *wt3 = nullptr;   // three-bf16-piece form for k_gemm_b3: [3][Kpad / 4][Npad] x (4 consecutive k as bf16); null = f32 path only
 };
 struct Block {
     int cin, cout, e, sq, k, stride;
@@ -65,6 +66,7 @@ struct pb_embedder {
     float *d_out_f32 = nullptr;
     uint8_t *d_out_u8 = nullptr;
     int n_cu = 256;
+    bool use_b3 = false;  // project / head / FC products from three bf16 pieces (k_gemm_b3) instead of the f32 MFMA chain
     std::map<std::pair<const void *, long>, std::pair<int, int>> gemm_cfg;  // (layer weights, rows) -> (MR, NR), measured; MR < 0: eight-wave form
     std::map<std::pair<const void *, long>, DwGeom> dw_cfg;
     std::map<std::pair<const void *, long>, int> front_cfg;  // (block, batch) -> 0: expand GEMM + depthwise kernels, else fused kernel config 16 * bands + nc
@@ -95,7 +97,7 @@ int upload(pb_embedder *e, float **dst, const std::vector<float> &src) {
 }
 
 // torch [N][K] (OI) -> k-major zero-padded [Kpad][Npad] + padded bias
-int make_gemm(pb_embedder *e, Gemm *g, const float *w, const float *b, int N, int K) {
+int make_gemm(pb_embedder *e, Gemm *g, const float *w, const float *b, int N, int K, bool pieces = false) {
     g->K = K;
     g->N = N;
     g->Kpad = round_up(K, 16);
@@ -106,7 +108,29 @@ int make_gemm(pb_embedder *e, Gemm *g, const float *w, const float *b, int N, in
     for (int n = 0; n < N; ++n) bp[n] = b[n];
     int rc = upload(e, &g->wt, wt);
     if (!rc) rc = upload(e, &g->bias, bp);
-    return rc;
+    if (rc || !pieces) return rc;
+    // w = hi + mid + lo exactly, each piece a bf16 (truncation split: 8 + 8 + 8 significand bits)
+    const int KQ = g->Kpad / 4;
+    std::vector<uint32_t> w3((size_t)3 * KQ * g->Npad * 2, 0u);
+    auto bits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+    auto flt = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
+    for (int k = 0; k < g->Kpad; ++k)
+        for (int n = 0; n < g->Npad; ++n) {
+            const float x = wt[(size_t)k * g->Npad + n];
+            const float r1 = x - flt(bits(x) & 0xFFFF0000u);
+            const float r2 = r1 - flt(bits(r1) & 0xFFFF0000u);
+            const uint32_t piece[3] = {bits(x) >> 16, bits(r1) >> 16, bits(r2) >> 16};
+            for (int pl = 0; pl < 3; ++pl) {
+                uint32_t &d = w3[(((size_t)pl * KQ + k / 4) * g->Npad + n) * 2 + ((k & 3) >> 1)];
+                d |= piece[pl] << (16 * (k & 1));
+            }
+        }
+    uint32_t *dw = nullptr;
+    rc = dalloc(e, &dw, w3.size());
+    if (rc) return rc;
+    PB_HIP(hipMemcpy(dw, w3.data(), w3.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    g->wt3 = reinterpret_cast<uint2 *>(dw);
+    return PB_OK;
 }
 
 size_t blob_floats(int D) {
@@ -185,14 +209,14 @@ int load_weights(pb_embedder *e, const uint8_t *blob, size_t len) {
                 if ((rc = upload(e, &bl.se_w2t, w2t)) || (rc = upload(e, &bl.se_b2, b2))) return rc;
                 p += (size_t)E * S + E;
             }
-            if ((rc = make_gemm(e, &bl.project, p, p + (size_t)bl.cout * E, bl.cout, E))) return rc;
+            if ((rc = make_gemm(e, &bl.project, p, p + (size_t)bl.cout * E, bl.cout, E, true))) return rc;
             p += (size_t)bl.cout * E + bl.cout;
             e->blocks.push_back(bl);
         }
-    if ((rc = make_gemm(e, &e->head, p, p + 1280 * 320, 1280, 320))) return rc;
+    if ((rc = make_gemm(e, &e->head, p, p + 1280 * 320, 1280, 320, true))) return rc;
     p += 1280 * 320 + 1280;
     PB_CHECK(e->D % 4 == 0, PB_ERR_FORMAT, "weight blob: D = %u must be a multiple of 4", e->D);
-    if ((rc = make_gemm(e, &e->fc, p, p + (size_t)e->D * 1280, (int)e->D, 1280))) return rc;
+    if ((rc = make_gemm(e, &e->fc, p, p + (size_t)e->D * 1280, (int)e->D, 1280, true))) return rc;
     return PB_OK;
 }
 
@@ -208,6 +232,35 @@ void launch_gemm_mr(int nr, dim3 grid, hipStream_t st, const float *act, int M, 
         PB_G(1) PB_G(2) PB_G(3) PB_G(4) PB_G(5) PB_G(6) PB_G(7) PB_G(8)
     }
 #undef PB_G
+}
+
+template <bool GATE, int NW>
+int launch_gemm_b3_t(int nr, hipStream_t st, const float *act, int M, const Gemm &g, const float *gate, int hw, const float *resid,
+                     int do_silu, float *out) {
+    const dim3 grid((unsigned)((M + 16 * NW - 1) / (16 * NW)), (unsigned)(g.Npad / 16 / nr));
+#define PB_G(NRV)                                                                                                        \
+    case NRV: {                                                                                                          \
+        constexpr int NT = 16 * NRV, LDP = NT + (NT % 32 == 0 ? 16 : 0);                                                 \
+        constexpr size_t lds = (size_t)2 * 48 * LDP * 8;                                                                 \
+        auto kern = k_gemm_b3<NRV, GATE, NW>;                                                                            \
+        if (lds > 48 * 1024)                                                                                             \
+            PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, act, M, g.K, g.wt3, g.Kpad, g.Npad, g.bias, g.N, gate, hw, resid, \
+                           do_silu, out);                                                                                \
+    } break;
+    switch (nr) {
+        PB_G(1) PB_G(2) PB_G(3) PB_G(4) PB_G(5) PB_G(6) PB_G(7) PB_G(8)
+    }
+#undef PB_G
+    return PB_OK;
+}
+int launch_gemm_b3(int nr, int nw, hipStream_t st, const float *act, long M, const Gemm &g, const float *gate, int hw,
+                   const float *resid, int do_silu, float *out) {
+    if (nw == 8)
+        return gate ? launch_gemm_b3_t<true, 8>(nr, st, act, (int)M, g, gate, hw, resid, do_silu, out)
+                    : launch_gemm_b3_t<false, 8>(nr, st, act, (int)M, g, gate, hw, resid, do_silu, out);
+    return gate ? launch_gemm_b3_t<true, 4>(nr, st, act, (int)M, g, gate, hw, resid, do_silu, out)
+                : launch_gemm_b3_t<false, 4>(nr, st, act, (int)M, g, gate, hw, resid, do_silu, out);
 }
 
 // Tile choice.  NR (16-column tiles per wave) must divide Npad/16; MR in {4,2,1} (64*MR rows per block).
@@ -252,6 +305,48 @@ int launch_gemm(pb_embedder *e, const float *act, long M, const Gemm &g, const f
     const int tiles = g.Npad / 16;
     const std::pair<const void *, long> key(g.wt, M);
     auto it = e->gemm_cfg.find(key);
+    if (g.wt3 && e->use_b3) {
+        // project / head / FC: the three-bf16-piece form for EVERY batch size (its numerics differ from the f32 chain,
+        // so the choice must not depend on M); only the tile shape (NR, NW) is measured
+        if (it == e->gemm_cfg.end()) {
+            int best_nr = 1, best_nw = 4;
+            float best_ms = 1e30f;
+            hipEvent_t e0, e1;
+            PB_HIP(hipEventCreate(&e0));
+            PB_HIP(hipEventCreate(&e1));
+            for (int nr = 8; nr >= 1; --nr) {
+                if (tiles % nr) continue;
+                for (int nw : {8, 4}) {
+                    if (nw == 8 && M <= 64) continue;
+                    int rc = launch_gemm_b3(nr, nw, e->stream, act, M, g, gate, hw, resid, do_silu, out);
+                    if (rc) return rc;
+                    PB_HIP(hipEventRecord(e0, e->stream));
+                    launch_gemm_b3(nr, nw, e->stream, act, M, g, gate, hw, resid, do_silu, out);
+                    launch_gemm_b3(nr, nw, e->stream, act, M, g, gate, hw, resid, do_silu, out);
+                    PB_HIP(hipEventRecord(e1, e->stream));
+                    PB_HIP(hipEventSynchronize(e1));
+                    PB_HIP(hipGetLastError());
+                    float ms = 0.f;
+                    PB_HIP(hipEventElapsedTime(&ms, e0, e1));
+                    if (ms < best_ms) {
+                        best_ms = ms;
+                        best_nr = nr;
+                        best_nw = nw;
+                    }
+                }
+            }
+            if (getenv("PB_TRACE_TUNE"))
+                fprintf(stderr, "gemm M%ld K%d N%d%s: bf16 pieces, best NR%d NW%d %.1f us = %.1f TFLOP/s\n", M, g.K, g.N, gate ? " gated" : "",
+                        best_nr, best_nw, best_ms * 500.f, 2.0 * (double)M * g.K * g.N / (best_ms * 0.5e-3) / 1e12);
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+            it = e->gemm_cfg.emplace(key, std::make_pair(200 + best_nw, best_nr)).first;
+        }
+        int rc = launch_gemm_b3(it->second.second, it->second.first - 200, e->stream, act, M, g, gate, hw, resid, do_silu, out);
+        if (rc) return rc;
+        PB_HIP(hipGetLastError());
+        return PB_OK;
+    }
     if (it == e->gemm_cfg.end()) {
         GemmCfg best{1, 1, 4};
         float best_ms = 1e30f;
@@ -787,6 +882,7 @@ int pb_embed_create(pb_embedder **out, int device, const void *weights_blob, siz
     PB_CHECK(e, PB_ERR_NOMEM, "out of host memory");
     e->device = device;
     e->max_batch = max_batch;
+    e->use_b3 = getenv("PB_GEMM_B3") != nullptr;  // experiment switch
     auto body = [&]() -> int {
         hipDeviceProp_t prop;
         PB_HIP(hipGetDeviceProperties(&prop, device));

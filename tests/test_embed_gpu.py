@@ -165,3 +165,21 @@ def test_other_input_sizes_and_latent_dims_vs_oracle(h, w, d, n):
     big = capi.Embedder(blob, max_batch=64)
     u8b, fb = big.embed(np.concatenate([imgs] * 16))
     assert np.array_equal(fb[:n].view(np.uint32), f.view(np.uint32)) and np.array_equal(fb[-n:].view(np.uint32), f.view(np.uint32))
+
+
+def test_bf16_piece_gemm_form_stays_within_tolerance(monkeypatch):
+    # PB_GEMM_B3=1 (read at pb_embed_create) routes the project / head / FC products through k_gemm_b3: f32 values split
+    # exactly into three bf16 pieces, six leading cross products on the bf16 matrix cores.  Off by default (measured: not
+    # faster in the present loop structure); the form must still meet the same bars.
+    monkeypatch.setenv("PB_GEMM_B3", "1")
+    blob = W.synthetic_blob(synth.SEED_WEIGHTS, 128, 128, 256)
+    imgs = synth.synthetic_images(synth.SEED_IMAGES, 300, 24, 128, 128)
+    emb = capi.Embedder(blob, max_batch=32)
+    u8, f = emb.embed(imgs)
+    ref_u8, ref_f = oracle.mlhash_batch(blob, imgs, 256, nthreads=8)
+    assert_embeddings_close(f, ref_f)
+    assert_bytes_match(u8, ref_u8, ref_f)
+    one = capi.Embedder(blob, max_batch=1)
+    for i in (0, 7, 23):  # the same bits for every batch size
+        _, f1 = one.embed(imgs[i:i + 1])
+        assert np.array_equal(f1.view(np.uint32), f[i:i + 1].view(np.uint32))
