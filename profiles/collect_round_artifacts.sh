@@ -1,5 +1,10 @@
+#!/bin/bash
+# Regenerates the round's evidence on a GPU box (run from the repo root: bash profiles/collect_round_artifacts.sh):
+# GPU tests, bench.py plain and under rocprofv3 --kernel-trace --stats, separate --pmc passes (FETCH_SIZE, WRITE_SIZE,
+# MFMA busy, SQ wave-cycle split) summarised on the box, embed error and mlhash latency.  Outputs: gpurun_out/r01z/;
+# the summaries are then copied to profiles/r01_*.
 set -x
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r01z; mkdir -p $O
+R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/r01z; mkdir -p $O
 cd $R && python -m pytest tests -x -q -m gpu 2>&1 | tail -3 > $O/gpu_tests.txt
 cd /tmp; export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
