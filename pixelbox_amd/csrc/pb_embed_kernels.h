@@ -1066,8 +1066,11 @@ __global__ __launch_bounds__(256, NC == 1 ? 4 : 2) void k_front_roll(
                 for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s2][e][c], av, acc[c], 0, 0, 0);
             }
         const bool ok = xok && iy >= 0 && iy < H;  // the depthwise zero padding applies to the EXPANDED activation
-        int b_off = 4 * kq;  // biases are re-read from LDS (kept out of long-lived registers, see tap_off below)
-        asm volatile("" : "+v"(b_off));
+        // biases are re-read from LDS (kept out of long-lived registers, see tap_off below); the opaque value is the quad
+        // index, not the offset, so that hipcc still sees a 16-byte-aligned address and reads with ds_read_b128
+        int kq_b = kq;
+        asm volatile("" : "+v"(kq_b));
+        const int b_off = 4 * kq_b;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             f32x4 v = acc[c];
@@ -1117,8 +1120,11 @@ __global__ __launch_bounds__(256, NC == 1 ? 4 : 2) void k_front_roll(
         }
         // the taps are re-read from LDS every row (broadcast reads, 4 addresses per wave); the opaque offset keeps
         // hipcc from hoisting all KS*KS*NC float4 out of the row loop into registers (and spilling)
-        int tap_off = 4 * kq;
-        asm volatile("" : "+v"(tap_off));
+        // (opaque quad index, aligned offset: with the offset itself opaque every tap read became two ds_read2_b32 plus an
+        // address add -- 72 + 42 of the ~1 050 instructions of a row of the 48-channel form)
+        int kq_t = kq;
+        asm volatile("" : "+v"(kq_t));
+        const int tap_off = 4 * kq_t;
         f32x4 o[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) o[c] = *reinterpret_cast<const f32x4 *>(s_dw + KS * KS * EC + EC + 16 * c + tap_off);
