@@ -958,7 +958,7 @@ __global__ __launch_bounds__(256) void k_dwconv_lds(const float *__restrict__ in
 // into the multiplies: v_mul_f32_dpp) and its y-neighbours from the ring.  A strip yields
 // OW = (16 - KS) / S + 1 output columns (14 / 7 / 12 / 6 for 3x3 s1 / 3x3 s2 / 5x5 s1 / 5x5 s2); the x halo is
 // recomputed (MFMA work is not the limit here), the y halo only at band boundaries.  No LDS traffic apart from
-// the broadcast reads of the filter taps.  Same k order, tap order and roundings as the unfused kernels: the
+// the broadcast reads of the filter taps.  Same k order, tap order and roundings as the two-kernel path (k_gemm1x1 + k_dwconv): the
 // outputs are bit-identical to k_gemm1x1 + k_dwconv.
 // grid = (ceil(n_strips * n_bands / 4), B, E / (16 NC)); block = 4 independent waves of one channel group.
 template <int CTRL>
