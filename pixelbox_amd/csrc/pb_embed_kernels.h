@@ -954,12 +954,12 @@ __global__ __launch_bounds__(256) void k_dwconv_lds(const float *__restrict__ in
 // Per input row it runs the expand on the matrix cores with the 16 columns as the MFMA's column index, so lane
 // (li, kq) ends up holding channels 16c + 4kq .. +3 of column li -- exactly the operand map of k_gemm1x1, with the
 // weight fragments held in registers for the whole walk.  The last KS expanded rows stay in a register ring; the
-// depthwise filter takes its x-neighbours from the adjacent lanes of the 16-lane row with DPP row shifts (fused
-// into the multiplies: v_mul_f32_dpp) and its y-neighbours from the ring.  A strip yields
+// depthwise filter takes its x-neighbours from the adjacent lanes of the 16-lane row with DPP row shifts (folded
+// into the fused multiply-adds: v_fmac_f32_dpp, see fmac_shift) and its y-neighbours from the ring.  A strip yields
 // OW = (16 - KS) / S + 1 output columns (14 / 7 / 12 / 6 for 3x3 s1 / 3x3 s2 / 5x5 s1 / 5x5 s2); the x halo is
 // recomputed (MFMA work is not the limit here), the y halo only at band boundaries.  No LDS traffic apart from
-// the broadcast reads of the filter taps.  Same k order, tap order and roundings as the two-kernel path (k_gemm1x1 + k_dwconv): the
-// outputs are bit-identical to k_gemm1x1 + k_dwconv.
+// the broadcast reads of the filter taps.  Same k order, tap order and roundings as the
+// two-kernel path: the outputs are bit-identical to k_gemm1x1 + k_dwconv.
 // grid = (ceil(n_strips * n_bands / 4), B, E / (16 NC)); block = 4 independent waves of one channel group.
 template <int CTRL>
 __device__ __forceinline__ float dpp_f32(float v) {
