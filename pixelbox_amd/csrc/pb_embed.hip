@@ -66,6 +66,8 @@ struct pb_embedder {
     float *d_out_f32 = nullptr;
     uint8_t *d_out_u8 = nullptr;
     int n_cu = 256;
+    int tune_pick = 0;    // PB_TUNE_PICK: 0 fastest candidate (default); 1 slowest; 2 a pseudo-random one -- test hook: every form must give the same bits
+    uint32_t tune_rng = 12345u;
     bool use_b3 = false;  // project / head / FC products from three bf16 pieces (k_gemm_b3) instead of the f32 MFMA chain
     std::map<std::pair<const void *, long>, std::pair<int, int>> gemm_cfg;  // (layer weights, rows) -> (MR, NR), measured; MR < 0: eight-wave form
     std::map<std::pair<const void *, long>, DwGeom> dw_cfg;
@@ -94,6 +96,16 @@ int upload(pb_embedder *e, float **dst, const std::vector<float> &src) {
     if (rc) return rc;
     PB_HIP(hipMemcpy(*dst, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice));
     return PB_OK;
+}
+
+// candidate selection of the per-layer timing loops (see pb_embedder::tune_pick)
+bool tune_take(pb_embedder *e, float ms, float best_ms) {
+    if (e->tune_pick == 1) return best_ms >= 1e29f || ms > best_ms;
+    if (e->tune_pick == 2) {
+        e->tune_rng = e->tune_rng * 1664525u + 1013904223u;
+        return best_ms >= 1e29f || (e->tune_rng >> 16) % 3 == 0;
+    }
+    return ms < best_ms;
 }
 
 // torch [N][K] (OI) -> k-major zero-padded [Kpad][Npad] + padded bias
@@ -328,7 +340,7 @@ int launch_gemm(pb_embedder *e, const float *act, long M, const Gemm &g, const f
                     PB_HIP(hipGetLastError());
                     float ms = 0.f;
                     PB_HIP(hipEventElapsedTime(&ms, e0, e1));
-                    if (ms < best_ms) {
+                    if (tune_take(e, ms, best_ms)) {
                         best_ms = ms;
                         best_nr = nr;
                         best_nw = nw;
@@ -371,7 +383,7 @@ int launch_gemm(pb_embedder *e, const float *act, long M, const Gemm &g, const f
                 PB_HIP(hipEventElapsedTime(&ms, e0, e1));
                 if (getenv("PB_TRACE_TUNE") && getenv("PB_TRACE_TUNE")[0] == '2')
                     fprintf(stderr, "  gemm M%ld K%d N%d: MR%d NR%d NW%d %.1f us\n", M, g.K, g.N, c.mr, c.nr, c.nw, ms * 500.f);
-                if (ms < best_ms) {
+                if (tune_take(e, ms, best_ms)) {
                     best_ms = ms;
                     best = c;
                 }
@@ -519,7 +531,7 @@ int launch_dw(pb_embedder *e, const Block &bl, const float *in, int B, int H, in
                 PB_HIP(hipEventSynchronize(e1));
                 float ms = 0.f;
                 PB_HIP(hipEventElapsedTime(&ms, e0, e1));
-                if (ms < best_ms) {
+                if (tune_take(e, ms, best_ms)) {
                     best_ms = ms;
                     best = c;
                 }
@@ -686,7 +698,7 @@ int run_front(pb_embedder *e, const Block &bl, const float *x, int n, int H, int
                 if ((rc = launch_front(e, bl, cfg, x, n, H, W, e->buf_dw, Ho, Wo))) return rc;  // warm-up
                 if ((rc = time_it(cfg, &ms))) return rc;
                 if (getenv("PB_TRACE_TUNE")) fprintf(stderr, "front k%d s%d e%d n%d: bands %d nc %d %.1f us (separate %.1f)\n", bl.k, bl.stride, bl.e, n, nb, nc, ms * 500.f, sep_ms * 500.f);
-                if (ms < best_ms) {
+                if (tune_take(e, ms, best_ms)) {
                     best_ms = ms;
                     best = cfg;
                 }
@@ -708,7 +720,7 @@ int run_front(pb_embedder *e, const Block &bl, const float *x, int n, int H, int
                     if (getenv("PB_TRACE_TUNE"))
                         fprintf(stderr, "front k%d s%d e%d n%d: small-map fused mr %d nr %d groups/wg %d%s %.1f us (separate %.1f)\n", bl.k, bl.stride, bl.e, n,
                                 mr, nr, 1 << (lg & 7), (lg & 8) ? " regs" : "", ms * 500.f, sep_ms * 500.f);
-                    if (ms < best_ms) {
+                    if (tune_take(e, ms, best_ms)) {
                         best_ms = ms;
                         best = cfg;
                     }
@@ -883,6 +895,7 @@ int pb_embed_create(pb_embedder **out, int device, const void *weights_blob, siz
     e->device = device;
     e->max_batch = max_batch;
     e->use_b3 = getenv("PB_GEMM_B3") != nullptr;  // experiment switch
+    if (const char *tp = getenv("PB_TUNE_PICK")) e->tune_pick = atoi(tp);
     auto body = [&]() -> int {
         hipDeviceProp_t prop;
         PB_HIP(hipGetDeviceProperties(&prop, device));

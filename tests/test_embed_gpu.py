@@ -183,3 +183,30 @@ def test_bf16_piece_gemm_form_stays_within_tolerance(monkeypatch):
     for i in (0, 7, 23):  # the same bits for every batch size
         _, f1 = one.embed(imgs[i:i + 1])
         assert np.array_equal(f1.view(np.uint32), f[i:i + 1].view(np.uint32))
+
+
+@pytest.mark.parametrize("pick", ["1", "2"])
+def test_every_kernel_form_gives_the_same_bits(monkeypatch, pick):
+    # The embedder times several kernel forms per layer and batch size (tile shapes of the GEMM, one-wave form, fused or
+    # separate expand + depthwise, strip / rolling / LDS depthwise, operands in registers or streamed) and keeps the
+    # fastest.  PB_TUNE_PICK=1 keeps the SLOWEST candidate instead, 2 a pseudo-random one: whatever mixture of forms
+    # results, the embedding must not change in a single bit.
+    blob = W.synthetic_blob(synth.SEED_WEIGHTS, 128, 128, 256)
+    imgs = synth.synthetic_images(synth.SEED_IMAGES, 500, 12, 128, 128)
+    ref = capi.Embedder(blob, max_batch=16)
+    u8_ref, f_ref = ref.embed(imgs)
+    monkeypatch.setenv("PB_TUNE_PICK", pick)
+    for max_batch, n in ((16, 12), (4, 3), (1, 1)):
+        other = capi.Embedder(blob, max_batch=max_batch)
+        u8, f = other.embed(imgs[:n])
+        assert np.array_equal(f.view(np.uint32), f_ref[:n].view(np.uint32))
+        assert np.array_equal(u8, u8_ref[:n])
+
+
+def test_stem_fused_with_first_depthwise_gives_the_same_bits(monkeypatch):
+    blob = W.synthetic_blob(synth.SEED_WEIGHTS, 128, 128, 256)
+    imgs = synth.synthetic_images(synth.SEED_IMAGES, 700, 6, 128, 128)
+    _, f_ref = capi.Embedder(blob, max_batch=8).embed(imgs)
+    monkeypatch.setenv("PB_NO_STEM_FUSION", "1")  # k_stem + k_dwconv instead of k_stem_dw
+    _, f = capi.Embedder(blob, max_batch=8).embed(imgs)
+    assert np.array_equal(f.view(np.uint32), f_ref.view(np.uint32))
