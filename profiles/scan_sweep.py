@@ -5,14 +5,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from pixelbox_amd import capi, synth
 
-n, d, B = 10_000_000, 256, 16
+n, d, B = int(os.environ.get("SWEEP_ROWS", "10000000")), 256, 16
 ix = capi.Index(d, n)
 ix.fill_synthetic(synth.SEED_INDEX, 0, n, 1)
 q = synth.fill_synthetic(synth.SEED_QUERY, 0, 64 * 16 * d).reshape(64, 16, d)
 # (variant bits, workgroups per CU, waves per workgroup)
 # + explicit grid (0 = wg/cu * CUs); variant bit 3 = wave-fastest tile mapping
 # variant bits: 1 = plain loads, 2/4 = U16/U4, 8 = wave-fastest mapping
-variants = [(0, 1, 8, 0), (1, 1, 8, 0), (0, 1, 16, 0), (0, 2, 8, 0), (0, 1, 8, 224), (0, 1, 8, 240), (2, 1, 16, 0), (8, 1, 8, 0)]
+variants = [(0, 1, 8, 0), (1, 1, 8, 0), (0, 1, 16, 0), (1, 1, 16, 0), (0, 2, 8, 0), (1, 2, 8, 0), (0, 1, 4, 0), (0, 2, 4, 0), (1, 2, 4, 0), (0, 1, 8, 224), (0, 1, 8, 240), (2, 1, 16, 0), (8, 1, 8, 0), (4, 2, 8, 0), (5, 2, 8, 0)]
 B = int(os.environ.get("SWEEP_B", "1"))
 res = {k: [] for k in variants}
 ix.set_option(capi.PB_OPT_PROFILE, 1)
