@@ -7,7 +7,9 @@ Metric (BASELINE.json): similarity queries/sec over a 10M x 256-dim u8 index (pl
 reported beside it), at 1/2/4/8 GPUs.  One STEP = one batch of `--queries` (default 64) independent
 batch-1 cosine-distance top-100 queries, each a full pass over the whole index (N*D bytes streamed per
 query: the HBM roofline of SURVEY.md section 8d), i.e. the reference's `query_by_image_hash_from_image`
-(engine.rs:363-396) 64 times.  With N > 1 the 10M rows are sharded by contiguous row range
+(engine.rs:363-396) 64 times.  The 64 passes of a step are ONE launch of k_scan_filter in which every workgroup
+streams its rows once per query, one query after the other (PB_OPT_SCAN_LAUNCH = 2, the library default): the same
+bytes from HBM as one launch per query, without 63 launch gaps.  With N > 1 the 10M rows are sharded by contiguous row range
 (STRONG scaling: total work fixed), each rank searches its shard, the per-shard top-100 lists are
 all-gathered over RCCL (torch.distributed, backend nccl) once per step and merged (pb_topk_merge).
 Inputs (index, queries) are resident in HBM / pinned staging before the timed region; the query bytes
@@ -180,7 +182,9 @@ def main():
                 "frac_of_measured_copy_6290": round(gbs / 6290.0, 4),
                 "avg_kernel_ms": round(st.profiled_ms / st.profiled_launches, 4),
                 "bytes_per_launch": int(st.profiled_bytes // st.profiled_launches),
-                "launches": int(st.profiled_launches), "traffic": None}
+                "launches": int(st.profiled_launches),
+                "table_passes_per_launch": int(round(st.profiled_bytes / st.profiled_launches / (len(sh.index) * d))),
+                "ms_per_table_pass": round(st.profiled_ms * len(sh.index) * d / st.profiled_bytes, 4), "traffic": None}
 
     if roof is not None:
         roof["traffic"] = pmc_traffic(roof["kernel"], roof["bytes_per_launch"])
@@ -211,7 +215,8 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{n_total}x{d} u8 index row-sharded over {world} GPU(s), {B} independent batch-1 "
-                                   f"top-{k} queries per step, max_dist={args.max_dist:g}",
+                                   f"top-{k} queries per step (one table pass per query, the {B} passes in one launch), "
+                                   f"max_dist={args.max_dist:g}",
                        "rows": n_total, "dim": d, "k": k, "queries_per_step": B, "parallelism": f"row-shard x{world}",
                        "search_path": "exact" if args.exact_path else "filter+rescore"},
             "ms_per_query": round(dt / (args.steps * B) * 1e3, 4), "latency_ms_single_query_call": round(lat_ms, 4),

@@ -144,7 +144,10 @@ int pb_index_fill_synthetic(pb_index *idx, uint64_t seed, uint64_t first_row, ui
 #define PB_OPT_SCAN_WG_PER_CU 5 /* workgroups per CU (default 1) */
 #define PB_OPT_SCAN_WAVES 6     /* waves per workgroup: 16, 8 (default) or 4 */
 #define PB_OPT_SCAN_GRID 7      /* explicit grid size (0 = workgroups per CU x CUs) */
-#define PB_OPT_SCAN_LAUNCH 8    /* 0 (default): one launch per query = one HBM pass each; 1: one launch for the chunk (queries share reads through the caches) */
+#define PB_OPT_SCAN_LAUNCH 8    /* 0: one launch per query = one HBM pass each; 1: one launch for the chunk, queries side by side (they share \
+                                   reads through the caches); 2 (default): one launch for the chunk in which every workgroup answers the \
+                                   queries one after the other, streaming its rows once per query (one HBM pass per query as with 0, \
+                                   without the launch gap / ramp / tail between them; dim 256, else as 0) */
 #define PB_OPT_MQ_WG_PER_CU 10  /* concurrent-query pass: workgroups per CU (default 2) */
 #define PB_OPT_MQ_PER_CHUNK 11  /* 1: bursts of > 64 queries run one 64-query pass at a time instead of sharing row tiles
                                   among 512 queries per workgroup (default 0; for measurement) */

@@ -92,7 +92,8 @@ struct pb_index {
     int opt_variant = 0;    // tuning knob (dim 256 only): bit 0 = plain (temporal) loads, bits 1-2 = U in {8,16,4}, bit 3 = wave-fastest tiles
     int opt_wg_per_cu = 1;  // filter-pass workgroups per CU
     int opt_waves = F_WAVES;  // filter-pass waves per workgroup (dim 256: 16, 8, 4)
-    int opt_mode = 0;       // 0 = one filter launch per query (independent HBM passes), 1 = one launch for the whole chunk
+    int opt_mode = 2;       // PB_OPT_SCAN_LAUNCH: 0 = one filter launch per query, 1 = one launch, queries side by side (shared reads),
+                            // 2 (default) = one launch, every workgroup answers the queries one after the other (one table pass each)
     int opt_mq_min_queries = 8;  // chunks with at least this many queries take the concurrent-query pass
     int opt_mq_wg_per_cu = 2;
     int opt_mq_per_chunk = 0;  // 1: bursts run one 64-query pass at a time (the pre-workgroup-sharing form, for comparison)
@@ -287,7 +288,13 @@ void finish_qparams(const pb_index *ix, float acc, int64_t sum_a, int64_t sum_a2
 template <int LPR, int U, bool NT, int NW, int MAPB>
 void launch_filter_t(pb_index *ix, int n_wg, uint32_t q_base, uint32_t nq) {
     hipLaunchKernelGGL((k_scan_filter<LPR, U, NT, NW, MAPB>), dim3(n_wg, nq), dim3(NW * 64), 0, ix->stream, ix->d_rows,
-                       ix->n_rows, ix->d_queries, ix->d_qp, ix->d_lists, ix->d_hdrs, (int)q_base);
+                       ix->n_rows, ix->d_queries, ix->d_qp, ix->d_lists, ix->d_hdrs, (int)q_base, 1);
+}
+// one launch, every workgroup answers the nq queries one after the other (k_scan_filter LOOPQ)
+template <int NW>
+void launch_filter_loop(pb_index *ix, int n_wg, uint32_t q_base, uint32_t nq) {
+    hipLaunchKernelGGL((k_scan_filter<16, 8, true, NW, 0, true>), dim3(n_wg, 1), dim3(NW * 64), 0, ix->stream, ix->d_rows,
+                       ix->n_rows, ix->d_queries, ix->d_qp, ix->d_lists, ix->d_hdrs, (int)q_base, (int)nq);
 }
 
 int filter_u(const pb_index *ix) {
@@ -343,11 +350,20 @@ int launch_filter(pb_index *ix, int n_wg, uint32_t q_base, uint32_t nq) {
     return PB_OK;
 }
 
+// PB_OPT_SCAN_LAUNCH = 2: the queries of a chunk in one launch, one table pass per query (dim 256, default load variant)
+bool loop_mode(const pb_index *ix, uint32_t nq) {
+    return ix->opt_mode == 2 && nq > 1 && ix->dim == 256 && (ix->opt_variant & 15) == 0 && (ix->opt_waves == 8 || ix->opt_waves == 4);
+}
+
 // fast path for nq staged queries; results + status land in d_res_*
 int run_fast(pb_index *ix, uint32_t nq) {
     const int n_wg = filter_grid(ix);
     if (ix->opt_profile) PB_HIP(hipEventRecord(ix->ev0, ix->stream));
-    if (ix->opt_mode == 0) {
+    if (loop_mode(ix, nq)) {
+        if (ix->opt_waves == 4) launch_filter_loop<4>(ix, n_wg, 0, nq);
+        else launch_filter_loop<8>(ix, n_wg, 0, nq);
+        PB_HIP(hipGetLastError());
+    } else if (ix->opt_mode == 0 || ix->opt_mode == 2) {
         for (uint32_t q = 0; q < nq; ++q) {
             int rc = launch_filter(ix, n_wg, q, 1);
             if (rc) return rc;
@@ -614,7 +630,7 @@ int search_chunk(pb_index *ix, uint32_t cq, uint32_t k, double max_dist, const f
         PB_HIP(hipMemcpyAsync(ix->h_res_hdr, ix->d_res_hdr, cq * sizeof(ResultHdr), hipMemcpyDeviceToHost, ix->stream));
         PB_HIP(hipStreamSynchronize(ix->stream));
         if (ix->opt_profile) {
-            int rc2 = use_multi ? account_profile(ix, 1, 1) : account_profile(ix, cq, ix->opt_mode == 0 ? cq : 1);
+            int rc2 = use_multi ? account_profile(ix, 1, 1) : account_profile(ix, cq, (ix->opt_mode == 1 || loop_mode(ix, cq)) ? 1 : cq);
             if (rc2) return rc2;
         }
         for (uint32_t q = 0; q < cq; ++q)
@@ -1202,7 +1218,7 @@ int pb_index_set_option(pb_index *ix, int option, int64_t value) {
             ix->opt_mq_per_chunk = (int)value;
             return PB_OK;
         case PB_OPT_SCAN_LAUNCH:
-            PB_CHECK(value == 0 || value == 1, PB_ERR_INVALID, "scan mode: 0 or 1");
+            PB_CHECK(value <= 2, PB_ERR_INVALID, "scan mode: 0, 1 or 2");
             ix->opt_mode = (int)value;
             return PB_OK;
         case PB_OPT_SCAN_GRID:

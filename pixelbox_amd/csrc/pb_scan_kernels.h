@@ -272,12 +272,17 @@ __global__ void k_row_norms(const uint8_t *__restrict__ rows, uint64_t first, ui
 
 // ------------------------------------------------------------------------------------------------
 // (1) HBM-bound filter pass.  LPR lanes share one row (16 B each); one wave-instruction = 64/LPR rows.
-template <int LPR, int U = 8, bool NT = true, int NW = F_WAVES, int MAPB = 0>
+// LOOPQ: the workgroup answers `nq_loop` queries one after the other in ONE launch -- for every query it streams its
+// rows again (a full pass over the table per query, ~0.4 ms apart: nothing of the previous pass is left in any cache
+// at 10M rows), but the launch gap and the ramp-up / tail of one launch per query (~12 us, a fifth of the pass over a
+// 1.25M-row shard) are paid once per batch.  Its own template instance, so that profilers list it apart from the
+// one-query launches.
+template <int LPR, int U = 8, bool NT = true, int NW = F_WAVES, int MAPB = 0, bool LOOPQ = false>
 __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__restrict__ rows, uint64_t n_rows,
                                                          const uint8_t *__restrict__ queries,
                                                          const QParams *__restrict__ qp,
                                                          uint64_t *__restrict__ lists,
-                                                         ListHdr *__restrict__ hdrs, int q_base) {
+                                                         ListHdr *__restrict__ hdrs, int q_base, int nq_loop) {
     constexpr int D = LPR * 16;
     constexpr int RPT = WAVE / LPR;                // rows per wave-instruction
     // U = loads in flight per lane (U KiB per wave); NT = non-temporal loads (the table is streamed once per query)
@@ -287,14 +292,17 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
     __shared__ int s_cnt[NW];
     __shared__ float s_drop[NW];
 
-    const int q = q_base + blockIdx.y;
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: loop bounds and LDS bases stay in SGPRs
     const int sub = lane % LPR;
     const int g = lane / LPR;
+    uint64_t *buf = s_buf[wave];
+    constexpr int ME = NW * F_KW / WAVE;  // entries per lane (workgroup merge)
+    __shared__ uint64_t s_merge[NW * F_KW];
+  for (int qi = 0; qi < (LOOPQ ? nq_loop : 1); ++qi) {
+    const int q = q_base + (LOOPQ ? qi : (int)blockIdx.y);
     const QParams P = qp[q];
     const uint4 qv = *reinterpret_cast<const uint4 *>(queries + (size_t)q * D + sub * 16);
-    uint64_t *buf = s_buf[wave];
 
     float thr = P.thr0;
     float dropped = 0.0f;
@@ -369,38 +377,39 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
         s_drop[wave] = dropped;
     }
     __syncthreads();
-    if (wave != 0) return;
-    // workgroup list: the F_KWG best of the <= 16*32 entries, sorted, by wave 0
-    constexpr int ME = NW * F_KW / WAVE;  // entries per lane
-    __shared__ uint64_t s_merge[NW * F_KW];
-    int total = 0;
-    float drop = 0.0f;
-    for (int w = 0; w < NW; ++w) {
-        const int c = s_cnt[w];
-        if (lane < c) s_merge[total + lane] = s_buf[w][lane];
-        total += c;
-        drop = fmaxf(drop, s_drop[w]);
+    if (wave == 0) {
+        // workgroup list: the F_KWG best of the <= 16*32 entries, sorted, by wave 0
+        int total = 0;
+        float drop = 0.0f;
+        for (int w = 0; w < NW; ++w) {
+            const int c = s_cnt[w];
+            if (lane < c) s_merge[total + lane] = s_buf[w][lane];
+            total += c;
+            drop = fmaxf(drop, s_drop[w]);
+        }
+        if (total > F_KWG) {
+            const uint64_t kth = wave_keep_smallest<ME>(s_merge, total, F_KWG);
+            total = F_KWG;
+            drop = fmaxf(drop, filter_key_cos(kth));
+        }
+        // rank sort (<= 32 distinct keys)
+        const uint64_t mykey = lane < total ? s_merge[lane] : ~0ull;
+        int rank = 0;
+        for (int j = 0; j < total; ++j) {
+            const uint64_t o = __shfl((unsigned long long)mykey, j);
+            rank += o < mykey ? 1 : 0;
+        }
+        uint64_t *out = lists + ((size_t)q * gridDim.x + blockIdx.x) * F_KWG;
+        if (lane < total) out[rank] = mykey;
+        if (lane == 0) {
+            ListHdr h;
+            h.count = (uint32_t)total;
+            h.dropped = drop;
+            hdrs[(size_t)q * gridDim.x + blockIdx.x] = h;
+        }
     }
-    if (total > F_KWG) {
-        const uint64_t kth = wave_keep_smallest<ME>(s_merge, total, F_KWG);
-        total = F_KWG;
-        drop = fmaxf(drop, filter_key_cos(kth));
-    }
-    // rank sort (<= 32 distinct keys)
-    const uint64_t mykey = lane < total ? s_merge[lane] : ~0ull;
-    int rank = 0;
-    for (int j = 0; j < total; ++j) {
-        const uint64_t o = __shfl((unsigned long long)mykey, j);
-        rank += o < mykey ? 1 : 0;
-    }
-    uint64_t *out = lists + ((size_t)q * gridDim.x + blockIdx.x) * F_KWG;
-    if (lane < total) out[rank] = mykey;
-    if (lane == 0) {
-        ListHdr h;
-        h.count = (uint32_t)total;
-        h.dropped = drop;
-        hdrs[(size_t)q * gridDim.x + blockIdx.x] = h;
-    }
+    if constexpr (LOOPQ) __syncthreads();  // the wave buffers are reused by the next query
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
