@@ -753,3 +753,29 @@ def test_randomized_sweep_byte_and_hamming(seed):
         c = int(got_c[qi])
         assert c == len(want_ids) and np.array_equal(got_ids[qi, :c], want_ids)
         assert np.array_equal(got_d[qi, :c].view(np.uint32), want_d.view(np.uint32))
+
+
+def test_launch_shapes_give_identical_results():
+    # PB_OPT_SCAN_LAUNCH: 0 = one launch per query, 1 = queries side by side in one grid, 2 (default) = one launch in
+    # which every workgroup answers the queries one after the other.  Same lists, same bits.
+    rng = np.random.default_rng(77)
+    n, d = 300_000, 256
+    rows = _random_table(rng, n, d, "clustered")
+    ids = np.arange(n, dtype=np.int64) + 5
+    q = _random_table(rng, 37, d, "clustered")
+    q[3] = rows[1234]
+    ix = capi.Index(d, n)
+    ix.load(ids, rows)
+    ix.set_option(capi.PB_OPT_SEARCH_PATH, 2)
+    outs = []
+    for mode in (0, 1, 2):
+        ix.set_option(capi.PB_OPT_SCAN_LAUNCH, mode)
+        outs.append(ix.search(q, 100, 10.0))
+    for o in outs[1:]:
+        assert np.array_equal(o[2], outs[0][2])
+        assert np.array_equal(o[0], outs[0][0])
+        assert np.array_equal(o[1].view(np.uint32), outs[0][1].view(np.uint32))
+    for qi in (0, 3, 36):
+        want_ids, want_d = oracle.scan_topk(q[qi], rows, ids, 100, 10.0)
+        c = int(outs[2][2][qi])
+        assert c == len(want_ids) and np.array_equal(outs[2][0][qi, :c], want_ids)
