@@ -382,10 +382,10 @@ int run_fast(pb_index *ix, uint32_t nq) {
 
 // byte_distance / hamming_distance: coalesced exact-key pass (one launch per query, like the cosine filter) + merge
 template <int METRIC>
-int launch_dist(pb_index *ix, int n_wg, uint32_t q) {
+int launch_dist(pb_index *ix, int n_wg, uint32_t q, uint32_t nq_loop) {
 #define PB_D(LPRV)                                                                                                   \
     hipLaunchKernelGGL((k_scan_dist<LPRV, METRIC>), dim3(n_wg, 1), dim3(F_WAVES * 64), 0, ix->stream, ix->d_rows, ix->n_rows, \
-                       ix->d_queries, ix->d_qp, ix->d_lists, ix->d_hdrs, ix->d_dropkeys, (int)q)
+                       ix->d_queries, ix->d_qp, ix->d_lists, ix->d_hdrs, ix->d_dropkeys, (int)q, (int)nq_loop)
     switch (ix->dim / 16) {
         case 1: PB_D(1); break;
         case 2: PB_D(2); break;
@@ -404,9 +404,14 @@ int launch_dist(pb_index *ix, int n_wg, uint32_t q) {
 int run_fast_dist(pb_index *ix, uint32_t nq) {
     const int n_wg = std::min(filter_grid(ix), (int)F_MAX_WG / 2);  // k_select_keys sorts 8192 keys: <= 256 lists
     if (ix->opt_profile) PB_HIP(hipEventRecord(ix->ev0, ix->stream));
-    for (uint32_t q = 0; q < nq; ++q) {
-        int rc = ix->metric == 1 ? launch_dist<1>(ix, n_wg, q) : launch_dist<2>(ix, n_wg, q);
+    if (ix->opt_mode == 2) {  // one launch, the queries one after the other (one table pass each)
+        int rc = ix->metric == 1 ? launch_dist<1>(ix, n_wg, 0, nq) : launch_dist<2>(ix, n_wg, 0, nq);
         if (rc) return rc;
+    } else {
+        for (uint32_t q = 0; q < nq; ++q) {
+            int rc = ix->metric == 1 ? launch_dist<1>(ix, n_wg, q, 1) : launch_dist<2>(ix, n_wg, q, 1);
+            if (rc) return rc;
+        }
     }
     if (ix->opt_profile) PB_HIP(hipEventRecord(ix->ev1, ix->stream));
     hipLaunchKernelGGL(k_select_keys, dim3(nq), dim3(SEL_BLOCK), 0, ix->stream, ix->d_ids, ix->d_qp, ix->d_lists, ix->d_hdrs,
@@ -630,7 +635,7 @@ int search_chunk(pb_index *ix, uint32_t cq, uint32_t k, double max_dist, const f
         PB_HIP(hipMemcpyAsync(ix->h_res_hdr, ix->d_res_hdr, cq * sizeof(ResultHdr), hipMemcpyDeviceToHost, ix->stream));
         PB_HIP(hipStreamSynchronize(ix->stream));
         if (ix->opt_profile) {
-            int rc2 = use_multi ? account_profile(ix, 1, 1) : account_profile(ix, cq, (ix->opt_mode == 1 || loop_mode(ix, cq)) ? 1 : cq);
+            int rc2 = use_multi ? account_profile(ix, 1, 1) : account_profile(ix, cq, (ix->opt_mode == 1 || loop_mode(ix, cq) || (use_dist && ix->opt_mode == 2)) ? 1 : cq);
             if (rc2) return rc2;
         }
         for (uint32_t q = 0; q < cq; ++q)

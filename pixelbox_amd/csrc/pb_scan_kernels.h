@@ -424,7 +424,7 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_dist(const uint8_t *__restri
                                                        const uint8_t *__restrict__ queries,
                                                        const QParams *__restrict__ qp, uint64_t *__restrict__ lists,
                                                        ListHdr *__restrict__ hdrs, uint64_t *__restrict__ drop_keys,
-                                                       int q_base) {
+                                                       int q_base, int nq_loop) {
     constexpr int D = LPR * 16;
     constexpr int RPT = WAVE / LPR;
     constexpr int ROWS_IT = U * RPT;
@@ -432,14 +432,18 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_dist(const uint8_t *__restri
     __shared__ uint64_t s_buf[NW][F_CAPW];
     __shared__ int s_cnt[NW];
     __shared__ uint64_t s_drop[NW];
-    const int q = q_base + blockIdx.y;
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: loop bounds and LDS bases stay in SGPRs
     const int sub = lane % LPR;
     const int g = lane / LPR;
+    uint64_t *buf = s_buf[wave];
+    constexpr int ME = NW * F_KW / WAVE;
+    __shared__ uint64_t s_merge[NW * F_KW];
+  // nq_loop queries one after the other in this launch (one table pass each), as k_scan_filter's LOOPQ form
+  for (int qi = 0; qi < nq_loop; ++qi) {
+    const int q = q_base + qi;
     const QParams P = qp[q];
     const uint4 qv = *reinterpret_cast<const uint4 *>(queries + (size_t)q * D + sub * 16);
-    uint64_t *buf = s_buf[wave];
     uint64_t thr_key = ~0ull;  // keep keys < thr_key
     uint64_t dropped = ~0ull;  // smallest key this wave dropped
     int cnt = 0;
@@ -507,9 +511,7 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_dist(const uint8_t *__restri
         s_drop[wave] = dropped;
     }
     __syncthreads();
-    if (wave != 0) return;
-    constexpr int ME = NW * F_KW / WAVE;
-    __shared__ uint64_t s_merge[NW * F_KW];
+    if (wave == 0) {
     int total = 0;
     uint64_t drop = ~0ull;
     for (int w = 0; w < NW; ++w) {
@@ -538,6 +540,9 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_dist(const uint8_t *__restri
         hdrs[(size_t)q * gridDim.x + blockIdx.x] = h;
         drop_keys[(size_t)q * gridDim.x + blockIdx.x] = drop;  // every key this workgroup saw and did not list is >= drop
     }
+    }
+    if (qi + 1 < nq_loop) __syncthreads();  // the wave buffers are reused by the next query
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
