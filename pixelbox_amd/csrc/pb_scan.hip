@@ -291,9 +291,9 @@ void launch_filter_t(pb_index *ix, int n_wg, uint32_t q_base, uint32_t nq) {
                        ix->n_rows, ix->d_queries, ix->d_qp, ix->d_lists, ix->d_hdrs, (int)q_base, 1);
 }
 // one launch, every workgroup answers the nq queries one after the other (k_scan_filter LOOPQ)
-template <int NW>
+template <int NW, int U = 8, int MAPB = 0>
 void launch_filter_loop(pb_index *ix, int n_wg, uint32_t q_base, uint32_t nq) {
-    hipLaunchKernelGGL((k_scan_filter<16, 8, true, NW, 0, true>), dim3(n_wg, 1), dim3(NW * 64), 0, ix->stream, ix->d_rows,
+    hipLaunchKernelGGL((k_scan_filter<16, U, true, NW, MAPB, true>), dim3(n_wg, 1), dim3(NW * 64), 0, ix->stream, ix->d_rows,
                        ix->n_rows, ix->d_queries, ix->d_qp, ix->d_lists, ix->d_hdrs, (int)q_base, (int)nq);
 }
 
@@ -352,7 +352,8 @@ int launch_filter(pb_index *ix, int n_wg, uint32_t q_base, uint32_t nq) {
 
 // PB_OPT_SCAN_LAUNCH = 2: the queries of a chunk in one launch, one table pass per query (dim 256, default load variant)
 bool loop_mode(const pb_index *ix, uint32_t nq) {
-    return ix->opt_mode == 2 && nq > 1 && ix->dim == 256 && (ix->opt_variant & 15) == 0 && (ix->opt_waves == 8 || ix->opt_waves == 4);
+    const int v = ix->opt_variant & 15;
+    return ix->opt_mode == 2 && nq > 1 && ix->dim == 256 && (ix->opt_waves == 8 ? (v == 0 || v == 8 || v == 2 || v == 4) : (ix->opt_waves == 4 && v == 0));
 }
 
 // fast path for nq staged queries; results + status land in d_res_*
@@ -360,7 +361,11 @@ int run_fast(pb_index *ix, uint32_t nq) {
     const int n_wg = filter_grid(ix);
     if (ix->opt_profile) PB_HIP(hipEventRecord(ix->ev0, ix->stream));
     if (loop_mode(ix, nq)) {
-        if (ix->opt_waves == 4) launch_filter_loop<4>(ix, n_wg, 0, nq);
+        const int v = ix->opt_variant & 15;
+        if (v == 8) launch_filter_loop<8, 8, 1>(ix, n_wg, 0, nq);
+        else if (v == 2) launch_filter_loop<8, 16, 0>(ix, n_wg, 0, nq);
+        else if (v == 4) launch_filter_loop<8, 4, 0>(ix, n_wg, 0, nq);
+        else if (ix->opt_waves == 4) launch_filter_loop<4>(ix, n_wg, 0, nq);
         else launch_filter_loop<8>(ix, n_wg, 0, nq);
         PB_HIP(hipGetLastError());
     } else if (ix->opt_mode == 0 || ix->opt_mode == 2) {
