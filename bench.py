@@ -356,15 +356,32 @@ def bench_end_to_end(args, torch, rank, world, device, distributed):
     barrier()
     t0 = time.perf_counter()
     t_gen = 0.0
-    for first in range(sh.row_lo, sh.row_hi, nb):
+    # embed and insert run on ONE stream with nothing waited for in between (PB_OPT_EMBED_STREAM, PB_OPT_STREAM,
+    # PB_OPT_APPEND_ASYNC): the host queues batch i+1 while the GPU works on batch i.  Two (images, hashes) buffer pairs;
+    # a pair is reused once the event recorded behind its insert has passed.
+    pipe = torch.cuda.Stream(device=device)
+    emb.set_option(capi.PB_OPT_EMBED_STREAM, pipe.cuda_stream)
+    sh.index.set_option(capi.PB_OPT_STREAM, pipe.cuda_stream)
+    sh.index.set_option(capi.PB_OPT_APPEND_ASYNC, 1)
+    bufs = [(imgs, out), (torch.empty_like(imgs), torch.empty_like(out))]
+    done = [None, None]
+    for i, first in enumerate(range(sh.row_lo, sh.row_hi, nb)):
         count = min(nb, sh.row_hi - first)
+        b_imgs, b_out = bufs[i & 1]
+        if done[i & 1] is not None:
+            done[i & 1].synchronize()
         tg = time.perf_counter()
-        capi.fill_synthetic_images_device(device, synth.SEED_IMAGES, first, count, 128, 128, imgs.data_ptr())
+        capi.fill_synthetic_images_device(device, synth.SEED_IMAGES, first, count, 128, 128, b_imgs.data_ptr())
         t_gen += time.perf_counter() - tg
-        emb.embed_device(imgs.data_ptr(), count, out.data_ptr())
-        torch.cuda.synchronize()
-        sh.index.append_device(np.arange(first + 1, first + count + 1, dtype=np.int64), out.data_ptr())
+        emb.embed_device(b_imgs.data_ptr(), count, b_out.data_ptr())
+        sh.index.append_device(np.arange(first + 1, first + count + 1, dtype=np.int64), b_out.data_ptr())
+        ev = torch.cuda.Event()
+        ev.record(pipe)
+        done[i & 1] = ev
     barrier()
+    emb.set_option(capi.PB_OPT_EMBED_STREAM, 0)
+    sh.index.set_option(capi.PB_OPT_STREAM, 0)
+    sh.index.set_option(capi.PB_OPT_APPEND_ASYNC, 0)
     t_index = time.perf_counter() - t0
     # 1000 query images, evenly spread over the collection; every rank recomputes their hashes (bit-identical on
     # every GPU and for every batch size)
@@ -400,7 +417,8 @@ def bench_end_to_end(args, torch, rank, world, device, distributed):
             "queries_with_zero_distance_first_hit": self_found, "queries_whose_first_hit_is_their_own_id": exact_self,
             "certified": int(st.fast_path), "second_chance": int(st.second_chance), "exhaustive_fallback": int(st.fallback),
             "note": "images generated on the GPU (pb_fill_synthetic_images), embedded in batches of 512, hashes inserted "
-                    "device-to-device through pb_index_append_device (per-row norms computed at insert); "
+                    "device-to-device through pb_index_append_device (per-row norms computed at insert), embed and insert queued "
+                    "on one stream with nothing waited for between batches (PB_OPT_APPEND_ASYNC); "
                     "the configuration itself is 1000000 images (--e2e-images 1000000).  The random-init network maps "
                     "the synthetic images onto few distinct hashes (~40 % exact duplicates, clusters of tens of "
                     "thousands of rows within 4e-4 of a query's 100th cosine): for such queries no candidate list "

@@ -149,6 +149,9 @@ int pb_index_fill_synthetic(pb_index *idx, uint64_t seed, uint64_t first_row, ui
                                    queries one after the other, streaming its rows once per query (one HBM pass per query as with 0, \
                                    without the launch gap / ramp / tail between them; dim 256, else as 0) */
 #define PB_OPT_MQ_WG_PER_CU 10  /* concurrent-query pass: workgroups per CU (default 2) */
+#define PB_OPT_APPEND_ASYNC 12 /* 1: pb_index_append_device returns with its copies and the per-row norms queued on the index's stream \
+                                 instead of waiting for them (a producer on the same stream -- PB_OPT_STREAM, PB_OPT_EMBED_STREAM -- \
+                                 can then run ahead of the GPU); searches wait as before */
 #define PB_OPT_MQ_PER_CHUNK 11  /* 1: bursts of > 64 queries run one 64-query pass at a time instead of sharing row tiles
                                   among 512 queries per workgroup (default 0; for measurement) */
 int pb_index_set_option(pb_index *idx, int option, int64_t value);

@@ -21,6 +21,8 @@ PB_OPT_STREAM = 3
 PB_OPT_MQ_MIN_QUERIES = 9
 PB_OPT_MQ_WG_PER_CU = 10
 PB_OPT_MQ_PER_CHUNK = 11
+PB_OPT_APPEND_ASYNC = 12
+PB_OPT_EMBED_STREAM = 3  # pb_embed_set_option: stream handle to launch on (0 = the embedder's own)
 PB_OPT_SCAN_LAUNCH = 8  # 0: one launch per query; 1: queries side by side in one grid; 2 (default): one launch, queries one after the other
 PB_METRIC_COSINE, PB_METRIC_BYTE, PB_METRIC_HAMMING = 0, 1, 2
 

@@ -48,6 +48,8 @@ struct pb_index {
     int32_t *d_denb = nullptr;
     int32_t *d_min_den = nullptr;     // min over stored rows of sum (2b-255)^2 (device scalar, kept by k_row_norms)
     int32_t min_den_b = 0x7FFFFFFF;   // host copy
+    bool min_dirty = false;           // d_min_den is newer than min_den_b (asynchronous appends): refreshed before the next search
+    int opt_append_async = 0;         // PB_OPT_APPEND_ASYNC
     float *d_lut = nullptr;
     std::vector<int64_t> h_ids;  // ascending, mirrors d_ids
     float lut[256];
@@ -189,9 +191,21 @@ int launch_norms(pb_index *ix, uint64_t first, uint64_t n) {
     hipLaunchKernelGGL(k_row_norms, dim3(grid), dim3(block), 0, ix->stream, ix->d_rows, first, n, (int)ix->dim,
                        ix->d_lut, ix->d_norms, ix->d_sumb, ix->d_denb, ix->d_min_den);
     PB_HIP(hipGetLastError());
-    // the running minimum feeds the per-query error margin (finish_qparams); every caller synchronises next
+    // the running minimum feeds the per-query error margin (finish_qparams)
+    if (ix->opt_append_async) {
+        ix->min_dirty = true;  // read back by refresh_min_den before the next search
+        return PB_OK;
+    }
     PB_HIP(hipMemcpyAsync(&ix->min_den_b, ix->d_min_den, sizeof(int32_t), hipMemcpyDeviceToHost, ix->stream));
     PB_HIP(hipStreamSynchronize(ix->stream));
+    return PB_OK;
+}
+
+int refresh_min_den(pb_index *ix) {
+    if (!ix->min_dirty) return PB_OK;
+    PB_HIP(hipMemcpyAsync(&ix->min_den_b, ix->d_min_den, sizeof(int32_t), hipMemcpyDeviceToHost, ix->stream));
+    PB_HIP(hipStreamSynchronize(ix->stream));
+    ix->min_dirty = false;
     return PB_OK;
 }
 
@@ -626,6 +640,7 @@ int search_chunk(pb_index *ix, uint32_t cq, uint32_t k, double max_dist, const f
     // cosine: filter pass + certificate; byte / hamming: coalesced exact-key pass + drop-bound check
     const bool use_dist = ix->metric != 0 && ix->opt_path != 1 && fast_dim(d);
     const bool use_fast = use_dist || (ix->metric == 0 && (ix->opt_path == 0 || ix->opt_path == 2 || ix->opt_path == 3) && fast_dim(d));
+    { int rcm = refresh_min_den(ix); if (rcm) return rcm; }
     make_qparams_batch(ix, hq, cq, k, max_dist, hp);
     PB_HIP(hipMemcpyAsync(ix->d_queries, hq, (size_t)cq * d, hipMemcpyHostToDevice, ix->stream));
     PB_HIP(hipMemcpyAsync(ix->d_qp, hp, (size_t)cq * sizeof(QParams), hipMemcpyHostToDevice, ix->stream));
@@ -726,6 +741,7 @@ int search_block_multi(pb_index *ix, const uint8_t *queries, uint32_t nq, uint32
     uint8_t *hq = ix->h_pipe;
     QParams *hp = reinterpret_cast<QParams *>(ix->h_pipe + (size_t)PIPE_Q * d);
     memcpy(hq, queries, (size_t)nq * d);
+    { int rcm = refresh_min_den(ix); if (rcm) return rcm; }
     make_qparams_batch(ix, hq, nq, k, max_dist, hp);
     PB_HIP(hipMemcpyAsync(ix->d_queries, hq, (size_t)nq * d, hipMemcpyHostToDevice, ix->stream));
     PB_HIP(hipMemcpyAsync(ix->d_qp, hp, (size_t)nq * sizeof(QParams), hipMemcpyHostToDevice, ix->stream));
@@ -902,7 +918,9 @@ int append_tail(pb_index *ix, const int64_t *ids, const uint8_t *rows, uint64_t 
     PB_HIP(hipMemcpyAsync(ix->d_ids + ix->n_rows, ids, n * sizeof(int64_t), hipMemcpyHostToDevice, ix->stream));
     int rc = launch_norms(ix, ix->n_rows, n);
     if (rc) return rc;
-    PB_HIP(hipStreamSynchronize(ix->stream));
+    // PB_OPT_APPEND_ASYNC: the device-to-device form returns with its work queued on the stream (the ids were staged by
+    // the runtime: `ids` is pageable host memory); everything that reads the index runs on the same stream or waits for it
+    if (!(ix->opt_append_async && kind == hipMemcpyDeviceToDevice)) PB_HIP(hipStreamSynchronize(ix->stream));
     ix->h_ids.insert(ix->h_ids.end(), ids, ids + n);
     ix->n_rows += n;
     return PB_OK;
@@ -1230,6 +1248,9 @@ int pb_index_set_option(pb_index *ix, int option, int64_t value) {
         case PB_OPT_SCAN_LAUNCH:
             PB_CHECK(value <= 2, PB_ERR_INVALID, "scan mode: 0, 1 or 2");
             ix->opt_mode = (int)value;
+            return PB_OK;
+        case PB_OPT_APPEND_ASYNC:
+            ix->opt_append_async = value != 0;
             return PB_OK;
         case PB_OPT_SCAN_GRID:
             ix->opt_grid = (int)value;

@@ -779,3 +779,32 @@ def test_launch_shapes_give_identical_results():
         want_ids, want_d = oracle.scan_topk(q[qi], rows, ids, 100, 10.0)
         c = int(outs[2][2][qi])
         assert c == len(want_ids) and np.array_equal(outs[2][0][qi, :c], want_ids)
+
+
+def test_append_device_async_on_a_shared_stream():
+    # PB_OPT_APPEND_ASYNC + PB_OPT_STREAM: appends queue their copies and norms on the producer's stream and return;
+    # a search afterwards sees every row (and the error margin's running minimum) as if the appends had been waited for.
+    import torch
+
+    rng = np.random.default_rng(5)
+    d, n, nb = 256, 6000, 500
+    rows = _random_table(rng, n, d, "clustered")
+    ids = np.arange(n, dtype=np.int64) * 3 + 7
+    ref = capi.Index(d, n)
+    ref.load(ids, rows)
+    ix = capi.Index(d, n)
+    s = torch.cuda.Stream()
+    ix.set_option(capi.PB_OPT_STREAM, s.cuda_stream)
+    ix.set_option(capi.PB_OPT_APPEND_ASYNC, 1)
+    dev = torch.from_numpy(rows).cuda()
+    with torch.cuda.stream(s):
+        for lo in range(0, n, nb):
+            staged = dev[lo:lo + nb].clone()  # produced on the same stream, consumed by the queued copy
+            ix.append_device(ids[lo:lo + nb], staged.data_ptr())
+    q = _random_table(rng, 9, d, "clustered")
+    q[0] = rows[4321]
+    got = ix.search(q, 100, 10.0)
+    want = ref.search(q, 100, 10.0)
+    assert np.array_equal(got[2], want[2]) and np.array_equal(got[0], want[0])
+    assert np.array_equal(got[1].view(np.uint32), want[1].view(np.uint32))
+    assert len(ix) == n
