@@ -155,3 +155,19 @@ def test_sharded_query_over_gloo(world, tmp_path):
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, out[-2000:]
         assert f"RANK {r} OK" in out
+
+
+def test_option_constants_of_the_python_binding_match_the_header():
+    import re
+
+    from pixelbox_amd import capi
+
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "pixelbox_hip.h")).read()
+    defs = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+(PB_(?:OPT|METRIC|ERR)_[A-Z0-9_]+)\s+(-?\d+)\b", hdr)}
+    assert defs, "no option constants found in the header"
+    checked = 0
+    for name, value in vars(capi).items():
+        if name.startswith(("PB_OPT_", "PB_METRIC_")) and name in defs:
+            assert defs[name] == value, (name, defs[name], value)
+            checked += 1
+    assert checked >= 8
