@@ -51,9 +51,14 @@ def parse():
     ap.add_argument("--embed-batch", type=int, default=512)
     ap.add_argument("--embed-steps", type=int, default=10)
     ap.add_argument("--no-embed", action="store_true")
-    ap.add_argument("--e2e-images", type=int, default=131072,
+    ap.add_argument("--e2e-images", type=int, default=1_000_000,
                     help="end-to-end leg (BASELINE configs[4]): embed + insert this many synthetic images, then serve "
-                         "1000 concurrent queries (0: skip; the configuration itself is 1000000)")
+                         "1000 concurrent queries (0: skip; the configuration itself is 1000000, the default)")
+    ap.add_argument("--e2e-parity-queries", type=int, default=8,
+                    help="end-to-end leg: this many of its queries are re-answered by the CPU oracle over the read-back table "
+                         "(outside the timed region) and compared bit for bit")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the 10M/20M/40M-row sweep, the cache-eviction variant and the "
+                                                            "1M-row (configs[1]) cold/warm leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=2_000_000)
     ap.add_argument("--exact-path", action="store_true", help="force the exhaustive exact scan (diagnostic)")
@@ -187,7 +192,24 @@ def main():
                 "ms_per_table_pass": round(st.profiled_ms * len(sh.index) * d / st.profiled_bytes, 4), "traffic": None}
 
     if roof is not None:
-        roof["traffic"] = pmc_traffic(roof["kernel"], roof["bytes_per_launch"])
+        # HBM bytes from PMC counters cannot be collected inside this process (rocprofv3 --pmc is a separate run of
+        # the same command): the field stays null here and the committed summary is cited by path
+        roof["traffic"] = None
+        roof["traffic_profile"] = latest_profile("scan_pmc")
+        # the reference's call shape: ONE query per call (engine.rs:363-396) -- wall time of the whole call
+        # (staging kernel, filter pass, re-scoring, results written to pinned host memory, one wait)
+        call_gbs = len(sh.index) * d / (lat_ms * 1e-3) / 1e9
+        roof_single = {"bound": "hbm", "what": "pb_index_search with one query: wall time of the call, host side included",
+                       "ms_per_call": round(lat_ms, 4), "achieved": round(call_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": round(call_gbs / HBM_PEAK_GBS, 4)}
+    else:
+        roof_single = None
+
+    sweep = None
+    if world == 1 and not args.no_sweep and not args.exact_path and d == 256:
+        del sh
+        sh = None
+        sweep = bench_sweep(args, torch, local_rank)
 
     embed = None
     if not args.no_embed:
@@ -198,7 +220,7 @@ def main():
 
     e2e = None
     if args.e2e_images > 0 and not args.no_embed and not args.exact_path:
-        del sh  # free the 10M-row shard first
+        sh = None  # free the 10M-row shard first
         try:
             e2e = bench_end_to_end(args, torch, rank, world, local_rank, distributed)
         except capi.PixelboxError as e:
@@ -222,8 +244,12 @@ def main():
             "ms_per_query": round(dt / (args.steps * B) * 1e3, 4), "latency_ms_single_query_call": round(lat_ms, 4),
             "path_counts": {"queries": int(st.queries), "filter_certified": int(st.fast_path),
                             "second_chance": int(st.second_chance), "exhaustive": int(st.fallback)},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_single_call": roof_single, "cpu_baseline": cpu,
         }
+        if sweep is not None:
+            out["roofline"]["n_sweep"] = sweep["n_sweep"]
+            out["roofline"]["evicted_between_passes"] = sweep["evicted"]
+            out["scan_1m"] = sweep["scan_1m"]
         if concurrent is not None:
             out["concurrent"] = concurrent
         if embed is not None:
@@ -239,25 +265,103 @@ def main():
         torch.distributed.destroy_process_group()
 
 
-def pmc_traffic(kernel: str, bytes_per_launch: int):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary (profiles/rNN_scan_pmc.json:
-    FETCH_SIZE x2 (gfx950 wide-stream correction) + WRITE_SIZE, separate passes, same command line).  PMC passes
-    cannot run inside this process; the number is reported only when the profiled launch had the same
-    algorithmic byte count as this run's, otherwise null."""
+def latest_profile(tag: str):
+    """Path (relative to the repo) of the newest committed rocprofv3 summary profiles/rNN_<tag>.json, or None.  The
+    bench cites it; it never copies numbers out of it."""
     import glob
 
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_scan_pmc.json")), reverse=True):
-        try:
-            with open(path) as f:
-                summ = json.load(f)
-        except Exception:
-            continue
-        for name, d in summ.items():
-            if kernel in name and "hbm_bytes_per_launch" in d:
-                hb = int(d["hbm_bytes_per_launch"])
-                if abs(hb - bytes_per_launch) <= 0.05 * bytes_per_launch:
-                    return hb
-    return None
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{tag}.json")), reverse=True)
+    return os.path.relpath(paths[0], ROOT) if paths else None
+
+
+def bench_sweep(args, torch, device):
+    """Is the headline rate an HBM rate?  (a) The same launch shape at 10M / 20M / 40M rows: whatever the 256 MiB
+    Infinity Cache contributes to a 2.56 GB sweep (at most 10 %) shrinks to 2.5 % at 10.24 GB.  (b) One launch per query
+    with a 512 MiB write between them: nothing of the table is left in any cache when a pass starts.  (c) BASELINE
+    configs[1]: a 1M-row table (256 MB: it FITS the Infinity Cache), batch-1 query, warm (passes back to back) and
+    cold (evicted in between).  Kernel times are HIP events around the filter kernel on its stream (PB_OPT_PROFILE)."""
+    from pixelbox_amd import capi, synth
+
+    d, k, B = args.dim, args.k, args.queries
+    q = synth.fill_synthetic(synth.SEED_QUERY + 7, 0, 4 * B * d).reshape(4, B, d)
+    ix = capi.Index(d, 40_000_000, device)
+    ix.set_option(capi.PB_OPT_SEARCH_PATH, 2)
+    out = {"n_sweep": [], "evicted": None, "scan_1m": None}
+
+    def timed(index, queries, reps):
+        index.search(queries, k, args.max_dist)
+        index.stats(reset=True)
+        index.set_option(capi.PB_OPT_PROFILE, 1)
+        for r in range(reps):
+            index.search(queries if queries.ndim == 2 else queries[r % len(queries)], k, args.max_dist)
+        index.set_option(capi.PB_OPT_PROFILE, 0)
+        st = index.stats()
+        return st.profiled_bytes / (st.profiled_ms * 1e-3) / 1e9, st.profiled_ms / max(1, st.profiled_launches), st
+
+    evict = torch.empty(512 << 20, dtype=torch.uint8, device=f"cuda:{device}")
+    filled = 0
+    for rows in (10_000_000, 20_000_000, 40_000_000):
+        ix.fill_synthetic(synth.SEED_INDEX, filled, rows - filled, filled + 1)
+        filled = rows
+        gbs, ms, st = timed(ix, q[0], 3)
+        out["n_sweep"].append({"rows": rows, "table_GB": round(rows * d / 1e9, 2), "GB/s": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
+                               "ms_per_table_pass": round(st.profiled_ms * rows * d / st.profiled_bytes, 4),
+                               "filter_certified": int(st.fast_path), "queries": int(st.queries)})
+        if rows == 10_000_000:
+            # (b) one launch per query, the caches flushed by a 512 MiB write before each
+            ix.set_option(capi.PB_OPT_SCAN_LAUNCH, 0)
+            ix.search(q[1][:1], k, args.max_dist)
+            ix.stats(reset=True)
+            ix.set_option(capi.PB_OPT_PROFILE, 1)
+            for i in range(8):
+                evict.fill_(i)
+                torch.cuda.synchronize()
+                ix.search(q[1][i:i + 1], k, args.max_dist)
+            ix.set_option(capi.PB_OPT_PROFILE, 0)
+            st = ix.stats()
+            gbs_e = st.profiled_bytes / (st.profiled_ms * 1e-3) / 1e9
+            # the same single-query launches back to back, for comparison
+            ix.stats(reset=True)
+            ix.set_option(capi.PB_OPT_PROFILE, 1)
+            for i in range(8):
+                ix.search(q[1][i:i + 1], k, args.max_dist)
+            ix.set_option(capi.PB_OPT_PROFILE, 0)
+            st2 = ix.stats()
+            gbs_b = st2.profiled_bytes / (st2.profiled_ms * 1e-3) / 1e9
+            ix.set_option(capi.PB_OPT_SCAN_LAUNCH, 2)
+            out["evicted"] = {"rows": rows, "launch": "one launch per query", "evict_bytes": 512 << 20,
+                              "GB/s_after_eviction": round(gbs_e, 1), "frac_after_eviction": round(gbs_e / HBM_PEAK_GBS, 4),
+                              "GB/s_back_to_back": round(gbs_b, 1), "frac_back_to_back": round(gbs_b / HBM_PEAK_GBS, 4)}
+    del ix
+    # (c) configs[1]: 1M rows
+    ix = capi.Index(d, 1_000_000, device)
+    ix.set_option(capi.PB_OPT_SEARCH_PATH, 2)
+    ix.set_option(capi.PB_OPT_SCAN_LAUNCH, 0)
+    ix.fill_synthetic(synth.SEED_INDEX, 0, 1_000_000, 1)
+    q1 = q[2]
+    ix.search(q1[:1], k, args.max_dist)
+    res = {}
+    for name, do_evict in (("warm", False), ("cold", True)):
+        ix.stats(reset=True)
+        ix.set_option(capi.PB_OPT_PROFILE, 1)
+        wall = []
+        for i in range(16):
+            if do_evict:
+                evict.fill_(i)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ix.search(q1[i:i + 1], k, args.max_dist)
+            wall.append((time.perf_counter() - t0) * 1e3)
+        ix.set_option(capi.PB_OPT_PROFILE, 0)
+        st = ix.stats()
+        kms = st.profiled_ms / max(1, st.profiled_launches)
+        res[name] = {"kernel_ms": round(kms, 4), "kernel_GB/s": round(1_000_000 * d / (kms * 1e-3) / 1e9, 1),
+                     "call_ms_median": round(sorted(wall)[len(wall) // 2], 4)}
+    res["note"] = ("BASELINE configs[1]: 1M x 256 u8, batch-1 query, one launch per query; the 256 MB table fits the 256 MiB "
+                   "Infinity Cache, so 'warm' (passes back to back) is a cache number and only 'cold' (512 MiB written between "
+                   "queries) is an HBM number")
+    out["scan_1m"] = res
+    return out
 
 
 def bench_embed(args, torch, device, distributed):
@@ -272,7 +376,8 @@ def bench_embed(args, torch, device, distributed):
     # a dedicated (non-null) torch stream: the kernels are launched on it, and the events that time them
     # are recorded on it (torch.cuda.Event only sees the stream it is recorded on)
     stream = torch.cuda.Stream(device=device)
-    emb.set_option(capi.PB_OPT_STREAM, stream.cuda_stream)
+    emb.set_option(capi.PB_OPT_EMBED_STREAM, stream.cuda_stream)
+    emb.set_option(capi.PB_OPT_EMBED_ASYNC, 1)  # the timed loop queues its batches; the events below bracket them on the stream
     assert stream.cuda_stream != 0
     torch.cuda.synchronize()
     with torch.cuda.stream(stream):
@@ -295,11 +400,13 @@ def bench_embed(args, torch, device, distributed):
            "value": round(ips * world, 1), "unit": "images/s", "batch": nb, "ms_per_batch": round(ms, 4), "dtype": "f32",
            "scaling": "weak (replicated weights, images split by rank; no collective)",
            "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None}}
+                        "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                        "traffic_profile": latest_profile("embed_pmc")}}
     # the boundary as the reference's callers see it: host buffers in, host buffers out (PCIe inclusive), and
     # the batch-1 `mlhash` latency (efficientnet.rs:31-42; engine.rs:355-358 prints this for a query image)
     host_imgs = synth.fill_synthetic(synth.SEED_IMAGES, 0, nb * 128 * 128 * 3).reshape(nb, 128, 128, 3)
-    emb.set_option(capi.PB_OPT_STREAM, 0)
+    emb.set_option(capi.PB_OPT_EMBED_STREAM, 0)
+    emb.set_option(capi.PB_OPT_EMBED_ASYNC, 0)
     emb.embed(host_imgs, want_f32=False)
     t0 = time.perf_counter()
     for _ in range(3):
@@ -361,6 +468,7 @@ def bench_end_to_end(args, torch, rank, world, device, distributed):
     # a pair is reused once the event recorded behind its insert has passed.
     pipe = torch.cuda.Stream(device=device)
     emb.set_option(capi.PB_OPT_EMBED_STREAM, pipe.cuda_stream)
+    emb.set_option(capi.PB_OPT_EMBED_ASYNC, 1)
     sh.index.set_option(capi.PB_OPT_STREAM, pipe.cuda_stream)
     sh.index.set_option(capi.PB_OPT_APPEND_ASYNC, 1)
     bufs = [(imgs, out), (torch.empty_like(imgs), torch.empty_like(out))]
@@ -380,6 +488,7 @@ def bench_end_to_end(args, torch, rank, world, device, distributed):
         done[i & 1] = ev
     barrier()
     emb.set_option(capi.PB_OPT_EMBED_STREAM, 0)
+    emb.set_option(capi.PB_OPT_EMBED_ASYNC, 0)
     sh.index.set_option(capi.PB_OPT_STREAM, 0)
     sh.index.set_option(capi.PB_OPT_APPEND_ASYNC, 0)
     t_index = time.perf_counter() - t0
@@ -408,6 +517,28 @@ def bench_end_to_end(args, torch, rank, world, device, distributed):
         t = torch.tensor([t_index, t_query], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         t_index, t_query = float(t[0].item()), float(t[1].item())
+    # parity (outside the timed region): the table is read back and a spread of the queries is re-answered by the CPU
+    # oracle (the checker, never the thing measured).  One GPU: the global answer; several: this rank's shard
+    parity = None
+    if args.e2e_parity_queries > 0 and rank == 0:
+        from oracle import capi as oracle
+
+        t_ids, t_rows = sh.index.read(0, len(sh.index))
+        sel = [(j * nq) // args.e2e_parity_queries for j in range(args.e2e_parity_queries)]
+        if world == 1:
+            g_ids, g_dist, g_cnt = ids, dist, cnt
+        else:
+            g_ids, g_dist, g_cnt = sh.index.search(qh[sel], args.k, args.max_dist)
+        ok = 0
+        for j, qi in enumerate(sel):
+            w_ids, w_d = oracle.scan_topk(qh[qi], t_rows, t_ids, args.k, args.max_dist)
+            row = qi if world == 1 else j
+            c = int(g_cnt[row])
+            ok += int(c == len(w_ids) and np.array_equal(g_ids[row, :c], w_ids)
+                      and np.array_equal(g_dist[row, :c].view(np.uint32), w_d.view(np.uint32)))
+        parity = {"parity_checked": len(sel), "parity_ok": ok,
+                  "against": "oracle.scan_topk over the read-back table" + ("" if world == 1 else " (rank 0's shard)")}
+        del t_rows
     # every query image is in the collection: its own id (or an identical hash with a smaller id) comes first
     self_found = int(np.sum((cnt > 0) & (dist[:, 0] <= 1e-6)))
     exact_self = int(np.sum(ids[:, 0] == pick + 1))
@@ -416,10 +547,11 @@ def bench_end_to_end(args, torch, rank, world, device, distributed):
             "queries": nq, "query_phase_ms": round(t_query * 1e3, 3), "queries_per_s": round(nq / t_query, 1),
             "queries_with_zero_distance_first_hit": self_found, "queries_whose_first_hit_is_their_own_id": exact_self,
             "certified": int(st.fast_path), "second_chance": int(st.second_chance), "exhaustive_fallback": int(st.fallback),
+            "parity": parity,
             "note": "images generated on the GPU (pb_fill_synthetic_images), embedded in batches of 512, hashes inserted "
                     "device-to-device through pb_index_append_device (per-row norms computed at insert), embed and insert queued "
                     "on one stream with nothing waited for between batches (PB_OPT_APPEND_ASYNC); "
-                    "the configuration itself is 1000000 images (--e2e-images 1000000).  The random-init network maps "
+                    "the configuration is 1000000 images.  The random-init network maps "
                     "the synthetic images onto few distinct hashes (~40 % exact duplicates, clusters of tens of "
                     "thousands of rows within 4e-4 of a query's 100th cosine): for such queries no candidate list "
                     "can certify the top-100 and they take the exhaustive pass (counted above)"}

@@ -68,6 +68,8 @@ int pb_index_create_metric(pb_index **out, int device, uint32_t dim, uint64_t ca
 int pb_index_destroy(pb_index *idx);
 int pb_index_size(const pb_index *idx, uint64_t *n_rows);
 int pb_index_dim(const pb_index *idx, uint32_t *dim);
+/* *found = 1 iff a row with this image_id is stored (the `image_id INTEGER PRIMARY KEY` lookup, engine.rs:48,109) */
+int pb_index_contains(const pb_index *idx, int64_t image_id, int *found);
 
 /* Replaces `INSERT OR IGNORE INTO semantic_hashes (image_id, hash) VALUES (?, ?)` (engine.rs:251-256),
  * batched: n (image_id, hash) pairs from HOST memory.  OR IGNORE semantics: a pair whose image_id is
@@ -123,6 +125,13 @@ int pb_topk_merge_packed(const int64_t *gathered, uint32_t n_lists, uint32_t nq,
 int pb_topk_merge(const int64_t *ids, const float *dist, const uint32_t *counts, uint32_t n_lists,
                   uint32_t stride, uint32_t k, int64_t *out_ids, float *out_dist, uint32_t *out_count);
 
+/* The same merge on the GPU: d_gathered is the all-gathered message block in DEVICE memory of `device` (one rank's receive
+ * buffer); results to HOST buffers.  One workgroup per query ranks every listed entry by binary searches over the other
+ * lists (pb_merge_kernels.h).  This is the merge pb_sharded_search runs internally; it is exported for hosts that run
+ * their own exchange (bench.py under torchrun: one process per GPU). */
+int pb_topk_merge_packed_device(int device, const int64_t *d_gathered, uint32_t n_lists, uint32_t nq, uint32_t k,
+                                int64_t *out_ids, float *out_dist, uint32_t *out_count);
+
 /* Read back stored rows [first, first+n) in image_id order to HOST buffers (either may be NULL):
  * the checkpoint path -- the SQLite file stays the system of record. */
 int pb_index_read(const pb_index *idx, uint64_t first, uint64_t n, int64_t *image_ids, uint8_t *rows);
@@ -152,6 +161,7 @@ int pb_index_fill_synthetic(pb_index *idx, uint64_t seed, uint64_t first_row, ui
 #define PB_OPT_APPEND_ASYNC 12 /* 1: pb_index_append_device returns with its copies and the per-row norms queued on the index's stream \
                                  instead of waiting for them (a producer on the same stream -- PB_OPT_STREAM, PB_OPT_EMBED_STREAM -- \
                                  can then run ahead of the GPU); searches wait as before */
+#define PB_OPT_EXACT_QN 13 /* exhaustive pass over 256-byte cosine rows: queries answered per table sweep (0 = auto, 1, 2, 4) */
 #define PB_OPT_MQ_PER_CHUNK 11  /* 1: bursts of > 64 queries run one 64-query pass at a time instead of sharing row tiles
                                   among 512 queries per workgroup (default 0; for measurement) */
 int pb_index_set_option(pb_index *idx, int option, int64_t value);
@@ -167,6 +177,39 @@ typedef struct pb_scan_stats {
                                  the error margin of the first attempt's k-th cosine listed and re-scored */
 } pb_scan_stats;                /* queries = fast_path + second_chance + fallback */
 int pb_index_get_stats(pb_index *idx, pb_scan_stats *out, int reset);
+
+/* ======================================================================================
+ *  scan half, row-sharded over the GPUs of one node -- ONE host process (the reference is one Rust process,
+ *  engine.rs:79-145), N devices.  SURVEY.md section 8b ("device_ids, n") / 8e.
+ * ====================================================================================== */
+typedef struct pb_sharded pb_sharded;
+
+/* `semantic_hashes` split by rows over n_devices device-resident shards (device_ids[g] = HIP ordinal of shard g;
+ * capacity_rows is the total, ceil(capacity_rows / n) per shard).  With more than one distinct device the library opens
+ * RCCL (dlopen librccl.so.1) and builds one communicator per device with ncclCommInitAll; a query batch is answered
+ * by every shard concurrently, the per-shard top-k messages (int64[nq][2k+1], pb_index_search_packed) are exchanged
+ * with ONE ncclAllGather per batch over xGMI and merged by a device kernel in (dist, image_id) order.  device_ids may
+ * repeat a device (several shards on one GPU: the 1-GPU test topology); such a set exchanges by device-to-device
+ * copies, since RCCL refuses duplicate devices. */
+int pb_sharded_create(pb_sharded **out, const int *device_ids, int n_devices, uint32_t dim, uint64_t capacity_rows);
+int pb_sharded_destroy(pb_sharded *s);
+/* n_shards; uses_rccl = 1 when the exchange is the RCCL all-gather; n_exchanges = exchanges issued so far */
+int pb_sharded_info(const pb_sharded *s, int *n_shards, int *uses_rccl, uint64_t *n_exchanges);
+/* total rows; per_shard (optional) receives n_shards counts */
+int pb_sharded_size(pb_sharded *s, uint64_t *n_rows, uint64_t *per_shard);
+/* Engine::open (engine.rs:117-145): bulk load, contiguous row ranges of ceil(n / n_shards) rows per shard */
+int pb_sharded_load(pb_sharded *s, const int64_t *image_ids, const uint8_t *rows, uint64_t n);
+/* INSERT OR IGNORE (engine.rs:251-256) over all shards: a pair whose image_id is stored on ANY shard is skipped; the new
+ * pairs of a call go to the least-full shard (spilling to the next when it fills up). */
+int pb_sharded_append(pb_sharded *s, const int64_t *image_ids, const uint8_t *rows, uint64_t n, uint64_t *n_inserted);
+/* Engine::query_by_image_hash_from_image (engine.rs:363-396) over all shards; arguments as pb_index_search */
+int pb_sharded_search(pb_sharded *s, const uint8_t *queries, uint32_t nq, uint32_t k, double max_dist, int64_t *out_ids,
+                      float *out_dist, uint32_t *out_count);
+/* rows [0, n) of synthetic stream `seed` (pb_index_fill_synthetic), contiguous ranges per shard, ids first_id + row */
+int pb_sharded_fill_synthetic(pb_sharded *s, uint64_t seed, uint64_t n, int64_t first_id);
+/* pb_index_set_option on every shard (PB_OPT_STREAM excepted: shards keep their own streams); stats summed over shards */
+int pb_sharded_set_option(pb_sharded *s, int option, int64_t value);
+int pb_sharded_get_stats(pb_sharded *s, pb_scan_stats *out, int reset);
 
 /* ======================================================================================
  *  embed half:  image_hashes::mlhash
@@ -187,7 +230,12 @@ int pb_embed_info(const pb_embedder *e, uint32_t *h, uint32_t *w, uint32_t *d, u
  * quantised hash of efficientnet.rs:39 (bit-exact quantiser).  out_f32 (optional): the D tanh outputs. */
 int pb_embed_batch(pb_embedder *e, const uint8_t *rgb, uint32_t n, uint8_t *out_u8, float *out_f32);
 
-/* Same with DEVICE input/output pointers (no PCIe in the timed region; bench.py uses this). */
+/* Same with DEVICE input/output pointers (no PCIe in the timed region; bench.py uses this).
+ * STREAM CONTRACT: the forward pass runs on the embedder's stream (its own non-blocking stream unless
+ * PB_OPT_EMBED_STREAM names another).  By default the call returns after that stream has been waited for, so the
+ * outputs are complete for any consumer (pb_index_append_device on the index's own stream, a hipMemcpy on the null
+ * stream, ...).  With PB_OPT_EMBED_ASYNC = 1 it returns with the work queued: d_out_* may then only be read by work
+ * queued on the SAME stream (give the index that stream with PB_OPT_STREAM) or after the caller has synchronised it. */
 int pb_embed_batch_device(pb_embedder *e, const uint8_t *d_rgb, uint32_t n, uint8_t *d_out_u8,
                           float *d_out_f32);
 
@@ -206,7 +254,8 @@ int pb_embed_batch_images(pb_embedder *e, const uint8_t *const *rgb, const uint3
 /* the pre-processed W x H RGB8 image itself (what the network sees before /255): out_rgb[H*W*3] */
 int pb_resize_to_fill(pb_embedder *e, const uint8_t *rgb, uint32_t width, uint32_t height, uint8_t *out_rgb);
 
-#define PB_OPT_EMBED_STREAM 3
+#define PB_OPT_EMBED_STREAM 3 /* value = hipStream_t the forward pass is launched on (0 = the embedder's own stream) */
+#define PB_OPT_EMBED_ASYNC 4  /* 1: pb_embed_batch_device returns with the forward pass queued (see its stream contract); default 0 */
 int pb_embed_set_option(pb_embedder *e, int option, int64_t value);
 
 /* ======================================================================================

@@ -22,7 +22,9 @@ PB_OPT_MQ_MIN_QUERIES = 9
 PB_OPT_MQ_WG_PER_CU = 10
 PB_OPT_MQ_PER_CHUNK = 11
 PB_OPT_APPEND_ASYNC = 12
+PB_OPT_EXACT_QN = 13
 PB_OPT_EMBED_STREAM = 3  # pb_embed_set_option: stream handle to launch on (0 = the embedder's own)
+PB_OPT_EMBED_ASYNC = 4   # pb_embed_set_option: 1 = pb_embed_batch_device returns with the forward pass queued (default 0: waits)
 PB_OPT_SCAN_LAUNCH = 8  # 0: one launch per query; 1: queries side by side in one grid; 2 (default): one launch, queries one after the other
 PB_METRIC_COSINE, PB_METRIC_BYTE, PB_METRIC_HAMMING = 0, 1, 2
 
@@ -30,7 +32,9 @@ PB_METRIC_COSINE, PB_METRIC_BYTE, PB_METRIC_HAMMING = 0, 1, 2
 # and the built library against both)
 SYMBOLS = [
     "pb_last_error", "pb_version", "pb_device_count",
-    "pb_index_create", "pb_index_create_metric", "pb_index_destroy", "pb_index_size", "pb_index_dim", "pb_index_append", "pb_index_append_device", "pb_index_load",
+    "pb_index_create", "pb_index_create_metric", "pb_index_destroy", "pb_index_size", "pb_index_dim", "pb_index_contains",
+    "pb_sharded_create", "pb_sharded_destroy", "pb_sharded_info", "pb_sharded_size", "pb_sharded_load", "pb_sharded_append",
+    "pb_sharded_search", "pb_sharded_fill_synthetic", "pb_sharded_set_option", "pb_sharded_get_stats", "pb_topk_merge_packed_device", "pb_index_append", "pb_index_append_device", "pb_index_load",
     "pb_index_search", "pb_index_search_device", "pb_index_search_packed", "pb_topk_merge_packed", "pb_topk_merge", "pb_index_read", "pb_index_fill_synthetic",
     "pb_index_set_option", "pb_index_get_stats",
     "pb_embed_create", "pb_embed_destroy", "pb_embed_info", "pb_embed_batch", "pb_embed_batch_device", "pb_mlhash",
@@ -87,6 +91,18 @@ def lib():
         L.pb_index_search_device.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, C.c_double, vp, vp, vp]
         L.pb_index_search_packed.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, C.c_double, vp]
         L.pb_topk_merge_packed.argtypes = [i64p, C.c_uint32, C.c_uint32, C.c_uint32, i64p, f32p, u32p]
+        L.pb_topk_merge_packed_device.argtypes = [C.c_int, vp, C.c_uint32, C.c_uint32, C.c_uint32, i64p, f32p, u32p]
+        L.pb_index_contains.argtypes = [vp, C.c_int64, C.POINTER(C.c_int)]
+        L.pb_sharded_create.argtypes = [C.POINTER(vp), C.POINTER(C.c_int), C.c_int, C.c_uint32, C.c_uint64]
+        L.pb_sharded_destroy.argtypes = [vp]
+        L.pb_sharded_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), u64p]
+        L.pb_sharded_size.argtypes = [vp, u64p, u64p]
+        L.pb_sharded_load.argtypes = [vp, i64p, u8p, C.c_uint64]
+        L.pb_sharded_append.argtypes = [vp, i64p, u8p, C.c_uint64, u64p]
+        L.pb_sharded_search.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, C.c_double, i64p, f32p, u32p]
+        L.pb_sharded_fill_synthetic.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int64]
+        L.pb_sharded_set_option.argtypes = [vp, C.c_int, C.c_int64]
+        L.pb_sharded_get_stats.argtypes = [vp, C.POINTER(ScanStats), C.c_int]
         L.pb_topk_merge.argtypes = [i64p, f32p, u32p, C.c_uint32, C.c_uint32, C.c_uint32, i64p, f32p, u32p]
         L.pb_index_read.argtypes = [vp, C.c_uint64, C.c_uint64, i64p, u8p]
         L.pb_index_fill_synthetic.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int64]
@@ -243,6 +259,85 @@ class Index:
         s = ScanStats()
         _check(lib().pb_index_get_stats(self._h, C.byref(s), int(reset)))
         return s
+
+
+class ShardedIndexC:
+    """pb_sharded_*: the row-sharded table driven by ONE process through the C ABI (RCCL all-gather inside the library)."""
+
+    def __init__(self, dim: int, capacity_rows: int, device_ids):
+        self._h = C.c_void_p()
+        self.dim = dim
+        devs = (C.c_int * len(device_ids))(*device_ids)
+        _check(lib().pb_sharded_create(C.byref(self._h), devs, len(device_ids), dim, capacity_rows))
+        self.n_shards = len(device_ids)
+
+    def close(self):
+        if self._h:
+            lib().pb_sharded_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        n, r, x = C.c_int(0), C.c_int(0), C.c_uint64(0)
+        _check(lib().pb_sharded_info(self._h, C.byref(n), C.byref(r), C.byref(x)))
+        return {"n_shards": n.value, "uses_rccl": bool(r.value), "n_exchanges": x.value}
+
+    def sizes(self):
+        tot = C.c_uint64(0)
+        per = np.zeros(self.n_shards, dtype=np.uint64)
+        _check(lib().pb_sharded_size(self._h, C.byref(tot), _p(per, C.c_uint64)))
+        return tot.value, per
+
+    def __len__(self):
+        return self.sizes()[0]
+
+    def load(self, image_ids, rows):
+        ids = np.ascontiguousarray(image_ids, dtype=np.int64)
+        rows = np.ascontiguousarray(rows, dtype=np.uint8).reshape(-1, self.dim)
+        _check(lib().pb_sharded_load(self._h, _p(ids, C.c_int64), _p(rows, C.c_uint8), ids.shape[0]))
+
+    def append(self, image_ids, rows) -> int:
+        ids = np.ascontiguousarray(image_ids, dtype=np.int64)
+        rows = np.ascontiguousarray(rows, dtype=np.uint8).reshape(-1, self.dim)
+        stored = C.c_uint64(0)
+        _check(lib().pb_sharded_append(self._h, _p(ids, C.c_int64), _p(rows, C.c_uint8), ids.shape[0], C.byref(stored)))
+        return stored.value
+
+    def fill_synthetic(self, seed: int, n: int, first_id: int = 1):
+        _check(lib().pb_sharded_fill_synthetic(self._h, seed, n, first_id))
+
+    def search(self, queries, k: int = 100, max_dist: float = 1e3):
+        q = np.ascontiguousarray(queries, dtype=np.uint8).reshape(-1, self.dim)
+        nq = q.shape[0]
+        ids = np.zeros((nq, k), dtype=np.int64)
+        dist = np.zeros((nq, k), dtype=np.float32)
+        cnt = np.zeros(nq, dtype=np.uint32)
+        _check(lib().pb_sharded_search(self._h, _p(q, C.c_uint8), nq, k, float(max_dist), _p(ids, C.c_int64), _p(dist, C.c_float),
+                                       _p(cnt, C.c_uint32)))
+        return ids, dist, cnt
+
+    def set_option(self, option: int, value: int):
+        _check(lib().pb_sharded_set_option(self._h, option, value))
+
+    def stats(self, reset: bool = False) -> ScanStats:
+        s = ScanStats()
+        _check(lib().pb_sharded_get_stats(self._h, C.byref(s), int(reset)))
+        return s
+
+
+def topk_merge_packed_device(device: int, d_gathered_ptr: int, n_lists: int, nq: int, k: int):
+    """Device-side merge of an all-gathered message block (int64 [n_lists, nq, 2k+1] in device memory) -> host arrays."""
+    ids = np.zeros((nq, k), dtype=np.int64)
+    dist = np.zeros((nq, k), dtype=np.float32)
+    cnt = np.zeros(nq, dtype=np.uint32)
+    _check(lib().pb_topk_merge_packed_device(device, C.c_void_p(d_gathered_ptr), n_lists, nq, k, _p(ids, C.c_int64),
+                                             _p(dist, C.c_float), _p(cnt, C.c_uint32)))
+    return ids, dist, cnt
 
 
 class Embedder:

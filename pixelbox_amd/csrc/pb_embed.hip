@@ -66,6 +66,9 @@ struct pb_embedder {
     float *d_out_f32 = nullptr;
     uint8_t *d_out_u8 = nullptr;
     int n_cu = 256;
+    int opt_async = 0;    // PB_OPT_EMBED_ASYNC
+    int trace_tune = 0;   // PB_TRACE_TUNE (1: chosen forms, 2: every candidate), PB_NO_STEM_FUSION: read once at create
+    bool no_stem_fusion = false;
     int tune_pick = 0;    // PB_TUNE_PICK: 0 fastest candidate (default); 1 slowest; 2 a pseudo-random one -- test hook: every form must give the same bits
     uint32_t tune_rng = 12345u;
     bool use_b3 = false;  // project / head / FC products from three bf16 pieces (k_gemm_b3) instead of the f32 MFMA chain
@@ -96,6 +99,17 @@ int upload(pb_embedder *e, float **dst, const std::vector<float> &src) {
     if (rc) return rc;
     PB_HIP(hipMemcpy(*dst, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice));
     return PB_OK;
+}
+
+// The per-layer timing loops cache their pick per (layer, bucket of the row / image count): buckets are powers of two,
+// so a front end that produces arbitrary batch sizes (BatchingEmbedder, tail batches) triggers at most
+// log2(max_batch) + 1 measurements per layer instead of one per distinct size, and the caches stay bounded.  Every
+// candidate's eligibility threshold (64, 128, 1024 rows) is a power of two, so a pick is valid for its whole bucket,
+// and all candidates give the same bits (tests), so the pick only affects speed.
+long tune_bucket(long m) {
+    long b = 1;
+    while (b < m) b <<= 1;
+    return b;
 }
 
 // candidate selection of the per-layer timing loops (see pb_embedder::tune_pick)
@@ -315,7 +329,7 @@ void launch_gemm_cfg(pb_embedder *e, GemmCfg c, const float *act, long M, const 
 int launch_gemm(pb_embedder *e, const float *act, long M, const Gemm &g, const float *gate, int hw, const float *resid,
                 int do_silu, float *out) {
     const int tiles = g.Npad / 16;
-    const std::pair<const void *, long> key(g.wt, M);
+    const std::pair<const void *, long> key(g.wt, tune_bucket(M));
     auto it = e->gemm_cfg.find(key);
     if (g.wt3 && e->use_b3) {
         // project / head / FC: the three-bf16-piece form for EVERY batch size (its numerics differ from the f32 chain,
@@ -347,7 +361,7 @@ int launch_gemm(pb_embedder *e, const float *act, long M, const Gemm &g, const f
                     }
                 }
             }
-            if (getenv("PB_TRACE_TUNE"))
+            if (e->trace_tune)
                 fprintf(stderr, "gemm M%ld K%d N%d%s: bf16 pieces, best NR%d NW%d %.1f us = %.1f TFLOP/s\n", M, g.K, g.N, gate ? " gated" : "",
                         best_nr, best_nw, best_ms * 500.f, 2.0 * (double)M * g.K * g.N / (best_ms * 0.5e-3) / 1e12);
             (void)hipEventDestroy(e0);
@@ -381,7 +395,7 @@ int launch_gemm(pb_embedder *e, const float *act, long M, const Gemm &g, const f
                 PB_HIP(hipGetLastError());
                 float ms = 0.f;
                 PB_HIP(hipEventElapsedTime(&ms, e0, e1));
-                if (getenv("PB_TRACE_TUNE") && getenv("PB_TRACE_TUNE")[0] == '2')
+                if (e->trace_tune >= 2)
                     fprintf(stderr, "  gemm M%ld K%d N%d: MR%d NR%d NW%d %.1f us\n", M, g.K, g.N, c.mr, c.nr, c.nw, ms * 500.f);
                 if (tune_take(e, ms, best_ms)) {
                     best_ms = ms;
@@ -389,7 +403,7 @@ int launch_gemm(pb_embedder *e, const float *act, long M, const Gemm &g, const f
                 }
             }
         }
-        if (getenv("PB_TRACE_TUNE"))
+        if (e->trace_tune)
             fprintf(stderr, "gemm M%ld K%d N%d%s: best MR%d NR%d NW%d %.1f us = %.1f TFLOP/s\n", M, g.K, g.N, gate ? " gated" : "", best.mr,
                     best.nr, best.nw, best_ms * 500.f, 2.0 * (double)M * g.K * g.N / (best_ms * 0.5e-3) / 1e12);
         (void)hipEventDestroy(e0);
@@ -509,7 +523,7 @@ int launch_dw_geom(pb_embedder *e, const Block &bl, const float *in, int B, int 
 // Depthwise launch; the kernel form (strip vs rolling window) is measured per (layer, batch) at first use.
 int launch_dw(pb_embedder *e, const Block &bl, const float *in, int B, int H, int W, float *out, int Ho, int Wo,
               DwGeom *used) {
-    const std::pair<const void *, long> key(bl.dw_w, (long)B);
+    const std::pair<const void *, long> key(bl.dw_w, tune_bucket(B));
     auto it = e->dw_cfg.find(key);
     if (it == e->dw_cfg.end()) {
         DwGeom cands[3] = {dw_geom(bl.e, Ho, Wo, B, e->n_cu), dw_geom_roll(bl.e, bl.k, Ho, Wo, B, e->n_cu),
@@ -654,7 +668,7 @@ int launch_dw(pb_embedder *e, const Block &bl, const float *in, int B, int H, in
 // expand + depthwise of one block: the fused kernel (per row-band count) and the two-kernel path are timed on
 // the real buffers at first use per (block, batch); returns the number of SE partial tiles written to buf_part
 int run_front(pb_embedder *e, const Block &bl, const float *x, int n, int H, int W, int Ho, int Wo, int *n_part_tiles) {
-    const std::pair<const void *, long> key(bl.expand.wt, (long)n);
+    const std::pair<const void *, long> key(bl.expand.wt, tune_bucket(n));
     auto separate = [&](int *tiles) -> int {
         int rc = launch_gemm(e, x, (long)n * H * W, bl.expand, nullptr, 1, nullptr, 1, e->buf_e);
         if (rc) return rc;
@@ -697,7 +711,7 @@ int run_front(pb_embedder *e, const Block &bl, const float *x, int n, int H, int
                 float ms = 0.f;
                 if ((rc = launch_front(e, bl, cfg, x, n, H, W, e->buf_dw, Ho, Wo))) return rc;  // warm-up
                 if ((rc = time_it(cfg, &ms))) return rc;
-                if (getenv("PB_TRACE_TUNE")) fprintf(stderr, "front k%d s%d e%d n%d: bands %d nc %d %.1f us (separate %.1f)\n", bl.k, bl.stride, bl.e, n, nb, nc, ms * 500.f, sep_ms * 500.f);
+                if (e->trace_tune) fprintf(stderr, "front k%d s%d e%d n%d: bands %d nc %d %.1f us (separate %.1f)\n", bl.k, bl.stride, bl.e, n, nb, nc, ms * 500.f, sep_ms * 500.f);
                 if (tune_take(e, ms, best_ms)) {
                     best_ms = ms;
                     best = cfg;
@@ -717,7 +731,7 @@ int run_front(pb_embedder *e, const Block &bl, const float *x, int n, int H, int
                     PB_HIP(hipEventRecord(e1, e->stream));
                     PB_HIP(hipEventSynchronize(e1));
                     PB_HIP(hipEventElapsedTime(&ms, e0, e1));
-                    if (getenv("PB_TRACE_TUNE"))
+                    if (e->trace_tune)
                         fprintf(stderr, "front k%d s%d e%d n%d: small-map fused mr %d nr %d groups/wg %d%s %.1f us (separate %.1f)\n", bl.k, bl.stride, bl.e, n,
                                 mr, nr, 1 << (lg & 7), (lg & 8) ? " regs" : "", ms * 500.f, sep_ms * 500.f);
                     if (tune_take(e, ms, best_ms)) {
@@ -751,7 +765,7 @@ int forward_device(pb_embedder *e, const uint8_t *d_rgb, int n, uint8_t *d_u8, f
     while (rpb > 4 && (long)n * ((H + rpb - 1) / rpb) < 2L * e->n_cu && (H + rpb / 2 - 1) / (rpb / 2) <= 32) rpb /= 2;
     const size_t fused_lds = (size_t)3 * (W + 2) * 36 * sizeof(float) + (size_t)(2 * rpb + 5) * (e->W * 3 + 4);
     const bool fuse_stem = !b0.has_expand && b0.k == 3 && b0.stride == 1 && b0.e == 32 && fused_lds <= 60 * 1024 &&
-                           (H + rpb - 1) / rpb <= 32 && !getenv("PB_NO_STEM_FUSION");
+                           (H + rpb - 1) / rpb <= 32 && !e->no_stem_fusion;
     int stem_bands = 0;
     if (fuse_stem) {
         stem_bands = (H + rpb - 1) / rpb;
@@ -896,6 +910,8 @@ int pb_embed_create(pb_embedder **out, int device, const void *weights_blob, siz
     e->max_batch = max_batch;
     e->use_b3 = getenv("PB_GEMM_B3") != nullptr;  // experiment switch
     if (const char *tp = getenv("PB_TUNE_PICK")) e->tune_pick = atoi(tp);
+    if (const char *tt = getenv("PB_TRACE_TUNE")) e->trace_tune = tt[0] == '2' ? 2 : 1;
+    e->no_stem_fusion = getenv("PB_NO_STEM_FUSION") != nullptr;
     auto body = [&]() -> int {
         hipDeviceProp_t prop;
         PB_HIP(hipGetDeviceProperties(&prop, device));
@@ -965,7 +981,14 @@ int pb_embed_batch_device(pb_embedder *e, const uint8_t *d_rgb, uint32_t n, uint
     if (n == 0) return PB_OK;
     std::lock_guard<std::mutex> lock(e->mu);
     pb::DeviceGuard guard(e->device);
-    return forward_device(e, d_rgb, (int)n, d_out_u8, d_out_f32);
+    int rc = forward_device(e, d_rgb, (int)n, d_out_u8, d_out_f32);
+    if (rc) return rc;
+    // Synchronous by default: on return the outputs are complete, whatever stream the consumer uses (the index
+    // owns a stream of its own).  PB_OPT_EMBED_ASYNC = 1 returns with the forward pass queued on the embedder's
+    // stream instead: the consumer must then run on that same stream (PB_OPT_EMBED_STREAM + PB_OPT_STREAM) or
+    // wait for it.
+    if (!e->opt_async) PB_HIP(hipStreamSynchronize(e->stream));
+    return PB_OK;
 }
 
 int pb_embed_batch(pb_embedder *e, const uint8_t *rgb, uint32_t n, uint8_t *out_u8, float *out_f32) {
@@ -1043,6 +1066,11 @@ int pb_embed_set_option(pb_embedder *e, int option, int64_t value) {
     std::lock_guard<std::mutex> lock(e->mu);
     if (option == PB_OPT_EMBED_STREAM) {
         e->stream = value ? reinterpret_cast<hipStream_t>(value) : e->own_stream;
+        return PB_OK;
+    }
+    if (option == PB_OPT_EMBED_ASYNC) {
+        PB_CHECK(value == 0 || value == 1, PB_ERR_INVALID, "PB_OPT_EMBED_ASYNC: 0 or 1");
+        e->opt_async = (int)value;
         return PB_OK;
     }
     return pb::fail(PB_ERR_INVALID, "pb_embed_set_option: unknown option %d", option);

@@ -50,6 +50,8 @@ struct pb_index {
     int32_t min_den_b = 0x7FFFFFFF;   // host copy
     bool min_dirty = false;           // d_min_den is newer than min_den_b (asynchronous appends): refreshed before the next search
     int opt_append_async = 0;         // PB_OPT_APPEND_ASYNC
+    uint64_t ids_dirty_lo = UINT64_MAX;  // d_ids[ids_dirty_lo ..) not uploaded yet (asynchronous appends keep the ids on the host
+                                         // until something reads d_ids: only the re-scoring kernels of a search do)
     float *d_lut = nullptr;
     std::vector<int64_t> h_ids;  // ascending, mirrors d_ids
     float lut[256];
@@ -68,6 +70,7 @@ struct pb_index {
     uint64_t *d_xlists[2] = {nullptr, nullptr};  // exact pass ping-pong: Q_CHUNK * X_MAX_WG * PB_MAX_K
     uint32_t *d_xcounts[2] = {nullptr, nullptr};
     uint32_t *d_qsel = nullptr;     // Q_CHUNK
+    float *d_qf = nullptr;          // Q_CHUNK * 256: de-quantised queries of the coalesced exhaustive pass
     float *d_tau = nullptr;         // multi-query pass: per-query candidate threshold (PIPE_Q)
     uint64_t *d_cand = nullptr;     // PIPE_Q * MQ_CAP
     uint32_t *d_cand_cnt = nullptr; // PIPE_Q
@@ -79,9 +82,16 @@ struct pb_index {
     uint64_t *d_cand2 = nullptr;    // Q_CHUNK * MQ_CAP2
     uint32_t *d_cand_cnt2 = nullptr;  // Q_CHUNK
     uint32_t *d_qsel2 = nullptr;    // Q_CHUNK
-    int64_t *d_res_ids = nullptr;   // Q_CHUNK * PB_MAX_K
+    int64_t *d_res_ids = nullptr;   // PIPE_Q * PB_MAX_K
     float *d_res_dist = nullptr;
     ResultHdr *d_res_hdr = nullptr;
+    // where the result-writing kernels of the current call put ids / distances / headers: the device arrays above, or
+    // -- for calls that hand results to the host -- the pinned host arrays below directly (hipHostMalloc memory is
+    // device-writable: the kernels' stores cross PCIe as posted writes and are visible once the stream has been waited
+    // for, so a query costs no device-to-host copy command at all and exactly ONE wait)
+    int64_t *r_ids = nullptr;
+    float *r_dist = nullptr;
+    ResultHdr *r_hdr = nullptr;
     // pinned host staging
     uint8_t *h_stage = nullptr;  // queries + params + qsel (one chunk)
     uint8_t *h_pipe = nullptr;   // queries + params of up to PIPE_Q queries (concurrent-query path)
@@ -89,6 +99,9 @@ struct pb_index {
     float *h_res_dist = nullptr;
     ResultHdr *h_res_hdr = nullptr;
 
+    bool env_exact_lane_rows = false;  // PB_EXACT_LANE_ROWS: the lane-per-row exhaustive kernel also for 256-byte cosine rows (comparison)
+    int opt_exact_qn = 0;              // PB_OPT_EXACT_QN: queries per sweep of the coalesced exhaustive pass (0 = auto: 2 when there are two)
+    bool env_no_second_chance = false, env_trace_cert = false;  // PB_NO_SECOND_CHANCE / PB_TRACE_CERT, read once at create
     int opt_path = 0;
     int opt_profile = 0;
     int opt_variant = 0;    // tuning knob (dim 256 only): bit 0 = plain (temporal) loads, bits 1-2 = U in {8,16,4}, bit 3 = wave-fastest tiles
@@ -120,6 +133,7 @@ int alloc_workspace(pb_index *ix) {
         PB_HIP(hipMalloc(&ix->d_xcounts[i], (size_t)Q_CHUNK * lists * sizeof(uint32_t)));
     }
     PB_HIP(hipMalloc(&ix->d_qsel, Q_CHUNK * sizeof(uint32_t)));
+    PB_HIP(hipMalloc(&ix->d_qf, (size_t)Q_CHUNK * 256 * sizeof(float)));
     PB_HIP(hipMalloc(&ix->d_tau, PIPE_Q * sizeof(float)));
     PB_HIP(hipMalloc(&ix->d_cand, (size_t)PIPE_Q * MQ_CAP * sizeof(uint64_t)));
     PB_HIP(hipMalloc(&ix->d_cand_cnt, PIPE_Q * sizeof(uint32_t)));
@@ -155,6 +169,7 @@ void free_all(pb_index *ix) {
         (void)hipFree(ix->d_xcounts[i]);
     }
     (void)hipFree(ix->d_qsel);
+    (void)hipFree(ix->d_qf);
     (void)hipFree(ix->d_tau);
     (void)hipFree(ix->d_cand);
     (void)hipFree(ix->d_cand_cnt);
@@ -201,11 +216,19 @@ int launch_norms(pb_index *ix, uint64_t first, uint64_t n) {
     return PB_OK;
 }
 
+// Catch up with asynchronous appends before anything reads the index: upload the image_ids they left on the host
+// (from the index's own h_ids, which outlives the caller's array -- the caller's may be a temporary that is gone by
+// the time a queued copy would run) and read back the running minimum that feeds the error margin.  One wait.
 int refresh_min_den(pb_index *ix) {
-    if (!ix->min_dirty) return PB_OK;
-    PB_HIP(hipMemcpyAsync(&ix->min_den_b, ix->d_min_den, sizeof(int32_t), hipMemcpyDeviceToHost, ix->stream));
-    PB_HIP(hipStreamSynchronize(ix->stream));
+    if (!ix->min_dirty && ix->ids_dirty_lo == UINT64_MAX) return PB_OK;
+    if (ix->ids_dirty_lo < ix->n_rows)
+        PB_HIP(hipMemcpyAsync(ix->d_ids + ix->ids_dirty_lo, ix->h_ids.data() + ix->ids_dirty_lo,
+                              (ix->n_rows - ix->ids_dirty_lo) * sizeof(int64_t), hipMemcpyHostToDevice, ix->stream));
+    if (ix->min_dirty)
+        PB_HIP(hipMemcpyAsync(&ix->min_den_b, ix->d_min_den, sizeof(int32_t), hipMemcpyDeviceToHost, ix->stream));
+    PB_HIP(hipStreamSynchronize(ix->stream));  // h_ids may be reallocated by the next append: the copy must have run
     ix->min_dirty = false;
+    ix->ids_dirty_lo = UINT64_MAX;
     return PB_OK;
 }
 
@@ -393,8 +416,8 @@ int run_fast(pb_index *ix, uint32_t nq) {
     }
     if (ix->opt_profile) PB_HIP(hipEventRecord(ix->ev1, ix->stream));
     hipLaunchKernelGGL(k_select_rescore, dim3(nq), dim3(SEL_BLOCK), 0, ix->stream, ix->d_rows, ix->d_ids, ix->d_norms,
-                       (int)ix->dim, ix->d_queries, ix->d_qp, ix->d_lut, ix->d_lists, ix->d_hdrs, n_wg, ix->d_res_ids,
-                       ix->d_res_dist, ix->d_res_hdr, (uint32_t)PB_MAX_K);
+                       (int)ix->dim, ix->d_queries, ix->d_qp, ix->d_lut, ix->d_lists, ix->d_hdrs, n_wg, ix->r_ids,
+                       ix->r_dist, ix->r_hdr, (uint32_t)PB_MAX_K);
     PB_HIP(hipGetLastError());
     return PB_OK;
 }
@@ -434,17 +457,41 @@ int run_fast_dist(pb_index *ix, uint32_t nq) {
     }
     if (ix->opt_profile) PB_HIP(hipEventRecord(ix->ev1, ix->stream));
     hipLaunchKernelGGL(k_select_keys, dim3(nq), dim3(SEL_BLOCK), 0, ix->stream, ix->d_ids, ix->d_qp, ix->d_lists, ix->d_hdrs,
-                       ix->d_dropkeys, n_wg, ix->d_res_ids, ix->d_res_dist, ix->d_res_hdr, (uint32_t)PB_MAX_K);
+                       ix->d_dropkeys, n_wg, ix->r_ids, ix->r_dist, ix->r_hdr, (uint32_t)PB_MAX_K);
     PB_HIP(hipGetLastError());
     return PB_OK;
 }
 
 // exhaustive exact pass for the n_sel queries listed in d_qsel
+template <int QN, int MAXE>
+int launch_exact_co(pb_index *ix, int n_lists, uint32_t n_sel, uint32_t k) {
+    const size_t cap = (size_t)k + WAVE;
+    const size_t lds = (size_t)XC_WAVES * WAVE * XC_PITCH + 256 * sizeof(float) + (size_t)XC_WAVES * QN * cap * sizeof(uint64_t) +
+                       (size_t)XC_WAVES * QN * sizeof(int);
+    auto kern = k_scan_exact_co<QN, MAXE>;
+    PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(n_lists, (n_sel + QN - 1) / QN), dim3(XC_WAVES * WAVE), lds, ix->stream, ix->d_rows, ix->d_norms,
+                       ix->n_rows, ix->d_qf, ix->d_qp, ix->d_qsel, (int)n_sel, ix->d_lut, ix->d_xlists[0], ix->d_xcounts[0],
+                       (uint32_t)PB_MAX_K);
+    return PB_OK;
+}
+
 int run_exact(pb_index *ix, uint32_t n_sel, uint32_t k) {
+    // cosine over 256-byte rows: the coalesced form, two queries per table sweep when there are two (k_scan_exact_co)
+    const bool coalesced = ix->metric == 0 && ix->dim == 256 && !ix->env_exact_lane_rows;
     const uint64_t n_tiles = (ix->n_rows + WAVE - 1) / WAVE;
-    const uint64_t want = (n_tiles + X_WAVES - 1) / X_WAVES;
-    int n_lists = (int)std::max<uint64_t>(1, std::min<uint64_t>(want, X_MAX_WG));
+    const uint64_t want = (n_tiles + (coalesced ? XC_WAVES : X_WAVES) - 1) / (coalesced ? XC_WAVES : X_WAVES);
+    int n_lists = (int)std::max<uint64_t>(1, std::min<uint64_t>(want, coalesced ? std::min<uint64_t>(X_MAX_WG, 2ull * ix->n_cu) : X_MAX_WG));
     if (ix->opt_profile && ix->opt_path == 1) PB_HIP(hipEventRecord(ix->ev0, ix->stream));
+    if (coalesced) {
+        hipLaunchKernelGGL(k_make_qf, dim3(n_sel), dim3(256), 0, ix->stream, ix->d_queries, ix->d_qsel, ix->d_lut, ix->d_qf);
+        PB_HIP(hipGetLastError());
+        const int qn = ix->opt_exact_qn ? ix->opt_exact_qn : (n_sel >= 2 ? 2 : 1);
+        int rc;
+        if (k <= 128) rc = qn >= 4 ? launch_exact_co<4, 3>(ix, n_lists, n_sel, k) : (qn == 2 ? launch_exact_co<2, 3>(ix, n_lists, n_sel, k) : launch_exact_co<1, 3>(ix, n_lists, n_sel, k));
+        else rc = qn >= 4 ? launch_exact_co<4, 5>(ix, n_lists, n_sel, k) : (qn == 2 ? launch_exact_co<2, 5>(ix, n_lists, n_sel, k) : launch_exact_co<1, 5>(ix, n_lists, n_sel, k));
+        if (rc) return rc;
+    } else {
 #define PB_X(MV)                                                                                                   \
     hipLaunchKernelGGL((k_scan_exact<MV>), dim3(n_lists, n_sel), dim3(X_BLOCK), 0, ix->stream, ix->d_rows, ix->d_norms, \
                        ix->n_rows, (int)ix->dim, ix->d_queries, ix->d_qp, ix->d_qsel, ix->d_lut, ix->d_xlists[0],  \
@@ -453,6 +500,7 @@ int run_exact(pb_index *ix, uint32_t n_sel, uint32_t k) {
     else if (ix->metric == 2) PB_X(2);
     else PB_X(0);
 #undef PB_X
+    }
     PB_HIP(hipGetLastError());
     if (ix->opt_profile && ix->opt_path == 1) PB_HIP(hipEventRecord(ix->ev1, ix->stream));
     int cur = 0;
@@ -461,8 +509,8 @@ int run_exact(pb_index *ix, uint32_t n_sel, uint32_t k) {
         const int final_out = n_groups == 1;
         hipLaunchKernelGGL(k_merge_lists, dim3(n_groups, n_sel), dim3(M_BLOCK), 0, ix->stream, ix->d_xlists[cur],
                            ix->d_xcounts[cur], n_lists, (uint32_t)PB_MAX_K, k, ix->d_xlists[cur ^ 1],
-                           ix->d_xcounts[cur ^ 1], (uint32_t)PB_MAX_K, final_out, ix->d_ids, ix->d_qsel, ix->d_res_ids,
-                           ix->d_res_dist, ix->d_res_hdr, (uint32_t)PB_MAX_K);
+                           ix->d_xcounts[cur ^ 1], (uint32_t)PB_MAX_K, final_out, ix->d_ids, ix->d_qsel, ix->r_ids,
+                           ix->r_dist, ix->r_hdr, (uint32_t)PB_MAX_K);
         PB_HIP(hipGetLastError());
         if (final_out) break;
         n_lists = n_groups;
@@ -527,8 +575,8 @@ int run_multi(pb_index *ix, uint32_t nq, uint32_t k, uint32_t base = 0) {
     if (ix->opt_profile && base == 0) PB_HIP(hipEventRecord(ix->ev1, ix->stream));
     hipLaunchKernelGGL(k_mq_rescore, dim3(nq), dim3(1024), 0, ix->stream, ix->d_rows, ix->d_ids, ix->d_norms, (int)ix->dim,
                        ix->d_queries + (size_t)base * ix->dim, ix->d_qp + base, ix->d_lut, ix->d_tau + base,
-                       ix->d_cand + (size_t)base * MQ_CAP, ix->d_cand_cnt + base, ix->d_res_ids + (size_t)base * PB_MAX_K,
-                       ix->d_res_dist + (size_t)base * PB_MAX_K, ix->d_res_hdr + base, (uint32_t)PB_MAX_K);
+                       ix->d_cand + (size_t)base * MQ_CAP, ix->d_cand_cnt + base, ix->r_ids + (size_t)base * PB_MAX_K,
+                       ix->r_dist + (size_t)base * PB_MAX_K, ix->r_hdr + base, (uint32_t)PB_MAX_K);
     PB_HIP(hipGetLastError());
     return PB_OK;
 }
@@ -565,8 +613,8 @@ int run_multi_block(pb_index *ix, uint32_t nq, uint32_t k) {
     PB_HIP(hipGetLastError());
     if (ix->opt_profile) PB_HIP(hipEventRecord(ix->ev1, ix->stream));
     hipLaunchKernelGGL(k_mq_rescore, dim3(nq), dim3(1024), 0, ix->stream, ix->d_rows, ix->d_ids, ix->d_norms, (int)ix->dim,
-                       ix->d_queries, ix->d_qp, ix->d_lut, ix->d_tau, ix->d_cand, ix->d_cand_cnt, ix->d_res_ids, ix->d_res_dist,
-                       ix->d_res_hdr, (uint32_t)PB_MAX_K);
+                       ix->d_queries, ix->d_qp, ix->d_lut, ix->d_tau, ix->d_cand, ix->d_cand_cnt, ix->r_ids, ix->r_dist,
+                       ix->r_hdr, (uint32_t)PB_MAX_K);
     PB_HIP(hipGetLastError());
     return PB_OK;
 }
@@ -575,7 +623,7 @@ int run_multi_block(pb_index *ix, uint32_t nq, uint32_t k) {
 // One shared sweep with 64 Ki-entry lists, then exact scoring of every listed row.  Results and headers land in the
 // queries' own slots; status 1 = list overflow or fewer than k results (-> exhaustive pass).
 bool second_chance_eligible(const pb_index *ix) {
-    return ix->metric == 0 && ix->dim == 256 && ix->n_rows >= 4096 && ix->opt_path != 1 && !getenv("PB_NO_SECOND_CHANCE");
+    return ix->metric == 0 && ix->dim == 256 && ix->n_rows >= 4096 && ix->opt_path != 1 && !ix->env_no_second_chance;
 }
 
 int run_second_chance(pb_index *ix, uint32_t n_sel) {
@@ -617,7 +665,7 @@ int run_second_chance(pb_index *ix, uint32_t n_sel) {
     PB_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_mq_rescore_big, dim3(n_sel), dim3(1024), 0, ix->stream, ix->d_rows, ix->d_ids, ix->d_norms, (int)ix->dim,
                        ix->d_queries2, ix->d_qp2, ix->d_lut, ix->d_cand2, ix->d_cand_cnt2, (uint32_t)MQ_CAP2, ix->d_qsel2,
-                       ix->d_res_ids, ix->d_res_dist, ix->d_res_hdr, (uint32_t)PB_MAX_K);
+                       ix->r_ids, ix->r_dist, ix->r_hdr, (uint32_t)PB_MAX_K);
     PB_HIP(hipGetLastError());
     return PB_OK;
 }
@@ -632,8 +680,18 @@ bool multi_eligible(const pb_index *ix, uint32_t nq) {
 // On return d_res_ids / d_res_dist / d_res_hdr hold the final results of the chunk and h_res_hdr mirrors
 // the headers.
 int search_chunk(pb_index *ix, uint32_t cq, uint32_t k, double max_dist, const float *ck_hint = nullptr,
-                 const uint32_t *hint_ncand = nullptr, const float *hint_omax = nullptr) {
+                 const uint32_t *hint_ncand = nullptr, const float *hint_omax = nullptr, bool host_out = false) {
     const uint32_t d = ix->dim;
+    // host_out: the kernels write ids / distances / headers straight into the pinned host arrays (h_res_*); otherwise
+    // into d_res_* and only the headers are copied back for the certificate check
+    ix->r_ids = host_out ? ix->h_res_ids : ix->d_res_ids;
+    ix->r_dist = host_out ? ix->h_res_dist : ix->d_res_dist;
+    ix->r_hdr = host_out ? ix->h_res_hdr : ix->d_res_hdr;
+    auto wait_headers = [&]() -> int {
+        if (!host_out) PB_HIP(hipMemcpyAsync(ix->h_res_hdr, ix->d_res_hdr, cq * sizeof(ResultHdr), hipMemcpyDeviceToHost, ix->stream));
+        PB_HIP(hipStreamSynchronize(ix->stream));
+        return PB_OK;
+    };
     uint8_t *hq = ix->h_stage;
     QParams *hp = reinterpret_cast<QParams *>(ix->h_stage + (size_t)Q_CHUNK * d);
     uint32_t *hsel = reinterpret_cast<uint32_t *>(ix->h_stage + (size_t)Q_CHUNK * (d + sizeof(QParams)));
@@ -642,8 +700,19 @@ int search_chunk(pb_index *ix, uint32_t cq, uint32_t k, double max_dist, const f
     const bool use_fast = use_dist || (ix->metric == 0 && (ix->opt_path == 0 || ix->opt_path == 2 || ix->opt_path == 3) && fast_dim(d));
     { int rcm = refresh_min_den(ix); if (rcm) return rcm; }
     make_qparams_batch(ix, hq, cq, k, max_dist, hp);
-    PB_HIP(hipMemcpyAsync(ix->d_queries, hq, (size_t)cq * d, hipMemcpyHostToDevice, ix->stream));
-    PB_HIP(hipMemcpyAsync(ix->d_qp, hp, (size_t)cq * sizeof(QParams), hipMemcpyHostToDevice, ix->stream));
+    if (cq == 1) {
+        // the reference's call shape (one query per call, engine.rs:363-396): query bytes and constants travel as
+        // kernel arguments of a one-wave staging kernel instead of two host-to-device copy commands
+        QArg a;
+        a.p = hp[0];
+        a.dim = d;
+        memcpy(a.q, hq, d);
+        hipLaunchKernelGGL(k_stage_query, dim3(1), dim3(256), 0, ix->stream, a, ix->d_queries, ix->d_qp);
+        PB_HIP(hipGetLastError());
+    } else {
+        PB_HIP(hipMemcpyAsync(ix->d_queries, hq, (size_t)cq * d, hipMemcpyHostToDevice, ix->stream));
+        PB_HIP(hipMemcpyAsync(ix->d_qp, hp, (size_t)cq * sizeof(QParams), hipMemcpyHostToDevice, ix->stream));
+    }
     uint32_t n_sel = 0;
     // concurrent-query pass: worth it from ~8 queries on a table large enough for the sample to mean something
     // (the host-buffer entry point routes concurrent bursts through search_block_multi; this chunk path serves
@@ -652,8 +721,7 @@ int search_chunk(pb_index *ix, uint32_t cq, uint32_t k, double max_dist, const f
     if (use_fast) {
         int rc = use_dist ? run_fast_dist(ix, cq) : (use_multi ? run_multi(ix, cq, k) : run_fast(ix, cq));
         if (rc) return rc;
-        PB_HIP(hipMemcpyAsync(ix->h_res_hdr, ix->d_res_hdr, cq * sizeof(ResultHdr), hipMemcpyDeviceToHost, ix->stream));
-        PB_HIP(hipStreamSynchronize(ix->stream));
+        { int rcw = wait_headers(); if (rcw) return rcw; }
         if (ix->opt_profile) {
             int rc2 = use_multi ? account_profile(ix, 1, 1) : account_profile(ix, cq, (ix->opt_mode == 1 || loop_mode(ix, cq) || (use_dist && ix->opt_mode == 2)) ? 1 : cq);
             if (rc2) return rc2;
@@ -661,7 +729,7 @@ int search_chunk(pb_index *ix, uint32_t cq, uint32_t k, double max_dist, const f
         for (uint32_t q = 0; q < cq; ++q)
             if (ix->h_res_hdr[q].status != 0) {
                 hsel[n_sel++] = q;
-                if (getenv("PB_TRACE_CERT"))
+                if (ix->env_trace_cert)
                     fprintf(stderr, "cert fail (chunk path, multi=%d): q=%u count=%u n_cand=%u o_max=%.7f thr0=%.7f\n", (int)use_multi, q,
                             ix->h_res_hdr[q].count, ix->h_res_hdr[q].n_cand, ix->h_res_hdr[q].o_max, hp[q].thr0);
             }
@@ -672,7 +740,7 @@ int search_chunk(pb_index *ix, uint32_t cq, uint32_t k, double max_dist, const f
     }
     // second chance: a query that HAS k results (ck = their smallest exact cosine, from the attempt above or handed
     // in by the burst path) but no certificate gets every row with cos_filter >= ck (1 - 1e-6) - 1.01 m scored exactly
-    if (n_sel && !use_dist && (ck_hint || use_fast) && (ck_hint ? ix->metric == 0 && ix->dim == 256 && ix->n_rows >= 4096 && !getenv("PB_NO_SECOND_CHANCE")
+    if (n_sel && !use_dist && (ck_hint || use_fast) && (ck_hint ? ix->metric == 0 && ix->dim == 256 && ix->n_rows >= 4096 && !ix->env_no_second_chance
                                                     : second_chance_eligible(ix))) {
         uint32_t sc_sel[Q_CHUNK], rest[Q_CHUNK];
         float sc_tau[Q_CHUNK];
@@ -699,12 +767,11 @@ int search_chunk(pb_index *ix, uint32_t cq, uint32_t k, double max_dist, const f
             PB_HIP(hipMemcpyAsync(ix->d_tau2, sc_tau, n_sc * sizeof(float), hipMemcpyHostToDevice, ix->stream));
             int rc = run_second_chance(ix, n_sc);
             if (rc) return rc;
-            PB_HIP(hipMemcpyAsync(ix->h_res_hdr, ix->d_res_hdr, cq * sizeof(ResultHdr), hipMemcpyDeviceToHost, ix->stream));
-            PB_HIP(hipStreamSynchronize(ix->stream));
+            { int rcw = wait_headers(); if (rcw) return rcw; }
             for (uint32_t i = 0; i < n_sc; ++i) {
                 if (ix->h_res_hdr[sc_sel[i]].status != 0) {
                     rest[n_rest++] = sc_sel[i];
-                    if (getenv("PB_TRACE_CERT"))
+                    if (ix->env_trace_cert)
                         fprintf(stderr, "second chance failed: q=%u listed=%u (cap %d) tau2=%.7f\n", sc_sel[i], ix->h_res_hdr[sc_sel[i]].n_cand,
                                 MQ_CAP2, sc_tau[i]);
                 } else {
@@ -720,8 +787,7 @@ int search_chunk(pb_index *ix, uint32_t cq, uint32_t k, double max_dist, const f
         PB_HIP(hipMemcpyAsync(ix->d_qsel, hsel, n_sel * sizeof(uint32_t), hipMemcpyHostToDevice, ix->stream));
         int rc = run_exact(ix, n_sel, k);
         if (rc) return rc;
-        PB_HIP(hipMemcpyAsync(ix->h_res_hdr, ix->d_res_hdr, cq * sizeof(ResultHdr), hipMemcpyDeviceToHost, ix->stream));
-        PB_HIP(hipStreamSynchronize(ix->stream));
+        { int rcw = wait_headers(); if (rcw) return rcw; }
         if (ix->opt_profile && ix->opt_path == 1) {
             int rc2 = account_profile(ix, n_sel, 1);
             if (rc2) return rc2;
@@ -740,6 +806,9 @@ int search_block_multi(pb_index *ix, const uint8_t *queries, uint32_t nq, uint32
     const uint32_t d = ix->dim;
     uint8_t *hq = ix->h_pipe;
     QParams *hp = reinterpret_cast<QParams *>(ix->h_pipe + (size_t)PIPE_Q * d);
+    ix->r_ids = ix->d_res_ids;
+    ix->r_dist = ix->d_res_dist;
+    ix->r_hdr = ix->d_res_hdr;
     memcpy(hq, queries, (size_t)nq * d);
     { int rcm = refresh_min_den(ix); if (rcm) return rcm; }
     make_qparams_batch(ix, hq, nq, k, max_dist, hp);
@@ -773,7 +842,7 @@ int search_block_multi(pb_index *ix, const uint8_t *queries, uint32_t nq, uint32
     for (uint32_t q = 0; q < nq; ++q)
         if (ix->h_res_hdr[q].status != 0) {
             failed.push_back(q);
-            if (getenv("PB_TRACE_CERT"))
+            if (ix->env_trace_cert)
                 fprintf(stderr, "cert fail (burst path): q=%u count=%u n_cand=%u o_max=%.7f thr0=%.7f\n", q, ix->h_res_hdr[q].count,
                         ix->h_res_hdr[q].n_cand, ix->h_res_hdr[q].o_max, hp[q].thr0);
         }
@@ -851,11 +920,9 @@ int search_locked(pb_index *ix, const uint8_t *queries, uint32_t nq, uint32_t k,
     for (uint32_t q0 = 0; q0 < nq; q0 += Q_CHUNK) {
         const uint32_t cq = std::min(Q_CHUNK, nq - q0);
         memcpy(ix->h_stage, queries + (size_t)q0 * d, (size_t)cq * d);
-        int rc = search_chunk(ix, cq, k, max_dist);
+        // results are written by the kernels into h_res_* (host_out): search_chunk's single wait is the call's only one
+        int rc = search_chunk(ix, cq, k, max_dist, nullptr, nullptr, nullptr, true);
         if (rc) return rc;
-        PB_HIP(hipMemcpyAsync(ix->h_res_ids, ix->d_res_ids, (size_t)cq * PB_MAX_K * sizeof(int64_t), hipMemcpyDeviceToHost, ix->stream));
-        PB_HIP(hipMemcpyAsync(ix->h_res_dist, ix->d_res_dist, (size_t)cq * PB_MAX_K * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
-        PB_HIP(hipStreamSynchronize(ix->stream));
         for (uint32_t q = 0; q < cq; ++q) {
             const uint32_t c = ix->h_res_hdr[q].count;
             out_count[q0 + q] = c;
@@ -866,19 +933,16 @@ int search_locked(pb_index *ix, const uint8_t *queries, uint32_t nq, uint32_t k,
     return PB_OK;
 }
 
-// results packed for the all-gather, left in DEVICE memory: d_packed[q][0..k) ids, [k..2k) dist bits, [2k] count
-int search_packed_locked(pb_index *ix, const uint8_t *queries, uint32_t nq, uint32_t k, double max_dist, int64_t *d_packed) {
+// Results left in DEVICE memory.  `emit(q0, cq)` is called once the final results of queries [q0, q0 + cq) sit in
+// d_res_ids / d_res_dist / d_res_hdr slots [0, cq) (stride PB_MAX_K); it queues a kernel on ix->stream that writes them
+// wherever the caller wants them (the all-gather message, plain id / distance / count arrays).
+template <class Emit>
+int search_to_device(pb_index *ix, const uint8_t *queries, uint32_t nq, uint32_t k, double max_dist, Emit emit) {
     const uint32_t d = ix->dim;
-    const size_t row = 2 * (size_t)k + 1;
-    if (ix->n_rows == 0) {
-        PB_HIP(hipMemsetAsync(d_packed, 0, (size_t)nq * row * sizeof(int64_t), ix->stream));
-        PB_HIP(hipStreamSynchronize(ix->stream));
-        return PB_OK;
-    }
     PB_CHECK(ix->n_rows < (1ull << 32), PB_ERR_CAPACITY, "more than 2^32 rows per shard are not supported");
     if (nq > Q_CHUNK && multi_eligible(ix, nq)) {
         // a burst: the concurrent-query path a block at a time; queries that needed the exhaustive pass were
-        // patched in the host copies, so those blocks are written back before packing
+        // patched in the host copies, so those blocks are written back before they are emitted
         for (uint32_t q0 = 0; q0 < nq; q0 += PIPE_Q) {
             const uint32_t cq = std::min(PIPE_Q, nq - q0);
             uint32_t n_failed = 0;
@@ -889,8 +953,7 @@ int search_packed_locked(pb_index *ix, const uint8_t *queries, uint32_t nq, uint
                 PB_HIP(hipMemcpyAsync(ix->d_res_dist, ix->h_res_dist, (size_t)cq * PB_MAX_K * sizeof(float), hipMemcpyHostToDevice, ix->stream));
                 PB_HIP(hipMemcpyAsync(ix->d_res_hdr, ix->h_res_hdr, cq * sizeof(ResultHdr), hipMemcpyHostToDevice, ix->stream));
             }
-            hipLaunchKernelGGL(k_pack_results, dim3(cq), dim3(256), 0, ix->stream, ix->d_res_ids, ix->d_res_dist, ix->d_res_hdr,
-                               (uint32_t)PB_MAX_K, k, d_packed + (size_t)q0 * row);
+            emit(q0, cq);
             PB_HIP(hipGetLastError());
             PB_HIP(hipStreamSynchronize(ix->stream));  // the next block reuses the staging buffers
         }
@@ -901,12 +964,27 @@ int search_packed_locked(pb_index *ix, const uint8_t *queries, uint32_t nq, uint
         memcpy(ix->h_stage, queries + (size_t)q0 * d, (size_t)cq * d);
         int rc = search_chunk(ix, cq, k, max_dist);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_pack_results, dim3(cq), dim3(256), 0, ix->stream, ix->d_res_ids, ix->d_res_dist, ix->d_res_hdr,
-                           (uint32_t)PB_MAX_K, k, d_packed + (size_t)q0 * row);
+        emit(q0, cq);
         PB_HIP(hipGetLastError());
     }
     PB_HIP(hipStreamSynchronize(ix->stream));
     return PB_OK;
+}
+
+// results packed for the all-gather: d_packed[q][0..k) ids, [k..2k) dist bits, [2k] count
+int search_packed_locked(pb_index *ix, const uint8_t *queries, uint32_t nq, uint32_t k, double max_dist, int64_t *d_packed) {
+    const size_t row = 2 * (size_t)k + 1;
+    if (ix->n_rows == 0) {  // k_pack_results' encoding of "no results": id INT64_MAX, dist +inf, count 0
+        hipLaunchKernelGGL(k_pack_results, dim3(nq), dim3(256), 0, ix->stream, (const int64_t *)nullptr, (const float *)nullptr,
+                           (const ResultHdr *)nullptr, (uint32_t)PB_MAX_K, k, d_packed);
+        PB_HIP(hipGetLastError());
+        PB_HIP(hipStreamSynchronize(ix->stream));
+        return PB_OK;
+    }
+    return search_to_device(ix, queries, nq, k, max_dist, [&](uint32_t q0, uint32_t cq) {
+        hipLaunchKernelGGL(k_pack_results, dim3(cq), dim3(256), 0, ix->stream, ix->d_res_ids, ix->d_res_dist, ix->d_res_hdr,
+                           (uint32_t)PB_MAX_K, k, d_packed + (size_t)q0 * row);
+    });
 }
 
 // append rows that are already on the device (or host) at the tail; ids ascending and > last
@@ -914,13 +992,16 @@ int append_tail(pb_index *ix, const int64_t *ids, const uint8_t *rows, uint64_t 
     PB_CHECK(ix->n_rows + n <= ix->capacity, PB_ERR_CAPACITY, "index full: %llu + %llu > capacity %llu",
              (unsigned long long)ix->n_rows, (unsigned long long)n, (unsigned long long)ix->capacity);
     const size_t d = ix->dim;
+    const bool async = ix->opt_append_async && kind == hipMemcpyDeviceToDevice;
     PB_HIP(hipMemcpyAsync(ix->d_rows + ix->n_rows * d, rows, n * d, kind, ix->stream));
-    PB_HIP(hipMemcpyAsync(ix->d_ids + ix->n_rows, ids, n * sizeof(int64_t), hipMemcpyHostToDevice, ix->stream));
+    // PB_OPT_APPEND_ASYNC: the device-to-device form returns with its row copy and norms queued on the stream.  The
+    // caller's `ids` array is NOT handed to an asynchronous copy (it is pageable memory the caller may free on return):
+    // the ids are kept in h_ids and uploaded by refresh_min_den before the next reader of d_ids
+    if (async) ix->ids_dirty_lo = std::min(ix->ids_dirty_lo, ix->n_rows);
+    else PB_HIP(hipMemcpyAsync(ix->d_ids + ix->n_rows, ids, n * sizeof(int64_t), hipMemcpyHostToDevice, ix->stream));
     int rc = launch_norms(ix, ix->n_rows, n);
     if (rc) return rc;
-    // PB_OPT_APPEND_ASYNC: the device-to-device form returns with its work queued on the stream (the ids were staged by
-    // the runtime: `ids` is pageable host memory); everything that reads the index runs on the same stream or waits for it
-    if (!(ix->opt_append_async && kind == hipMemcpyDeviceToDevice)) PB_HIP(hipStreamSynchronize(ix->stream));
+    if (!async) PB_HIP(hipStreamSynchronize(ix->stream));
     ix->h_ids.insert(ix->h_ids.end(), ids, ids + n);
     ix->n_rows += n;
     return PB_OK;
@@ -929,6 +1010,7 @@ int append_tail(pb_index *ix, const int64_t *ids, const uint8_t *rows, uint64_t 
 // insert one row at sorted position pos < n_rows (rare path): shift the tail through a temporary
 int insert_at(pb_index *ix, uint64_t pos, int64_t id, const uint8_t *row) {
     PB_CHECK(ix->n_rows + 1 <= ix->capacity, PB_ERR_CAPACITY, "index full");
+    { int rcm = refresh_min_den(ix); if (rcm) return rcm; }  // d_ids is about to be shifted: pending uploads first
     const size_t d = ix->dim;
     const uint64_t tail = ix->n_rows - pos;
     void *tmp = nullptr;
@@ -993,6 +1075,9 @@ int pb_index_create(pb_index **out, int device, uint32_t dim, uint64_t capacity_
     ix->device = device;
     ix->dim = dim;
     ix->capacity = capacity_rows;
+    ix->env_no_second_chance = getenv("PB_NO_SECOND_CHANCE") != nullptr;  // diagnostics switches
+    ix->env_trace_cert = getenv("PB_TRACE_CERT") != nullptr;
+    ix->env_exact_lane_rows = getenv("PB_EXACT_LANE_ROWS") != nullptr;
     make_lut(ix->lut);
     auto body = [&]() -> int {
         hipDeviceProp_t prop;
@@ -1052,6 +1137,13 @@ int pb_index_size(const pb_index *ix, uint64_t *n_rows) {
     return PB_OK;
 }
 
+int pb_index_contains(const pb_index *ix, int64_t image_id, int *found) {
+    PB_CHECK(ix && found, PB_ERR_INVALID, "pb_index_contains: null pointer");
+    std::lock_guard<std::mutex> lock(ix->mu);
+    *found = std::binary_search(ix->h_ids.begin(), ix->h_ids.end(), image_id) ? 1 : 0;
+    return PB_OK;
+}
+
 int pb_index_dim(const pb_index *ix, uint32_t *dim) {
     PB_CHECK(ix && dim, PB_ERR_INVALID, "pb_index_dim: null pointer");
     *dim = ix->dim;
@@ -1078,7 +1170,10 @@ int pb_index_append(pb_index *ix, const int64_t *image_ids, const uint8_t *rows,
         }
         if (j > i) {
             int rc = append_tail(ix, image_ids + i, rows + i * d, j - i, hipMemcpyHostToDevice);
-            if (rc) return rc;
+            if (rc) {
+                if (n_inserted) *n_inserted = stored;  // what earlier runs of this call did store
+                return rc;
+            }
             stored += j - i;
             i = j;
             continue;
@@ -1088,7 +1183,10 @@ int pb_index_append(pb_index *ix, const int64_t *image_ids, const uint8_t *rows,
         auto it = std::lower_bound(ix->h_ids.begin(), ix->h_ids.end(), id);
         if (it == ix->h_ids.end() || *it != id) {
             int rc = insert_at(ix, (uint64_t)(it - ix->h_ids.begin()), id, rows + i * d);
-            if (rc) return rc;
+            if (rc) {
+                if (n_inserted) *n_inserted = stored;
+                return rc;
+            }
             ++stored;
         }
         ++i;
@@ -1124,8 +1222,14 @@ int pb_index_load(pb_index *ix, const int64_t *image_ids, const uint8_t *rows, u
     pb::DeviceGuard guard(ix->device);
     PB_CHECK(n <= ix->capacity, PB_ERR_CAPACITY, "pb_index_load: %llu rows > capacity %llu", (unsigned long long)n,
              (unsigned long long)ix->capacity);
+    PB_HIP(hipStreamSynchronize(ix->stream));
     ix->n_rows = 0;
     ix->h_ids.clear();
+    ix->ids_dirty_lo = UINT64_MAX;
+    // the error margin's minimum belongs to the rows that are being replaced
+    ix->min_den_b = 0x7FFFFFFF;
+    ix->min_dirty = false;
+    PB_HIP(hipMemcpy(ix->d_min_den, &ix->min_den_b, sizeof(int32_t), hipMemcpyHostToDevice));
     if (n == 0) return PB_OK;
     return append_tail(ix, image_ids, rows, n, hipMemcpyHostToDevice);
 }
@@ -1163,7 +1267,7 @@ int pb_index_read(const pb_index *ix, uint64_t first, uint64_t n, int64_t *image
     PB_CHECK(ix, PB_ERR_INVALID, "pb_index_read: null index");
     std::lock_guard<std::mutex> lock(ix->mu);
     pb::DeviceGuard guard(ix->device);
-    PB_CHECK(first + n <= ix->n_rows, PB_ERR_INVALID, "pb_index_read: range [%llu, %llu) beyond %llu rows",
+    PB_CHECK(first <= ix->n_rows && n <= ix->n_rows - first, PB_ERR_INVALID, "pb_index_read: range [%llu, %llu) beyond %llu rows",
              (unsigned long long)first, (unsigned long long)(first + n), (unsigned long long)ix->n_rows);
     PB_HIP(hipStreamSynchronize(ix->stream));
     if (image_ids) memcpy(image_ids, ix->h_ids.data() + first, n * sizeof(int64_t));
@@ -1188,18 +1292,20 @@ int pb_index_search_device(pb_index *ix, const uint8_t *queries, uint32_t nq, ui
     PB_CHECK(k >= 1 && k <= PB_MAX_K, PB_ERR_INVALID, "pb_index_search_device: k = %u outside 1..%u", k, PB_MAX_K);
     PB_CHECK(nq == 0 || (queries && d_out_ids && d_out_dist && d_out_count), PB_ERR_INVALID, "null buffer");
     if (nq == 0) return PB_OK;
-    std::vector<int64_t> ids((size_t)nq * k, std::numeric_limits<int64_t>::max());
-    std::vector<float> dist((size_t)nq * k, std::numeric_limits<float>::infinity());
-    std::vector<uint32_t> cnt(nq, 0);
     std::lock_guard<std::mutex> lock(ix->mu);
     pb::DeviceGuard guard(ix->device);
-    int rc = search_locked(ix, queries, nq, k, max_dist, ids.data(), dist.data(), cnt.data());
-    if (rc) return rc;
-    PB_HIP(hipMemcpyAsync(d_out_ids, ids.data(), ids.size() * sizeof(int64_t), hipMemcpyHostToDevice, ix->stream));
-    PB_HIP(hipMemcpyAsync(d_out_dist, dist.data(), dist.size() * sizeof(float), hipMemcpyHostToDevice, ix->stream));
-    PB_HIP(hipMemcpyAsync(d_out_count, cnt.data(), cnt.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ix->stream));
-    PB_HIP(hipStreamSynchronize(ix->stream));
-    return PB_OK;
+    if (ix->n_rows == 0) {
+        hipLaunchKernelGGL(k_export_results, dim3(nq), dim3(256), 0, ix->stream, (const int64_t *)nullptr, (const float *)nullptr,
+                           (const ResultHdr *)nullptr, (uint32_t)PB_MAX_K, k, d_out_ids, d_out_dist, d_out_count);
+        PB_HIP(hipGetLastError());
+        PB_HIP(hipStreamSynchronize(ix->stream));
+        return PB_OK;
+    }
+    // device to device: the results never visit the host (the certificate headers do, 20 bytes per query)
+    return search_to_device(ix, queries, nq, k, max_dist, [&](uint32_t q0, uint32_t cq) {
+        hipLaunchKernelGGL(k_export_results, dim3(cq), dim3(256), 0, ix->stream, ix->d_res_ids, ix->d_res_dist, ix->d_res_hdr,
+                           (uint32_t)PB_MAX_K, k, d_out_ids + (size_t)q0 * k, d_out_dist + (size_t)q0 * k, d_out_count + q0);
+    });
 }
 
 int pb_index_search_packed(pb_index *ix, const uint8_t *queries, uint32_t nq, uint32_t k, double max_dist, int64_t *d_packed) {
@@ -1227,6 +1333,7 @@ int pb_index_set_option(pb_index *ix, int option, int64_t value) {
             ix->stream = value ? reinterpret_cast<hipStream_t>(value) : ix->own_stream;
             return PB_OK;
         case PB_OPT_SCAN_VARIANT:
+            PB_CHECK(value >= 0 && value <= 15 && ((value >> 1) & 3) != 3, PB_ERR_INVALID, "PB_OPT_SCAN_VARIANT: bits 0-3, loads-in-flight field 0..2");
             ix->opt_variant = (int)value;
             return PB_OK;
         case PB_OPT_SCAN_WG_PER_CU:
@@ -1246,13 +1353,18 @@ int pb_index_set_option(pb_index *ix, int option, int64_t value) {
             ix->opt_mq_per_chunk = (int)value;
             return PB_OK;
         case PB_OPT_SCAN_LAUNCH:
-            PB_CHECK(value <= 2, PB_ERR_INVALID, "scan mode: 0, 1 or 2");
+            PB_CHECK(value >= 0 && value <= 2, PB_ERR_INVALID, "PB_OPT_SCAN_LAUNCH: 0, 1 or 2");
             ix->opt_mode = (int)value;
             return PB_OK;
         case PB_OPT_APPEND_ASYNC:
             ix->opt_append_async = value != 0;
             return PB_OK;
+        case PB_OPT_EXACT_QN:
+            PB_CHECK(value == 0 || value == 1 || value == 2 || value == 4, PB_ERR_INVALID, "PB_OPT_EXACT_QN: 0 (auto), 1, 2 or 4");
+            ix->opt_exact_qn = (int)value;
+            return PB_OK;
         case PB_OPT_SCAN_GRID:
+            PB_CHECK(value >= 0 && value <= (int64_t)F_MAX_WG, PB_ERR_INVALID, "PB_OPT_SCAN_GRID: 0..%d workgroups", (int)F_MAX_WG);
             ix->opt_grid = (int)value;
             return PB_OK;
         case PB_OPT_SCAN_WAVES:

@@ -59,6 +59,14 @@ struct QParams {
     float m;             // |cos_filter - cos_ref| <= m for this query against every stored row
 };
 
+// one query with its constants as a kernel argument (k_stage_query)
+struct QArg {
+    QParams p;
+    uint32_t dim;
+    uint32_t pad_;
+    uint8_t q[1024];
+};
+
 struct ListHdr {
     uint32_t count;
     float dropped;  // every row this workgroup saw and did not list has cos_filter <= dropped (0: none)
@@ -221,6 +229,34 @@ __device__ __forceinline__ float ref_fold_dot(const uint8_t *__restrict__ row, c
         }
     }
     return dot;
+}
+
+// The same fold for a 256-byte row with ALL sixteen 16-byte loads requested before the first use: the candidates of a
+// re-scoring kernel are random rows in HBM, and the loop above (runtime d, one load per trip) pays one memory round
+// trip per 16 bytes -- sixteen dependent trips per candidate on the latency-bound tail of every query.  Same operations
+// in the same order: bit-identical.
+__device__ __forceinline__ float ref_fold_dot256(const uint8_t *__restrict__ row, const float *s_qf, const float *s_lut) {
+    uint4 v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = *reinterpret_cast<const uint4 *>(row + 16 * j);
+    float dot = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const uint32_t w[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const float x = s_lut[(w[c] >> (8 * b)) & 0xFF];
+                const float p = s_qf[16 * j + 4 * c + b] * x;
+                dot = dot + p;
+            }
+        }
+    }
+    return dot;
+}
+__device__ __forceinline__ float ref_fold_dot_any(const uint8_t *__restrict__ row, const float *s_qf, const float *s_lut, int d) {
+    return d == 256 ? ref_fold_dot256(row, s_qf, s_lut) : ref_fold_dot(row, s_qf, s_lut, d);
 }
 
 __device__ __forceinline__ float ref_distance(float dot, float sqrt_sa, float row_norm, float *cs_out) {
@@ -674,7 +710,7 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
     bool filtered = false;
     if (tid < n_cand) {
         const uint32_t r = (uint32_t)s_key[tid];
-        const float dot = ref_fold_dot(rows + (uint64_t)r * d, s_qf, s_lut, d);
+        const float dot = ref_fold_dot_any(rows + (uint64_t)r * d, s_qf, s_lut, d);
         float cs;
         const float dist = ref_distance(dot, P.sqrt_sa, norms[r], &cs);
         my_cs = cs;
@@ -901,6 +937,159 @@ __global__ __launch_bounds__(X_BLOCK) void k_scan_exact(
     uint64_t *out = lists + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * list_stride;
     for (int i = threadIdx.x; i < n_out; i += X_BLOCK) out[i] = s_sort[i];
     if (threadIdx.x == 0) list_counts[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = (uint32_t)n_out;
+}
+
+// (2b) the exhaustive pass for 256-byte rows, COALESCED, for QN queries at once.  k_scan_exact above lets every lane
+// walk its own row (64 lanes x 16 B at a 256-B stride per load: 1.3 TB/s).  Here a wave streams a tile of 64 rows =
+// 16 KiB with sixteen 1-KiB wave loads (16 B per lane, non-temporal: the table is read once), parks it in a
+// wave-private LDS image with a 272-byte row pitch (the 16-B pad makes both the 16-B stores of the staging order and the
+// lane-per-row 16-B reads conflict-free), and then every lane folds ITS row exactly as the reference does
+// (engine.rs:575-587: table de-quantisation, dot = fl(dot + fl(a*b)) left to right) -- once for each of the QN queries
+// of the group, so a row is fetched, staged and de-quantised once per QN queries.  The next tile's loads are in flight
+// (64 registers) while the current one is folded.  Query values come from a global [slot][256] f32 array through the
+// scalar cache (uniform index: s_load), not from LDS.  What bounds it: the 256 table gathers per row (ds_read_b32 at
+// random banks) and ~2 + 2 QN vector instructions per byte -- LDS / VALU issue, not HBM.
+// Output = k_scan_exact's: one sorted list of <= k exact keys per (query, workgroup) for k_merge_lists.
+constexpr int XC_WAVES = 4;
+constexpr int XC_PITCH = 272;
+template <int QN, int MAXE>
+__global__ __launch_bounds__(XC_WAVES * WAVE, 2) void k_scan_exact_co(
+    const uint8_t *__restrict__ rows, const float *__restrict__ norms, uint64_t n_rows,
+    const float *__restrict__ qf, const QParams *__restrict__ qp, const uint32_t *__restrict__ qsel, int n_sel,
+    const float *__restrict__ lut, uint64_t *__restrict__ lists, uint32_t *__restrict__ list_counts, uint32_t list_stride) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+    // layout: [XC_WAVES][64 * XC_PITCH] tiles | lut[256] | [XC_WAVES][QN][cap] key buffers | counts
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int slot0 = (int)blockIdx.y * QN;
+    int K = 0;
+    QParams P[QN];
+#pragma unroll
+    for (int j = 0; j < QN; ++j) {
+        const int sl = slot0 + j < n_sel ? slot0 + j : n_sel - 1;  // a short last group repeats its last query (never written)
+        P[j] = qp[qsel[sl]];
+        K = (int)P[j].k;
+    }
+    const int cap = K + WAVE;
+    uint8_t *tile = s_dyn + (size_t)wave * (WAVE * XC_PITCH);
+    float *s_lut = reinterpret_cast<float *>(s_dyn + (size_t)XC_WAVES * WAVE * XC_PITCH);
+    uint64_t *s_keys = reinterpret_cast<uint64_t *>(s_lut + 256);
+    for (int i = threadIdx.x; i < 256; i += XC_WAVES * WAVE) s_lut[i] = lut[i];
+    __syncthreads();
+    uint64_t *buf[QN];
+    int cnt[QN];
+    uint64_t thr_key[QN];
+#pragma unroll
+    for (int j = 0; j < QN; ++j) {
+        buf[j] = s_keys + ((size_t)wave * QN + j) * cap;
+        cnt[j] = 0;
+        thr_key[j] = ~0ull;
+    }
+    const float *qfs[QN];
+#pragma unroll
+    for (int j = 0; j < QN; ++j) qfs[j] = qf + (size_t)(slot0 + j < n_sel ? slot0 + j : n_sel - 1) * 256;
+
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const uint64_t n_tiles = (n_rows + WAVE - 1) / WAVE;
+    const uint64_t stride = (uint64_t)gridDim.x * XC_WAVES;
+    const uint64_t last_chunk = (n_rows * 256 - 16) / 16;  // last 16-byte piece inside the table
+    auto request = [&](uint64_t t, u32x4 (&v)[16]) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            uint64_t c = t * 1024 + (uint64_t)j * 64 + lane;  // 16-byte piece index
+            c = c < last_chunk ? c : last_chunk;
+            v[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(rows) + c);
+        }
+    };
+    uint64_t t = (uint64_t)wave * gridDim.x + blockIdx.x;
+    u32x4 nxt[16];
+    if (t < n_tiles) request(t, nxt);
+    for (; t < n_tiles; t += stride) {
+        // park the tile: piece j of lane l is row 4 j + l / 16, bytes [16 (l % 16), +16)
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            *reinterpret_cast<u32x4 *>(tile + (size_t)(4 * j + (lane >> 4)) * XC_PITCH + 16 * (lane & 15)) = nxt[j];
+        const uint64_t tn = t + stride;
+        if (tn < n_tiles) request(tn, nxt);
+        const uint64_t r = t * WAVE + lane;
+        const float nrm = norms[r < n_rows ? r : n_rows - 1];
+        float dot[QN];
+#pragma unroll
+        for (int j = 0; j < QN; ++j) dot[j] = 0.0f;
+        const uint8_t *myrow = tile + (size_t)lane * XC_PITCH;
+        // a real loop over the sixteen 16-byte pieces of the row (fully unrolled, the scheduler hoists all 256 QN scalar
+        // query loads to the top and spills); the next piece is read from LDS while this one is folded
+        u32x4 wn = *reinterpret_cast<const u32x4 *>(myrow);
+#pragma unroll 1
+        for (int c = 0; c < 16; ++c) {
+            const u32x4 w = wn;
+            wn = *reinterpret_cast<const u32x4 *>(myrow + 16 * (c < 15 ? c + 1 : 15));
+            const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const float x = s_lut[(ww[e] >> (8 * b)) & 0xFF];
+#pragma unroll
+                    for (int j = 0; j < QN; ++j) {
+                        const float p = qfs[j][16 * c + 4 * e + b] * x;
+                        dot[j] = dot[j] + p;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < QN; ++j) {
+            float cs;
+            const float dist = ref_distance(dot[j], P[j].sqrt_sa, nrm, &cs);
+            uint64_t key = ~0ull;
+            if (r < n_rows && (double)dist < P[j].max_dist) key = ((uint64_t)sortable_f32(dist) << 32) | (uint32_t)r;
+            const bool pass = key < thr_key[j];
+            const uint64_t m = __ballot(pass);
+            if (m) {
+                if (pass) buf[j][cnt[j] + mbcnt(m)] = key;
+                cnt[j] += __popcll(m);
+                if (cnt[j] > K) {  // buffer capacity is K + 64
+                    thr_key[j] = wave_keep_smallest<MAXE>(buf[j], cnt[j], K);
+                    cnt[j] = K;
+                }
+            }
+        }
+    }
+    // workgroup list per query = the K best of the XC_WAVES wave lists, sorted (the tile area is free now)
+    int *s_cnt = reinterpret_cast<int *>(s_keys + (size_t)XC_WAVES * QN * cap);
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < QN; ++j) s_cnt[wave * QN + j] = cnt[j];
+    }
+    __syncthreads();
+    uint64_t *s_sort = reinterpret_cast<uint64_t *>(s_dyn);  // XC_WAVES * 256 keys <= 8 KiB
+#pragma unroll
+    for (int j = 0; j < QN; ++j) {
+        if (slot0 + j >= n_sel) break;
+        int total = 0, offs[XC_WAVES];
+        for (int w = 0; w < XC_WAVES; ++w) {
+            offs[w] = total;
+            total += s_cnt[w * QN + j];
+        }
+        int nsort = 64;
+        while (nsort < total) nsort <<= 1;
+        __syncthreads();
+        for (int i = threadIdx.x; i < nsort; i += XC_WAVES * WAVE) s_sort[i] = ~0ull;
+        __syncthreads();
+        for (int w = 0; w < XC_WAVES; ++w)
+            for (int i = threadIdx.x; i < s_cnt[w * QN + j]; i += XC_WAVES * WAVE) s_sort[offs[w] + i] = s_keys[((size_t)w * QN + j) * cap + i];
+        block_bitonic_sort(s_sort, nsort);
+        const int n_out = total < K ? total : K;
+        uint64_t *out = lists + ((size_t)(slot0 + j) * gridDim.x + blockIdx.x) * list_stride;
+        for (int i = threadIdx.x; i < n_out; i += XC_WAVES * WAVE) out[i] = s_sort[i];
+        if (threadIdx.x == 0) list_counts[(size_t)(slot0 + j) * gridDim.x + blockIdx.x] = (uint32_t)n_out;
+    }
+}
+// de-quantised queries of the selected slots for k_scan_exact_co: qf[slot][i] = lut[queries[qsel[slot]][i]]
+__global__ void k_make_qf(const uint8_t *__restrict__ queries, const uint32_t *__restrict__ qsel, const float *__restrict__ lut,
+                          float *__restrict__ qf) {
+    qf[(size_t)blockIdx.x * 256 + threadIdx.x] = lut[queries[(size_t)qsel[blockIdx.x] * 256 + threadIdx.x]];
 }
 
 // merge up to M_FANIN sorted lists of <= k exact keys into one (k smallest, sorted). grid = (n_groups, nq).
@@ -1463,7 +1652,7 @@ __global__ __launch_bounds__(1024) void k_mq_rescore(
         xcs[j] = 3.0f;
         if (i < cnt) {
             const uint32_t r = (uint32_t)cand[(size_t)q * MQ_CAP + i];
-            const float dot = ref_fold_dot(rows + (uint64_t)r * d, s_qf, s_lut, d);
+            const float dot = ref_fold_dot_any(rows + (uint64_t)r * d, s_qf, s_lut, d);
             float cs;
             const float dist = ref_distance(dot, P.sqrt_sa, norms[r], &cs);
             xcs[j] = cs;
@@ -1603,7 +1792,7 @@ __global__ __launch_bounds__(1024) void k_mq_rescore_big(
             uint64_t key = ~0ull;
             if (base + i < cnt) {
                 const uint32_t r = (uint32_t)cand[(size_t)q * cap + base + i];
-                const float dot = ref_fold_dot(rows + (uint64_t)r * d, s_qf, s_lut, d);
+                const float dot = ref_fold_dot_any(rows + (uint64_t)r * d, s_qf, s_lut, d);
                 float cs;
                 const float dist = ref_distance(dot, P.sqrt_sa, norms[r], &cs);
                 if ((double)dist < P.max_dist) key = ((uint64_t)sortable_f32(dist) << 32) | r;
@@ -1635,19 +1824,40 @@ __global__ __launch_bounds__(1024) void k_mq_rescore_big(
     }
 }
 
+// single-query calls: the query and its constants arrive as kernel arguments and are put where every kernel of
+// the search path expects them (slot 0 of the staged query / parameter arrays)
+__global__ void k_stage_query(const QArg a, uint8_t *__restrict__ d_queries, QParams *__restrict__ d_qp) {
+    for (uint32_t i = threadIdx.x; i < a.dim; i += blockDim.x) d_queries[i] = a.q[i];
+    if (threadIdx.x == 0) d_qp[0] = a.p;
+}
+
 // results -> the all-gather message: packed[q][0..k) = ids, [k..2k) = dist bits (zero-extended), [2k] = count
 __global__ void k_pack_results(const int64_t *__restrict__ ids, const float *__restrict__ dist,
                                const ResultHdr *__restrict__ hdr, uint32_t res_stride, uint32_t k,
                                int64_t *__restrict__ packed) {
     const uint32_t q = blockIdx.x;
     int64_t *row = packed + (size_t)q * (2 * k + 1);
-    const uint32_t c = hdr[q].count;
+    const uint32_t c = hdr ? hdr[q].count : 0u;  // hdr == nullptr: an empty shard's message
     for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) {
         const bool v = i < c;
         row[i] = v ? ids[(size_t)q * res_stride + i] : INT64_MAX;
         row[k + i] = v ? (int64_t)__float_as_uint(dist[(size_t)q * res_stride + i]) : (int64_t)0x7F800000u;
     }
     if (threadIdx.x == 0) row[2 * k] = (int64_t)c;
+}
+// results -> plain device arrays (pb_index_search_device): ids[q][k], dist[q][k], count[q]; unused slots hold
+// id = INT64_MAX, dist = +inf
+__global__ void k_export_results(const int64_t *__restrict__ ids, const float *__restrict__ dist,
+                                 const ResultHdr *__restrict__ hdr, uint32_t res_stride, uint32_t k,
+                                 int64_t *__restrict__ out_ids, float *__restrict__ out_dist, uint32_t *__restrict__ out_count) {
+    const uint32_t q = blockIdx.x;
+    const uint32_t c = hdr ? hdr[q].count : 0u;
+    for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) {
+        const bool v = i < c;
+        out_ids[(size_t)q * k + i] = v ? ids[(size_t)q * res_stride + i] : INT64_MAX;
+        out_dist[(size_t)q * k + i] = v ? dist[(size_t)q * res_stride + i] : __uint_as_float(0x7F800000u);
+    }
+    if (threadIdx.x == 0) out_count[q] = c;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -8,6 +8,11 @@ runs the same G-way merge (`pb_topk_merge_packed`, (dist, image_id) order).  The
 per rank (25.7 KB for 16 queries, k = 100): latency-bound, so queries are batched per collective.
 
 Reference API being replaced: Engine::query_by_image_hash_from_image (engine.rs:363-396), one table.
+
+This module is the LAUNCHER-SIDE form (bench.py under torchrun: one process per GPU, the driver's contract).  The product
+form for a single-process host such as the reference is in the library itself: `pb_sharded_create(device_ids, n, ...)` /
+`pb_sharded_search` (pixelbox_amd/csrc/pb_sharded.hip: worker thread per shard, ncclCommInitAll + ncclAllGather, the same
+device merge kernel), bound as capi.ShardedIndexC.
 """
 from __future__ import annotations
 
@@ -73,5 +78,9 @@ class ShardedIndex:
             packed.copy_(torch.from_numpy(capi.pack_results(l_ids[:, :k], l_dist[:, :k], l_cnt)))
         gathered = torch.empty((self.world * nq, 2 * k + 1), dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(gathered, packed, group=self.group)
-        g = gathered.cpu().numpy().reshape(self.world, nq, 2 * k + 1)
+        if on_gpu:
+            # merged on the device by the kernel pb_sharded_search uses (pb_merge_kernels.h); only the k results travel
+            torch.cuda.current_stream(dev).synchronize()
+            return capi.topk_merge_packed_device(self.device, gathered.data_ptr(), self.world, nq, k)
+        g = gathered.numpy().reshape(self.world, nq, 2 * k + 1)
         return capi.topk_merge_packed(g, k)

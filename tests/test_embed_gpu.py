@@ -54,6 +54,75 @@ def test_batches_vs_oracle(n, max_batch):
     assert np.array_equal(f_b[::-1], f) and np.array_equal(u8_b[::-1], u8)
 
 
+def test_config3_batch_512_vs_oracle():
+    # BASELINE.json configs[2]: the batch the embed rate is quoted on.  The tuner picks kernel forms per (layer,
+    # row-count bucket), so batch 512 runs candidates no smaller batch sees: all 512 images against the CPU oracle
+    # (1e-5 on the floats / byte rule), the quantiser bit-exact on the device's own floats, and 8 sampled images
+    # re-embedded one per call give the same bits.
+    blob = W.synthetic_blob(synth.SEED_WEIGHTS, 128, 128, 256)
+    imgs = synth.synthetic_images(synth.SEED_IMAGES, 0, 512, 128, 128)
+    emb = capi.Embedder(blob, max_batch=512)
+    u8, f = emb.embed(imgs)
+    ref_u8, ref_f = oracle.mlhash_batch(blob, imgs, 256, nthreads=8)
+    assert_embeddings_close(f, ref_f)
+    assert np.array_equal(u8, no.quantize(f))
+    assert_bytes_match(u8, ref_u8, ref_f)
+    one = capi.Embedder(blob, max_batch=1)
+    for i in (0, 1, 63, 64, 200, 255, 256, 511):
+        u8_1, f_1 = one.embed(imgs[i:i + 1])
+        assert np.array_equal(f_1[0].view(np.uint32), f[i].view(np.uint32)), i
+        assert np.array_equal(u8_1[0], u8[i]), i
+    # the device-pointer entry point (what bench.py times) gives the same bits as the host-buffer one
+    import torch
+
+    d_img = torch.from_numpy(imgs).cuda()
+    d_u8 = torch.zeros((512, 256), dtype=torch.uint8, device="cuda")
+    emb.embed_device(d_img.data_ptr(), 512, d_u8.data_ptr())  # synchronous by default
+    assert np.array_equal(d_u8.cpu().numpy(), u8)
+
+
+def test_embed_device_then_append_device_on_default_streams():
+    # The pipeline the header advertises (embed_batch_device -> pb_index_append_device) with NOTHING configured: the
+    # embedder and the index each own a non-blocking stream.  pb_embed_batch_device waits for its stream by default,
+    # so the hashes are complete when the index's copy (its own stream) and a null-stream copy read them.
+    import torch
+
+    blob = W.synthetic_blob(synth.SEED_WEIGHTS, 128, 128, 256)
+    n, nb = 96, 32
+    imgs = synth.synthetic_images(synth.SEED_IMAGES, 40, n, 128, 128)
+    emb = capi.Embedder(blob, max_batch=nb)
+    want_u8, _ = emb.embed(imgs)
+    ix = capi.Index(256, n)
+    d_img = torch.from_numpy(imgs).cuda()
+    for lo in range(0, n, nb):
+        d_u8 = torch.zeros((nb, 256), dtype=torch.uint8, device="cuda")
+        emb.embed_device(d_img[lo:lo + nb].data_ptr(), nb, d_u8.data_ptr())
+        ix.append_device(np.arange(lo + 1, lo + nb + 1, dtype=np.int64), d_u8.data_ptr())
+        assert np.array_equal(d_u8.cpu().numpy(), want_u8[lo:lo + nb])  # plain copy on torch's stream
+    ids, rows = ix.read(0, n)
+    assert np.array_equal(ids, np.arange(1, n + 1)) and np.array_equal(rows, want_u8)
+    # opt-in asynchronous form: correct when producer and consumer share a stream
+    s = torch.cuda.Stream()
+    emb.set_option(capi.PB_OPT_EMBED_STREAM, s.cuda_stream)
+    emb.set_option(capi.PB_OPT_EMBED_ASYNC, 1)
+    ix2 = capi.Index(256, n)
+    ix2.set_option(capi.PB_OPT_STREAM, s.cuda_stream)
+    ix2.set_option(capi.PB_OPT_APPEND_ASYNC, 1)
+    bufs = []
+    for lo in range(0, n, nb):
+        d_u8 = torch.zeros((nb, 256), dtype=torch.uint8, device="cuda")
+        bufs.append(d_u8)
+        emb.embed_device(d_img[lo:lo + nb].data_ptr(), nb, d_u8.data_ptr())
+        ix2.append_device(np.arange(lo + 1, lo + nb + 1, dtype=np.int64), d_u8.data_ptr())  # ids: a temporary, freed on return
+    ids2, rows2 = ix2.read(0, n)
+    assert np.array_equal(ids2, ids) and np.array_equal(rows2, want_u8)
+    got = ix2.search(want_u8[:3], 5, 1e3)
+    ref = ix.search(want_u8[:3], 5, 1e3)
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1].view(np.uint32), ref[1].view(np.uint32))
+    with pytest.raises(capi.PixelboxError):
+        emb.set_option(capi.PB_OPT_EMBED_ASYNC, 2)
+
+
 def test_hash_is_bitwise_independent_of_batch_size():
     # The reference hashes one image per call (efficientnet.rs:31-42), so an image has ONE hash.  Batching must
     # not change it: the autotuned kernel forms differ per batch size (GEMM tile shapes, depthwise strip / rolling

@@ -573,6 +573,19 @@ def test_full_size_10m_properties():
         r = int(ids_a[i]) - 1
         row = synth.fill_synthetic(synth.SEED_INDEX, r * d, d)
         assert oracle.cosine_distance(q, row).view(np.uint32) == d_a[i].view(np.uint32)
+    # one full oracle top-100 at the metric's size: 10M rows through the CPU restatement, a million rows at a time
+    # (~3 s of CPU), merged with the reference's (dist, image_id) order
+    cand_ids, cand_d = [], []
+    step = 1_000_000
+    for lo in range(0, n, step):
+        rows = synth.fill_synthetic(synth.SEED_INDEX, lo * d, step * d).reshape(step, d)
+        oi, od = oracle.scan_topk(q, rows, np.arange(lo + 1, lo + step + 1, dtype=np.int64), 100, 1e3)
+        cand_ids.append(oi)
+        cand_d.append(od)
+    cand_ids, cand_d = np.concatenate(cand_ids), np.concatenate(cand_d)
+    order = np.lexsort((cand_ids, cand_d))[:100]
+    assert np.array_equal(ids_a, cand_ids[order])
+    assert np.array_equal(d_a.view(np.uint32), cand_d[order].view(np.uint32))
     # (b) plant duplicates beyond the synthetic ids
     ix.set_option(capi.PB_OPT_SEARCH_PATH, AUTO)
     ix.append([n + 5, n + 6, n + 7], np.tile(q, (3, 1)))
@@ -808,3 +821,166 @@ def test_append_device_async_on_a_shared_stream():
     assert np.array_equal(got[2], want[2]) and np.array_equal(got[0], want[0])
     assert np.array_equal(got[1].view(np.uint32), want[1].view(np.uint32))
     assert len(ix) == n
+
+
+def test_search_device_leaves_results_on_the_device():
+    # pb_index_search_device: ids / distances / counts written by a device kernel (no host round trip for the results),
+    # unused slots id = INT64_MAX, dist = +inf; chunked (> 64 queries) and burst paths, empty index
+    import torch
+
+    rng = np.random.default_rng(11)
+    d, n, k = 256, 70_000, 100
+    rows = _random_table(rng, n, d, "uniform")
+    ix = capi.Index(d, n)
+    for nq, md in ((1, 1e3), (70, 1e3), (9, 2.9)):
+        q = _random_table(rng, nq, d, "uniform")
+        d_ids = torch.zeros((nq, k), dtype=torch.int64, device="cuda")
+        d_dist = torch.zeros((nq, k), dtype=torch.float32, device="cuda")
+        d_cnt = torch.full((nq,), 77, dtype=torch.int32, device="cuda")
+        if len(ix) == 0:
+            ix.search_device(q, k, md, d_ids.data_ptr(), d_dist.data_ptr(), d_cnt.data_ptr())
+            assert np.all(d_cnt.cpu().numpy() == 0) and np.all(d_ids.cpu().numpy() == np.iinfo(np.int64).max)
+            assert np.all(np.isinf(d_dist.cpu().numpy()))
+            ix.load(np.arange(1, n + 1, dtype=np.int64), rows)
+        ix.search_device(q, k, md, d_ids.data_ptr(), d_dist.data_ptr(), d_cnt.data_ptr())
+        want = ix.search(q, k, md)
+        cnt = d_cnt.cpu().numpy().astype(np.uint32)
+        assert np.array_equal(cnt, want[2])
+        gi, gd = d_ids.cpu().numpy(), d_dist.cpu().numpy()
+        for i in range(nq):
+            c = int(cnt[i])
+            assert np.array_equal(gi[i, :c], want[0][i, :c])
+            assert np.array_equal(gd[i, :c].view(np.uint32), want[1][i, :c].view(np.uint32))
+            assert np.all(gi[i, c:] == np.iinfo(np.int64).max) and np.all(np.isinf(gd[i, c:]))
+
+
+@pytest.mark.parametrize("qn", [0, 1, 2, 4])
+@pytest.mark.parametrize("k", [100, 256])
+def test_coalesced_exhaustive_pass_vs_oracle(qn, k):
+    # k_scan_exact_co: 64-row tiles staged through LDS, QN queries per sweep; ragged last tile, odd query counts,
+    # k beyond 128 (the larger key buffers), duplicates of the query (ties broken by image_id)
+    rng = np.random.default_rng(100 + qn)
+    d, n = 256, 64 * 300 + 37
+    rows = _random_table(rng, n, d, "clustered")
+    ids = np.arange(n, dtype=np.int64) * 2 + 5
+    q = _random_table(rng, 5, d, "clustered")
+    q[1] = rows[n - 1]
+    rows[100:104] = q[2]
+    ix = capi.Index(d, n)
+    ix.load(ids, rows)
+    ix.set_option(capi.PB_OPT_SEARCH_PATH, EXACT)
+    ix.set_option(capi.PB_OPT_EXACT_QN, qn)
+    for md in (1e3, 0.5):
+        got = ix.search(q, k, md)
+        for i in range(len(q)):
+            wi, wd = oracle.scan_topk(q[i], rows, ids, k, md)
+            c = int(got[2][i])
+            assert c == len(wi)
+            assert np.array_equal(got[0][i, :c], wi) and np.array_equal(got[1][i, :c].view(np.uint32), wd.view(np.uint32))
+    assert ix.stats().fallback == 10
+    with pytest.raises(capi.PixelboxError):
+        ix.set_option(capi.PB_OPT_EXACT_QN, 3)
+
+
+def test_option_values_are_range_checked():
+    ix = capi.Index(256, 16)
+    for opt, bad in ((capi.PB_OPT_SCAN_LAUNCH, -1), (capi.PB_OPT_SCAN_LAUNCH, 3), (4, 16), (4, -1), (4, 6), (7, -5), (7, 100000)):
+        with pytest.raises(capi.PixelboxError):
+            ix.set_option(opt, bad)
+    # a failing append reports what earlier runs of the call stored
+    ix.append(np.arange(1, 11, dtype=np.int64), np.zeros((10, 256), np.uint8))
+    with pytest.raises(capi.PixelboxError):
+        ix.append(np.arange(11, 31, dtype=np.int64), np.zeros((20, 256), np.uint8))  # capacity 16
+    assert len(ix) == 10
+    assert capi.lib().pb_index_read(ix._h, 2**63, 2**63 + 3, None, None) == -1  # first + n wraps: PB_ERR_INVALID
+
+
+@pytest.mark.parametrize("n_shards", [1, 2, 3])
+def test_sharded_index_through_the_c_abi(n_shards):
+    # pb_sharded_*: one process, N shards (all on device 0 here: the copy exchange; N distinct devices take the RCCL
+    # all-gather), per-shard packed top-k, device merge -- against the oracle over the whole table and against a
+    # single index; loads split by contiguous ranges, appends go to the least-full shard with INSERT OR IGNORE over
+    # ALL shards
+    rng = np.random.default_rng(40 + n_shards)
+    d, n = 256, 30_011
+    rows = _random_table(rng, n, d, "clustered")
+    ids = np.arange(n, dtype=np.int64) * 3 + 11
+    sh = capi.ShardedIndexC(d, n + 600, [0] * n_shards)
+    assert sh.info()["n_shards"] == n_shards
+    sh.load(ids, rows)
+    tot, per = sh.sizes()
+    assert tot == n and per.max() - per.min() <= n_shards and int(per.sum()) == n
+    q = _random_table(rng, 70, d, "clustered")
+    q[0] = rows[17]
+    q[1] = rows[n - 1]
+    for k, md in ((100, 1e3), (7, 0.5), (256, 2e6)):
+        got = sh.search(q, k, md)
+        for i in (0, 1, 2, 33, 69):
+            wi, wd = oracle.scan_topk(q[i], rows, ids, k, md)
+            c = int(got[2][i])
+            assert c == len(wi)
+            assert np.array_equal(got[0][i, :c], wi) and np.array_equal(got[1][i, :c].view(np.uint32), wd.view(np.uint32))
+    assert sh.info()["n_exchanges"] >= 3
+    # appends: 500 new rows + 20 ids that exist on some shard + a repeat inside the call -> 500 stored
+    new_rows = _random_table(rng, 500, d, "clustered")
+    new_ids = np.arange(500, dtype=np.int64) + 10_000_000
+    app_ids = np.concatenate([new_ids, ids[::1500][:20], new_ids[:1]])
+    app_rows = np.concatenate([new_rows, 255 - rows[::1500][:20], new_rows[:1]])
+    assert sh.append(app_ids, app_rows) == 500
+    all_rows, all_ids = np.concatenate([rows, new_rows]), np.concatenate([ids, new_ids])
+    got = sh.search(new_rows[:4], 50, 1e3)
+    for i in range(4):
+        wi, wd = oracle.scan_topk(new_rows[i], all_rows, all_ids, 50, 1e3)
+        assert np.array_equal(got[0][i, :len(wi)], wi) and np.array_equal(got[1][i, :len(wi)].view(np.uint32), wd.view(np.uint32))
+    # capacity is the total: 100 slots are left
+    with pytest.raises(capi.PixelboxError) as ei:
+        sh.append(np.arange(200, dtype=np.int64) + 20_000_000, np.zeros((200, d), np.uint8))
+    assert ei.value.code == -4
+    assert len(sh) == n + 600
+    st = sh.stats()
+    assert st.queries > 0
+
+
+def test_sharded_index_single_shard_through_rccl(monkeypatch):
+    # PB_SHARDED_FORCE_RCCL=1: a one-device communicator (ncclCommInitAll with n = 1) runs the real all-gather path
+    monkeypatch.setenv("PB_SHARDED_FORCE_RCCL", "1")
+    rng = np.random.default_rng(77)
+    d, n = 256, 9000
+    rows = _random_table(rng, n, d, "uniform")
+    ids = np.arange(1, n + 1, dtype=np.int64)
+    sh = capi.ShardedIndexC(d, n, [0])
+    assert sh.info()["uses_rccl"]
+    sh.load(ids, rows)
+    q = _random_table(rng, 5, d, "uniform")
+    got = sh.search(q, 100, 1e3)
+    for i in range(5):
+        wi, wd = oracle.scan_topk(q[i], rows, ids, 100, 1e3)
+        assert np.array_equal(got[0][i, :len(wi)], wi) and np.array_equal(got[1][i, :len(wi)].view(np.uint32), wd.view(np.uint32))
+
+
+def test_device_merge_kernel_matches_the_host_merge():
+    import torch
+
+    rng = np.random.default_rng(3)
+    for n_lists, nq, k in ((1, 3, 100), (8, 40, 100), (8, 5, 256), (20, 4, 200)):  # the last: beyond the LDS staging
+        cnt = rng.integers(0, k + 1, size=(n_lists, nq))
+        g = np.zeros((n_lists, nq, 2 * k + 1), dtype=np.int64)
+        for a in range(n_lists):
+            for b in range(nq):
+                c = int(cnt[a, b])
+                dist = np.sort(rng.choice(np.array([0.0, 0.5, 1.25, 3.0, 999999.0, -1.1920929e-07], np.float32), size=c))
+                idv = rng.choice(10**6, size=c, replace=False).astype(np.int64) * n_lists + a  # unique across lists
+                order = np.lexsort((idv, dist))
+                g[a, b, :c] = idv[order]
+                g[a, b, k:k + c] = dist[order].view(np.uint32).astype(np.int64)
+                g[a, b, :k][c:] = np.iinfo(np.int64).max
+                g[a, b, k:2 * k][c:] = 0x7F800000
+                g[a, b, 2 * k] = c
+        want = capi.topk_merge_packed(g, k)
+        dg = torch.from_numpy(g).cuda()
+        got = capi.topk_merge_packed_device(0, dg.data_ptr(), n_lists, nq, k)
+        assert np.array_equal(got[2], want[2])
+        for b in range(nq):
+            c = int(want[2][b])
+            assert np.array_equal(got[0][b, :c], want[0][b, :c])
+            assert np.array_equal(got[1][b, :c].view(np.uint32), want[1][b, :c].view(np.uint32))
