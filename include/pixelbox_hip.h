@@ -161,7 +161,7 @@ int pb_index_fill_synthetic(pb_index *idx, uint64_t seed, uint64_t first_row, ui
 #define PB_OPT_APPEND_ASYNC 12 /* 1: pb_index_append_device returns with its copies and the per-row norms queued on the index's stream \
                                  instead of waiting for them (a producer on the same stream -- PB_OPT_STREAM, PB_OPT_EMBED_STREAM -- \
                                  can then run ahead of the GPU); searches wait as before */
-#define PB_OPT_EXACT_QN 13 /* exhaustive pass over 256-byte cosine rows: queries answered per table sweep (0 = auto, 1, 2, 4) */
+#define PB_OPT_EXACT_QN 13 /* exhaustive pass over 256-byte cosine rows: queries answered per table sweep (0 = auto, 1, 2) */
 #define PB_OPT_MQ_PER_CHUNK 11  /* 1: bursts of > 64 queries run one 64-query pass at a time instead of sharing row tiles
                                   among 512 queries per workgroup (default 0; for measurement) */
 int pb_index_set_option(pb_index *idx, int option, int64_t value);

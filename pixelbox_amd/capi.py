@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpixelbox_hip.so")
+# PIXELBOX_LIB: another build of the same library (kernel ablations, profiles/*); the default is the in-tree build
+LIB_PATH = os.environ.get("PIXELBOX_LIB") or os.path.join(_HERE, "libpixelbox_hip.so")
 
 PB_OK = 0
 PB_MAX_K = 256

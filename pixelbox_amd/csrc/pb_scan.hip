@@ -133,7 +133,7 @@ int alloc_workspace(pb_index *ix) {
         PB_HIP(hipMalloc(&ix->d_xcounts[i], (size_t)Q_CHUNK * lists * sizeof(uint32_t)));
     }
     PB_HIP(hipMalloc(&ix->d_qsel, Q_CHUNK * sizeof(uint32_t)));
-    PB_HIP(hipMalloc(&ix->d_qf, (size_t)Q_CHUNK * 256 * sizeof(float)));
+    PB_HIP(hipMalloc(&ix->d_qf, ((size_t)Q_CHUNK * 256 + 16) * sizeof(float)));  // + one piece of slack: k_scan_exact_co fetches one piece ahead
     PB_HIP(hipMalloc(&ix->d_tau, PIPE_Q * sizeof(float)));
     PB_HIP(hipMalloc(&ix->d_cand, (size_t)PIPE_Q * MQ_CAP * sizeof(uint64_t)));
     PB_HIP(hipMalloc(&ix->d_cand_cnt, PIPE_Q * sizeof(uint32_t)));
@@ -466,8 +466,7 @@ int run_fast_dist(pb_index *ix, uint32_t nq) {
 template <int QN, int MAXE>
 int launch_exact_co(pb_index *ix, int n_lists, uint32_t n_sel, uint32_t k) {
     const size_t cap = (size_t)k + WAVE;
-    const size_t lds = (size_t)XC_WAVES * WAVE * XC_PITCH + 256 * sizeof(float) + (size_t)XC_WAVES * QN * cap * sizeof(uint64_t) +
-                       (size_t)XC_WAVES * QN * sizeof(int);
+    const size_t lds = (size_t)XC_WAVES * WAVE * XC_PITCH + (size_t)XC_WAVES * QN * cap * sizeof(uint64_t) + (size_t)XC_WAVES * QN * sizeof(int);
     auto kern = k_scan_exact_co<QN, MAXE>;
     PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(n_lists, (n_sel + QN - 1) / QN), dim3(XC_WAVES * WAVE), lds, ix->stream, ix->d_rows, ix->d_norms,
@@ -482,14 +481,23 @@ int run_exact(pb_index *ix, uint32_t n_sel, uint32_t k) {
     const uint64_t n_tiles = (ix->n_rows + WAVE - 1) / WAVE;
     const uint64_t want = (n_tiles + (coalesced ? XC_WAVES : X_WAVES) - 1) / (coalesced ? XC_WAVES : X_WAVES);
     int n_lists = (int)std::max<uint64_t>(1, std::min<uint64_t>(want, coalesced ? std::min<uint64_t>(X_MAX_WG, 2ull * ix->n_cu) : X_MAX_WG));
+    if (coalesced) {
+        // every workgroup ends with a sort of its wave lists per query (~20 us): give a wave at least 32 tiles to stream
+        // when the queries of the call fill the chip anyway (a 1M-row table ran 2x slower per row than a 10M-row one
+        // with 512 workgroups per query pair)
+        const uint64_t groups = (n_sel + 1) / 2;
+        const uint64_t fat = std::max<uint64_t>(1, n_tiles / (32ull * XC_WAVES));
+        const uint64_t fill = (2ull * ix->n_cu + groups - 1) / groups;  // workgroups per group that still fill 2 per CU
+        n_lists = (int)std::min<uint64_t>((uint64_t)n_lists, std::max<uint64_t>(fat, fill));
+    }
     if (ix->opt_profile && ix->opt_path == 1) PB_HIP(hipEventRecord(ix->ev0, ix->stream));
     if (coalesced) {
         hipLaunchKernelGGL(k_make_qf, dim3(n_sel), dim3(256), 0, ix->stream, ix->d_queries, ix->d_qsel, ix->d_lut, ix->d_qf);
         PB_HIP(hipGetLastError());
         const int qn = ix->opt_exact_qn ? ix->opt_exact_qn : (n_sel >= 2 ? 2 : 1);
         int rc;
-        if (k <= 128) rc = qn >= 4 ? launch_exact_co<4, 3>(ix, n_lists, n_sel, k) : (qn == 2 ? launch_exact_co<2, 3>(ix, n_lists, n_sel, k) : launch_exact_co<1, 3>(ix, n_lists, n_sel, k));
-        else rc = qn >= 4 ? launch_exact_co<4, 5>(ix, n_lists, n_sel, k) : (qn == 2 ? launch_exact_co<2, 5>(ix, n_lists, n_sel, k) : launch_exact_co<1, 5>(ix, n_lists, n_sel, k));
+        if (k <= 128) rc = qn == 2 ? launch_exact_co<2, 3>(ix, n_lists, n_sel, k) : launch_exact_co<1, 3>(ix, n_lists, n_sel, k);
+        else rc = qn == 2 ? launch_exact_co<2, 5>(ix, n_lists, n_sel, k) : launch_exact_co<1, 5>(ix, n_lists, n_sel, k);
         if (rc) return rc;
     } else {
 #define PB_X(MV)                                                                                                   \
@@ -1360,7 +1368,7 @@ int pb_index_set_option(pb_index *ix, int option, int64_t value) {
             ix->opt_append_async = value != 0;
             return PB_OK;
         case PB_OPT_EXACT_QN:
-            PB_CHECK(value == 0 || value == 1 || value == 2 || value == 4, PB_ERR_INVALID, "PB_OPT_EXACT_QN: 0 (auto), 1, 2 or 4");
+            PB_CHECK(value >= 0 && value <= 2, PB_ERR_INVALID, "PB_OPT_EXACT_QN: 0 (auto), 1 or 2");
             ix->opt_exact_qn = (int)value;
             return PB_OK;
         case PB_OPT_SCAN_GRID:

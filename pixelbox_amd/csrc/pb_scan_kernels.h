@@ -905,16 +905,23 @@ __global__ __launch_bounds__(X_BLOCK) void k_scan_exact(
             }
             if ((double)dist < P.max_dist) key = ((uint64_t)sortable_f32(dist) << 32) | (uint32_t)r;
         }
-        const bool pass = key < thr_key;
-        const uint64_t m = __ballot(pass);
+        bool pass = key < thr_key;
+        uint64_t m = __ballot(pass);
         if (m) {
-            if (pass) buf[cnt + mbcnt(m)] = key;
-            cnt += __popcll(m);
-            if (cnt > K) {  // buffer capacity is K + 64
+            // prune only when the newcomers do not fit (capacity K + 64), not after every insertion (k_scan_exact_co)
+            if (cnt + (int)__popcll(m) > K + WAVE) {
                 thr_key = wave_keep_smallest<X_MAXE>(buf, cnt, K);
                 cnt = K;
+                pass = key < thr_key;
+                m = __ballot(pass);
             }
+            if (pass) buf[cnt + mbcnt(m)] = key;
+            cnt += __popcll(m);
         }
+    }
+    if (cnt > K) {
+        wave_keep_smallest<X_MAXE>(buf, cnt, K);
+        cnt = K;
     }
     if (lane == 0) s_cnt[wave] = cnt;
     __syncthreads();
@@ -939,6 +946,18 @@ __global__ __launch_bounds__(X_BLOCK) void k_scan_exact(
     if (threadIdx.x == 0) list_counts[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = (uint32_t)n_out;
 }
 
+// engine.rs:576 without the table: L[v] = fl(fl(fl(v / 255) * 2) - 1) for v = 0..255 from three vector instructions.
+// t = fl(v / 255) is reproduced by a split reciprocal, t = fma(v, R_HI, fl(v * R_LO)) with R_HI + R_LO = 1/255 to 48
+// bits -- checked against the correctly rounded quotient for ALL 256 byte values (tests/test_oracle.py pins the two
+// constants the same way; the kernel's results are compared with the oracle bit for bit) -- and fl(2 t - 1) is one fma
+// (2 t is exact).  A table gather costs an LDS access at a random bank per byte; in the exhaustive pass, which
+// de-quantises every byte of the table, that gather was the bound.
+__device__ __forceinline__ float dequant_exact(float v) {
+    const float R_HI = 0x1.010102p-8f, R_LO = -0x1.fdfdfep-33f;
+    const float t = __builtin_fmaf(v, R_HI, v * R_LO);
+    return __builtin_fmaf(t, 2.0f, -1.0f);
+}
+
 // (2b) the exhaustive pass for 256-byte rows, COALESCED, for QN queries at once.  k_scan_exact above lets every lane
 // walk its own row (64 lanes x 16 B at a 256-B stride per load: 1.3 TB/s).  Here a wave streams a tile of 64 rows =
 // 16 KiB with sixteen 1-KiB wave loads (16 B per lane, non-temporal: the table is read once), parks it in a
@@ -946,19 +965,20 @@ __global__ __launch_bounds__(X_BLOCK) void k_scan_exact(
 // lane-per-row 16-B reads conflict-free), and then every lane folds ITS row exactly as the reference does
 // (engine.rs:575-587: table de-quantisation, dot = fl(dot + fl(a*b)) left to right) -- once for each of the QN queries
 // of the group, so a row is fetched, staged and de-quantised once per QN queries.  The next tile's loads are in flight
-// (64 registers) while the current one is folded.  Query values come from a global [slot][256] f32 array through the
-// scalar cache (uniform index: s_load), not from LDS.  What bounds it: the 256 table gathers per row (ds_read_b32 at
-// random banks) and ~2 + 2 QN vector instructions per byte -- LDS / VALU issue, not HBM.
+// (64 registers) while the current one is folded.  Query values are broadcast LDS reads, and the
+// de-quantisation is arithmetic (dequant_exact: the first version gathered from the 256-entry table in LDS and was
+// bound by that gather, 0.88 ms per 10M-row sweep).  What bounds it now: 4 + 2 QN vector instructions per byte
+// against the HBM stream.
 // Output = k_scan_exact's: one sorted list of <= k exact keys per (query, workgroup) for k_merge_lists.
 constexpr int XC_WAVES = 4;
 constexpr int XC_PITCH = 272;
-template <int QN, int MAXE>
+template <int QN, int MAXE>  // QN = 1 or 2
 __global__ __launch_bounds__(XC_WAVES * WAVE, 2) void k_scan_exact_co(
     const uint8_t *__restrict__ rows, const float *__restrict__ norms, uint64_t n_rows,
     const float *__restrict__ qf, const QParams *__restrict__ qp, const uint32_t *__restrict__ qsel, int n_sel,
     const float *__restrict__ lut, uint64_t *__restrict__ lists, uint32_t *__restrict__ list_counts, uint32_t list_stride) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
-    // layout: [XC_WAVES][64 * XC_PITCH] tiles | lut[256] | [XC_WAVES][QN][cap] key buffers | counts
+    // layout: [XC_WAVES][64 * XC_PITCH] tiles (queries in their pad bytes) | [XC_WAVES][QN][cap] key buffers | counts
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int slot0 = (int)blockIdx.y * QN;
@@ -972,10 +992,7 @@ __global__ __launch_bounds__(XC_WAVES * WAVE, 2) void k_scan_exact_co(
     }
     const int cap = K + WAVE;
     uint8_t *tile = s_dyn + (size_t)wave * (WAVE * XC_PITCH);
-    float *s_lut = reinterpret_cast<float *>(s_dyn + (size_t)XC_WAVES * WAVE * XC_PITCH);
-    uint64_t *s_keys = reinterpret_cast<uint64_t *>(s_lut + 256);
-    for (int i = threadIdx.x; i < 256; i += XC_WAVES * WAVE) s_lut[i] = lut[i];
-    __syncthreads();
+    uint64_t *s_keys = reinterpret_cast<uint64_t *>(s_dyn + (size_t)XC_WAVES * WAVE * XC_PITCH);
     uint64_t *buf[QN];
     int cnt[QN];
     uint64_t thr_key[QN];
@@ -985,9 +1002,15 @@ __global__ __launch_bounds__(XC_WAVES * WAVE, 2) void k_scan_exact_co(
         cnt[j] = 0;
         thr_key[j] = ~0ull;
     }
-    const float *qfs[QN];
+    // the de-quantised queries live in the 16 pad bytes behind every row of the tile images: value i of query j in
+    // float i % 4 of the pad of row i / 4 of tile j (the parking stores never touch the pads)
 #pragma unroll
-    for (int j = 0; j < QN; ++j) qfs[j] = qf + (size_t)(slot0 + j < n_sel ? slot0 + j : n_sel - 1) * 256;
+    for (int j = 0; j < QN; ++j) {
+        const int i = threadIdx.x;  // 256 threads, 256 values
+        const float v = qf[(size_t)(slot0 + j < n_sel ? slot0 + j : n_sel - 1) * 256 + i];
+        *reinterpret_cast<float *>(s_dyn + (size_t)j * (WAVE * XC_PITCH) + (size_t)(i >> 2) * XC_PITCH + 256 + 4 * (i & 3)) = v;
+    }
+    __syncthreads();
 
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const uint64_t n_tiles = (n_rows + WAVE - 1) / WAVE;
@@ -1017,46 +1040,121 @@ __global__ __launch_bounds__(XC_WAVES * WAVE, 2) void k_scan_exact_co(
 #pragma unroll
         for (int j = 0; j < QN; ++j) dot[j] = 0.0f;
         const uint8_t *myrow = tile + (size_t)lane * XC_PITCH;
-        // a real loop over the sixteen 16-byte pieces of the row (fully unrolled, the scheduler hoists all 256 QN scalar
-        // query loads to the top and spills); the next piece is read from LDS while this one is folded
-        u32x4 wn = *reinterpret_cast<const u32x4 *>(myrow);
-#pragma unroll 1
-        for (int c = 0; c < 16; ++c) {
-            const u32x4 w = wn;
-            wn = *reinterpret_cast<const u32x4 *>(myrow + 16 * (c < 15 ? c + 1 : 15));
-            const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+        // The sixteen 16-byte pieces of the row, two per loop trip, software-pipelined by hand: the LDS read of a piece
+        // and the scalar loads of its 16 QN query values are issued one piece ahead.  Scalar loads return out of
+        // order, so any wait for one of them is `lgkmcnt(0)` -- a wait for EVERYTHING outstanding; the empty asm
+        // statements "use" a piece's operands BEFORE the next piece's loads are issued, which pins that wait to a
+        // point where nothing else is in flight (left to itself the compiler waited at the top of every piece for the
+        // loads it had just issued: ~35 % of the loop).
+        // The loads and the wait are inline asm so that they stay where they are written: left to the compiler the
+        // prefetch is sunk back to the top of the next trip, next to its use (tried with plain loads + empty asm
+        // "uses" + a memory clobber: all re-rolled).  asm volatile statements keep their order; the wait statement
+        // passes the piece through ("+" operands), so every fold instruction depends on it.
+        // The row in sixteen 16-byte pieces; with a piece come the 16 QN query values it meets, as 4 QN broadcast LDS
+        // reads (every lane the same address: conflict-free) from the pad bytes of the tile images, where the queries
+        // were parked at kernel start.  LDS returns in order, and these loads are asm so that they stay one piece
+        // ahead of their use.  Two other ways to supply the query values were measured on the 10M-row sweep
+        // (profiles/exact_probe.py; no supply at all, i.e. garbage registers: 0.50 ms at QN = 1, 0.56 ms at QN = 2):
+        // s_load_dwordx16 per piece from a global array 0.69 / 1.13 ms, pipelined or not (scalar-cache latency and, at
+        // QN = 2, scalar registers); v_readlane broadcasts from 4 QN resident registers 0.81 / 1.33 ms (a readlane and
+        // its wait states per multiply).
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        struct Piece {
+            u32x4 w;
+            f32x4 q[QN][4];
+        };
+        const uint32_t lds_row = (uint32_t)(uintptr_t)myrow;  // low 32 bits of a shared-aperture address = LDS offset
+        const uint32_t lds_q = (uint32_t)(uintptr_t)s_dyn + 256u;
+        // `other` is the piece about to be folded: it rides through the first load as an in/out operand, so its fold
+        // cannot be scheduled ahead of the loads
+        auto fetch = [&](Piece &pc, int c, Piece &other) {
+            // ONE statement for all loads of the piece (separate statements get spread out: the query reads were sunk
+            // behind the fold they should run under); outputs are early-clobber, the address registers stay live
+            const uint32_t aw = lds_row + 16u * (uint32_t)c, aq = lds_q + (uint32_t)(4 * c) * XC_PITCH;
+            if constexpr (QN == 1)
+                asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %7\n\tds_read_b128 %2, %7 offset:272\n\t"
+                             "ds_read_b128 %3, %7 offset:544\n\tds_read_b128 %4, %7 offset:816"
+                             : "=&v"(pc.w), "=&v"(pc.q[0][0]), "=&v"(pc.q[0][1]), "=&v"(pc.q[0][2]), "=&v"(pc.q[0][3]), "+v"(other.w)
+                             : "v"(aw), "v"(aq));
+            else
+                asm volatile("ds_read_b128 %0, %10\n\tds_read_b128 %1, %11\n\tds_read_b128 %2, %11 offset:272\n\t"
+                             "ds_read_b128 %3, %11 offset:544\n\tds_read_b128 %4, %11 offset:816\n\t"
+                             "ds_read_b128 %5, %11 offset:17408\n\tds_read_b128 %6, %11 offset:17680\n\t"
+                             "ds_read_b128 %7, %11 offset:17952\n\tds_read_b128 %8, %11 offset:18224"
+                             : "=&v"(pc.w), "=&v"(pc.q[0][0]), "=&v"(pc.q[0][1]), "=&v"(pc.q[0][2]), "=&v"(pc.q[0][3]), "=&v"(pc.q[1][0]),
+                               "=&v"(pc.q[1][1]), "=&v"(pc.q[1][2]), "=&v"(pc.q[1][3]), "+v"(other.w)
+                             : "v"(aw), "v"(aq));
+        };
+        static_assert(XC_PITCH == 272 && WAVE * XC_PITCH == 17408, "the offsets in the asm above are written out");
+        // the running sums ride through the wait: it cannot be hoisted above the fold of the piece before it
+        auto settle = [&](Piece &pc) {
+            if constexpr (QN == 1)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pc.w), "+v"(pc.q[0][0]), "+v"(pc.q[0][1]), "+v"(pc.q[0][2]), "+v"(pc.q[0][3]), "+v"(dot[0]));
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pc.w), "+v"(pc.q[0][0]), "+v"(pc.q[0][1]), "+v"(pc.q[0][2]), "+v"(pc.q[0][3]),
+                             "+v"(pc.q[1][0]), "+v"(pc.q[1][1]), "+v"(pc.q[1][2]), "+v"(pc.q[1][3]), "+v"(dot[0]), "+v"(dot[1]));
+        };
+        auto fold = [&](const Piece &pc) {
+#if defined(PB_XC_ABL) && (PB_XC_ABL == 1)
+            dot[0] += (float)pc.w[0];  // ablation: no fold
+            return;
+#endif
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
-                    const float x = s_lut[(ww[e] >> (8 * b)) & 0xFF];
+                    const float x = dequant_exact((float)((pc.w[e] >> (8 * b)) & 0xFF));  // v_cvt_f32_ubyteN + 3 VALU, no LDS gather
 #pragma unroll
                     for (int j = 0; j < QN; ++j) {
-                        const float p = qfs[j][16 * c + 4 * e + b] * x;
+                        const float p = pc.q[j][e][b] * x;
                         dot[j] = dot[j] + p;
                     }
                 }
             }
+        };
+        Piece pa, pb;
+        pb.w = u32x4{0, 0, 0, 0};
+        fetch(pa, 0, pb);
+#pragma unroll 1
+        for (int c = 0; c < 16; c += 2) {
+            settle(pa);
+            fetch(pb, c + 1, pa);
+            fold(pa);
+            settle(pb);
+            fetch(pa, c + 2 < 16 ? c + 2 : 15, pb);
+            fold(pb);
         }
+        settle(pa);  // nothing of ours may be in flight when compiler-tracked LDS traffic resumes
 #pragma unroll
         for (int j = 0; j < QN; ++j) {
             float cs;
             const float dist = ref_distance(dot[j], P[j].sqrt_sa, nrm, &cs);
             uint64_t key = ~0ull;
             if (r < n_rows && (double)dist < P[j].max_dist) key = ((uint64_t)sortable_f32(dist) << 32) | (uint32_t)r;
-            const bool pass = key < thr_key[j];
-            const uint64_t m = __ballot(pass);
+            bool pass = key < thr_key[j];
+            uint64_t m = __ballot(pass);
             if (m) {
-                if (pass) buf[j][cnt[j] + mbcnt(m)] = key;
-                cnt[j] += __popcll(m);
-                if (cnt[j] > K) {  // buffer capacity is K + 64
+                // Prune only when the newcomers do not fit (capacity K + 64): pruning after every insertion -- what
+                // "if (cnt > K) prune" amounts to once the buffer holds K keys -- ran the 64-step radix select some
+                // K ln(rows / K) ~ 400 times per wave; this way it runs once per ~64 insertions.
+                if (cnt[j] + (int)__popcll(m) > cap) {
                     thr_key[j] = wave_keep_smallest<MAXE>(buf[j], cnt[j], K);
                     cnt[j] = K;
+                    pass = key < thr_key[j];
+                    m = __ballot(pass);
                 }
+                if (pass) buf[j][cnt[j] + mbcnt(m)] = key;
+                cnt[j] += __popcll(m);
             }
         }
     }
     // workgroup list per query = the K best of the XC_WAVES wave lists, sorted (the tile area is free now)
+#pragma unroll
+    for (int j = 0; j < QN; ++j)
+        if (cnt[j] > K) {
+            wave_keep_smallest<MAXE>(buf[j], cnt[j], K);
+            cnt[j] = K;
+        }
     int *s_cnt = reinterpret_cast<int *>(s_keys + (size_t)XC_WAVES * QN * cap);
     if (lane == 0) {
 #pragma unroll

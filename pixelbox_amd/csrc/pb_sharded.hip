@@ -406,7 +406,14 @@ int pb_sharded_append(pb_sharded *s, const int64_t *image_ids, const uint8_t *ro
         data.insert(data.end(), rows + i * d, rows + (i + 1) * d);
     }
     uint64_t stored = 0, pos = 0;
+    uint64_t room = s->capacity;  // the TOTAL is the contract (per-shard capacities round up: their sum may exceed it)
+    for (int g = 0; g < s->n; ++g) room -= std::min<uint64_t>(room, shard_size(s, g));
     while (pos < ids.size()) {
+        if (room == 0) {
+            if (n_inserted) *n_inserted = stored;
+            return pb::fail(PB_ERR_CAPACITY, "pb_sharded_append: index full: capacity %llu rows (%llu rows of this call stored)",
+                            (unsigned long long)s->capacity, (unsigned long long)stored);
+        }
         int best = -1;
         uint64_t best_free = 0, best_size = 0;
         for (int g = 0; g < s->n; ++g) {
@@ -421,10 +428,11 @@ int pb_sharded_append(pb_sharded *s, const int64_t *image_ids, const uint8_t *ro
             if (n_inserted) *n_inserted = stored;
             return pb::fail(PB_ERR_CAPACITY, "pb_sharded_append: every shard is full (%llu rows stored of this call)", (unsigned long long)stored);
         }
-        const uint64_t take = std::min<uint64_t>(best_free, ids.size() - pos);
+        const uint64_t take = std::min<uint64_t>(std::min<uint64_t>(best_free, room), ids.size() - pos);
         uint64_t got = 0;
         int rc = pb_index_append(s->shards[best], ids.data() + pos, data.data() + pos * d, take, &got);
         stored += got;
+        room -= std::min<uint64_t>(room, got);
         if (rc) {
             if (n_inserted) *n_inserted = stored;
             return rc;

@@ -47,3 +47,33 @@ def test_inline_asm_dpp_reads_keep_their_wait_states(tmp_path):
         for back in range(1, 6):
             assert not ins[k - back].startswith("v_cmpx"), f"VALU write of EXEC {back} instruction(s) before a DPP read: {t}"
     assert n > 0, "fmac_shift no longer compiles to v_fmac_f32_dpp"
+
+
+@pytest.mark.timeout(600)
+def test_exact_pass_keeps_its_lds_reads_one_piece_ahead(tmp_path):
+    # k_scan_exact_co issues the LDS reads of a 16-byte piece (row bytes + 4 QN broadcast reads of query values) through
+    # inline asm, one piece ahead of their use (pb_scan_kernels.h).  Read the ISA: the piece loop of every instance has no
+    # scratch access, exactly two waits, and each wait is followed at once by the next piece's 1 + 4 QN reads -- left to
+    # the scheduler the prefetch is sunk back next to its use and every piece pays the LDS latency.
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    out = tmp_path / "pb_scan.s"
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+                           "--cuda-device-only", "-S", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "pixelbox_amd", "csrc", "pb_scan.hip"), "-o", str(out)],
+                          stderr=subprocess.DEVNULL)
+    s = open(out).read()
+    found = 0
+    for m in re.finditer(r"^(_ZN3pbk15k_scan_exact_coILi(\d)ELi(\d)E\w*):[^\n]*\n(.*?)\.end_amdhsa_kernel", s, re.S | re.M):
+        qn = int(m.group(2))
+        body = m.group(4)
+        assert "scratch_" not in body
+        blocks = re.split(r"\n(?=\.LBB\d+_\d+:)", body)
+        loop = max(blocks, key=lambda b: len(re.findall(r"v_fma_f32|v_fmac_f32|v_pk_fma_f32", b)))
+        loop = loop[: loop.index("s_cbranch_scc")]  # up to the back edge
+        ops = [l.strip().split()[0] for l in loop.split("\n") if re.search(r"s_waitcnt lgkmcnt|ds_read_b", l)]
+        want = ["s_waitcnt"] + ["ds_read_b128"] * (1 + 4 * qn)
+        assert ops == want * 2, (m.group(1), ops)
+        found += 1
+    assert found == 4
