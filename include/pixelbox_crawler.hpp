@@ -1,0 +1,195 @@
+// pixelbox_crawler.hpp -- the crawler -> embed stage re-built for a GPU, mirroring
+// src/crawler.rs:10-123 + the hashing half of IndexedImage::from_memory (src/indexed_image.rs:47-91).
+//
+// Reference: one glob thread walks "<folder>/**/*.*" and keeps the files whose extension is one of twelve (crawler.rs:7,
+// :35-65); N worker threads (PARALLEL_FILE_PROCESSORS = 4, engine.rs:22) each read + decode + thumbnail + hash ONE image at
+// a time -- `mlhash` is a batch-1 `MODEL.run` per image (efficientnet.rs:34) -- and push IndexedImages into a bounded(128)
+// channel that the insert thread drains (crawler.rs:27-28, engine.rs:186-203).
+//
+// Here the workers only READ and DECODE (CPU codecs; the decoder is the host's callback, PNM built in) and hand the
+// decoded pixels, at whatever size, to ONE embed thread, which gathers up to `max_batch` (512) of them and runs
+// `resize_to_fill(W, H, Triangle)` + the network for the whole batch on the GPU (pb_embed_batch_images) and `phash` per
+// image (pb_phash_image); the finished IndexedImages go into the same bounded channel, which the caller drains with
+// recv() exactly as engine.rs:189-200 drains its Receiver.  Same 12-extension allow-list, same "undecodable files are
+// skipped" rule (crawler.rs:78), same back-pressure (a full channel stalls the producers).
+#pragma once
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <filesystem>
+#include <mutex>
+#include <thread>
+
+#include "pixelbox_host.hpp"
+
+namespace pixelbox {
+
+class Crawler {
+  public:
+    static constexpr size_t MAX_PENDING_TX = 128;  // crawler.rs:8
+    static inline const char *const SUPPORTED_IMAGE_EXTENSIONS[12] = {"png", "bmp", "jpg",  "jpeg", "jfif", "gif",
+                                                                      "tiff", "pnm", "webp", "ico",  "tga",  "exr"};  // crawler.rs:7
+
+    Crawler(const Embedder &model, const PHasher *hasher, Decoder decode = decode_pnm, uint32_t max_batch = 512)
+        : model_(model), hasher_(hasher), decode_(std::move(decode)), max_batch_(max_batch) {}
+    ~Crawler() { join(); }
+    Crawler(const Crawler &) = delete;
+
+    // crawler.rs:21-122.  Returns at once; the IndexedImages arrive through recv().
+    void start_indexing(std::vector<std::string> folders, size_t num_workers) {
+        join();
+        files_done_ = false;
+        decoders_left_ = num_workers;
+        out_closed_ = false;
+        stats_ = Stats{};
+        threads_.emplace_back([this, folders] { glob_thread(folders); });
+        for (size_t i = 0; i < num_workers; ++i) threads_.emplace_back([this] { decode_worker(); });
+        threads_.emplace_back([this] { embed_thread(); });
+    }
+
+    // the Receiver<IndexedImage>: blocks for the next image; false once every file has been processed
+    bool recv(IndexedImage &out) {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_out_.wait(lk, [&] { return !out_.empty() || out_closed_; });
+        if (out_.empty()) return false;
+        out = std::move(out_.front());
+        out_.pop_front();
+        cv_space_.notify_all();
+        return true;
+    }
+
+    struct Stats {
+        uint64_t files_seen = 0, files_matched = 0, decoded = 0, skipped = 0, batches = 0, largest_batch = 0;
+    };
+    Stats stats() const {
+        std::lock_guard<std::mutex> lk(mu_);
+        return stats_;
+    }
+
+    static bool is_image_file(const std::filesystem::path &p) {
+        std::string ext = p.extension().string();  // ".png"
+        if (ext.size() < 2) return false;          // "*.*": files without an extension are skipped (crawler.rs:57)
+        ext = ext.substr(1);
+        std::transform(ext.begin(), ext.end(), ext.begin(), [](unsigned char c) { return (char)std::tolower(c); });  // eq_ignore_ascii_case
+        for (const char *e : SUPPORTED_IMAGE_EXTENSIONS)
+            if (ext == e) return true;
+        return false;
+    }
+
+  private:
+    struct Decoded {
+        std::string filename, path;
+        RgbImage img;
+    };
+
+    void join() {
+        for (std::thread &t : threads_)
+            if (t.joinable()) t.join();
+        threads_.clear();
+    }
+
+    void glob_thread(const std::vector<std::string> &folders) {  // crawler.rs:35-65
+        namespace fs = std::filesystem;
+        for (const std::string &dir : folders) {
+            std::error_code ec;
+            for (fs::recursive_directory_iterator it(dir, fs::directory_options::skip_permission_denied, ec), end; !ec && it != end; it.increment(ec)) {
+                if (!it->is_regular_file(ec)) continue;
+                std::lock_guard<std::mutex> lk(mu_);
+                ++stats_.files_seen;
+                if (!is_image_file(it->path())) continue;
+                ++stats_.files_matched;
+                files_.push_back(it->path().string());
+                cv_files_.notify_one();
+            }
+        }
+        std::lock_guard<std::mutex> lk(mu_);
+        files_done_ = true;
+        cv_files_.notify_all();
+    }
+
+    void decode_worker() {  // the CPU half of crawler.rs:68-119 / indexed_image.rs:35-56
+        for (;;) {
+            std::string path;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_files_.wait(lk, [&] { return !files_.empty() || files_done_; });
+                if (files_.empty()) break;
+                path = std::move(files_.front());
+                files_.pop_front();
+            }
+            std::optional<std::vector<uint8_t>> bytes = read_file(path);
+            std::optional<RgbImage> img = bytes ? decode_(*bytes) : std::nullopt;
+            std::unique_lock<std::mutex> lk(mu_);
+            if (!img) {  // crawler.rs:78: `if let Ok(img) = ...` -- anything else is dropped silently
+                ++stats_.skipped;
+                continue;
+            }
+            ++stats_.decoded;
+            // back-pressure: decoded pixels are the big items; hold at most two batches of them
+            cv_space_.wait(lk, [&] { return decoded_.size() < 2 * (size_t)max_batch_; });
+            Decoded d;
+            d.path = path;
+            const size_t slash = path.find_last_of('/');
+            d.filename = slash == std::string::npos ? path : path.substr(slash + 1);
+            d.img = std::move(*img);
+            decoded_.push_back(std::move(d));
+            cv_decoded_.notify_one();
+        }
+        std::lock_guard<std::mutex> lk(mu_);
+        if (--decoders_left_ == 0) cv_decoded_.notify_all();
+    }
+
+    void embed_thread() {  // the GPU half: whatever is pending, up to max_batch images per forward pass
+        for (;;) {
+            std::vector<Decoded> batch;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_decoded_.wait(lk, [&] { return !decoded_.empty() || decoders_left_ == 0; });
+                if (decoded_.empty()) break;
+                while (!decoded_.empty() && batch.size() < max_batch_) {
+                    batch.push_back(std::move(decoded_.front()));
+                    decoded_.pop_front();
+                }
+                ++stats_.batches;
+                stats_.largest_batch = std::max<uint64_t>(stats_.largest_batch, batch.size());
+                cv_space_.notify_all();
+            }
+            std::vector<RgbImage> imgs;
+            imgs.reserve(batch.size());
+            for (Decoded &d : batch) imgs.push_back(std::move(d.img));
+            const std::vector<std::vector<uint8_t>> hashes = image_hashes::mlhash_batch(model_, imgs);  // resize_to_fill + network, one batch
+            for (size_t i = 0; i < batch.size(); ++i) {
+                IndexedImage r;
+                r.filename = batch[i].filename;
+                r.path = batch[i].path;
+                r.resolution = {imgs[i].width, imgs[i].height};
+                if (hasher_) r.phash = image_hashes::phash(*hasher_, imgs[i]);
+                r.visual_hash = hashes[i];
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_space_.wait(lk, [&] { return out_.size() < MAX_PENDING_TX; });  // bounded(128): a slow consumer stalls the stage
+                out_.push_back(std::move(r));
+                cv_out_.notify_one();
+            }
+        }
+        std::lock_guard<std::mutex> lk(mu_);
+        out_closed_ = true;
+        cv_out_.notify_all();
+    }
+
+    const Embedder &model_;
+    const PHasher *hasher_;
+    Decoder decode_;
+    uint32_t max_batch_;
+    mutable std::mutex mu_;
+    std::condition_variable cv_files_, cv_decoded_, cv_out_, cv_space_;
+    std::deque<std::string> files_;
+    std::deque<Decoded> decoded_;
+    std::deque<IndexedImage> out_;
+    bool files_done_ = true, out_closed_ = true;
+    size_t decoders_left_ = 0;
+    Stats stats_;
+    std::vector<std::thread> threads_;
+};
+
+}  // namespace pixelbox

@@ -259,6 +259,22 @@ int pb_resize_to_fill(pb_embedder *e, const uint8_t *rgb, uint32_t width, uint32
 int pb_embed_set_option(pb_embedder *e, int option, int64_t value);
 
 /* ======================================================================================
+ *  image_hashes::phash (src/image_hashes/phash.rs:3-22) -- the reference's other hash, stored in `phashes`
+ *  (engine.rs:106-109,248-250) and compared with hamming_distance (engine.rs:594-604; pb_index_create_metric)
+ * ====================================================================================== */
+typedef struct pb_phasher pb_phasher;
+int pb_phash_create(pb_phasher **out, int device);
+int pb_phash_destroy(pb_phasher *p);
+/* phash(img) -> Vec<u8>: `img.resize(16, 16, Gaussian)` (the aspect ratio is KEPT: 16 x n or n x 16), `grayscale`, mean
+ * threshold with the reference's fixed divisor 256, LSB-first bytes.  rgb: width*height*3 bytes, RGB8, row-major, any size.
+ * out must hold 32 bytes; *n_bytes receives the hash length (w2 * h2) / 8: 32 for a square image, fewer otherwise, as in
+ * the reference.  The resampling (image 0.25.x semantics, restated: oracle/pb_oracle_phash.c) runs on the GPU; its filter
+ * weights are computed on the host with libm's expf. */
+int pb_phash_image(pb_phasher *p, const uint8_t *rgb, uint32_t width, uint32_t height, uint8_t *out, size_t out_len, uint32_t *n_bytes);
+/* the resized image itself (what `small` holds in phash.rs:7): out_rgb[<= 16*16*3], its size in *out_w x *out_h */
+int pb_phash_small_image(pb_phasher *p, const uint8_t *rgb, uint32_t width, uint32_t height, uint8_t *out_rgb, uint32_t *out_w, uint32_t *out_h);
+
+/* ======================================================================================
  *  utilities
  * ====================================================================================== */
 /* splitmix64 byte stream on the device: d_out[0..nbytes) = bytes [byte_offset, ..) of stream `seed`

@@ -7,14 +7,20 @@
 //                                                                      src/indexed_image.rs:16-32
 //   pixelbox::Engine::insert_image_from_memory(IndexedImage)           src/engine.rs:224-259
 //   pixelbox::Engine::query_by_image_hash_from_image(&IndexedImage)    src/engine.rs:363-396
+//   pixelbox::Engine::query_by_image_hash_from_file(&Path)             src/engine.rs:352-361
 //   pixelbox::Engine::get_query_results() -> Option<Vec<IndexedImage>> src/engine.rs:398-400
+//   pixelbox::image_hashes::phash(hasher, img) -> Vec<u8>             src/image_hashes/phash.rs:3-22
+//   pixelbox::IndexedImage::from_file_path / from_memory              src/indexed_image.rs:35-91 (decode is a callback)
 //   pixelbox::Engine::max_distance_from_query (default 1e3)            src/engine.rs:23,92
 //
 // What stays in SQLite in a real integration (images/tags tables, persistence) is modelled here by an
 // in-memory `images` map: enough to reproduce the INNER JOIN of engine.rs:377 (results whose image row
 // is missing are dropped) and the UNIQUE(path) + INSERT OR IGNORE behaviour of engine.rs:40,230-233.
 #pragma once
+#include <chrono>
 #include <cstdint>
+#include <cstdio>
+#include <functional>
 #include <map>
 #include <memory>
 #include <optional>
@@ -63,7 +69,33 @@ class Embedder {
     uint32_t width_ = 0, height_ = 0, dim_ = 0, max_batch_ = 0;
 };
 
+class PHasher {
+  public:
+    explicit PHasher(int device = 0) {
+        pb_phasher *h = nullptr;
+        check(pb_phash_create(&h, device));
+        h_.reset(h);
+    }
+    pb_phasher *raw() const { return h_.get(); }
+
+  private:
+    struct Del {
+        void operator()(pb_phasher *p) const { pb_phash_destroy(p); }
+    };
+    std::unique_ptr<pb_phasher, Del> h_;
+};
+
 namespace image_hashes {
+// pub fn phash(img:&DynamicImage) -> Vec<u8>   (phash.rs:3-22; 32 bytes for a square image, (w2 * h2) / 8 otherwise)
+inline std::vector<uint8_t> phash(const PHasher &hasher, const RgbImage &img) {
+    if (img.width == 0 || img.height == 0 || img.pixels.size() != (size_t)img.width * img.height * 3)
+        throw Error(PB_ERR_INVALID, "phash: empty image or pixel buffer of the wrong size");
+    std::vector<uint8_t> out(32);
+    uint32_t n = 0;
+    check(pb_phash_image(hasher.raw(), img.pixels.data(), img.width, img.height, out.data(), out.size(), &n));
+    out.resize(n);
+    return out;
+}
 // pub fn mlhash(img:&DynamicImage) -> Vec<u8>   (the model is an explicit handle instead of a lazy static)
 // Any image size: `resize_to_fill(W, H, Triangle)` of efficientnet.rs:20 runs on the GPU (pb_mlhash_image); an
 // image that already has the model's input size goes straight in, as in the image crate.
@@ -98,9 +130,87 @@ struct IndexedImage {
     std::string filename;
     std::string path;
     std::pair<uint32_t, uint32_t> resolution{0, 0};
+    std::optional<std::vector<uint8_t>> phash;
     std::optional<std::vector<uint8_t>> visual_hash;
     std::optional<double> distance_from_query;
 };
+
+// ---- decode: the image crate's job in the reference (indexed_image.rs:47-56 `ImageReader::with_guessed_format().decode()`).
+// Codecs stay on the CPU and outside this library; a host plugs its decoder in as a callback.  Built in: binary PNM (P6 RGB,
+// P5 grey, maxval <= 255) -- "pnm" is one of the twelve extensions the crawler accepts (crawler.rs:7) and needs no codec.
+using Decoder = std::function<std::optional<RgbImage>(const std::vector<uint8_t> &bytes)>;
+
+inline std::optional<RgbImage> decode_pnm(const std::vector<uint8_t> &b) {
+    size_t pos = 0;
+    auto token = [&]() -> std::string {
+        for (;;) {  // whitespace and # comments
+            while (pos < b.size() && (b[pos] == ' ' || b[pos] == '\n' || b[pos] == '\r' || b[pos] == '\t')) ++pos;
+            if (pos < b.size() && b[pos] == '#') {
+                while (pos < b.size() && b[pos] != '\n') ++pos;
+                continue;
+            }
+            break;
+        }
+        std::string t;
+        while (pos < b.size() && b[pos] > ' ') t.push_back((char)b[pos++]);
+        return t;
+    };
+    const std::string magic = token();
+    if (magic != "P6" && magic != "P5") return std::nullopt;
+    const std::string ws = token(), hs = token(), ms = token();
+    if (ws.empty() || hs.empty() || ms.empty()) return std::nullopt;
+    const long w = std::strtol(ws.c_str(), nullptr, 10), h = std::strtol(hs.c_str(), nullptr, 10), mx = std::strtol(ms.c_str(), nullptr, 10);
+    if (w < 1 || h < 1 || w > 65535 || h > 65535 || mx < 1 || mx > 255) return std::nullopt;
+    ++pos;  // the single whitespace byte after maxval
+    const size_t ch = magic == "P6" ? 3 : 1, need = (size_t)w * h * ch;
+    if (pos + need > b.size()) return std::nullopt;
+    RgbImage img;
+    img.width = (uint32_t)w;
+    img.height = (uint32_t)h;
+    img.pixels.resize((size_t)w * h * 3);
+    for (size_t i = 0; i < (size_t)w * h; ++i)
+        for (size_t c = 0; c < 3; ++c) {
+            const uint32_t v = b[pos + i * ch + (ch == 3 ? c : 0)];
+            img.pixels[3 * i + c] = (uint8_t)(mx == 255 ? v : (v * 255 + mx / 2) / mx);
+        }
+    return img;
+}
+
+inline std::optional<std::vector<uint8_t>> read_file(const std::string &path) {
+    FILE *f = std::fopen(path.c_str(), "rb");
+    if (!f) return std::nullopt;
+    std::vector<uint8_t> bytes;
+    uint8_t buf[1 << 16];
+    size_t n;
+    while ((n = std::fread(buf, 1, sizeof(buf), f)) > 0) bytes.insert(bytes.end(), buf, buf + n);
+    std::fclose(f);
+    return bytes;
+}
+
+// IndexedImage::from_memory (indexed_image.rs:47-91): decode, hashes (phash, mlhash).  The thumbnail / QOI / EXIF steps of
+// the reference are CPU work outside the hot path and are not modelled.  std::nullopt = undecodable (the crawler skips it,
+// crawler.rs:78).
+inline std::optional<IndexedImage> indexed_image_from_memory(const std::vector<uint8_t> &bytes, const std::string &filename,
+                                                             const std::string &path, const Embedder &model, const PHasher *hasher,
+                                                             const Decoder &decode = decode_pnm) {
+    std::optional<RgbImage> img = decode(bytes);
+    if (!img) return std::nullopt;
+    IndexedImage r;
+    r.filename = filename;
+    r.path = path;
+    r.resolution = {img->width, img->height};
+    if (hasher) r.phash = image_hashes::phash(*hasher, *img);   // indexed_image.rs:70
+    r.visual_hash = image_hashes::mlhash(model, *img);          // indexed_image.rs:71
+    return r;
+}
+// IndexedImage::from_file_path (indexed_image.rs:35-45)
+inline std::optional<IndexedImage> indexed_image_from_file_path(const std::string &path, const Embedder &model, const PHasher *hasher,
+                                                                const Decoder &decode = decode_pnm) {
+    std::optional<std::vector<uint8_t>> bytes = read_file(path);
+    if (!bytes) return std::nullopt;
+    const size_t slash = path.find_last_of('/');
+    return indexed_image_from_memory(*bytes, slash == std::string::npos ? path : path.substr(slash + 1), path, model, hasher, decode);
+}
 
 class Engine {
   public:
@@ -131,25 +241,48 @@ class Engine {
         }
     }
 
+    // engine.rs:352-361: hash the file (decode + resize_to_fill + network, all but the decode on the GPU), then query.
+    // Returns false where the reference would panic (`from_file_path(img).unwrap()`): unreadable or undecodable file.
+    bool query_by_image_hash_from_file(const std::string &path, const Embedder &model, const PHasher *hasher = nullptr,
+                                       const Decoder &decode = decode_pnm) {
+        cached_search_results_.reset();
+        const auto t0 = std::chrono::steady_clock::now();
+        std::optional<IndexedImage> indexed_image = indexed_image_from_file_path(path, model, hasher, decode);
+        last_hash_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();  // engine.rs:355-358
+        if (!indexed_image) return false;
+        query_by_image_hash_from_image(*indexed_image);
+        return true;
+    }
+
     // engine.rs:363-396
     void query_by_image_hash_from_image(const IndexedImage &indexed_image) {
         if (!indexed_image.visual_hash) return;  // engine.rs:364-368: logs and returns
         cached_search_results_.reset();
-        std::vector<int64_t> ids(RESULT_LIMIT);
-        std::vector<float> dist(RESULT_LIMIT);
-        uint32_t count = 0;
-        check(pb_index_search(idx_.get(), indexed_image.visual_hash->data(), 1, RESULT_LIMIT, max_distance_from_query,
-                              ids.data(), dist.data(), &count));
+        const auto t0 = std::chrono::steady_clock::now();
+        // The reference's INNER JOIN runs BEFORE `LIMIT 100`: a hash whose image row is missing does not use up a result
+        // slot.  Ask the index for more than 100 when orphans turn up (PB_MAX_K at most) and cut after the join.
         std::vector<IndexedImage> out;
-        for (uint32_t i = 0; i < count; ++i) {
-            auto it = images_.find(ids[i]);
-            if (it == images_.end()) continue;  // INNER JOIN images ON images.id = semantic_hashes.image_id
-            IndexedImage r = it->second;
-            r.distance_from_query = (double)dist[i];  // engine.rs:619 `Ok(dist as f64)`
-            out.push_back(std::move(r));
+        for (uint32_t k = RESULT_LIMIT;; k = PB_MAX_K) {
+            std::vector<int64_t> ids(k);
+            std::vector<float> dist(k);
+            uint32_t count = 0;
+            check(pb_index_search(idx_.get(), indexed_image.visual_hash->data(), 1, k, max_distance_from_query, ids.data(), dist.data(),
+                                  &count));
+            out.clear();
+            for (uint32_t i = 0; i < count && out.size() < RESULT_LIMIT; ++i) {
+                auto it = images_.find(ids[i]);
+                if (it == images_.end()) continue;  // INNER JOIN images ON images.id = semantic_hashes.image_id
+                IndexedImage r = it->second;
+                r.distance_from_query = (double)dist[i];  // engine.rs:619 `Ok(dist as f64)`
+                out.push_back(std::move(r));
+            }
+            if (out.size() == RESULT_LIMIT || count < k || k == PB_MAX_K) break;
         }
         cached_search_results_ = std::move(out);
+        last_search_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();  // engine.rs:391-395
     }
+    // the two timings the reference prints (engine.rs:355-358, 391-395)
+    double last_hash_ms = 0.0, last_search_ms = 0.0;
 
     // engine.rs:398-400
     std::optional<std::vector<IndexedImage>> get_query_results() const { return cached_search_results_; }

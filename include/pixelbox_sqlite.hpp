@@ -39,6 +39,7 @@ struct SqliteApi {
     long long (*last_insert_rowid)(void *) = nullptr;
     int (*changes)(void *) = nullptr;
     const char *(*errmsg)(void *) = nullptr;
+    void (*free_)(void *) = nullptr;
 
     static const SqliteApi &get() {
         static SqliteApi api = [] {
@@ -55,7 +56,7 @@ struct SqliteApi {
             PB_SYM(bind_text, "sqlite3_bind_text"); PB_SYM(column_int64, "sqlite3_column_int64");
             PB_SYM(column_blob, "sqlite3_column_blob"); PB_SYM(column_bytes, "sqlite3_column_bytes");
             PB_SYM(column_text, "sqlite3_column_text"); PB_SYM(last_insert_rowid, "sqlite3_last_insert_rowid");
-            PB_SYM(changes, "sqlite3_changes"); PB_SYM(errmsg, "sqlite3_errmsg");
+            PB_SYM(changes, "sqlite3_changes"); PB_SYM(errmsg, "sqlite3_errmsg"); PB_SYM(free_, "sqlite3_free");
 #undef PB_SYM
             return a;
         }();
@@ -71,6 +72,27 @@ class PersistentEngine {
     // Engine::new + Engine::open: create the tables if absent, then mirror semantic_hashes onto the GPU.
     PersistentEngine(const std::string &db_path, uint32_t hash_dim, uint64_t capacity_rows, int device = 0)
         : S(SqliteApi::get()), dim_(hash_dim) {
+        try {
+            open_and_load(db_path, hash_dim, capacity_rows, device);
+        } catch (...) {
+            close_all();  // a throwing constructor runs no destructor: release the statements and the connection here
+            throw;
+        }
+    }
+    // hashes in `semantic_hashes` whose length differs from the index dimension (left out of the device table)
+    uint64_t num_skipped_hashes() const { return skipped_hashes_; }
+
+  private:
+    void close_all() {
+        for (void **st : {&ins_img_, &ins_hash_, &sel_img_, &sel_hash_})
+            if (*st) {
+                S.finalize(*st);
+                *st = nullptr;
+            }
+        if (db_) S.close_v2(db_);
+        db_ = nullptr;
+    }
+    void open_and_load(const std::string &db_path, uint32_t hash_dim, uint64_t capacity_rows, int device) {
         constexpr int RW_CREATE = 0x2 | 0x4;  // SQLITE_OPEN_READWRITE | SQLITE_OPEN_CREATE
         if (S.open_v2(db_path.c_str(), &db_, RW_CREATE, nullptr) != 0) fail("open");
         run("CREATE TABLE IF NOT EXISTS images (id INTEGER PRIMARY KEY, filename TEXT NOT NULL, path TEXT NOT NULL, "
@@ -82,26 +104,31 @@ class PersistentEngine {
         idx_.reset(h);
         // bulk load in image_id order, chunked (hashes of another length are skipped: fixed dim per index)
         void *st = prepare("SELECT image_id, hash FROM semantic_hashes ORDER BY image_id");
+        struct Fin {  // the statement is finalised however this scope is left
+            const SqliteApi &S;
+            void *st;
+            ~Fin() { S.finalize(st); }
+        } fin{S, st};
         std::vector<int64_t> ids;
         std::vector<uint8_t> rows;
         while (S.step(st) == 100 /*SQLITE_ROW*/) {
-            if (S.column_bytes(st, 1) != (int)dim_) continue;
+            if (S.column_bytes(st, 1) != (int)dim_) {  // the reference keeps such rows (engine.rs:585 zip-truncates); the device
+                ++skipped_hashes_;                     // table has ONE row length, so they are left out and COUNTED
+                continue;
+            }
             ids.push_back(S.column_int64(st, 0));
             const uint8_t *p = static_cast<const uint8_t *>(S.column_blob(st, 1));
             rows.insert(rows.end(), p, p + dim_);
         }
-        S.finalize(st);
         if (!ids.empty()) check(pb_index_load(idx_.get(), ids.data(), rows.data(), ids.size()));
         ins_img_ = prepare("INSERT OR IGNORE INTO images (filename, path, image_width, image_height, thumbnail) VALUES (?, ?, ?, ?, ?)");
         ins_hash_ = prepare("INSERT OR IGNORE INTO semantic_hashes (image_id, hash) VALUES (?, ?)");
         sel_img_ = prepare("SELECT images.id, images.filename, images.path, images.image_width, images.image_height FROM images WHERE id = ?");
         sel_hash_ = prepare("SELECT hash FROM semantic_hashes WHERE image_id = ?");
     }
-    ~PersistentEngine() {
-        for (void *st : {ins_img_, ins_hash_, sel_img_, sel_hash_})
-            if (st) S.finalize(st);
-        if (db_) S.close_v2(db_);
-    }
+
+  public:
+    ~PersistentEngine() { close_all(); }
     PersistentEngine(const PersistentEngine &) = delete;
 
     // engine.rs:228-259.  Returns the image id SQLite assigned (or the stale last_insert_rowid when the path is
@@ -129,32 +156,48 @@ class PersistentEngine {
         return img.id;
     }
 
+    // engine.rs:352-361 (see Engine::query_by_image_hash_from_file)
+    bool query_by_image_hash_from_file(const std::string &path, const Embedder &model, const PHasher *hasher = nullptr,
+                                       const Decoder &decode = decode_pnm) {
+        cached_.reset();
+        std::optional<IndexedImage> indexed_image = indexed_image_from_file_path(path, model, hasher, decode);
+        if (!indexed_image) return false;
+        query_by_image_hash_from_image(*indexed_image);
+        return true;
+    }
+
     void query_by_image_hash_from_image(const IndexedImage &indexed_image) {
         if (!indexed_image.visual_hash) return;  // engine.rs:364-368
         cached_.reset();
-        std::vector<int64_t> ids(RESULT_LIMIT);
-        std::vector<float> dist(RESULT_LIMIT);
-        uint32_t count = 0;
-        check(pb_index_search(idx_.get(), indexed_image.visual_hash->data(), 1, RESULT_LIMIT, max_distance_from_query,
-                              ids.data(), dist.data(), &count));
+        // INNER JOIN before LIMIT 100 (engine.rs:377-381): hashes without an `images` row must not use up result slots, so
+        // the index is asked for more (PB_MAX_K at most) when orphans turn up
         std::vector<IndexedImage> out;
-        for (uint32_t i = 0; i < count; ++i) {
-            S.reset(sel_img_);
-            S.bind_int64(sel_img_, 1, ids[i]);
-            if (S.step(sel_img_) != 100) continue;  // INNER JOIN: no images row -> dropped
-            IndexedImage r;
-            r.id = S.column_int64(sel_img_, 0);
-            r.filename = reinterpret_cast<const char *>(S.column_text(sel_img_, 1));
-            r.path = reinterpret_cast<const char *>(S.column_text(sel_img_, 2));
-            r.resolution = {(uint32_t)S.column_int64(sel_img_, 3), (uint32_t)S.column_int64(sel_img_, 4)};
-            S.reset(sel_hash_);
-            S.bind_int64(sel_hash_, 1, ids[i]);
-            if (S.step(sel_hash_) == 100) {
-                const uint8_t *p = static_cast<const uint8_t *>(S.column_blob(sel_hash_, 0));
-                r.visual_hash = std::vector<uint8_t>(p, p + S.column_bytes(sel_hash_, 0));  // row.get(6)
+        for (uint32_t k = RESULT_LIMIT;; k = PB_MAX_K) {
+            std::vector<int64_t> ids(k);
+            std::vector<float> dist(k);
+            uint32_t count = 0;
+            check(pb_index_search(idx_.get(), indexed_image.visual_hash->data(), 1, k, max_distance_from_query, ids.data(), dist.data(),
+                                  &count));
+            out.clear();
+            for (uint32_t i = 0; i < count && out.size() < RESULT_LIMIT; ++i) {
+                S.reset(sel_img_);
+                S.bind_int64(sel_img_, 1, ids[i]);
+                if (S.step(sel_img_) != 100) continue;  // INNER JOIN: no images row -> dropped
+                IndexedImage r;
+                r.id = S.column_int64(sel_img_, 0);
+                r.filename = reinterpret_cast<const char *>(S.column_text(sel_img_, 1));
+                r.path = reinterpret_cast<const char *>(S.column_text(sel_img_, 2));
+                r.resolution = {(uint32_t)S.column_int64(sel_img_, 3), (uint32_t)S.column_int64(sel_img_, 4)};
+                S.reset(sel_hash_);
+                S.bind_int64(sel_hash_, 1, ids[i]);
+                if (S.step(sel_hash_) == 100) {
+                    const uint8_t *p = static_cast<const uint8_t *>(S.column_blob(sel_hash_, 0));
+                    r.visual_hash = std::vector<uint8_t>(p, p + S.column_bytes(sel_hash_, 0));  // row.get(6)
+                }
+                r.distance_from_query = (double)dist[i];  // row.get(7)
+                out.push_back(std::move(r));
             }
-            r.distance_from_query = (double)dist[i];  // row.get(7)
-            out.push_back(std::move(r));
+            if (out.size() == RESULT_LIMIT || count < k || k == PB_MAX_K) break;
         }
         cached_ = std::move(out);
     }
@@ -169,7 +212,9 @@ class PersistentEngine {
     void fail(const char *what) const { throw Error(PB_ERR_INTERNAL, std::string("sqlite ") + what + ": " + S.errmsg(db_)); }
     void run(const char *sql) {
         char *err = nullptr;
-        if (S.exec(db_, sql, nullptr, nullptr, &err) != 0) fail(sql);
+        const int rc = S.exec(db_, sql, nullptr, nullptr, &err);
+        if (err) S.free_(err);  // the message is also available through sqlite3_errmsg (fail)
+        if (rc != 0) fail(sql);
     }
     void *prepare(const char *sql) {
         void *st = nullptr;
@@ -185,6 +230,7 @@ class PersistentEngine {
     std::unique_ptr<pb_index, Del> idx_;
     void *ins_img_ = nullptr, *ins_hash_ = nullptr, *sel_img_ = nullptr, *sel_hash_ = nullptr;
     std::optional<std::vector<IndexedImage>> cached_;
+    uint64_t skipped_hashes_ = 0;
 };
 
 }  // namespace pixelbox

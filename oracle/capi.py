@@ -17,7 +17,7 @@ _lib = None
 
 
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(_HERE, f) for f in ("pb_oracle.c", "pb_oracle_effnet.c", "pb_oracle_resize.c", "pb_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("pb_oracle.c", "pb_oracle_effnet.c", "pb_oracle_resize.c", "pb_oracle_phash.c", "pb_oracle.h")]
     stale = not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-B", "libpb_oracle.so"], stdout=subprocess.DEVNULL)
@@ -53,6 +53,11 @@ def lib():
         L.pbo_resize_to_fill_rgb8.argtypes = [u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u8p]
         L.pbo_resize_to_fill_rgb8.restype = C.c_int
         L.pbo_resize_dimensions_fill.argtypes = [C.c_uint32] * 4 + [C.POINTER(C.c_uint32)] * 2
+        L.pbo_resize_dimensions_fit.argtypes = [C.c_uint32] * 4 + [C.POINTER(C.c_uint32)] * 2
+        L.pbo_gaussian_kernel.argtypes = [C.c_float]
+        L.pbo_gaussian_kernel.restype = C.c_float
+        L.pbo_phash_rgb8.argtypes = [u8p, C.c_uint32, C.c_uint32, u8p, C.POINTER(C.c_uint32), u8p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.pbo_phash_rgb8.restype = C.c_int
         _lib = L
     return _lib
 
@@ -184,3 +189,18 @@ def resize_dimensions_fill(w: int, h: int, nw: int, nh: int) -> tuple[int, int]:
     a, b = C.c_uint32(0), C.c_uint32(0)
     lib().pbo_resize_dimensions_fill(w, h, nw, nh, C.byref(a), C.byref(b))
     return a.value, b.value
+
+
+def phash(rgb: np.ndarray, want_small: bool = False):
+    """phash.rs:3-22 for an RGB8 image [h, w, 3] -> hash bytes (<= 32); with want_small also the resized image."""
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    h, w = rgb.shape[:2]
+    out = np.zeros(32, dtype=np.uint8)
+    small = np.zeros(16 * 16 * 3, dtype=np.uint8)
+    n, sw, sh = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+    rc = lib().pbo_phash_rgb8(_u8(rgb), w, h, _u8(out), C.byref(n), _u8(small), C.byref(sw), C.byref(sh))
+    if rc != 0:
+        raise ValueError("empty image")
+    if want_small:
+        return out[: n.value].copy(), small[: sw.value * sh.value * 3].reshape(sh.value, sw.value, 3).copy()
+    return out[: n.value].copy()

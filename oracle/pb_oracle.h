@@ -85,6 +85,14 @@ int pbo_mlhash_batch(const uint8_t *blob, size_t blob_len, const uint8_t *imgs, 
 void pbo_resize_dimensions_fill(uint32_t w, uint32_t h, uint32_t nw, uint32_t nh, uint32_t *ow, uint32_t *oh);
 int pbo_resize_to_fill_rgb8(const uint8_t *src, uint32_t w, uint32_t h, uint32_t nw, uint32_t nh, uint8_t *out);
 
+/* ---- phash (pb_oracle_phash.c): src/image_hashes/phash.rs:3-22 -- Gaussian resize to fit 16x16 (aspect kept), luma, mean
+ * threshold, LSB-first bytes.  Pinned by phash.rs:36-41 (flat white -> 32 zero bytes); the image crate's arithmetic is unpinned. */
+void pbo_resize_dimensions_fit(uint32_t w, uint32_t h, uint32_t nw, uint32_t nh, uint32_t *ow, uint32_t *oh);
+float pbo_gaussian_kernel(float x);
+uint32_t pbo_gaussian_weights(uint32_t o, uint32_t in_size, uint32_t out_size, float *ws, uint32_t *count);
+int pbo_phash_rgb8(const uint8_t *src, uint32_t w, uint32_t h, uint8_t *out, uint32_t *n_bytes, uint8_t *small_rgb, uint32_t *sw,
+                   uint32_t *sh);
+
 #ifdef __cplusplus
 }
 #endif

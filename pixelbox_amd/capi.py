@@ -41,6 +41,7 @@ SYMBOLS = [
     "pb_embed_create", "pb_embed_destroy", "pb_embed_info", "pb_embed_batch", "pb_embed_batch_device", "pb_mlhash",
     "pb_mlhash_image", "pb_embed_batch_images", "pb_resize_to_fill",
     "pb_embed_set_option", "pb_fill_synthetic", "pb_fill_synthetic_images",
+    "pb_phash_create", "pb_phash_destroy", "pb_phash_image", "pb_phash_small_image",
 ]
 
 
@@ -119,6 +120,10 @@ def lib():
         L.pb_embed_batch_images.argtypes = [vp, C.POINTER(u8p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint32, u8p, C.POINTER(C.c_float)]
         L.pb_resize_to_fill.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, u8p]
         L.pb_embed_set_option.argtypes = [vp, C.c_int, C.c_int64]
+        L.pb_phash_create.argtypes = [C.POINTER(vp), C.c_int]
+        L.pb_phash_destroy.argtypes = [vp]
+        L.pb_phash_image.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, u8p, C.c_size_t, u32p]
+        L.pb_phash_small_image.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, u8p, u32p, u32p]
         L.pb_fill_synthetic.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, vp]
         L.pb_fill_synthetic_images.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, vp]
         _lib = L
@@ -412,6 +417,41 @@ class Embedder:
 
     def set_option(self, option: int, value: int):
         _check(lib().pb_embed_set_option(self._h, option, value))
+
+
+class PHasher:
+    """`image_hashes::phash` (reference: src/image_hashes/phash.rs:3-22) on the GPU."""
+
+    def __init__(self, device: int = 0):
+        self._h = C.c_void_p()
+        _check(lib().pb_phash_create(C.byref(self._h), device))
+
+    def close(self):
+        if self._h:
+            lib().pb_phash_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def phash(self, rgb: np.ndarray) -> np.ndarray:
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        h, w = rgb.shape[:2]
+        out = np.zeros(32, dtype=np.uint8)
+        n = C.c_uint32(0)
+        _check(lib().pb_phash_image(self._h, _p(rgb, C.c_uint8), w, h, _p(out, C.c_uint8), 32, C.byref(n)))
+        return out[: n.value].copy()
+
+    def small_image(self, rgb: np.ndarray) -> np.ndarray:
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        h, w = rgb.shape[:2]
+        out = np.zeros(16 * 16 * 3, dtype=np.uint8)
+        ow, oh = C.c_uint32(0), C.c_uint32(0)
+        _check(lib().pb_phash_small_image(self._h, _p(rgb, C.c_uint8), w, h, _p(out, C.c_uint8), C.byref(ow), C.byref(oh)))
+        return out[: ow.value * oh.value * 3].reshape(oh.value, ow.value, 3).copy()
 
 
 def fill_synthetic_device(device: int, seed: int, byte_offset: int, nbytes: int, d_ptr: int):

@@ -6,7 +6,8 @@ implements the one architecture `resources/train.py:30-46` exports -- torchvisio
 -> AdaptiveAvgPool2d(1) -> Flatten -> Linear(1280, D) -> Tanh, opset 11, constant-folded, so every BatchNorm
 is already folded into its Conv (`train.py:167-174`).  The importer therefore reads only
   * graph.input[0]'s shape           -> H, W
-  * the Conv nodes in graph order    -> stem, then per MBConv block (expand) / depthwise / se_reduce /
+  * the Conv nodes in DEPENDENCY order (the node list is topologically sorted here, so the file's own node order does
+    not matter)                      -> stem, then per MBConv block (expand) / depthwise / se_reduce /
                                         se_expand / project, then the head conv; each with weight + bias
   * the final Gemm (or MatMul + Add) -> Linear(1280, D)
 checks every shape against the architecture, and writes the blob layout of pixelbox_amd/weights.py.
@@ -101,10 +102,12 @@ def _tensor(buf: bytes):
 
 
 def _node(buf: bytes):
-    inputs, op, attrs = [], "", {}
+    inputs, outputs, op, attrs = [], [], "", {}
     for fno, wt, v in _fields(buf):
         if fno == 1:
             inputs.append(v.decode())
+        elif fno == 2:
+            outputs.append(v.decode())
         elif fno == 4:
             op = v.decode()
         elif fno == 5:
@@ -115,7 +118,31 @@ def _node(buf: bytes):
                 elif f2 == 3:  # AttributeProto.i
                     aint = v2
             attrs[aname] = aint
-    return op, inputs, attrs
+    return op, inputs, attrs, outputs
+
+
+def _topological(nodes, available):
+    """Nodes in dependency order (stable: among ready nodes, file order).  ONNX requires a topologically sorted node
+    list but exporters and graph editors differ in how they order independent branches; the architecture leaves no
+    freedom among its Conv nodes (expand -> depthwise -> se_reduce -> se_expand -> project are data-dependent in that
+    order, block after block), so sorting by dependencies makes the Conv sequence independent of the file's node order."""
+    have = set(available)
+    left = list(nodes)
+    out = []
+    while left:
+        rest = []
+        progressed = False
+        for nd in left:
+            if all((not nm) or nm in have for nm in nd[1]):
+                out.append(nd)
+                have.update(nd[3])
+                progressed = True
+            else:
+                rest.append(nd)
+        if not progressed:
+            raise OnnxImportError("graph has a cycle or a node input nothing produces: " + ", ".join(sorted({nm for nd in rest for nm in nd[1] if nm and nm not in have})[:4]))
+        left = rest
+    return out
 
 
 def _input_hw(buf: bytes):
@@ -159,15 +186,17 @@ def parse_onnx(data: bytes):
             nodes.append(_node(v))
         elif fno == 11:
             inputs.append(v)
+    input_names = []
     for v in inputs:  # the data input is the graph input that is not an initializer
         name = ""
         for fno, _, x in _fields(v):
             if fno == 1:
                 name = x.decode()
-        if name not in init_names:
+        input_names.append(name)
+        if name not in init_names and hw == (None, None):
             hw = _input_hw(v)
-            break
-    return inits, nodes, hw
+    nodes = _topological(nodes, init_names | set(input_names))
+    return inits, [(op, ins, at) for op, ins, at, _ in nodes], hw
 
 
 def import_onnx(data: bytes, h: int | None = None, w: int | None = None) -> bytes:

@@ -52,7 +52,11 @@ def value_info(name: str, dims) -> bytes:
     return _ld(1, name.encode()) + _ld(2, _ld(1, ttype))
 
 
-def export_like_torch(blob: bytes, raw: bool = True, gemm: bool = True, with_bn: bool = False, drop_conv: bool = False) -> bytes:
+def export_like_torch(blob: bytes, raw: bool = True, gemm: bool = True, with_bn: bool = False, drop_conv: bool = False,
+                      node_order=None, inits_first: bool = False) -> bytes:
+    """node_order: None (export order), "reversed", or an int seed for a random permutation of the node list -- a graph
+    editor / another exporter may list independent branches (and, in a sloppy file, everything) in another order; the
+    importer sorts by dependencies.  inits_first: initialisers before the nodes in the byte stream."""
     h, w, d, t = W.parse_blob(blob)
     nodes, inits = [], []
     cur, n = "input", 0
@@ -106,6 +110,13 @@ def export_like_torch(blob: bytes, raw: bool = True, gemm: bool = True, with_bn:
         nodes.append(node("MatMul", ["flat", "fc_wT"], ["mm"]))
         nodes.append(node("Add", ["mm", "fc_b"], ["lin"]))
     nodes.append(node("Tanh", ["lin"], ["output"]))
-    graph = b"".join(_ld(1, x) for x in nodes) + _ld(2, b"main_graph") + b"".join(_ld(5, x) for x in inits)
+    if node_order == "reversed":
+        nodes = nodes[::-1]
+    elif node_order is not None:
+        nodes = [nodes[i] for i in np.random.default_rng(int(node_order)).permutation(len(nodes))]
+    if inits_first:
+        graph = b"".join(_ld(5, x) for x in inits) + b"".join(_ld(1, x) for x in nodes) + _ld(2, b"main_graph")
+    else:
+        graph = b"".join(_ld(1, x) for x in nodes) + _ld(2, b"main_graph") + b"".join(_ld(5, x) for x in inits)
     graph += _ld(11, value_info("input", ["batch_size", 3, h, w])) + _ld(12, value_info("output", ["batch_size", d]))
     return _vi(1, 6) + _ld(2, b"pytorch") + _ld(7, graph) + _ld(8, _ld(1, b"") + _vi(2, 11))
