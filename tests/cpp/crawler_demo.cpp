@@ -46,9 +46,10 @@ int main(int argc, char **argv) {
                          hex(*g.phash).c_str());
         const bool ok = engine.query_by_image_hash_from_file(argv[3], model, &hasher);
         std::fprintf(out, "query %d hash_ms %.3f search_ms %.3f\n", (int)ok, engine.last_hash_ms, engine.last_search_ms);
-        if (ok)
-            for (const pixelbox::IndexedImage &r : *engine.get_query_results())
-                std::fprintf(out, "res %s %.9g\n", r.filename.c_str(), *r.distance_from_query);
+        if (ok) {
+            const auto res = engine.get_query_results();  // Option<Vec<IndexedImage>>, cloned like engine.rs:398-400
+            for (const pixelbox::IndexedImage &r : *res) std::fprintf(out, "res %s %.9g\n", r.filename.c_str(), *r.distance_from_query);
+        }
         const bool bad = engine.query_by_image_hash_from_file("/nonexistent/file.pnm", model, &hasher);
         std::fprintf(out, "missing %d\n", (int)bad);
         std::fclose(out);

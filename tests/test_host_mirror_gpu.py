@@ -85,7 +85,7 @@ def test_sqlite_persistence_bridge(tmp_path):
     out = tmp_path / "out.txt"
     subprocess.check_call([str(exe), str(db), str(d), str(tmp_path / "new.u8"), "3", str(out)])
     lines = out.read_text().splitlines()
-    assert lines[0] == f"loaded {n + 1}"  # 400 + the orphan; the short blob is skipped
+    assert lines[0] == f"loaded {n + 1} skipped 1"  # 400 + the orphan; the short blob is left out and counted
     new_ids = [int(x.split()[1]) for x in lines[1:4]]
     assert new_ids == [801, 802, 803]  # rowids continue after max(images.id) = 800; they sort BEFORE the orphan 5001
     assert lines[4] == f"indexed {n + 4}"  # the re-insert of a known path changed nothing
@@ -99,9 +99,12 @@ def test_sqlite_persistence_bridge(tmp_path):
         hdr = lines[pos].split()
         assert hdr[:2] == ["query", str(qi)]
         cnt = int(hdr[3])
-        want_ids, want_d = oracle.scan_topk(new[qi], all_rows, all_ids, 100, 1e3)
-        keep = want_ids != 5001  # INNER JOIN: the orphan hash has no images row
-        want_ids, want_d = want_ids[keep], want_d[keep]
+        # the reference's INNER JOIN runs before LIMIT 100 (engine.rs:377-381): the orphan hash (no images row) does not
+        # use up a result slot, the 100 results are the best 100 among the joined rows
+        want_ids, want_d = oracle.scan_topk(new[qi], all_rows, all_ids, 256, 1e3)
+        keep = want_ids != 5001
+        want_ids, want_d = want_ids[keep][:100], want_d[keep][:100]
+        assert len(want_ids) == 100
         assert cnt == len(want_ids)
         for j in range(cnt):
             rid, dist, path, hlen = lines[pos + 1 + j].split()
