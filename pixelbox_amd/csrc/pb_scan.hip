@@ -92,6 +92,8 @@ struct pb_index {
     int64_t *r_ids = nullptr;
     float *r_dist = nullptr;
     ResultHdr *r_hdr = nullptr;
+    QArg256 argq{};             // a single query travelling as a kernel argument of the filter launch (search_chunk -> run_fast)
+    bool argq_pending = false;
     // pinned host staging
     uint8_t *h_stage = nullptr;  // queries + params + qsel (one chunk)
     uint8_t *h_pipe = nullptr;   // queries + params of up to PIPE_Q queries (concurrent-query path)
@@ -325,13 +327,15 @@ void finish_qparams(const pb_index *ix, float acc, int64_t sum_a, int64_t sum_a2
 template <int LPR, int U, bool NT, int NW, int MAPB>
 void launch_filter_t(pb_index *ix, int n_wg, uint32_t q_base, uint32_t nq) {
     hipLaunchKernelGGL((k_scan_filter<LPR, U, NT, NW, MAPB>), dim3(n_wg, nq), dim3(NW * 64), 0, ix->stream, ix->d_rows,
-                       ix->n_rows, ix->d_queries, ix->d_qp, ix->d_lists, ix->d_hdrs, (int)q_base, 1);
+                       ix->n_rows, ix->d_queries, ix->d_qp, ix->d_lists, ix->d_hdrs, (int)q_base, 1, (uint8_t *)nullptr,
+                       (QParams *)nullptr, QArg256{});
 }
 // one launch, every workgroup answers the nq queries one after the other (k_scan_filter LOOPQ)
 template <int NW, int U = 8, int MAPB = 0>
 void launch_filter_loop(pb_index *ix, int n_wg, uint32_t q_base, uint32_t nq) {
     hipLaunchKernelGGL((k_scan_filter<16, U, true, NW, MAPB, true>), dim3(n_wg, 1), dim3(NW * 64), 0, ix->stream, ix->d_rows,
-                       ix->n_rows, ix->d_queries, ix->d_qp, ix->d_lists, ix->d_hdrs, (int)q_base, (int)nq);
+                       ix->n_rows, ix->d_queries, ix->d_qp, ix->d_lists, ix->d_hdrs, (int)q_base, (int)nq, (uint8_t *)nullptr,
+                       (QParams *)nullptr, QArg256{});
 }
 
 int filter_u(const pb_index *ix) {
@@ -397,7 +401,14 @@ bool loop_mode(const pb_index *ix, uint32_t nq) {
 int run_fast(pb_index *ix, uint32_t nq) {
     const int n_wg = filter_grid(ix);
     if (ix->opt_profile) PB_HIP(hipEventRecord(ix->ev0, ix->stream));
-    if (loop_mode(ix, nq)) {
+    if (ix->argq_pending) {
+        // one 256-byte query, default launch shape: the query rides in the kernel arguments (k_scan_filter ARGQ)
+        ix->argq_pending = false;
+        hipLaunchKernelGGL((k_scan_filter<16, 8, true, F_WAVES, 0, false, true>), dim3(n_wg, 1), dim3(F_WAVES * 64), 0, ix->stream,
+                           ix->d_rows, ix->n_rows, ix->d_queries, ix->d_qp, ix->d_lists, ix->d_hdrs, 0, 1, ix->d_queries, ix->d_qp,
+                           ix->argq);
+        PB_HIP(hipGetLastError());
+    } else if (loop_mode(ix, nq)) {
         const int v = ix->opt_variant & 15;
         if (v == 8) launch_filter_loop<8, 8, 1>(ix, n_wg, 0, nq);
         else if (v == 2) launch_filter_loop<8, 16, 0>(ix, n_wg, 0, nq);
@@ -708,9 +719,15 @@ int search_chunk(pb_index *ix, uint32_t cq, uint32_t k, double max_dist, const f
     const bool use_fast = use_dist || (ix->metric == 0 && (ix->opt_path == 0 || ix->opt_path == 2 || ix->opt_path == 3) && fast_dim(d));
     { int rcm = refresh_min_den(ix); if (rcm) return rcm; }
     make_qparams_batch(ix, hq, cq, k, max_dist, hp);
-    if (cq == 1) {
-        // the reference's call shape (one query per call, engine.rs:363-396): query bytes and constants travel as
-        // kernel arguments of a one-wave staging kernel instead of two host-to-device copy commands
+    const bool default_shape = ix->opt_variant == 0 && ix->opt_waves == F_WAVES && ix->opt_wg_per_cu == 1 && ix->opt_grid == 0;
+    if (cq == 1 && d == 256 && ix->metric == 0 && default_shape && (ix->opt_path == 0 || ix->opt_path == 2) && !multi_eligible(ix, cq)) {
+        // the reference's call shape (one query per call, engine.rs:363-396) on the filter path: the query bytes and
+        // constants are arguments of the filter launch itself (run_fast), which parks them for the kernels behind it
+        ix->argq.p = hp[0];
+        memcpy(ix->argq.q, hq, 256);
+        ix->argq_pending = true;
+    } else if (cq == 1) {
+        // other single-query shapes: a one-wave staging kernel instead of two host-to-device copy commands
         QArg a;
         a.p = hp[0];
         a.dim = d;

@@ -313,12 +313,21 @@ __global__ void k_row_norms(const uint8_t *__restrict__ rows, uint64_t first, ui
 // at 10M rows), but the launch gap and the ramp-up / tail of one launch per query (~12 us, a fifth of the pass over a
 // 1.25M-row shard) are paid once per batch.  Its own template instance, so that profilers list it apart from the
 // one-query launches.
-template <int LPR, int U = 8, bool NT = true, int NW = F_WAVES, int MAPB = 0, bool LOOPQ = false>
+// ARGQ (single-query calls, 256-byte rows): the query and its constants arrive as a kernel ARGUMENT (QArg256 by value, read
+// through the kernarg segment) instead of being staged in device memory by a copy or a staging kernel first -- the filter
+// launch is then the first command of the call; workgroup 0 parks them in slot 0 of the staged arrays for the kernels
+// that follow (k_select_rescore, the fallbacks).
+struct QArg256 {
+    QParams p;
+    uint8_t q[256];
+};
+template <int LPR, int U = 8, bool NT = true, int NW = F_WAVES, int MAPB = 0, bool LOOPQ = false, bool ARGQ = false>
 __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__restrict__ rows, uint64_t n_rows,
-                                                         const uint8_t *__restrict__ queries,
-                                                         const QParams *__restrict__ qp,
+                                                         const uint8_t *queries, const QParams *qp,
                                                          uint64_t *__restrict__ lists,
-                                                         ListHdr *__restrict__ hdrs, int q_base, int nq_loop) {
+                                                         ListHdr *__restrict__ hdrs, int q_base, int nq_loop,
+                                                         uint8_t *stage_q, QParams *stage_p, const QArg256 qarg) {
+    static_assert(!ARGQ || (LPR == 16 && !LOOPQ), "ARGQ: one 256-byte query per launch");
     constexpr int D = LPR * 16;
     constexpr int RPT = WAVE / LPR;                // rows per wave-instruction
     // U = loads in flight per lane (U KiB per wave); NT = non-temporal loads (the table is streamed once per query)
@@ -337,8 +346,19 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
     __shared__ uint64_t s_merge[NW * F_KW];
   for (int qi = 0; qi < (LOOPQ ? nq_loop : 1); ++qi) {
     const int q = q_base + (LOOPQ ? qi : (int)blockIdx.y);
-    const QParams P = qp[q];
-    const uint4 qv = *reinterpret_cast<const uint4 *>(queries + (size_t)q * D + sub * 16);
+    QParams P;
+    uint4 qv;
+    if constexpr (ARGQ) {
+        P = qarg.p;
+        qv = *reinterpret_cast<const uint4 *>(qarg.q + sub * 16);
+        if (blockIdx.x == 0 && threadIdx.x < 16) {
+            reinterpret_cast<uint4 *>(stage_q)[threadIdx.x] = *reinterpret_cast<const uint4 *>(qarg.q + threadIdx.x * 16);
+            if (threadIdx.x == 0) stage_p[0] = qarg.p;
+        }
+    } else {
+        P = qp[q];
+        qv = *reinterpret_cast<const uint4 *>(queries + (size_t)q * D + sub * 16);
+    }
 
     float thr = P.thr0;
     float dropped = 0.0f;
@@ -604,6 +624,13 @@ __device__ __forceinline__ void block_bitonic_sort(uint64_t *s, int n) {
 }
 
 // (1b) candidate selection from the workgroup lists, exact re-scoring, certificate.  One block per query.
+// This kernel is the latency tail of every query (one workgroup, a chain of dependent phases), so it is written to make
+// as few round trips as it can: every thread fetches its share of the list slots and headers ONCE (all loads in flight
+// together) and serves both the lower-bound histogram and the candidate selection from registers; a candidate's row, norm
+// and image_id are requested together; and up to SEL_RANK_MAX candidates are ordered by counting (each candidate counts the
+// keys below its own from LDS: one barrier) instead of a 36-barrier bitonic network -- 29 -> ~17 us per query.
+constexpr int SEL_SLOTS = F_MAX_WG * F_KWG / SEL_BLOCK;  // list slots per thread (16)
+constexpr int SEL_RANK_MAX = 256;
 __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
     const uint8_t *__restrict__ rows, const int64_t *__restrict__ ids, const float *__restrict__ norms,
     int d, const uint8_t *__restrict__ queries, const QParams *__restrict__ qp,
@@ -614,8 +641,9 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
     __shared__ float s_qf[1024];
     __shared__ uint32_t s_hist[SEL_BINS];
     __shared__ uint64_t s_key[SEL_MAX_CAND];   // candidates (filter keys), then exact keys
-    __shared__ float s_cs[SEL_MAX_CAND];       // exact cos of each candidate
     __shared__ float s_red[SEL_BLOCK / WAVE];
+    __shared__ float s_ck[SEL_BLOCK / WAVE];
+    __shared__ uint32_t s_wsum[SEL_BINS / WAVE];
     __shared__ uint32_t s_u[8];
     const int q = blockIdx.x;
     const int tid = threadIdx.x;
@@ -623,11 +651,23 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
     const uint64_t *ql = lists + (size_t)q * n_lists * F_KWG;
     const ListHdr *qh = hdrs + (size_t)q * n_lists;
 
-    for (int i = tid; i < 256; i += SEL_BLOCK) s_lut[i] = lut[i];
+    // ---- one round trip: this thread's list slots (slot i = list i / 32, entry i % 32) and their headers
+    const int total_slots = n_lists * F_KWG;
+    uint64_t my_key[SEL_SLOTS];
+    ListHdr my_hdr[SEL_SLOTS];
+#pragma unroll
+    for (int j = 0; j < SEL_SLOTS; ++j) {
+        const int i = tid + j * SEL_BLOCK;
+        const int ic = i < total_slots ? i : total_slots - 1;
+        my_key[j] = ql[ic];
+        my_hdr[j] = qh[ic / F_KWG];
+    }
+    const uint8_t qbyte = tid < d ? queries[(size_t)q * d + tid] : (uint8_t)0;
+    s_lut[tid & 255] = lut[tid & 255];
     for (int i = tid; i < SEL_BINS; i += SEL_BLOCK) s_hist[i] = 0;
     if (tid < 8) s_u[tid] = 0;
     __syncthreads();
-    for (int i = tid; i < d; i += SEL_BLOCK) s_qf[i] = s_lut[queries[(size_t)q * d + i]];
+    if (tid < d) s_qf[tid] = s_lut[qbyte];
 
     // ---- lower bound LB on the k-th largest filter cosine: histogram over the first j entries of
     //      every (sorted) list, j = ceil(k / n_lists)
@@ -636,49 +676,53 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
     const float scale = (float)SEL_BINS / span;
     float dmax = 0.0f;
     uint32_t n_top = 0;
-    for (int l = tid; l < n_lists; l += SEL_BLOCK) {
-        const ListHdr h = qh[l];
-        dmax = fmaxf(dmax, h.dropped);
-        const int c = (int)h.count < j_top ? (int)h.count : j_top;
-        for (int e = 0; e < c; ++e) {
-            const float cs = filter_key_cos(ql[(size_t)l * F_KWG + e]);
+#pragma unroll
+    for (int j = 0; j < SEL_SLOTS; ++j) {
+        const int i = tid + j * SEL_BLOCK;
+        const int e = i % F_KWG;
+        const bool live = i < total_slots && e < (int)my_hdr[j].count;
+        if (i < total_slots) dmax = fmaxf(dmax, my_hdr[j].dropped);
+        if (live && e < j_top) {
+            const float cs = filter_key_cos(my_key[j]);
             int bin = (int)((cs - P.thr0) * scale);
             bin = bin < 0 ? 0 : (bin >= SEL_BINS ? SEL_BINS - 1 : bin);
             atomicAdd(&s_hist[bin], 1u);
+            ++n_top;
         }
-        n_top += (uint32_t)c;
     }
-    for (int off = 32; off >= 1; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off));
-    if ((tid & 63) == 0) s_red[tid >> 6] = dmax;
-    if (n_top) atomicAdd(&s_u[0], n_top);
+    for (int off = 32; off >= 1; off >>= 1) {
+        dmax = fmaxf(dmax, __shfl_xor(dmax, off));
+        n_top += (uint32_t)__shfl_xor((int)n_top, off);
+    }
+    if ((tid & 63) == 0) {
+        s_red[tid >> 6] = dmax;
+        if (n_top) atomicAdd(&s_u[0], n_top);
+    }
     __syncthreads();
     dmax = 0.0f;
     for (int w = 0; w < SEL_BLOCK / WAVE; ++w) dmax = fmaxf(dmax, s_red[w]);
     const uint32_t top_total = s_u[0];
     float lb = P.thr0;
     if (top_total >= P.k) {
-        // suffix scan by thread 0 of each 64-bin chunk would need another pass; 1024 bins: serial scan
-        // from the top by one wave is ~16 steps of 64 bins
-        if (tid < WAVE) {
-            uint32_t acc = 0;
-            int found = -1;
-            for (int chunk = SEL_BINS / WAVE - 1; chunk >= 0 && found < 0; --chunk) {
-                const int bin = chunk * WAVE + (WAVE - 1 - tid);  // lane 0 = highest bin of the chunk
-                uint32_t v = s_hist[bin];
-                // inclusive prefix over lanes (descending bins)
-                uint32_t incl = v;
-                for (int off = 1; off < WAVE; off <<= 1) {
-                    const uint32_t o = __shfl_up(incl, off);
-                    if (tid >= off) incl += o;
-                }
-                const uint64_t hit = __ballot(acc + incl >= P.k);
-                if (hit) {
-                    const int first = __ffsll((unsigned long long)hit) - 1;
-                    found = chunk * WAVE + (WAVE - 1 - first);
-                }
-                acc += __shfl(incl, WAVE - 1);
-            }
-            if (tid == 0) s_u[1] = (uint32_t)found;
+        // suffix scan from the top bin: every wave sums its 64-bin chunk, wave 0 finds the chunk in which the running
+        // count reaches k and scans inside it
+        const int chunk = tid >> 6;                       // 16 chunks of 64 bins, chunk 15 = highest
+        const int bin = chunk * WAVE + (WAVE - 1 - (tid & 63));  // lane 0 = highest bin of the chunk
+        const uint32_t v = s_hist[bin];
+        uint32_t incl = v;
+        for (int off = 1; off < WAVE; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off);
+            if ((tid & 63) >= off) incl += o;
+        }
+        if ((tid & 63) == WAVE - 1) s_wsum[chunk] = incl;
+        __syncthreads();
+        uint32_t above = 0;  // count in the chunks above this one
+        for (int c = SEL_BINS / WAVE - 1; c > chunk; --c) above += s_wsum[c];
+        const uint64_t hit = __ballot(above + incl >= P.k);
+        // the chunk that crosses k: above < k <= above + chunk total
+        if (above < P.k && above + s_wsum[chunk] >= P.k && (tid & 63) == 0) {
+            const int first = __ffsll((unsigned long long)hit) - 1;
+            s_u[1] = (uint32_t)(chunk * WAVE + (WAVE - 1 - first));
         }
         __syncthreads();
         const int found = (int)s_u[1];
@@ -687,16 +731,14 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
     }
     const float cut = lb - 2.0f * P.m;
 
-    // ---- candidates: every listed entry with cos_filter >= cut
-    const int total_slots = n_lists * F_KWG;
-    for (int i = tid; i < total_slots; i += SEL_BLOCK) {
-        const int l = i / F_KWG, e = i % F_KWG;
-        if (e < (int)qh[l].count) {
-            const uint64_t key = ql[i];
-            if (filter_key_cos(key) >= cut) {
-                const uint32_t pos = atomicAdd(&s_u[2], 1u);
-                if (pos < SEL_MAX_CAND) s_key[pos] = key;
-            }
+    // ---- candidates: every listed entry with cos_filter >= cut (from the registers loaded above)
+#pragma unroll
+    for (int j = 0; j < SEL_SLOTS; ++j) {
+        const int i = tid + j * SEL_BLOCK;
+        const bool live = i < total_slots && (i % F_KWG) < (int)my_hdr[j].count;
+        if (live && filter_key_cos(my_key[j]) >= cut) {
+            const uint32_t pos = atomicAdd(&s_u[2], 1u);
+            if (pos < SEL_MAX_CAND) s_key[pos] = my_key[j];
         }
     }
     __syncthreads();
@@ -704,16 +746,21 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
     const int n_cand = n_cand_raw < SEL_MAX_CAND ? (int)n_cand_raw : SEL_MAX_CAND;
     const bool overflow = n_cand_raw > SEL_MAX_CAND;
 
-    // ---- exact re-scoring, one candidate per thread (reference arithmetic, engine.rs:575-587)
+    // ---- exact re-scoring, one candidate per thread (reference arithmetic, engine.rs:575-587); the row, its norm and
+    //      its image_id are requested together
     uint64_t xkey = ~0ull;
-    float my_cs = -2.0f;
+    float my_cs = -2.0f, my_dist = 0.0f;
+    int64_t my_id = 0;
     bool filtered = false;
     if (tid < n_cand) {
         const uint32_t r = (uint32_t)s_key[tid];
+        const float nrm = norms[r];
+        my_id = ids[r];
         const float dot = ref_fold_dot_any(rows + (uint64_t)r * d, s_qf, s_lut, d);
         float cs;
-        const float dist = ref_distance(dot, P.sqrt_sa, norms[r], &cs);
+        const float dist = ref_distance(dot, P.sqrt_sa, nrm, &cs);
         my_cs = cs;
+        my_dist = dist;
         if ((double)dist < P.max_dist) xkey = ((uint64_t)sortable_f32(dist) << 32) | r;
         else filtered = true;
     }
@@ -725,38 +772,42 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
     if ((tid & 63) == 0) s_red[tid >> 6] = cfilt;
     int nsort = 64;
     while (nsort < n_cand) nsort <<= 1;
-    if (tid < nsort) {
-        s_key[tid] = xkey;
-    }
+    if (tid < nsort) s_key[tid] = xkey;
+    const uint64_t vm = __ballot(xkey != ~0ull);
+    if ((tid & 63) == 0 && vm) atomicAdd(&s_u[3], (uint32_t)__popcll(vm));
     __syncthreads();
     cfilt = -2.0f;
     for (int w = 0; w < SEL_BLOCK / WAVE; ++w) cfilt = fmaxf(cfilt, s_red[w]);
-    // exact cos per row position for the certificate: stash by thread, then sort keys
-    if (tid < n_cand) s_cs[tid] = my_cs;
-    block_bitonic_sort(s_key, nsort);
-    // count valid
-    uint32_t valid = (tid < nsort && s_key[tid] != ~0ull) ? 1u : 0u;
-    const uint64_t vm = __ballot(valid != 0);
-    if ((tid & 63) == 0 && vm) atomicAdd(&s_u[3], (uint32_t)__popcll(vm));
-    __syncthreads();
     const uint32_t n_valid = s_u[3];
     const uint32_t n_out = n_valid < P.k ? n_valid : P.k;
-    if (tid < (int)n_out) {
-        const uint64_t key = s_key[tid];
-        const uint32_t r = (uint32_t)key;
-        out_ids[(size_t)q * out_stride + tid] = ids[r];
-        out_dist[(size_t)q * out_stride + tid] = unsortable_f32((uint32_t)(key >> 32));
+    float ck = 3.0f;  // smallest exact cosine among the n_out selected
+    if (n_cand <= SEL_RANK_MAX) {
+        // order by counting: keys are distinct (row in the low word), rank = number of exact keys below mine
+        if (tid < n_cand && xkey != ~0ull) {
+            uint32_t rank = 0;
+            for (int j = 0; j < n_cand; ++j) rank += s_key[j] < xkey ? 1u : 0u;
+            if (rank < n_out) {
+                out_ids[(size_t)q * out_stride + rank] = my_id;
+                out_dist[(size_t)q * out_stride + rank] = my_dist;
+                ck = my_cs;
+            }
+        }
+    } else {
+        block_bitonic_sort(s_key, nsort);
+        if (tid < (int)n_out) {
+            const uint64_t key = s_key[tid];
+            const uint32_t r = (uint32_t)key;
+            out_ids[(size_t)q * out_stride + tid] = ids[r];
+            out_dist[(size_t)q * out_stride + tid] = unsortable_f32((uint32_t)(key >> 32));
+        }
+        if (n_out > 0) {
+            const uint64_t kth_key = s_key[n_out - 1];
+            // thread `tid` owns candidate tid (unsorted order): selected iff its exact key <= kth_key
+            if (tid < n_cand && xkey <= kth_key) ck = my_cs;
+        }
     }
     // ---- certificate (DESIGN.md "certificate"): exact cosine of the k-th result vs. the best any
     //      unexamined row could reach
-    // c_k = smallest exact cos among the n_out selected: find it through the unsorted (row -> cs) table
-    __shared__ float s_ck[SEL_BLOCK / WAVE];
-    float ck = 3.0f;
-    if (n_out > 0) {
-        const uint64_t kth_key = s_key[n_out - 1];
-        // thread `tid` owns candidate tid (unsorted order): selected iff its exact key <= kth_key
-        if (tid < n_cand && xkey <= kth_key) ck = my_cs;
-    }
     for (int off = 32; off >= 1; off >>= 1) ck = fminf(ck, __shfl_xor(ck, off));
     if ((tid & 63) == 0) s_ck[tid >> 6] = ck;
     __syncthreads();
