@@ -260,15 +260,15 @@ void launch_gemm_mr(int nr, dim3 grid, hipStream_t st, const float *act, int M, 
 #undef PB_G
 }
 
-template <bool GATE, int NW>
+template <bool GATE, int NW, int KC>
 int launch_gemm_b3_t(int nr, hipStream_t st, const float *act, int M, const Gemm &g, const float *gate, int hw, const float *resid,
                      int do_silu, float *out) {
     const dim3 grid((unsigned)((M + 16 * NW - 1) / (16 * NW)), (unsigned)(g.Npad / 16 / nr));
 #define PB_G(NRV)                                                                                                        \
     case NRV: {                                                                                                          \
         constexpr int NT = 16 * NRV, LDP = NT + (NT % 32 == 0 ? 16 : 0);                                                 \
-        constexpr size_t lds = (size_t)2 * 48 * LDP * 8;                                                                 \
-        auto kern = k_gemm_b3<NRV, GATE, NW>;                                                                            \
+        constexpr size_t lds = (size_t)2 * 3 * (KC / 4) * LDP * 8;                                                       \
+        auto kern = k_gemm_b3<NRV, GATE, NW, KC>;                                                                        \
         if (lds > 48 * 1024)                                                                                             \
             PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, act, M, g.K, g.wt3, g.Kpad, g.Npad, g.bias, g.N, gate, hw, resid, \
@@ -280,13 +280,17 @@ int launch_gemm_b3_t(int nr, hipStream_t st, const float *act, int M, const Gemm
 #undef PB_G
     return PB_OK;
 }
+// nw: 4 or 8 waves per block; + 100: the 128-deep chunk form (eight k-steps of activations in flight)
 int launch_gemm_b3(int nr, int nw, hipStream_t st, const float *act, long M, const Gemm &g, const float *gate, int hw,
                    const float *resid, int do_silu, float *out) {
-    if (nw == 8)
-        return gate ? launch_gemm_b3_t<true, 8>(nr, st, act, (int)M, g, gate, hw, resid, do_silu, out)
-                    : launch_gemm_b3_t<false, 8>(nr, st, act, (int)M, g, gate, hw, resid, do_silu, out);
-    return gate ? launch_gemm_b3_t<true, 4>(nr, st, act, (int)M, g, gate, hw, resid, do_silu, out)
-                : launch_gemm_b3_t<false, 4>(nr, st, act, (int)M, g, gate, hw, resid, do_silu, out);
+#define PB_B3(NWV, KCV)                                                                                          \
+    (gate ? launch_gemm_b3_t<true, NWV, KCV>(nr, st, act, (int)M, g, gate, hw, resid, do_silu, out)              \
+          : launch_gemm_b3_t<false, NWV, KCV>(nr, st, act, (int)M, g, gate, hw, resid, do_silu, out))
+    if (nw == 108) return PB_B3(8, 128);
+    if (nw == 104) return PB_B3(4, 128);
+    if (nw == 8) return PB_B3(8, 64);
+    return PB_B3(4, 64);
+#undef PB_B3
 }
 
 // Tile choice.  NR (16-column tiles per wave) must divide Npad/16; MR in {4,2,1} (64*MR rows per block).
@@ -342,8 +346,9 @@ int launch_gemm(pb_embedder *e, const float *act, long M, const Gemm &g, const f
             PB_HIP(hipEventCreate(&e1));
             for (int nr = 8; nr >= 1; --nr) {
                 if (tiles % nr) continue;
-                for (int nw : {8, 4}) {
-                    if (nw == 8 && M <= 64) continue;
+                for (int nw : {8, 4, 108, 104}) {
+                    if (nw % 100 == 8 && M <= 64) continue;
+                    if (nw > 100 && (g.Kpad < 256 || nr > 5)) continue;  // 128-deep chunks: LDS 2 x 96 rows x (16 nr + pad) x 8 B <= 150 KB
                     int rc = launch_gemm_b3(nr, nw, e->stream, act, M, g, gate, hw, resid, do_silu, out);
                     if (rc) return rc;
                     PB_HIP(hipEventRecord(e0, e->stream));
@@ -362,7 +367,7 @@ int launch_gemm(pb_embedder *e, const float *act, long M, const Gemm &g, const f
                 }
             }
             if (e->trace_tune)
-                fprintf(stderr, "gemm M%ld K%d N%d%s: bf16 pieces, best NR%d NW%d %.1f us = %.1f TFLOP/s\n", M, g.K, g.N, gate ? " gated" : "",
+                fprintf(stderr, "gemm M%ld K%d N%d%s: bf16 pieces, best NR%d NW%d (+100: 128-deep chunks) %.1f us = %.1f TFLOP/s\n", M, g.K, g.N, gate ? " gated" : "",
                         best_nr, best_nw, best_ms * 500.f, 2.0 * (double)M * g.K * g.N / (best_ms * 0.5e-3) / 1e12);
             (void)hipEventDestroy(e0);
             (void)hipEventDestroy(e1);

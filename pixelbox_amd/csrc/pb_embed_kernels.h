@@ -490,16 +490,19 @@ __global__ __launch_bounds__(64 * NW) void k_gemm1x1(const float *__restrict__ a
 // plane and tile).  Same chunking (64 k per LDS buffer, one barrier per chunk), operand ring and epilogue.
 // dynamic LDS: 2 buffers x 3 planes x 16 x LDP 8-byte units.
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
-template <int NR, bool GATE, int NW>
+// KC = k per LDS chunk (64 or 128); the activation ring is KC / 16 k-steps deep: a bf16 k-step is ~5x shorter than an f32
+// one, so the four steps in flight that cover the memory latency of k_gemm1x1 do not cover it here
+template <int NR, bool GATE, int NW, int KC = 64>
 __global__ __launch_bounds__(64 * NW) void k_gemm_b3(const float *__restrict__ act, int M, int K, const uint2 *__restrict__ wt3,
                                                    int Kpad, int Npad, const float *__restrict__ bias, int N,
                                                    const float *__restrict__ gate, int hw, const float *__restrict__ resid,
                                                    int do_silu, float *__restrict__ out) {
     constexpr int NT = 16 * NR;
     constexpr int LDP = NT + (NT % 32 == 0 ? 16 : 0);  // row pitch (8-byte units): rows kk and kk + 1 land on opposite bank halves
-    constexpr int PD = 4;
+    constexpr int PD = KC / 16;
+    constexpr int KQC = KC / 4;                         // k-quads per chunk
     constexpr int NTHR = 64 * NW;
-    constexpr int ROWS = 3 * 16;                        // (plane, k-quad) rows of a chunk
+    constexpr int ROWS = 3 * KQC;                       // (plane, k-quad) rows of a chunk
     constexpr int W4 = ROWS * (NT / 2);                 // 16-byte pieces per chunk
     constexpr int WREGS = (W4 + NTHR - 1) / NTHR;
     extern __shared__ __attribute__((aligned(16))) uint2 s_w3[];  // [2][ROWS][LDP]
@@ -517,7 +520,7 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_b3(const float *__restrict__ a
 #pragma unroll
     for (int c = 0; c < NR; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int n_steps = Kpad / 16;
-    const int n_chunks = (Kpad + G_KC - 1) / G_KC;
+    const int n_chunks = (Kpad + KC - 1) / KC;
     f32x4 aring[PD], gring[GATE ? PD : 1];
     auto load_act = [&](int t, int slot) __attribute__((always_inline)) {
         const int kbase = t * 16 + 4 * kk;
@@ -535,8 +538,8 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_b3(const float *__restrict__ a
             const int i = threadIdx.x + j * NTHR;
             const int ic = i < W4 ? i : 0;
             const int row = ic / (NT / 2), c2 = ic % (NT / 2);
-            const int pl = row / 16, r = row % 16;
-            int kq = chunk * 16 + r;
+            const int pl = row / KQC, r = row % KQC;
+            int kq = chunk * KQC + r;
             kq = kq < KQ ? kq : KQ - 1;  // clamp: k-quads beyond Kpad are never used
             wreg[j] = *reinterpret_cast<const u32x4 *>(wt3 + ((size_t)pl * KQ + kq) * Npad + n0 + 2 * c2);
         }
@@ -555,8 +558,8 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_b3(const float *__restrict__ a
     store_w(0);
     __syncthreads();
     auto do_chunk = [&](int chunk, auto full) __attribute__((always_inline)) {
-        const int k0 = chunk * G_KC;
-        const int kc = (Kpad - k0) < G_KC ? (Kpad - k0) : G_KC;
+        const int k0 = chunk * KC;
+        const int kc = (Kpad - k0) < KC ? (Kpad - k0) : KC;
         if constexpr (decltype(full)::value) load_w(chunk + 1 < n_chunks ? chunk + 1 : n_chunks - 1);
         const uint2 *sw = s_w3 + (size_t)(chunk & 1) * ROWS * LDP + li;
         auto k_step = [&](int q, int u) __attribute__((always_inline)) {
@@ -574,7 +577,7 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_b3(const float *__restrict__ a
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-                for (int c = 0; c < NR; ++c) wq[pl][c] = sw[(size_t)(pl * 16 + 4 * q + kk) * LDP + 16 * c];
+                for (int c = 0; c < NR; ++c) wq[pl][c] = sw[(size_t)(pl * KQC + 4 * q + kk) * LDP + 16 * c];
             // split the four activations: hi = top 16 bits, r1 = a - hi (exact), mid = top 16 bits of r1, lo = r1 - mid
             uint32_t hb[4], mb[4], lb[4];
 #pragma unroll
@@ -593,30 +596,33 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_b3(const float *__restrict__ a
             const u32x2 pl2 = {__builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u), __builtin_amdgcn_perm(lb[3], lb[2], 0x07060302u)};
             const bf16x4 ah = __builtin_bit_cast(bf16x4, ph), am = __builtin_bit_cast(bf16x4, pm), al = __builtin_bit_cast(bf16x4, pl2);
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int c = 0; c < NR; ++c) {
-                const bf16x4 wh = __builtin_bit_cast(bf16x4, wq[0][c]), wm = __builtin_bit_cast(bf16x4, wq[1][c]), wl = __builtin_bit_cast(bf16x4, wq[2][c]);
-                acc[c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wl, ah, acc[c], 0, 0, 0);
-                acc[c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh, al, acc[c], 0, 0, 0);
-                acc[c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wm, am, acc[c], 0, 0, 0);
-                acc[c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wm, ah, acc[c], 0, 0, 0);
-                acc[c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh, am, acc[c], 0, 0, 0);
-                acc[c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh, ah, acc[c], 0, 0, 0);
-            }
+            // piece products outermost, column tiles innermost: consecutive MFMAs write DIFFERENT accumulators (six in a row
+            // on one accumulator is a dependent chain that runs at the MFMA's result latency, not its issue rate); every
+            // accumulator still receives its six products in the same order, smallest first
+#define PB_B3_PASS(WP, AP)                                                                                          \
+    _Pragma("unroll") for (int c = 0; c < NR; ++c)                                                                  \
+        acc[c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(bf16x4, wq[WP][c]), AP, acc[c], 0, 0, 0);
+            PB_B3_PASS(2, ah)
+            PB_B3_PASS(0, al)
+            PB_B3_PASS(1, am)
+            PB_B3_PASS(1, ah)
+            PB_B3_PASS(0, am)
+            PB_B3_PASS(0, ah)
+#undef PB_B3_PASS
             __builtin_amdgcn_sched_barrier(0);
         };
         if constexpr (decltype(full)::value) {
 #pragma unroll
-            for (int q = 0; q < G_KC / 16; ++q) k_step(q, q % PD);
+            for (int q = 0; q < KC / 16; ++q) k_step(q, q % PD);
         } else {
 #pragma unroll
-            for (int q = 0; q < G_KC / 16; ++q)
+            for (int q = 0; q < KC / 16; ++q)
                 if (16 * q < kc) k_step(q, q % PD);
         }
         if constexpr (decltype(full)::value) store_w((chunk + 1) & 1);
         __syncthreads();
     };
-    const int n_full = Kpad / G_KC;
+    const int n_full = Kpad / KC;
     for (int chunk = 0; chunk < n_full; ++chunk) do_chunk(chunk, std::true_type{});
     if (n_full < n_chunks) do_chunk(n_full, std::false_type{});
     if (!mval) return;

@@ -1742,28 +1742,52 @@ __global__ __launch_bounds__(NWQ * WAVE) void k_scan_multi_wg(
 }
 
 // per query: tau = lower edge of the highest histogram bin at which the sampled count reaches `target_sample`
-// (never below thr0); one wave per query
+// (never below thr0); one wave per query.
+// A bin that holds far more than the target (a table full of near-duplicates of the query: all of them land in one bin)
+// would put more rows above tau than a candidate list holds, and the collect pass would spend its time queueing
+// survivors of lists that overflow anyway (23 ms instead of 1.5 ms per 512 queries on the end-to-end table).  Such a
+// query is GATED: tau = 2 + h, unreachable for the collect pass (cosines are <= 1), where h in [0, 1) hands the second
+// chance its starting point -- h = (lower edge of the bin at which the SAMPLED count reaches k) - m.  The k-th largest
+// cos_filter of a subset is <= the k-th largest of the whole table, so at least k rows have an exact cosine >= h: h is a
+// lower bound of the true k-th exact cosine, which is all the second chance needs (pb_scan_kernels.h (4)); h = 0: none.
 __global__ void k_mq_pick_tau(const uint32_t *__restrict__ ghist, const QParams *__restrict__ qp, int n_q,
                               uint32_t target_sample, float *__restrict__ tau) {
     const int q = blockIdx.x;
     if (q >= n_q) return;
     const int lane = lane_id();
-    uint32_t acc = 0;
-    int found = -1;
-    for (int chunk = MQ_BINS / WAVE - 1; chunk >= 0 && found < 0; --chunk) {
+    const uint32_t k = qp[q].k;
+    uint32_t acc = 0, cum = 0;
+    int found = -1, found_k = -1;
+    for (int chunk = MQ_BINS / WAVE - 1; chunk >= 0 && (found < 0 || found_k < 0); --chunk) {
         const int bin = chunk * WAVE + (WAVE - 1 - lane);
         uint32_t incl = ghist[(size_t)q * MQ_BINS + bin];
         for (int off = 1; off < WAVE; off <<= 1) {
             const uint32_t o = __shfl_up(incl, off);
             if (lane >= off) incl += o;
         }
-        const uint64_t hit = __ballot(acc + incl >= target_sample);
-        if (hit) found = chunk * WAVE + (WAVE - 1 - (__ffsll((unsigned long long)hit) - 1));
+        if (found < 0) {
+            const uint64_t hit = __ballot(acc + incl >= target_sample);
+            if (hit) {
+                const int first = __ffsll((unsigned long long)hit) - 1;
+                found = chunk * WAVE + (WAVE - 1 - first);
+                cum = acc + __shfl(incl, first);  // sampled rows at or above the chosen edge
+            }
+        }
+        if (found_k < 0) {
+            const uint64_t hit = __ballot(acc + incl >= k);
+            if (hit) found_k = chunk * WAVE + (WAVE - 1 - (__ffsll((unsigned long long)hit) - 1));
+        }
         acc += __shfl(incl, WAVE - 1);
     }
     if (lane == 0) {
         float t = found >= 0 ? (float)found / (float)MQ_BINS - 2e-6f : 0.0f;
-        tau[q] = fmaxf(t, qp[q].thr0);
+        t = fmaxf(t, qp[q].thr0);
+        if ((uint64_t)cum * MQ_SAMPLE > (uint64_t)MQ_CAP) {
+            float h = found_k >= 0 ? (float)found_k / (float)MQ_BINS - 4e-6f - qp[q].m : 0.0f;
+            h = h > 0.0f && h < 0.999f ? h : 0.0f;
+            t = 2.0f + h;
+        }
+        tau[q] = t;
     }
 }
 
@@ -1863,6 +1887,11 @@ __global__ __launch_bounds__(1024) void k_mq_rescore(
         h.n_cand = raw;
         h.o_max = o_max;
         h.ck = n_out == P.k ? ck : -1.0f;
+        if (tau[q] >= 2.0f) {  // gated by k_mq_pick_tau: nothing was collected; hand on its lower bound of the k-th cosine
+            const float hint = tau[q] - 2.0f - 1e-6f;
+            h.status = 1u;
+            h.ck = hint > 0.0f ? hint : -1.0f;
+        }
         out_hdr[q] = h;
     }
 }
