@@ -197,13 +197,39 @@ def main():
         roof["traffic"] = None
         roof["traffic_profile"] = latest_profile("scan_pmc")
         # the reference's call shape: ONE query per call (engine.rs:363-396) -- wall time of the whole call
-        # (staging kernel, filter pass, re-scoring, results written to pinned host memory, one wait)
+        # (filter launch carrying the query as a kernel argument, re-scoring, results written to pinned host memory, one wait)
         call_gbs = len(sh.index) * d / (lat_ms * 1e-3) / 1e9
         roof_single = {"bound": "hbm", "what": "pb_index_search with one query: wall time of the call, host side included",
                        "ms_per_call": round(lat_ms, 4), "achieved": round(call_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": round(call_gbs / HBM_PEAK_GBS, 4)}
     else:
         roof_single = None
+
+    # N > 1: the strong-scaling shards of a 10M-row table are small (1.25M rows = 320 MB at 8 GPUs: about the size of the
+    # 256 MiB Infinity Cache), so a second leg keeps 10M rows PER GPU (weak scaling: N x 10M rows in all) -- every rank
+    # streams 2.56 GB from HBM per query as in the 1-GPU headline, and what is left of linear scaling is the exchange
+    weak = None
+    shard_rows = len(sh.index)
+    if distributed and not args.exact_path:
+        sh = None
+        wsh = ShardedIndex(d, n_total * world, rank=rank, world=world, device=local_rank, group=torch.distributed.group.WORLD)
+        wsh.fill_synthetic(synth.SEED_INDEX, first_id=1)
+        wsh.index.set_option(capi.PB_OPT_SEARCH_PATH, 2)
+        wsh.search(qbytes[0], k, args.max_dist)
+        barrier()
+        t1 = time.perf_counter()
+        for s in range(args.warmup, n_steps_total):
+            wsh.search(qbytes[s], k, args.max_dist)
+        barrier()
+        dtw = time.perf_counter() - t1
+        t = torch.tensor([dtw], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dtw = float(t.item())
+        weak = {"scaling": "weak", "rows_per_gpu": n_total, "rows_total": n_total * world, "value": round(args.steps * B / dtw, 2),
+                "unit": "queries/s over the N x 10M-row table", "ms_per_step": round(dtw / args.steps * 1e3, 4),
+                "table_bytes_streamed_per_second_all_gpus": round(args.steps * B * n_total * world * d / dtw / 1e12, 3),
+                "unit2": "TB/s"}
+        del wsh
 
     sweep = None
     if world == 1 and not args.no_sweep and not args.exact_path and d == 256:
@@ -240,6 +266,12 @@ def main():
                                    f"top-{k} queries per step (one table pass per query, the {B} passes in one launch), "
                                    f"max_dist={args.max_dist:g}",
                        "rows": n_total, "dim": d, "k": k, "queries_per_step": B, "parallelism": f"row-shard x{world}",
+                       "shard_rows": shard_rows, "shard_bytes": shard_rows * d,
+                       "shard_vs_infinity_cache": ("shard larger than the 256 MiB Infinity Cache by %.1fx: an HBM stream"
+                                                   % (shard_rows * d / (256 << 20))) if shard_rows * d > 1.5 * (256 << 20) else
+                                                  ("shard of %.0f MB is about the size of the 256 MiB Infinity Cache: NOT a pure HBM "
+                                                   "number (non-temporal loads keep most of it out of the cache; see weak_scaling "
+                                                   "for 10M rows per GPU)" % (shard_rows * d / 1e6)),
                        "search_path": "exact" if args.exact_path else "filter+rescore"},
             "ms_per_query": round(dt / (args.steps * B) * 1e3, 4), "latency_ms_single_query_call": round(lat_ms, 4),
             "path_counts": {"queries": int(st.queries), "filter_certified": int(st.fast_path),
@@ -250,6 +282,8 @@ def main():
             out["roofline"]["n_sweep"] = sweep["n_sweep"]
             out["roofline"]["evicted_between_passes"] = sweep["evicted"]
             out["scan_1m"] = sweep["scan_1m"]
+        if weak is not None:
+            out["weak_scaling"] = weak
         if concurrent is not None:
             out["concurrent"] = concurrent
         if embed is not None:
