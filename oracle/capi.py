@@ -17,7 +17,7 @@ _lib = None
 
 
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(_HERE, f) for f in ("pb_oracle.c", "pb_oracle_effnet.c", "pb_oracle_resize.c", "pb_oracle_phash.c", "pb_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("pb_oracle.c", "pb_oracle_effnet.c", "pb_oracle_resize.c", "pb_oracle_phash.c", "pb_oracle_sqlite.c", "pb_oracle.h")]
     stale = not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-B", "libpb_oracle.so"], stdout=subprocess.DEVNULL)
@@ -58,6 +58,9 @@ def lib():
         L.pbo_gaussian_kernel.restype = C.c_float
         L.pbo_phash_rgb8.argtypes = [u8p, C.c_uint32, C.c_uint32, u8p, C.POINTER(C.c_uint32), u8p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.pbo_phash_rgb8.restype = C.c_int
+        L.pbo_sqlite_scan.argtypes = [u8p, i64p, C.c_size_t, C.c_size_t, u8p, C.c_size_t, C.c_size_t, C.c_double, i64p, f32p,
+                                      C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
+        L.pbo_sqlite_scan.restype = C.c_int
         _lib = L
     return _lib
 
@@ -204,3 +207,24 @@ def phash(rgb: np.ndarray, want_small: bool = False):
     if want_small:
         return out[: n.value].copy(), small[: sw.value * sh.value * 3].reshape(sh.value, sw.value, 3).copy()
     return out[: n.value].copy()
+
+
+def sqlite_scan(queries, rows, ids=None, max_dist=1e3):
+    """The reference's query through a real SQLite (schema, registered cosine_distance UDF, literal SQL text, LIMIT 100).
+    -> (ids [nq, 100], dist [nq, 100] f32, count [nq], seconds per query)."""
+    rows = np.ascontiguousarray(rows, dtype=np.uint8)
+    n, d = rows.shape
+    q = np.ascontiguousarray(queries, dtype=np.uint8).reshape(-1, d)
+    ids = np.arange(1, n + 1, dtype=np.int64) if ids is None else np.ascontiguousarray(ids, dtype=np.int64)
+    nq, k = q.shape[0], 100
+    out_ids = np.zeros((nq, k), dtype=np.int64)
+    out_d = np.zeros((nq, k), dtype=np.float32)
+    cnt = np.zeros(nq, dtype=np.uint32)
+    secs = C.c_double(0.0)
+    rc = lib().pbo_sqlite_scan(_u8(rows), _i64(ids), n, d, _u8(q), nq, k, float(max_dist), _i64(out_ids), _f32(out_d),
+                               cnt.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(secs))
+    if rc == -1:
+        raise RuntimeError("libsqlite3.so.0 is not loadable")
+    if rc != 0:
+        raise RuntimeError("SQL error (see stderr)")
+    return out_ids, out_d, cnt, secs.value

@@ -93,6 +93,12 @@ uint32_t pbo_gaussian_weights(uint32_t o, uint32_t in_size, uint32_t out_size, f
 int pbo_phash_rgb8(const uint8_t *src, uint32_t w, uint32_t h, uint8_t *out, uint32_t *n_bytes, uint8_t *small_rgb, uint32_t *sw,
                    uint32_t *sh);
 
+/* ---- the scan through SQLite (pb_oracle_sqlite.c): reference schema, cosine_distance registered as a scalar function
+ * (engine.rs:608-622), the reference's literal query text (engine.rs:375-381).  Checker and the "scan-cpu-sqlite" baseline
+ * of BASELINE.md section 3.  k must be 100 (the text says LIMIT 100).  Returns 0, -1 (no libsqlite3), -2 (SQL error). */
+int pbo_sqlite_scan(const uint8_t *rows, const int64_t *ids, size_t n, size_t d, const uint8_t *queries, size_t nq, size_t k,
+                    double max_dist, int64_t *out_ids, float *out_dist, uint32_t *out_count, double *secs_per_query);
+
 #ifdef __cplusplus
 }
 #endif
