@@ -73,9 +73,11 @@ int pb_index_contains(const pb_index *idx, int64_t image_id, int *found);
 
 /* Replaces `INSERT OR IGNORE INTO semantic_hashes (image_id, hash) VALUES (?, ?)` (engine.rs:251-256),
  * batched: n (image_id, hash) pairs from HOST memory.  OR IGNORE semantics: a pair whose image_id is
- * already present is skipped (first write wins).  ids greater than every stored id append at the end
- * (the common case: ids come from last_insert_rowid(), engine.rs:233); an id that falls between stored
- * ids is inserted in place (device memmove).  *n_inserted (optional) receives the number stored. */
+ * already present, or appeared earlier in the same call, is skipped (first write wins).  ids greater than every
+ * stored id append at the end (the common case: ids come from last_insert_rowid(), engine.rs:233); any other order
+ * is accepted too: the new pairs of a call are appended and merged into image_id order in ONE permutation pass over
+ * the affected suffix.  *n_inserted (optional) receives the number stored -- also when the call fails: an index that
+ * runs full stores what fits and returns PB_ERR_CAPACITY. */
 int pb_index_append(pb_index *idx, const int64_t *image_ids, const uint8_t *rows, uint64_t n,
                     uint64_t *n_inserted);
 

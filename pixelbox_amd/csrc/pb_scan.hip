@@ -8,6 +8,7 @@
 #include <limits>
 #include <mutex>
 #include <new>
+#include <unordered_set>
 #include <vector>
 
 #include "pb_common.h"
@@ -1032,37 +1033,63 @@ int append_tail(pb_index *ix, const int64_t *ids, const uint8_t *rows, uint64_t 
     return PB_OK;
 }
 
-// insert one row at sorted position pos < n_rows (rare path): shift the tail through a temporary
-int insert_at(pb_index *ix, uint64_t pos, int64_t id, const uint8_t *row) {
-    PB_CHECK(ix->n_rows + 1 <= ix->capacity, PB_ERR_CAPACITY, "index full");
-    { int rcm = refresh_min_den(ix); if (rcm) return rcm; }  // d_ids is about to be shifted: pending uploads first
+// Out-of-order inserts (ids at or below the current maximum): the new pairs of a call are first appended at the tail in
+// call order (append_unsorted), then ONE permutation pass puts the affected suffix of every per-row array back into
+// ascending image_id order -- O(suffix) device traffic per CALL.  (Round 1 shifted the tail once per inserted row: a bulk
+// load in descending order was quadratic.)
+int merge_unsorted_tail(pb_index *ix, uint64_t n_sorted) {
+    const uint64_t n_all = ix->n_rows;
+    if (n_sorted >= n_all) return PB_OK;
+    // new ids with their tail positions, sorted; the affected range starts at the first stored id above the smallest new one
+    std::vector<std::pair<int64_t, uint32_t>> fresh;
+    fresh.reserve(n_all - n_sorted);
+    for (uint64_t p = n_sorted; p < n_all; ++p) fresh.emplace_back(ix->h_ids[p], (uint32_t)p);
+    std::sort(fresh.begin(), fresh.end());
+    const uint64_t lo = (uint64_t)(std::lower_bound(ix->h_ids.begin(), ix->h_ids.begin() + (ptrdiff_t)n_sorted, fresh.front().first) - ix->h_ids.begin());
+    const uint64_t n_aff = n_all - lo;
+    std::vector<uint32_t> perm(n_aff);   // perm[i] = current position (relative to lo) of the row that belongs at lo + i
+    std::vector<int64_t> merged(n_aff);
+    uint64_t a = lo, f = 0, o = 0;
+    while (a < n_sorted || f < fresh.size()) {
+        const bool take_old = f == fresh.size() || (a < n_sorted && ix->h_ids[a] < fresh[f].first);
+        if (take_old) {
+            perm[o] = (uint32_t)(a - lo);
+            merged[o++] = ix->h_ids[a++];
+        } else {
+            perm[o] = fresh[f].second - (uint32_t)lo;
+            merged[o++] = fresh[f++].first;
+        }
+    }
     const size_t d = ix->dim;
-    const uint64_t tail = ix->n_rows - pos;
-    void *tmp = nullptr;
-    PB_HIP(hipMalloc(&tmp, tail * std::max<size_t>(d, sizeof(int64_t))));
-    auto shift = [&](void *base, size_t elt) -> int {
-        char *p = static_cast<char *>(base) + pos * elt;
-        PB_HIP(hipMemcpyAsync(tmp, p, tail * elt, hipMemcpyDeviceToDevice, ix->stream));
-        PB_HIP(hipMemcpyAsync(p + elt, tmp, tail * elt, hipMemcpyDeviceToDevice, ix->stream));
+    uint32_t *d_perm = nullptr;
+    uint8_t *d_tmp = nullptr;
+    auto body = [&]() -> int {
+        PB_HIP(hipMalloc(&d_perm, n_aff * sizeof(uint32_t)));
+        PB_HIP(hipMalloc(&d_tmp, n_aff * std::max<size_t>(d, sizeof(int64_t))));
+        PB_HIP(hipMemcpyAsync(d_perm, perm.data(), n_aff * sizeof(uint32_t), hipMemcpyHostToDevice, ix->stream));
+        auto permute = [&](void *base, size_t elt) -> int {
+            uint8_t *p = static_cast<uint8_t *>(base) + lo * elt;
+            const uint64_t pieces = n_aff * (elt % 16 == 0 ? elt / 16 : (elt % 4 == 0 ? elt / 4 : elt));
+            const int grid = (int)std::min<uint64_t>((pieces + 255) / 256, (uint64_t)ix->n_cu * 16);
+            hipLaunchKernelGGL(k_gather_elts, dim3(grid), dim3(256), 0, ix->stream, p, d_perm, n_aff, (uint32_t)elt, d_tmp);
+            PB_HIP(hipGetLastError());
+            PB_HIP(hipMemcpyAsync(p, d_tmp, n_aff * elt, hipMemcpyDeviceToDevice, ix->stream));
+            return PB_OK;
+        };
+        int rc = permute(ix->d_rows, d);
+        if (!rc) rc = permute(ix->d_ids, sizeof(int64_t));
+        if (!rc) rc = permute(ix->d_norms, sizeof(float));
+        if (!rc) rc = permute(ix->d_sumb, sizeof(int32_t));
+        if (!rc) rc = permute(ix->d_denb, sizeof(int32_t));
+        if (rc) return rc;
+        PB_HIP(hipStreamSynchronize(ix->stream));
         return PB_OK;
     };
-    int rc = shift(ix->d_rows, d);
-    if (!rc) rc = shift(ix->d_ids, sizeof(int64_t));
-    if (!rc) rc = shift(ix->d_norms, sizeof(float));
-    if (!rc) rc = shift(ix->d_sumb, sizeof(int32_t));
-    if (!rc) rc = shift(ix->d_denb, sizeof(int32_t));
-    if (rc) {
-        (void)hipFree(tmp);
-        return rc;
-    }
-    PB_HIP(hipMemcpyAsync(ix->d_rows + pos * d, row, d, hipMemcpyHostToDevice, ix->stream));
-    PB_HIP(hipMemcpyAsync(ix->d_ids + pos, &id, sizeof(int64_t), hipMemcpyHostToDevice, ix->stream));
-    rc = launch_norms(ix, pos, 1);
-    PB_HIP(hipStreamSynchronize(ix->stream));
-    (void)hipFree(tmp);
+    const int rc = body();
+    (void)hipFree(d_perm);
+    (void)hipFree(d_tmp);
     if (rc) return rc;
-    ix->h_ids.insert(ix->h_ids.begin() + (ptrdiff_t)pos, id);
-    ix->n_rows += 1;
+    std::copy(merged.begin(), merged.end(), ix->h_ids.begin() + (ptrdiff_t)lo);
     return PB_OK;
 }
 
@@ -1180,43 +1207,46 @@ int pb_index_append(pb_index *ix, const int64_t *image_ids, const uint8_t *rows,
     PB_CHECK(n == 0 || (image_ids && rows), PB_ERR_INVALID, "pb_index_append: null ids/rows");
     std::lock_guard<std::mutex> lock(ix->mu);
     pb::DeviceGuard guard(ix->device);
-    uint64_t stored = 0;
     if (n_inserted) *n_inserted = 0;
+    if (n == 0) return PB_OK;
     const size_t d = ix->dim;
-    uint64_t i = 0;
-    while (i < n) {
-        const int64_t last = ix->h_ids.empty() ? std::numeric_limits<int64_t>::min() : ix->h_ids.back();
-        // longest run of strictly increasing ids beyond the current maximum -> one tail append
-        uint64_t j = i;
-        int64_t prev = last;
-        while (j < n && image_ids[j] > prev && (ix->h_ids.empty() || image_ids[j] > last)) {
-            prev = image_ids[j];
-            ++j;
+    // common case (ids are fresh last_insert_rowid() values, engine.rs:233): strictly ascending and beyond everything stored
+    const int64_t last = ix->h_ids.empty() ? std::numeric_limits<int64_t>::min() : ix->h_ids.back();
+    bool ascending = ix->h_ids.empty() ? true : image_ids[0] > last;
+    for (uint64_t i = 1; i < n && ascending; ++i) ascending = image_ids[i] > image_ids[i - 1];
+    if (ascending) {
+        const uint64_t room = ix->capacity - ix->n_rows, take = std::min<uint64_t>(room, n);
+        if (take) {
+            int rc = append_tail(ix, image_ids, rows, take, hipMemcpyHostToDevice);
+            if (rc) return rc;
         }
-        if (j > i) {
-            int rc = append_tail(ix, image_ids + i, rows + i * d, j - i, hipMemcpyHostToDevice);
-            if (rc) {
-                if (n_inserted) *n_inserted = stored;  // what earlier runs of this call did store
-                return rc;
-            }
-            stored += j - i;
-            i = j;
-            continue;
-        }
-        // id <= current maximum: INSERT OR IGNORE
-        const int64_t id = image_ids[i];
-        auto it = std::lower_bound(ix->h_ids.begin(), ix->h_ids.end(), id);
-        if (it == ix->h_ids.end() || *it != id) {
-            int rc = insert_at(ix, (uint64_t)(it - ix->h_ids.begin()), id, rows + i * d);
-            if (rc) {
-                if (n_inserted) *n_inserted = stored;
-                return rc;
-            }
-            ++stored;
-        }
-        ++i;
+        if (n_inserted) *n_inserted = take;
+        PB_CHECK(take == n, PB_ERR_CAPACITY, "index full: capacity %llu rows (%llu of this call stored)", (unsigned long long)ix->capacity,
+                 (unsigned long long)take);
+        return PB_OK;
     }
-    if (n_inserted) *n_inserted = stored;
+    // general case -- INSERT OR IGNORE: a pair whose image_id is stored already, or appeared earlier in this call, is
+    // skipped (first write wins); the others are appended in call order and merged into place in one pass
+    { int rcm = refresh_min_den(ix); if (rcm) return rcm; }  // d_ids is about to be permuted: pending uploads first
+    std::unordered_set<int64_t> seen;
+    std::vector<int64_t> new_ids;
+    std::vector<uint8_t> new_rows;
+    for (uint64_t i = 0; i < n; ++i) {
+        const int64_t id = image_ids[i];
+        if (std::binary_search(ix->h_ids.begin(), ix->h_ids.end(), id) || !seen.insert(id).second) continue;
+        new_ids.push_back(id);
+        new_rows.insert(new_rows.end(), rows + i * d, rows + (i + 1) * d);
+    }
+    const uint64_t room = ix->capacity - ix->n_rows, take = std::min<uint64_t>(room, new_ids.size());
+    const uint64_t n_sorted = ix->n_rows;
+    if (take) {
+        int rc = append_tail(ix, new_ids.data(), new_rows.data(), take, hipMemcpyHostToDevice);  // unsorted for the moment
+        if (!rc) rc = merge_unsorted_tail(ix, n_sorted);
+        if (rc) return rc;
+    }
+    if (n_inserted) *n_inserted = take;
+    PB_CHECK(take == new_ids.size(), PB_ERR_CAPACITY, "index full: capacity %llu rows (%llu of this call stored)",
+             (unsigned long long)ix->capacity, (unsigned long long)take);
     return PB_OK;
 }
 

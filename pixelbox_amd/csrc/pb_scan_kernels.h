@@ -2074,6 +2074,23 @@ __global__ void k_fill_synth_images(uint64_t seed, uint64_t start, uint64_t per,
         out[i] = o;
     }
 }
+// out[i] = src[perm[i]] for i < n: the gather step of an out-of-order insert (rows of `elt` bytes, 16-byte pieces when
+// elt % 16 == 0, else 4-byte or single bytes); perm holds positions relative to `src`
+__global__ void k_gather_elts(const uint8_t *__restrict__ src, const uint32_t *__restrict__ perm, uint64_t n, uint32_t elt,
+                              uint8_t *__restrict__ dst) {
+    const uint32_t piece = (elt % 16 == 0) ? 16u : ((elt % 4 == 0) ? 4u : 1u);
+    const uint32_t per = elt / piece;
+    const uint64_t total = n * per;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = i / per;
+        const uint32_t c = (uint32_t)(i % per);
+        const uint8_t *s = src + (uint64_t)perm[r] * elt + (uint64_t)c * piece;
+        uint8_t *t = dst + r * elt + (uint64_t)c * piece;
+        if (piece == 16) *reinterpret_cast<uint4 *>(t) = *reinterpret_cast<const uint4 *>(s);
+        else if (piece == 4) *reinterpret_cast<uint32_t *>(t) = *reinterpret_cast<const uint32_t *>(s);
+        else *t = *s;
+    }
+}
 __global__ void k_iota_ids(int64_t first_id, uint64_t n, int64_t *__restrict__ out) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (uint64_t)gridDim.x * blockDim.x)

@@ -887,11 +887,15 @@ def test_option_values_are_range_checked():
     for opt, bad in ((capi.PB_OPT_SCAN_LAUNCH, -1), (capi.PB_OPT_SCAN_LAUNCH, 3), (4, 16), (4, -1), (4, 6), (7, -5), (7, 100000)):
         with pytest.raises(capi.PixelboxError):
             ix.set_option(opt, bad)
-    # a failing append reports what earlier runs of the call stored
+    # an append that runs out of capacity stores what fits, reports how many, and fails with PB_ERR_CAPACITY
     ix.append(np.arange(1, 11, dtype=np.int64), np.zeros((10, 256), np.uint8))
-    with pytest.raises(capi.PixelboxError):
-        ix.append(np.arange(11, 31, dtype=np.int64), np.zeros((20, 256), np.uint8))  # capacity 16
-    assert len(ix) == 10
+    import ctypes as C
+
+    ids20 = np.arange(11, 31, dtype=np.int64)
+    rows20 = np.zeros((20, 256), np.uint8)
+    stored = C.c_uint64(77)
+    rc = capi.lib().pb_index_append(ix._h, ids20.ctypes.data_as(C.POINTER(C.c_int64)), rows20.ctypes.data_as(C.POINTER(C.c_uint8)), 20, C.byref(stored))
+    assert rc == -4 and stored.value == 6 and len(ix) == 16  # capacity 16
     assert capi.lib().pb_index_read(ix._h, 2**63, 2**63 + 3, None, None) == -1  # first + n wraps: PB_ERR_INVALID
 
 
@@ -984,3 +988,32 @@ def test_device_merge_kernel_matches_the_host_merge():
             c = int(want[2][b])
             assert np.array_equal(got[0][b, :c], want[0][b, :c])
             assert np.array_equal(got[1][b, :c].view(np.uint32), want[1][b, :c].view(np.uint32))
+
+
+def test_bulk_insert_in_any_order_is_one_merge_pass_per_call():
+    # INSERT OR IGNORE with ids in descending / shuffled order, duplicates of stored ids and repeats inside the call: the new
+    # pairs are appended and merged into image_id order in ONE permutation pass per call (round 1 shifted the tail per row)
+    import time
+
+    rng = np.random.default_rng(31)
+    d, n = 256, 40_000
+    rows = _random_table(rng, n, d, "uniform")
+    ids = rng.permutation(np.arange(1, n + 1, dtype=np.int64) * 5)
+    ix = capi.Index(d, n + 10)
+    half = n // 2
+    assert ix.append(ids[:half][::-1], rows[:half][::-1]) == half  # any order
+    t0 = time.perf_counter()
+    # second call: the other half shuffled, plus 100 ids that are stored already, plus a repeat of its own first pair
+    mix_ids = np.concatenate([ids[half:], ids[:100], ids[half:half + 1]])
+    mix_rows = np.concatenate([rows[half:], 255 - rows[:100], 255 - rows[half:half + 1]])
+    assert ix.append(mix_ids, mix_rows) == n - half
+    assert time.perf_counter() - t0 < 5.0
+    got_ids, got_rows = ix.read(0, n)
+    order = np.argsort(ids)
+    assert np.array_equal(got_ids, ids[order]) and np.array_equal(got_rows, rows[order])  # first write won everywhere
+    q = rows[order][[0, n // 3, n - 1]]
+    check_against_oracle(ix, rows[order], ids[order], q)
+    # ascending tail appends still take the fast path, and a row in the middle goes where it belongs
+    assert ix.append([5 * n + 7, 3], np.stack([rows[0], rows[1]])) == 2
+    got_ids, _ = ix.read(0, n + 2)
+    assert got_ids[0] == 3 and got_ids[-1] == 5 * n + 7 and np.all(np.diff(got_ids) > 0)
