@@ -66,6 +66,7 @@ struct pb_embedder {
     float *d_out_f32 = nullptr;
     uint8_t *d_out_u8 = nullptr;
     int n_cu = 256;
+    hipEvent_t tune_e0 = nullptr, tune_e1 = nullptr;  // timing pair of the per-layer candidate measurements
     int opt_async = 0;    // PB_OPT_EMBED_ASYNC
     int trace_tune = 0;   // PB_TRACE_TUNE (1: chosen forms, 2: every candidate), PB_NO_STEM_FUSION: read once at create
     bool no_stem_fusion = false;
@@ -341,9 +342,7 @@ int launch_gemm(pb_embedder *e, const float *act, long M, const Gemm &g, const f
         if (it == e->gemm_cfg.end()) {
             int best_nr = 1, best_nw = 4;
             float best_ms = 1e30f;
-            hipEvent_t e0, e1;
-            PB_HIP(hipEventCreate(&e0));
-            PB_HIP(hipEventCreate(&e1));
+            const hipEvent_t e0 = e->tune_e0, e1 = e->tune_e1;  // the embedder's own pair: nothing to release on an early return
             for (int nr = 8; nr >= 1; --nr) {
                 if (tiles % nr) continue;
                 for (int nw : {8, 4, 108, 104}) {
@@ -369,8 +368,6 @@ int launch_gemm(pb_embedder *e, const float *act, long M, const Gemm &g, const f
             if (e->trace_tune)
                 fprintf(stderr, "gemm M%ld K%d N%d%s: bf16 pieces, best NR%d NW%d (+100: 128-deep chunks) %.1f us = %.1f TFLOP/s\n", M, g.K, g.N, gate ? " gated" : "",
                         best_nr, best_nw, best_ms * 500.f, 2.0 * (double)M * g.K * g.N / (best_ms * 0.5e-3) / 1e12);
-            (void)hipEventDestroy(e0);
-            (void)hipEventDestroy(e1);
             it = e->gemm_cfg.emplace(key, std::make_pair(200 + best_nw, best_nr)).first;
         }
         int rc = launch_gemm_b3(it->second.second, it->second.first - 200, e->stream, act, M, g, gate, hw, resid, do_silu, out);
@@ -381,9 +378,7 @@ int launch_gemm(pb_embedder *e, const float *act, long M, const Gemm &g, const f
     if (it == e->gemm_cfg.end()) {
         GemmCfg best{1, 1, 4};
         float best_ms = 1e30f;
-        hipEvent_t e0, e1;
-        PB_HIP(hipEventCreate(&e0));
-        PB_HIP(hipEventCreate(&e1));
+        const hipEvent_t e0 = e->tune_e0, e1 = e->tune_e1;  // the embedder's own pair: nothing to release on an early return
         for (int nr = 8; nr >= 1; --nr) {
             if (tiles % nr) continue;
             for (int mr : {4, 2, 1, 0, -1}) {  // 0: the eight-wave form of MR = 1; -1: the one-wave form (k_gemm_thin)
@@ -411,8 +406,6 @@ int launch_gemm(pb_embedder *e, const float *act, long M, const Gemm &g, const f
         if (e->trace_tune)
             fprintf(stderr, "gemm M%ld K%d N%d%s: best MR%d NR%d NW%d %.1f us = %.1f TFLOP/s\n", M, g.K, g.N, gate ? " gated" : "", best.mr,
                     best.nr, best.nw, best_ms * 500.f, 2.0 * (double)M * g.K * g.N / (best_ms * 0.5e-3) / 1e12);
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
         it = e->gemm_cfg.emplace(key, std::make_pair(best.nw == 1 ? 100 : best.mr * (best.nw == 8 ? -1 : 1), best.nr)).first;
     }
     const int enc = it->second.first;  // 100: one-wave form; negative: eight-wave form
@@ -536,9 +529,7 @@ int launch_dw(pb_embedder *e, const Block &bl, const float *in, int B, int H, in
         int best = 0;
         if (cands[1].roll || cands[2].roll) {
             float best_ms = 1e30f;
-            hipEvent_t e0, e1;
-            PB_HIP(hipEventCreate(&e0));
-            PB_HIP(hipEventCreate(&e1));
+            const hipEvent_t e0 = e->tune_e0, e1 = e->tune_e1;  // the embedder's own pair: nothing to release on an early return
             for (int c = 0; c < 3; ++c) {
                 if (c > 0 && !cands[c].roll) continue;  // form not applicable to this layer
                 int rc = launch_dw_geom(e, bl, in, B, H, W, out, Ho, Wo, cands[c]);
@@ -555,8 +546,6 @@ int launch_dw(pb_embedder *e, const Block &bl, const float *in, int B, int H, in
                     best = c;
                 }
             }
-            (void)hipEventDestroy(e0);
-            (void)hipEventDestroy(e1);
         }
         it = e->dw_cfg.emplace(key, cands[best]).first;
     }
@@ -689,9 +678,7 @@ int run_front(pb_embedder *e, const Block &bl, const float *x, int n, int H, int
         int tiles = 0;
         int rc = separate(&tiles);  // also warms the GEMM / depthwise selections
         if (rc) return rc;
-        hipEvent_t e0, e1;
-        PB_HIP(hipEventCreate(&e0));
-        PB_HIP(hipEventCreate(&e1));
+        const hipEvent_t e0 = e->tune_e0, e1 = e->tune_e1;  // the embedder's own pair: nothing to release on an early return
         auto time_it = [&](int nb, float *ms) -> int {
             PB_HIP(hipEventRecord(e0, e->stream));
             for (int rep = 0; rep < 2; ++rep) {
@@ -744,8 +731,6 @@ int run_front(pb_embedder *e, const Block &bl, const float *x, int n, int H, int
                         best = cfg;
                     }
                 }
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
         it = e->front_cfg.emplace(key, best).first;
     }
     if (it->second >= 0x1000) {
@@ -846,6 +831,8 @@ void destroy(pb_embedder *e) {
     for (void *p : e->allocs) (void)hipFree(p);
     (void)hipFree(e->d_src);
     (void)hipFree(e->d_tmp);
+    if (e->tune_e0) (void)hipEventDestroy(e->tune_e0);
+    if (e->tune_e1) (void)hipEventDestroy(e->tune_e1);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
 }
 
@@ -923,6 +910,8 @@ int pb_embed_create(pb_embedder **out, int device, const void *weights_blob, siz
         e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         PB_HIP(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
         e->stream = e->own_stream;
+        PB_HIP(hipEventCreate(&e->tune_e0));
+        PB_HIP(hipEventCreate(&e->tune_e1));
         int rc = load_weights(e, static_cast<const uint8_t *>(weights_blob), blob_len);
         if (rc) return rc;
         // workspace sized for max_batch images (NHWC f32)
