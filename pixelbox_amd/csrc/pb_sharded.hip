@@ -508,12 +508,11 @@ int pb_sharded_search(pb_sharded *s, const uint8_t *queries, uint32_t nq, uint32
         rc = exchange(s, (size_t)cq * row);
         if (rc) return rc;
         pb::DeviceGuard guard(s->devices[0]);
+        // the merge kernel writes the k results per query straight into pinned host memory (device-visible): no copy
+        // commands behind it, one wait
         hipLaunchKernelGGL(pbm::k_merge_packed, dim3(cq), dim3(pbm::MERGE_BLOCK), 0, s->streams[0], s->d_gathered[0], (uint32_t)s->n, cq, k,
-                           s->d_out_ids, s->d_out_dist, s->d_out_count);
+                           s->h_out_ids, s->h_out_dist, s->h_out_count);
         PB_HIP(hipGetLastError());
-        PB_HIP(hipMemcpyAsync(s->h_out_ids, s->d_out_ids, (size_t)cq * k * sizeof(int64_t), hipMemcpyDeviceToHost, s->streams[0]));
-        PB_HIP(hipMemcpyAsync(s->h_out_dist, s->d_out_dist, (size_t)cq * k * sizeof(float), hipMemcpyDeviceToHost, s->streams[0]));
-        PB_HIP(hipMemcpyAsync(s->h_out_count, s->d_out_count, (size_t)cq * sizeof(uint32_t), hipMemcpyDeviceToHost, s->streams[0]));
         PB_HIP(hipStreamSynchronize(s->streams[0]));
         memcpy(out_ids + (size_t)q0 * k, s->h_out_ids, (size_t)cq * k * sizeof(int64_t));
         memcpy(out_dist + (size_t)q0 * k, s->h_out_dist, (size_t)cq * k * sizeof(float));
@@ -532,25 +531,45 @@ int pb_topk_merge_packed_device(int device, const int64_t *d_gathered, uint32_t 
     if (nq == 0) return PB_OK;
     pb::DeviceGuard guard(device);
     PB_CHECK(guard.ok, PB_ERR_HIP, "hipSetDevice(%d) failed", device);
-    int64_t *d_ids = nullptr;
-    float *d_dist = nullptr;
-    uint32_t *d_cnt = nullptr;
-    auto body = [&]() -> int {
-        PB_HIP(hipMalloc(&d_ids, (size_t)nq * k * sizeof(int64_t)));
-        PB_HIP(hipMalloc(&d_dist, (size_t)nq * k * sizeof(float)));
-        PB_HIP(hipMalloc(&d_cnt, (size_t)nq * sizeof(uint32_t)));
-        hipLaunchKernelGGL(pbm::k_merge_packed, dim3(nq), dim3(pbm::MERGE_BLOCK), 0, nullptr, d_gathered, n_lists, nq, k, d_ids, d_dist, d_cnt);
-        PB_HIP(hipGetLastError());
-        PB_HIP(hipMemcpy(out_ids, d_ids, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost));
-        PB_HIP(hipMemcpy(out_dist, d_dist, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost));
-        PB_HIP(hipMemcpy(out_count, d_cnt, (size_t)nq * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        return PB_OK;
+    // scratch per device, grown on demand and kept for the life of the process: this entry point sits in a per-batch
+    // loop (bench.py under torchrun), where a hipMalloc / hipFree triple per call would cost more than the merge
+    struct Scratch {
+        int64_t *d_ids = nullptr, *h_ids = nullptr;
+        float *d_dist = nullptr, *h_dist = nullptr;
+        uint32_t *d_cnt = nullptr, *h_cnt = nullptr;
+        size_t cap = 0;  // in (query, k) slots
+        size_t cap_q = 0;
     };
-    const int rc = body();
-    (void)hipFree(d_ids);
-    (void)hipFree(d_dist);
-    (void)hipFree(d_cnt);
-    return rc;
+    static std::mutex mu;
+    static Scratch scratch[64];
+    PB_CHECK(device >= 0 && device < 64, PB_ERR_INVALID, "pb_topk_merge_packed_device: device %d", device);
+    std::lock_guard<std::mutex> lock(mu);
+    Scratch &S = scratch[device];
+    const size_t slots = (size_t)nq * k;
+    if (slots > S.cap || nq > S.cap_q) {
+        (void)hipFree(S.d_ids); (void)hipFree(S.d_dist); (void)hipFree(S.d_cnt);
+        if (S.h_ids) (void)hipHostFree(S.h_ids);
+        if (S.h_dist) (void)hipHostFree(S.h_dist);
+        if (S.h_cnt) (void)hipHostFree(S.h_cnt);
+        S = Scratch{};
+        const size_t want = std::max<size_t>(slots, (size_t)64 * PB_MAX_K), want_q = std::max<size_t>(nq, 64);
+        PB_HIP(hipMalloc(&S.d_ids, want * sizeof(int64_t)));
+        PB_HIP(hipMalloc(&S.d_dist, want * sizeof(float)));
+        PB_HIP(hipMalloc(&S.d_cnt, want_q * sizeof(uint32_t)));
+        PB_HIP(hipHostMalloc(&S.h_ids, want * sizeof(int64_t), hipHostMallocDefault));
+        PB_HIP(hipHostMalloc(&S.h_dist, want * sizeof(float), hipHostMallocDefault));
+        PB_HIP(hipHostMalloc(&S.h_cnt, want_q * sizeof(uint32_t), hipHostMallocDefault));
+        S.cap = want;
+        S.cap_q = want_q;
+    }
+    // the kernel writes straight into pinned host memory: no copy commands, one wait
+    hipLaunchKernelGGL(pbm::k_merge_packed, dim3(nq), dim3(pbm::MERGE_BLOCK), 0, nullptr, d_gathered, n_lists, nq, k, S.h_ids, S.h_dist, S.h_cnt);
+    PB_HIP(hipGetLastError());
+    PB_HIP(hipStreamSynchronize(nullptr));
+    memcpy(out_ids, S.h_ids, slots * sizeof(int64_t));
+    memcpy(out_dist, S.h_dist, slots * sizeof(float));
+    memcpy(out_count, S.h_cnt, (size_t)nq * sizeof(uint32_t));
+    return PB_OK;
 }
 
 }  // extern "C"
