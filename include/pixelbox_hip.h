@@ -164,6 +164,9 @@ int pb_index_fill_synthetic(pb_index *idx, uint64_t seed, uint64_t first_row, ui
                                  instead of waiting for them (a producer on the same stream -- PB_OPT_STREAM, PB_OPT_EMBED_STREAM -- \
                                  can then run ahead of the GPU); searches wait as before */
 #define PB_OPT_EXACT_QN 13 /* exhaustive pass over 256-byte cosine rows: queries answered per table sweep (0 = auto, 1, 2) */
+#define PB_OPT_SECOND_CHANCE 14 /* uncertified queries that have k results: 0 = a second filter pass at the error margin of
+                                   their k-th cosine when a cost model (table size, queries, its success rate so far on
+                                   this index) puts it below the exhaustive pass, 1 = always, 2 = never */
 #define PB_OPT_MQ_PER_CHUNK 11  /* 1: bursts of > 64 queries run one 64-query pass at a time instead of sharing row tiles
                                   among 512 queries per workgroup (default 0; for measurement) */
 int pb_index_set_option(pb_index *idx, int option, int64_t value);

@@ -24,6 +24,7 @@ PB_OPT_MQ_WG_PER_CU = 10
 PB_OPT_MQ_PER_CHUNK = 11
 PB_OPT_APPEND_ASYNC = 12
 PB_OPT_EXACT_QN = 13
+PB_OPT_SECOND_CHANCE = 14
 PB_OPT_EMBED_STREAM = 3  # pb_embed_set_option: stream handle to launch on (0 = the embedder's own)
 PB_OPT_EMBED_ASYNC = 4   # pb_embed_set_option: 1 = pb_embed_batch_device returns with the forward pass queued (default 0: waits)
 PB_OPT_SCAN_LAUNCH = 8  # 0: one launch per query; 1: queries side by side in one grid; 2 (default): one launch, queries one after the other

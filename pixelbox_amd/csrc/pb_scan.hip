@@ -71,6 +71,7 @@ struct pb_index {
     uint64_t *d_xlists[2] = {nullptr, nullptr};  // exact pass ping-pong: Q_CHUNK * X_MAX_WG * PB_MAX_K
     uint32_t *d_xcounts[2] = {nullptr, nullptr};
     uint32_t *d_qsel = nullptr;     // Q_CHUNK
+    uint32_t *d_tail = nullptr;     // DYN_REGIONS ticket counters of the one-query filter launch (zero between launches)
     float *d_qf = nullptr;          // Q_CHUNK * 256: de-quantised queries of the coalesced exhaustive pass
     float *d_tau = nullptr;         // multi-query pass: per-query candidate threshold (PIPE_Q)
     uint64_t *d_cand = nullptr;     // PIPE_Q * MQ_CAP
@@ -102,7 +103,11 @@ struct pb_index {
     float *h_res_dist = nullptr;
     ResultHdr *h_res_hdr = nullptr;
 
+    bool env_static_tail = false;      // PB_STATIC_TAIL: the one-query filter launch without the ticketed tail (comparison)
     bool env_exact_lane_rows = false;  // PB_EXACT_LANE_ROWS: the lane-per-row exhaustive kernel also for 256-byte cosine rows (comparison)
+    int opt_second_chance = 0;         // PB_OPT_SECOND_CHANCE: 0 = cost model, 1 = always, 2 = never
+    float sc_success = 1.0f;           // running success rate of the second chance on this index (optimistic start)
+    uint32_t sc_skipped = 0;           // eligible chunks sent straight to the exhaustive pass since the last attempt
     int opt_exact_qn = 0;              // PB_OPT_EXACT_QN: queries per sweep of the coalesced exhaustive pass (0 = auto: 2 when there are two)
     bool env_no_second_chance = false, env_trace_cert = false;  // PB_NO_SECOND_CHANCE / PB_TRACE_CERT, read once at create
     int opt_path = 0;
@@ -136,6 +141,8 @@ int alloc_workspace(pb_index *ix) {
         PB_HIP(hipMalloc(&ix->d_xcounts[i], (size_t)Q_CHUNK * lists * sizeof(uint32_t)));
     }
     PB_HIP(hipMalloc(&ix->d_qsel, Q_CHUNK * sizeof(uint32_t)));
+    PB_HIP(hipMalloc(&ix->d_tail, (size_t)DYN_REGIONS * DYN_CTR_STRIDE * sizeof(uint32_t)));
+    PB_HIP(hipMemset(ix->d_tail, 0, (size_t)DYN_REGIONS * DYN_CTR_STRIDE * sizeof(uint32_t)));
     PB_HIP(hipMalloc(&ix->d_qf, ((size_t)Q_CHUNK * 256 + 16) * sizeof(float)));  // + one piece of slack: k_scan_exact_co fetches one piece ahead
     PB_HIP(hipMalloc(&ix->d_tau, PIPE_Q * sizeof(float)));
     PB_HIP(hipMalloc(&ix->d_cand, (size_t)PIPE_Q * MQ_CAP * sizeof(uint64_t)));
@@ -173,6 +180,7 @@ void free_all(pb_index *ix) {
     }
     (void)hipFree(ix->d_qsel);
     (void)hipFree(ix->d_qf);
+    (void)hipFree(ix->d_tail);
     (void)hipFree(ix->d_tau);
     (void)hipFree(ix->d_cand);
     (void)hipFree(ix->d_cand_cnt);
@@ -401,13 +409,21 @@ bool loop_mode(const pb_index *ix, uint32_t nq) {
 // fast path for nq staged queries; results + status land in d_res_*
 int run_fast(pb_index *ix, uint32_t nq) {
     const int n_wg = filter_grid(ix);
+    bool dyn = false;
     if (ix->opt_profile) PB_HIP(hipEventRecord(ix->ev0, ix->stream));
     if (ix->argq_pending) {
         // one 256-byte query, default launch shape: the query rides in the kernel arguments (k_scan_filter ARGQ)
         ix->argq_pending = false;
-        hipLaunchKernelGGL((k_scan_filter<16, 8, true, F_WAVES, 0, false, true>), dim3(n_wg, 1), dim3(F_WAVES * 64), 0, ix->stream,
-                           ix->d_rows, ix->n_rows, ix->d_queries, ix->d_qp, ix->d_lists, ix->d_hdrs, 0, 1, ix->d_queries, ix->d_qp,
-                           ix->argq);
+        if (ix->env_static_tail) {
+            hipLaunchKernelGGL((k_scan_filter<16, 8, true, F_WAVES, 0, false, true>), dim3(n_wg, 1), dim3(F_WAVES * 64), 0,
+                               ix->stream, ix->d_rows, ix->n_rows, ix->d_queries, ix->d_qp, ix->d_lists, ix->d_hdrs, 0, 1,
+                               ix->d_queries, ix->d_qp, ix->argq, nullptr);
+        } else {
+            hipLaunchKernelGGL((k_scan_filter<16, 8, true, F_WAVES, 0, false, true, true>), dim3(n_wg, 1), dim3(F_WAVES * 64),
+                               0, ix->stream, ix->d_rows, ix->n_rows, ix->d_queries, ix->d_qp, ix->d_lists, ix->d_hdrs, 0, 1,
+                               ix->d_queries, ix->d_qp, ix->argq, ix->d_tail);
+            dyn = true;
+        }
         PB_HIP(hipGetLastError());
     } else if (loop_mode(ix, nq)) {
         const int v = ix->opt_variant & 15;
@@ -429,7 +445,7 @@ int run_fast(pb_index *ix, uint32_t nq) {
     if (ix->opt_profile) PB_HIP(hipEventRecord(ix->ev1, ix->stream));
     hipLaunchKernelGGL(k_select_rescore, dim3(nq), dim3(SEL_BLOCK), 0, ix->stream, ix->d_rows, ix->d_ids, ix->d_norms,
                        (int)ix->dim, ix->d_queries, ix->d_qp, ix->d_lut, ix->d_lists, ix->d_hdrs, n_wg, ix->r_ids,
-                       ix->r_dist, ix->r_hdr, (uint32_t)PB_MAX_K);
+                       ix->r_dist, ix->r_hdr, (uint32_t)PB_MAX_K, dyn ? ix->d_tail : nullptr);
     PB_HIP(hipGetLastError());
     return PB_OK;
 }
@@ -690,6 +706,30 @@ int run_second_chance(pb_index *ix, uint32_t n_sel) {
     return PB_OK;
 }
 
+// Second chance or straight to the exhaustive pass?  The second chance costs one i8-MFMA sweep of the table for the
+// chunk (k_scan_multi, ~0.27 us per 1000 rows per 16 queries, plus its 1/32 sample) and the exact re-scoring of lists
+// of up to 64 Ki rows per query, and whatever it cannot answer takes the exhaustive pass anyway; the exhaustive pass
+// (k_scan_exact_co, two queries per sweep) costs ~0.034 us per 1000 rows per query.  So the second chance pays only on
+// large tables, for well-filled chunks, and while it keeps succeeding: its success rate on this index is tracked
+// (clustered collections whose near-tie sets overflow the lists fail it query after query) and it is re-tried every
+// 32nd time so that a changed collection is noticed.  Measured on the 1M-image end-to-end table: 183 of 574
+// uncertified queries rescued at 119 us each against 46 us for the exhaustive pass.
+bool second_chance_pays(pb_index *ix, uint32_t n_sc) {
+    if (ix->opt_second_chance == 1) return true;
+    if (ix->opt_second_chance == 2) return false;
+    const double rows = (double)ix->n_rows;
+    const double qt = (double)std::min<uint32_t>(4, (n_sc + 15) / 16);
+    const double sc_ms = rows * 2.7e-7 * qt * (1.0 + 1.0 / 32) + 0.03 * n_sc;
+    const double ex_ms = n_sc * (rows * 3.4e-8 + 0.012);
+    const bool pays = sc_ms + (1.0 - (double)ix->sc_success) * ex_ms < 0.9 * ex_ms;
+    if (pays) return true;
+    if (sc_ms < 0.9 * ex_ms && ++ix->sc_skipped >= 32) {  // worth it at a higher success rate: look again now and then
+        ix->sc_skipped = 0;
+        return true;
+    }
+    return false;
+}
+
 bool multi_eligible(const pb_index *ix, uint32_t nq) {
     return ix->metric == 0 && fast_dim(ix->dim) && ix->dim == 256 && ix->n_rows >= 65536 &&
            (ix->opt_path == 3 || (ix->opt_path == 0 && nq >= (uint32_t)ix->opt_mq_min_queries));
@@ -788,12 +828,19 @@ int search_chunk(pb_index *ix, uint32_t cq, uint32_t k, double max_dist, const f
                 rest[n_rest++] = q;
             }
         }
+        if (n_sc && !second_chance_pays(ix, n_sc)) {
+            for (uint32_t i = 0; i < n_sc; ++i) rest[n_rest++] = sc_sel[i];
+            n_sc = 0;
+            std::sort(rest, rest + n_rest);
+            for (uint32_t i = 0; i < n_rest; ++i) hsel[i] = rest[i];
+        }
         if (n_sc) {
             PB_HIP(hipMemcpyAsync(ix->d_qsel2, sc_sel, n_sc * sizeof(uint32_t), hipMemcpyHostToDevice, ix->stream));
             PB_HIP(hipMemcpyAsync(ix->d_tau2, sc_tau, n_sc * sizeof(float), hipMemcpyHostToDevice, ix->stream));
             int rc = run_second_chance(ix, n_sc);
             if (rc) return rc;
             { int rcw = wait_headers(); if (rcw) return rcw; }
+            const uint32_t n_rest_before = n_rest;
             for (uint32_t i = 0; i < n_sc; ++i) {
                 if (ix->h_res_hdr[sc_sel[i]].status != 0) {
                     rest[n_rest++] = sc_sel[i];
@@ -804,6 +851,7 @@ int search_chunk(pb_index *ix, uint32_t cq, uint32_t k, double max_dist, const f
                     ++ix->stats.second_chance;
                 }
             }
+            ix->sc_success = 0.5f * ix->sc_success + 0.5f * (float)(n_sc - (n_rest - n_rest_before)) / (float)n_sc;
             std::sort(rest, rest + n_rest);
             n_sel = n_rest;
             for (uint32_t i = 0; i < n_rest; ++i) hsel[i] = rest[i];
@@ -1130,6 +1178,7 @@ int pb_index_create(pb_index **out, int device, uint32_t dim, uint64_t capacity_
     ix->env_no_second_chance = getenv("PB_NO_SECOND_CHANCE") != nullptr;  // diagnostics switches
     ix->env_trace_cert = getenv("PB_TRACE_CERT") != nullptr;
     ix->env_exact_lane_rows = getenv("PB_EXACT_LANE_ROWS") != nullptr;
+    ix->env_static_tail = getenv("PB_STATIC_TAIL") != nullptr;
     make_lut(ix->lut);
     auto body = [&]() -> int {
         hipDeviceProp_t prop;
@@ -1413,6 +1462,12 @@ int pb_index_set_option(pb_index *ix, int option, int64_t value) {
             return PB_OK;
         case PB_OPT_APPEND_ASYNC:
             ix->opt_append_async = value != 0;
+            return PB_OK;
+        case PB_OPT_SECOND_CHANCE:
+            PB_CHECK(value >= 0 && value <= 2, PB_ERR_INVALID, "PB_OPT_SECOND_CHANCE: 0 (cost model), 1 (always) or 2 (never)");
+            ix->opt_second_chance = (int)value;
+            ix->sc_success = 1.0f;
+            ix->sc_skipped = 0;
             return PB_OK;
         case PB_OPT_EXACT_QN:
             PB_CHECK(value >= 0 && value <= 2, PB_ERR_INVALID, "PB_OPT_EXACT_QN: 0 (auto), 1 or 2");

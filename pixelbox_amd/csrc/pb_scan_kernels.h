@@ -321,13 +321,25 @@ struct QArg256 {
     QParams p;
     uint8_t q[256];
 };
-template <int LPR, int U = 8, bool NT = true, int NW = F_WAVES, int MAPB = 0, bool LOOPQ = false, bool ARGQ = false>
+#ifndef PB_DYN_DEN
+#define PB_DYN_DEN 8
+#endif
+#ifndef PB_DYN_CH
+#define PB_DYN_CH 4
+#endif
+constexpr int DYN_DEN = PB_DYN_DEN;  // k_scan_filter DYN: 1/DYN_DEN of the table is handed out dynamically
+constexpr int DYN_CH = PB_DYN_CH;    // super-tiles per ticket
+constexpr int DYN_REGIONS = 32;     // ticket counters
+constexpr int DYN_CTR_STRIDE = 64;  // uint32 between counters (256 B: different L2 channels)
+template <int LPR, int U = 8, bool NT = true, int NW = F_WAVES, int MAPB = 0, bool LOOPQ = false, bool ARGQ = false, bool DYN = false>
 __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__restrict__ rows, uint64_t n_rows,
                                                          const uint8_t *queries, const QParams *qp,
                                                          uint64_t *__restrict__ lists,
                                                          ListHdr *__restrict__ hdrs, int q_base, int nq_loop,
-                                                         uint8_t *stage_q, QParams *stage_p, const QArg256 qarg) {
+                                                         uint8_t *stage_q, QParams *stage_p, const QArg256 qarg,
+                                                         uint32_t *tail_ctr = nullptr) {
     static_assert(!ARGQ || (LPR == 16 && !LOOPQ), "ARGQ: one 256-byte query per launch");
+    static_assert(!DYN || (ARGQ && MAPB == 0), "DYN: the one-query launch only");
     constexpr int D = LPR * 16;
     constexpr int RPT = WAVE / LPR;                // rows per wave-instruction
     // U = loads in flight per lane (U KiB per wave); NT = non-temporal loads (the table is streamed once per query)
@@ -371,7 +383,51 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
     // super-tile -> wave mapping: MAPB = 0: workgroup fastest (adjacent 8-KiB pieces on different CUs),
     // 1: wave fastest (a workgroup reads NW adjacent pieces)
     const uint64_t first = MAPB ? (uint64_t)blockIdx.x * NW + wave : (uint64_t)wave * gridDim.x + blockIdx.x;
-    for (uint64_t s = first; s < n_super; s += stride) {
+    // DYN (one-query call): the last 1/DYN_DEN of the table is handed out in DYN_CH-tile chunks through DYN_REGIONS
+    // ticket counters (one per group of 8 consecutive workgroups = one per XCD each), so that a wave which finished its
+    // static share early takes more of the tail instead of idling; the ticket for the next chunk is requested before
+    // the current chunk's loads, so its latency hides behind them.  k_select_rescore zeroes the counters afterwards.
+    uint64_t s = first;
+    uint64_t n_static = n_super, dyn_lo = 0, dyn_hi = 0, dyn_cur = 0;
+    uint32_t dyn_left = 0, dyn_pend = 0;
+    bool dyn_on = false, dyn_done = false;
+    uint32_t *dyn_ctr = nullptr;
+    if constexpr (DYN) {
+        n_static = (n_super - n_super / DYN_DEN) / stride * stride;
+        const uint32_t groups = (gridDim.x + 7) >> 3;
+        const uint32_t n_reg = groups < (uint32_t)DYN_REGIONS ? groups : (uint32_t)DYN_REGIONS;  // every region has takers
+        const uint64_t per_reg = ((n_super - n_static + n_reg - 1) / n_reg + DYN_CH - 1) / DYN_CH * DYN_CH;
+        const uint32_t reg = (blockIdx.x >> 3) % n_reg;
+        dyn_lo = n_static + (uint64_t)reg * per_reg;
+        dyn_hi = dyn_lo + per_reg < n_super ? dyn_lo + per_reg : n_super;
+        dyn_ctr = tail_ctr + reg * DYN_CTR_STRIDE;
+        if (lane == 0) dyn_pend = atomicAdd(dyn_ctr, 1u);
+    }
+    auto next_dyn = [&]() -> uint64_t {
+        if (dyn_left) {
+            --dyn_left;
+            return ++dyn_cur;
+        }
+        if (dyn_done) return ~0ull;
+        const uint32_t t = __builtin_amdgcn_readfirstlane(dyn_pend);
+        const uint64_t s0 = dyn_lo + (uint64_t)t * DYN_CH;
+        if (s0 >= dyn_hi) {
+            dyn_done = true;
+            return ~0ull;
+        }
+        if (lane == 0) dyn_pend = atomicAdd(dyn_ctr, 1u);
+        dyn_cur = s0;
+        const uint64_t rest = dyn_hi - s0 - 1;
+        dyn_left = rest < (uint64_t)(DYN_CH - 1) ? (uint32_t)rest : (uint32_t)(DYN_CH - 1);
+        return s0;
+    };
+    if constexpr (DYN) {
+        if (s >= n_static) {
+            dyn_on = true;
+            s = next_dyn();
+        }
+    }
+    for (; DYN ? (s != ~0ull) : (s < n_super);) {
         const uint64_t row0 = s * ROWS_IT;
         uint4 b[U];
 #pragma unroll
@@ -421,6 +477,19 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
                     dropped = thr;
                 }
             }
+        }
+        if constexpr (DYN) {
+            if (!dyn_on) {
+                s += stride;
+                if (s >= n_static) {
+                    dyn_on = true;
+                    s = next_dyn();
+                }
+            } else {
+                s = next_dyn();
+            }
+        } else {
+            s += stride;
         }
     }
     if (cnt > F_KW) {
@@ -636,7 +705,9 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
     int d, const uint8_t *__restrict__ queries, const QParams *__restrict__ qp,
     const float *__restrict__ lut, const uint64_t *__restrict__ lists, const ListHdr *__restrict__ hdrs,
     int n_lists, int64_t *__restrict__ out_ids, float *__restrict__ out_dist, ResultHdr *__restrict__ out_hdr,
-    uint32_t out_stride) {
+    uint32_t out_stride, uint32_t *tail_ctr = nullptr) {
+    // the filter launch before this one handed out its tail through these counters (k_scan_filter DYN): clear them
+    if (tail_ctr && blockIdx.x == 0 && threadIdx.x < DYN_REGIONS) tail_ctr[threadIdx.x * DYN_CTR_STRIDE] = 0u;
     __shared__ float s_lut[256];
     __shared__ float s_qf[1024];
     __shared__ uint32_t s_hist[SEL_BINS];

@@ -103,6 +103,27 @@ def test_uniform_sizes(n, path):
     check_against_oracle(ix, rows, ids, queries)
 
 
+@pytest.mark.parametrize("n", [31, 32 * 2048 + 5, 300007, 2100001])
+def test_one_query_calls_hand_out_the_table_tail_by_tickets(n, monkeypatch):
+    # a one-query call's filter launch gives the last eighth of the table out in ticketed chunks (k_scan_filter DYN):
+    # neighbours planted at both ends of the static share, across the ticket regions and in the last rows must all be
+    # found, twice in a row (the counters are cleared between launches), and PB_STATIC_TAIL=1 gives the same answer
+    rng = np.random.default_rng(4242 + n)
+    rows = rng.integers(0, 256, size=(n, 256), dtype=np.uint8)
+    ids = np.arange(n, dtype=np.int64) * 3 + 1
+    q = rng.integers(0, 256, size=256, dtype=np.uint8)
+    spots = np.unique(np.concatenate([np.arange(min(n, 8)), n - 1 - np.arange(min(n, 40)),
+                                      (n * 7 // 8 + np.arange(-20, 20) * 32) % n, rng.integers(0, n, size=60)]))
+    for j, r in enumerate(spots):
+        rows[r] = q
+        rows[r, j % 256] ^= np.uint8(1 + j % 7)
+    ix = make_index(rows, ids)
+    for _ in range(3):
+        check_against_oracle(ix, rows, ids, q[None, :])
+    monkeypatch.setenv("PB_STATIC_TAIL", "1")
+    check_against_oracle(make_index(rows, ids), rows, ids, q[None, :])
+
+
 @pytest.mark.parametrize("k", [1, 7, 100, 256])
 def test_k_values(k):
     rng = np.random.default_rng(5)
@@ -451,13 +472,19 @@ def test_second_chance_answers_tight_clusters_exactly(path):
     ids = np.arange(n, dtype=np.int64) * 2 + 1
     q = np.concatenate([centre[None, :], rows[where[:5]], rng.integers(0, 256, size=(6, 256), dtype=np.uint8)])
     ix = make_index(rows, ids, path=path)
+    ix.set_option(capi.PB_OPT_SECOND_CHANCE, 1)  # always (on a table this small the cost model prefers the exhaustive pass)
     check_against_oracle(ix, rows, ids, q)
     st = ix.stats()
     assert st.second_chance >= 3 and st.queries == st.fast_path + st.second_chance + st.fallback
+    # left to the cost model (default) the same queries take the exhaustive pass here: 120k rows cost it ~10 us a query
+    ix3 = make_index(rows, ids, path=path)
+    check_against_oracle(ix3, rows, ids, q[:3])
+    assert ix3.stats().second_chance == 0 and ix3.stats().fallback >= 2
     # and with the second chance disabled the same queries take the exhaustive pass (same answers)
     os.environ["PB_NO_SECOND_CHANCE"] = "1"
     try:
         ix2 = make_index(rows, ids, path=path)
+        ix2.set_option(capi.PB_OPT_SECOND_CHANCE, 1)  # the environment switch wins
         check_against_oracle(ix2, rows, ids, q[:3])
         assert ix2.stats().second_chance == 0 and ix2.stats().fallback >= 2
     finally:
@@ -475,6 +502,7 @@ def test_second_chance_in_a_burst_and_list_overflow():
     q = rng.integers(0, 256, size=(90, 256), dtype=np.uint8)
     q[3], q[40], q[41], q[77] = centre, rows[where[0]], rows[where[1]], v
     ix = make_index(rows, ids, path=MULTI)
+    ix.set_option(capi.PB_OPT_SECOND_CHANCE, 1)
     check_against_oracle(ix, rows, ids, q[[3, 40, 41, 77, 0, 89]])
     ix.stats(reset=True)
     got = ix.search(q, 100, 1e3)
@@ -884,7 +912,8 @@ def test_coalesced_exhaustive_pass_vs_oracle(qn, k):
 
 def test_option_values_are_range_checked():
     ix = capi.Index(256, 16)
-    for opt, bad in ((capi.PB_OPT_SCAN_LAUNCH, -1), (capi.PB_OPT_SCAN_LAUNCH, 3), (4, 16), (4, -1), (4, 6), (7, -5), (7, 100000)):
+    for opt, bad in ((capi.PB_OPT_SCAN_LAUNCH, -1), (capi.PB_OPT_SCAN_LAUNCH, 3), (4, 16), (4, -1), (4, 6), (7, -5), (7, 100000),
+                     (capi.PB_OPT_SECOND_CHANCE, 3), (capi.PB_OPT_SECOND_CHANCE, -1)):
         with pytest.raises(capi.PixelboxError):
             ix.set_option(opt, bad)
     # an append that runs out of capacity stores what fits, reports how many, and fails with PB_ERR_CAPACITY
