@@ -163,7 +163,7 @@ int pb_index_fill_synthetic(pb_index *idx, uint64_t seed, uint64_t first_row, ui
 #define PB_OPT_APPEND_ASYNC 12 /* 1: pb_index_append_device returns with its copies and the per-row norms queued on the index's stream \
                                  instead of waiting for them (a producer on the same stream -- PB_OPT_STREAM, PB_OPT_EMBED_STREAM -- \
                                  can then run ahead of the GPU); searches wait as before */
-#define PB_OPT_EXACT_QN 13 /* exhaustive pass over 256-byte cosine rows: queries answered per table sweep (0 = auto, 1, 2) */
+#define PB_OPT_EXACT_QN 13 /* exhaustive pass over 256-byte cosine rows: queries answered per table sweep (0 = auto, 1, 2, 4) */
 #define PB_OPT_SECOND_CHANCE 14 /* uncertified queries that have k results: 0 = a second filter pass at the error margin of
                                    their k-th cosine when a cost model (table size, queries, its success rate so far on
                                    this index) puts it below the exhaustive pass, 1 = always, 2 = never */

@@ -108,7 +108,7 @@ struct pb_index {
     int opt_second_chance = 0;         // PB_OPT_SECOND_CHANCE: 0 = cost model, 1 = always, 2 = never
     float sc_success = 1.0f;           // running success rate of the second chance on this index (optimistic start)
     uint32_t sc_skipped = 0;           // eligible chunks sent straight to the exhaustive pass since the last attempt
-    int opt_exact_qn = 0;              // PB_OPT_EXACT_QN: queries per sweep of the coalesced exhaustive pass (0 = auto: 2 when there are two)
+    int opt_exact_qn = 0;              // PB_OPT_EXACT_QN: queries per sweep of the coalesced exhaustive pass (0 = auto: 4 from three queries on, 2 for two)
     bool env_no_second_chance = false, env_trace_cert = false;  // PB_NO_SECOND_CHANCE / PB_TRACE_CERT, read once at create
     int opt_path = 0;
     int opt_profile = 0;
@@ -503,6 +503,17 @@ int launch_exact_co(pb_index *ix, int n_lists, uint32_t n_sel, uint32_t k) {
     return PB_OK;
 }
 
+template <int MAXE>
+int launch_exact_co4(pb_index *ix, int n_lists, uint32_t n_sel, uint32_t k) {
+    const size_t cap = (size_t)k + WAVE;
+    const size_t lds = (size_t)XC_WAVES * XC4_IMAGE + (size_t)XC_WAVES * 4 * cap * sizeof(uint64_t) + (size_t)XC_WAVES * 4 * sizeof(int);
+    auto kern = k_scan_exact_co4<MAXE>;
+    PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(n_lists, (n_sel + 3) / 4), dim3(XC_WAVES * WAVE), lds, ix->stream, ix->d_rows, ix->d_norms, ix->n_rows,
+                       ix->d_qf, ix->d_qp, ix->d_qsel, (int)n_sel, ix->d_xlists[0], ix->d_xcounts[0], (uint32_t)PB_MAX_K);
+    return PB_OK;
+}
+
 int run_exact(pb_index *ix, uint32_t n_sel, uint32_t k) {
     // cosine over 256-byte rows: the coalesced form, two queries per table sweep when there are two (k_scan_exact_co)
     const bool coalesced = ix->metric == 0 && ix->dim == 256 && !ix->env_exact_lane_rows;
@@ -513,7 +524,8 @@ int run_exact(pb_index *ix, uint32_t n_sel, uint32_t k) {
         // every workgroup ends with a sort of its wave lists per query (~20 us): give a wave at least 32 tiles to stream
         // when the queries of the call fill the chip anyway (a 1M-row table ran 2x slower per row than a 10M-row one
         // with 512 workgroups per query pair)
-        const uint64_t groups = (n_sel + 1) / 2;
+        const int qn_sizing = ix->opt_exact_qn ? ix->opt_exact_qn : (n_sel >= 3 ? 4 : n_sel == 2 ? 2 : 1);
+        const uint64_t groups = (n_sel + qn_sizing - 1) / qn_sizing;
         const uint64_t fat = std::max<uint64_t>(1, n_tiles / (32ull * XC_WAVES));
         const uint64_t fill = (2ull * ix->n_cu + groups - 1) / groups;  // workgroups per group that still fill 2 per CU
         n_lists = (int)std::min<uint64_t>((uint64_t)n_lists, std::max<uint64_t>(fat, fill));
@@ -522,9 +534,10 @@ int run_exact(pb_index *ix, uint32_t n_sel, uint32_t k) {
     if (coalesced) {
         hipLaunchKernelGGL(k_make_qf, dim3(n_sel), dim3(256), 0, ix->stream, ix->d_queries, ix->d_qsel, ix->d_lut, ix->d_qf);
         PB_HIP(hipGetLastError());
-        const int qn = ix->opt_exact_qn ? ix->opt_exact_qn : (n_sel >= 2 ? 2 : 1);
+        const int qn = ix->opt_exact_qn ? ix->opt_exact_qn : (n_sel >= 3 ? 4 : n_sel == 2 ? 2 : 1);
         int rc;
-        if (k <= 128) rc = qn == 2 ? launch_exact_co<2, 3>(ix, n_lists, n_sel, k) : launch_exact_co<1, 3>(ix, n_lists, n_sel, k);
+        if (qn == 4) rc = k <= 128 ? launch_exact_co4<3>(ix, n_lists, n_sel, k) : launch_exact_co4<5>(ix, n_lists, n_sel, k);
+        else if (k <= 128) rc = qn == 2 ? launch_exact_co<2, 3>(ix, n_lists, n_sel, k) : launch_exact_co<1, 3>(ix, n_lists, n_sel, k);
         else rc = qn == 2 ? launch_exact_co<2, 5>(ix, n_lists, n_sel, k) : launch_exact_co<1, 5>(ix, n_lists, n_sel, k);
         if (rc) return rc;
     } else {
@@ -1470,7 +1483,7 @@ int pb_index_set_option(pb_index *ix, int option, int64_t value) {
             ix->sc_skipped = 0;
             return PB_OK;
         case PB_OPT_EXACT_QN:
-            PB_CHECK(value >= 0 && value <= 2, PB_ERR_INVALID, "PB_OPT_EXACT_QN: 0 (auto), 1 or 2");
+            PB_CHECK(value == 0 || value == 1 || value == 2 || value == 4, PB_ERR_INVALID, "PB_OPT_EXACT_QN: 0 (auto), 1, 2 or 4");
             ix->opt_exact_qn = (int)value;
             return PB_OK;
         case PB_OPT_SCAN_GRID:

@@ -1228,8 +1228,11 @@ __global__ __launch_bounds__(XC_WAVES * WAVE, 2) void k_scan_exact_co(
                     const float x = dequant_exact((float)((pc.w[e] >> (8 * b)) & 0xFF));  // v_cvt_f32_ubyteN + 3 VALU, no LDS gather
 #pragma unroll
                     for (int j = 0; j < QN; ++j) {
-                        const float p = pc.q[j][e][b] * x;
-                        dot[j] = dot[j] + p;
+                        // asm: left to the compiler pairs of these are packed (v_pk_mul_f32 / v_pk_add_f32) at the price
+                        // of register moves, and a packed instruction costs 1.7 issue slots (profiles/r02_valu_rate.txt)
+                        float p;
+                        asm("v_mul_f32 %0, %1, %2" : "=v"(p) : "v"(pc.q[j][e][b]), "v"(x));
+                        asm("v_add_f32 %0, %1, %2" : "=v"(dot[j]) : "v"(dot[j]), "v"(p));
                     }
                 }
             }
@@ -1260,6 +1263,211 @@ __global__ __launch_bounds__(XC_WAVES * WAVE, 2) void k_scan_exact_co(
                 // "if (cnt > K) prune" amounts to once the buffer holds K keys -- ran the 64-step radix select some
                 // K ln(rows / K) ~ 400 times per wave; this way it runs once per ~64 insertions.
                 if (cnt[j] + (int)__popcll(m) > cap) {
+                    thr_key[j] = wave_keep_smallest<MAXE>(buf[j], cnt[j], K);
+                    cnt[j] = K;
+                    pass = key < thr_key[j];
+                    m = __ballot(pass);
+                }
+                if (pass) buf[j][cnt[j] + mbcnt(m)] = key;
+                cnt[j] += __popcll(m);
+            }
+        }
+    }
+    // workgroup list per query = the K best of the XC_WAVES wave lists, sorted (the tile area is free now)
+#pragma unroll
+    for (int j = 0; j < QN; ++j)
+        if (cnt[j] > K) {
+            wave_keep_smallest<MAXE>(buf[j], cnt[j], K);
+            cnt[j] = K;
+        }
+    int *s_cnt = reinterpret_cast<int *>(s_keys + (size_t)XC_WAVES * QN * cap);
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < QN; ++j) s_cnt[wave * QN + j] = cnt[j];
+    }
+    __syncthreads();
+    uint64_t *s_sort = reinterpret_cast<uint64_t *>(s_dyn);  // XC_WAVES * 256 keys <= 8 KiB
+#pragma unroll
+    for (int j = 0; j < QN; ++j) {
+        if (slot0 + j >= n_sel) break;
+        int total = 0, offs[XC_WAVES];
+        for (int w = 0; w < XC_WAVES; ++w) {
+            offs[w] = total;
+            total += s_cnt[w * QN + j];
+        }
+        int nsort = 64;
+        while (nsort < total) nsort <<= 1;
+        __syncthreads();
+        for (int i = threadIdx.x; i < nsort; i += XC_WAVES * WAVE) s_sort[i] = ~0ull;
+        __syncthreads();
+        for (int w = 0; w < XC_WAVES; ++w)
+            for (int i = threadIdx.x; i < s_cnt[w * QN + j]; i += XC_WAVES * WAVE) s_sort[offs[w] + i] = s_keys[((size_t)w * QN + j) * cap + i];
+        block_bitonic_sort(s_sort, nsort);
+        const int n_out = total < K ? total : K;
+        uint64_t *out = lists + ((size_t)(slot0 + j) * gridDim.x + blockIdx.x) * list_stride;
+        for (int i = threadIdx.x; i < n_out; i += XC_WAVES * WAVE) out[i] = s_sort[i];
+        if (threadIdx.x == 0) list_counts[(size_t)(slot0 + j) * gridDim.x + blockIdx.x] = (uint32_t)n_out;
+    }
+}
+// (2c) the same pass for FOUR queries per sweep.  The fold is bound by vector-instruction issue (profiles/r02_valu_rate.txt),
+// and of its 4.45 + 2 QN issue slots per byte (conversion 1.45, de-quantisation 3, multiply + add per query) the first
+// 4.45 are shared by the queries of a group: 4.2 slots per byte and query at QN = 2, 3.1 at QN = 4.  Sixteen query
+// values per query and 16-byte piece are 64 registers per piece in flight, twice (one piece ahead), so the table
+// stream gives up half of its registers: a tile is parked and folded in two column HALVES (bytes [0,128) and [128,256) of
+// its 64 rows: eight 1-KiB wave loads per half, each covering 8 full 128-byte lines; 144-byte row pitch in LDS, 16 pad
+// bytes holding the queries as in k_scan_exact_co), the running sums stay in registers across the halves.  Half the
+// bytes in flight per wave is enough here: at four folds per byte the sweep needs a third of the HBM rate.
+constexpr int XC4_PITCH = 144;
+constexpr int XC4_IMAGE = WAVE * XC4_PITCH;  // 9216
+template <int MAXE>
+__global__ __launch_bounds__(XC_WAVES * WAVE, 2) void k_scan_exact_co4(
+    const uint8_t *__restrict__ rows, const float *__restrict__ norms, uint64_t n_rows,
+    const float *__restrict__ qf, const QParams *__restrict__ qp, const uint32_t *__restrict__ qsel, int n_sel,
+    uint64_t *__restrict__ lists, uint32_t *__restrict__ list_counts, uint32_t list_stride) {
+    constexpr int QN = 4;
+    static_assert(QN <= XC_WAVES, "one tile image per query for the parked query values");
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+    // layout: [XC_WAVES] half-tile images (queries in their pad bytes) | [XC_WAVES][QN][cap] key buffers | counts
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int slot0 = (int)blockIdx.y * QN;
+    int K = 0;
+    QParams P[QN];
+#pragma unroll
+    for (int j = 0; j < QN; ++j) {
+        const int sl = slot0 + j < n_sel ? slot0 + j : n_sel - 1;  // a short last group repeats its last query (never written)
+        P[j] = qp[qsel[sl]];
+        K = (int)P[j].k;
+    }
+    const int cap = K + WAVE;
+    uint8_t *tile = s_dyn + (size_t)wave * XC4_IMAGE;
+    uint64_t *s_keys = reinterpret_cast<uint64_t *>(s_dyn + (size_t)XC_WAVES * XC4_IMAGE);
+    uint64_t *buf[QN];
+    int cnt[QN];
+    uint64_t thr_key[QN];
+#pragma unroll
+    for (int j = 0; j < QN; ++j) {
+        buf[j] = s_keys + ((size_t)wave * QN + j) * cap;
+        cnt[j] = 0;
+        thr_key[j] = ~0ull;
+    }
+    // value i of query j: float i % 4 of the pad of row i / 4 of image j
+#pragma unroll
+    for (int j = 0; j < QN; ++j) {
+        const int i = threadIdx.x;  // 256 threads, 256 values
+        const float v = qf[(size_t)(slot0 + j < n_sel ? slot0 + j : n_sel - 1) * 256 + i];
+        *reinterpret_cast<float *>(s_dyn + (size_t)j * XC4_IMAGE + (size_t)(i >> 2) * XC4_PITCH + 128 + 4 * (i & 3)) = v;
+    }
+    __syncthreads();
+
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const uint64_t n_tiles = (n_rows + WAVE - 1) / WAVE;
+    const uint64_t stride = (uint64_t)gridDim.x * XC_WAVES;
+    const uint64_t last_chunk = (n_rows * 256 - 16) / 16;  // last 16-byte piece inside the table
+    // half h of tile t: load j of lane l is row 8 j + l / 8 of the tile, bytes [128 h + 16 (l % 8), +16)
+    auto request = [&](uint64_t t, int h, u32x4 (&v)[8]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uint64_t c = (t * WAVE + (uint64_t)(8 * j + (lane >> 3))) * 16 + (uint64_t)(8 * h + (lane & 7));  // 16-byte piece index
+            c = c < last_chunk ? c : last_chunk;
+            v[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(rows) + c);
+        }
+    };
+    struct Piece {
+        u32x4 w;
+        f32x4 q[QN][4];
+    };
+    const uint32_t lds_row = (uint32_t)(uintptr_t)(tile + (size_t)lane * XC4_PITCH);  // low 32 bits of a shared-aperture address = LDS offset
+    const uint32_t lds_q = (uint32_t)(uintptr_t)s_dyn + 128u;
+    uint64_t t = (uint64_t)wave * gridDim.x + blockIdx.x;
+    u32x4 nxt[8];
+    if (t < n_tiles) request(t, 0, nxt);
+    for (; t < n_tiles; t += stride) {
+        const uint64_t r = t * WAVE + lane;
+        const float nrm = norms[r < n_rows ? r : n_rows - 1];
+        float dot[QN];
+#pragma unroll
+        for (int j = 0; j < QN; ++j) dot[j] = 0.0f;
+        // the loads of a piece (row bytes + 16 broadcast reads of query values) in ONE asm statement, one piece ahead of
+        // their use; `other` (the piece about to be folded) rides through as an in/out operand (see k_scan_exact_co)
+        auto fetch = [&](Piece &pc, int h, int c, Piece &other) {
+            const uint32_t aw = lds_row + 16u * (uint32_t)c, aq = lds_q + (uint32_t)(32 * h + 4 * c) * XC4_PITCH;
+            asm volatile("ds_read_b128 %0, %18\n\t"
+                         "ds_read_b128 %1, %19\n\tds_read_b128 %2, %19 offset:144\n\tds_read_b128 %3, %19 offset:288\n\tds_read_b128 %4, %19 offset:432\n\t"
+                         "ds_read_b128 %5, %19 offset:9216\n\tds_read_b128 %6, %19 offset:9360\n\tds_read_b128 %7, %19 offset:9504\n\tds_read_b128 %8, %19 offset:9648\n\t"
+                         "ds_read_b128 %9, %19 offset:18432\n\tds_read_b128 %10, %19 offset:18576\n\tds_read_b128 %11, %19 offset:18720\n\tds_read_b128 %12, %19 offset:18864\n\t"
+                         "ds_read_b128 %13, %19 offset:27648\n\tds_read_b128 %14, %19 offset:27792\n\tds_read_b128 %15, %19 offset:27936\n\tds_read_b128 %16, %19 offset:28080"
+                         : "=&v"(pc.w), "=&v"(pc.q[0][0]), "=&v"(pc.q[0][1]), "=&v"(pc.q[0][2]), "=&v"(pc.q[0][3]), "=&v"(pc.q[1][0]),
+                           "=&v"(pc.q[1][1]), "=&v"(pc.q[1][2]), "=&v"(pc.q[1][3]), "=&v"(pc.q[2][0]), "=&v"(pc.q[2][1]), "=&v"(pc.q[2][2]),
+                           "=&v"(pc.q[2][3]), "=&v"(pc.q[3][0]), "=&v"(pc.q[3][1]), "=&v"(pc.q[3][2]), "=&v"(pc.q[3][3]), "+v"(other.w)
+                         : "v"(aw), "v"(aq));
+        };
+        static_assert(XC4_PITCH == 144 && XC4_IMAGE == 9216, "the offsets in the asm above are written out");
+        // the wait, and behind it two empty statements that the rest of the piece and the running sums pass through
+        // (an asm statement takes 30 operands): nothing of the fold can be scheduled above the wait
+        auto settle = [&](Piece &pc) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pc.w), "+v"(pc.q[0][0]), "+v"(pc.q[0][1]), "+v"(pc.q[0][2]), "+v"(pc.q[0][3]),
+                         "+v"(pc.q[1][0]), "+v"(pc.q[1][1]), "+v"(pc.q[1][2]), "+v"(pc.q[1][3]), "+v"(dot[0]), "+v"(dot[1]));
+            asm volatile("" : "+v"(pc.q[2][0]), "+v"(pc.q[2][1]), "+v"(pc.q[2][2]), "+v"(pc.q[2][3]), "+v"(pc.q[3][0]), "+v"(pc.q[3][1]),
+                         "+v"(pc.q[3][2]), "+v"(pc.q[3][3]), "+v"(dot[2]), "+v"(dot[3]));
+        };
+        auto fold = [&](const Piece &pc) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const float x = dequant_exact((float)((pc.w[e] >> (8 * b)) & 0xFF));
+#pragma unroll
+                    for (int j = 0; j < QN; ++j) {
+#ifdef PB_XC4_PLAIN
+                        const float p = pc.q[j][e][b] * x;
+                        dot[j] = dot[j] + p;
+#else
+                        // asm: left to the compiler pairs of these are packed (v_pk_mul_f32 / v_pk_add_f32) at the price
+                        // of register moves, and a packed instruction costs 1.7 issue slots (profiles/r02_valu_rate.txt)
+                        float p;
+                        asm("v_mul_f32 %0, %1, %2" : "=v"(p) : "v"(pc.q[j][e][b]), "v"(x));
+                        asm("v_add_f32 %0, %1, %2" : "=v"(dot[j]) : "v"(dot[j]), "v"(p));
+#endif
+                    }
+                }
+            }
+        };
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            // park the half-tile: load j of lane l is row 8 j + l / 8, bytes [16 (l % 8), +16) of the half
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                *reinterpret_cast<u32x4 *>(tile + (size_t)(8 * j + (lane >> 3)) * XC4_PITCH + 16 * (lane & 7)) = nxt[j];
+            if (h == 0) request(t, 1, nxt);
+            else if (t + stride < n_tiles) request(t + stride, 0, nxt);
+            asm volatile("" ::: "memory");  // the asm reads below are not memory operations to the compiler
+            Piece pa, pb;
+            pb.w = u32x4{0, 0, 0, 0};
+            fetch(pa, h, 0, pb);
+#pragma unroll 1
+            for (int c = 0; c < 8; c += 2) {
+                settle(pa);
+                fetch(pb, h, c + 1, pa);
+                fold(pa);
+                settle(pb);
+                fetch(pa, h, c + 2 < 8 ? c + 2 : 7, pb);
+                fold(pb);
+            }
+            settle(pa);  // nothing of ours may be in flight when compiler-tracked LDS traffic resumes
+            asm volatile("" ::: "memory");
+        }
+#pragma unroll
+        for (int j = 0; j < QN; ++j) {
+            float cs;
+            const float dist = ref_distance(dot[j], P[j].sqrt_sa, nrm, &cs);
+            uint64_t key = ~0ull;
+            if (r < n_rows && (double)dist < P[j].max_dist) key = ((uint64_t)sortable_f32(dist) << 32) | (uint32_t)r;
+            bool pass = key < thr_key[j];
+            uint64_t m = __ballot(pass);
+            if (m) {
+                if (cnt[j] + (int)__popcll(m) > cap) {  // lazy pruning, as in k_scan_exact_co
                     thr_key[j] = wave_keep_smallest<MAXE>(buf[j], cnt[j], K);
                     cnt[j] = K;
                     pass = key < thr_key[j];

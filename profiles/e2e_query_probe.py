@@ -70,8 +70,30 @@ def summarize(d):
         print(f"{ns / 1e6:9.3f} ms {c:7d} calls  {name[:110]}")
 
 
+def timeline(d, last_ms=32.0):
+    """Kernels and copies of the last `last_ms` of the trace: start offset, duration, gap to the previous one."""
+    import csv
+
+    ev = []
+    for pat in ("*kernel_trace.csv", "*memory_copy_trace.csv"):
+        for f in glob.glob(os.path.join(d, "**", pat), recursive=True):
+            with open(f) as fh:
+                for r in csv.DictReader(fh):
+                    name = r.get("Kernel_Name") or ("copy " + r.get("Direction", ""))
+                    ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name.split("(")[0][-60:]))
+    ev.sort()
+    t_end = ev[-1][1]
+    ev = [e for e in ev if e[0] >= t_end - last_ms * 1e6]
+    prev = ev[0][0]
+    for s, e, name in ev:
+        print(f"{(s - ev[0][0]) / 1e3:10.1f} us  +{(s - prev) / 1e3:8.1f} gap  {(e - s) / 1e3:9.1f} us  {name}")
+        prev = e
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 2 and sys.argv[1] == "--summarize":
+    if len(sys.argv) > 2 and sys.argv[1] == "--timeline":
+        timeline(sys.argv[2])
+    elif len(sys.argv) > 2 and sys.argv[1] == "--summarize":
         summarize(sys.argv[2])
     else:
         run()

@@ -12,7 +12,7 @@ ix = capi.Index(256, rows)
 ix.fill_synthetic(synth.SEED_INDEX, 0, rows, 1)
 ix.set_option(capi.PB_OPT_SEARCH_PATH, 1)
 q = synth.fill_synthetic(synth.SEED_QUERY, 0, 64 * 256).reshape(64, 256)
-for qn in (1, 2):
+for qn in (1, 2, 4):
     ix.set_option(capi.PB_OPT_EXACT_QN, qn)
     ix.search(q[:8])
     ix.stats(reset=True)

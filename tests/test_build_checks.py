@@ -75,5 +75,20 @@ def test_exact_pass_keeps_its_lds_reads_one_piece_ahead(tmp_path):
         ops = [l.strip().split()[0] for l in loop.split("\n") if re.search(r"s_waitcnt lgkmcnt|ds_read_b", l)]
         want = ["s_waitcnt"] + ["ds_read_b128"] * (1 + 4 * qn)
         assert ops == want * 2, (m.group(1), ops)
+        # the multiplies and adds of the fold are scalar instructions (asm): no packed pairs, no register shuffling
+        assert len(re.findall(r"v_pk_mul_f32|v_pk_add_f32", loop)) == 0 and len(re.findall(r"\bv_add_f32 ", loop)) == 32 * qn
         found += 1
     assert found == 4
+    # the four-query form (k_scan_exact_co4): 1 + 16 reads behind each wait
+    found = 0
+    for m in re.finditer(r"^(_ZN3pbk16k_scan_exact_co4ILi(\d)E\w*):[^\n]*\n(.*?)\.end_amdhsa_kernel", s, re.S | re.M):
+        body = m.group(3)
+        assert "scratch_" not in body
+        blocks = re.split(r"\n(?=\.LBB\d+_\d+:)", body)
+        loop = max(blocks, key=lambda b: len(re.findall(r"\bv_add_f32 ", b)))
+        loop = loop[: loop.index("s_cbranch_scc")]
+        ops = [l.strip().split()[0] for l in loop.split("\n") if re.search(r"s_waitcnt lgkmcnt|ds_read_b", l)]
+        assert ops == (["s_waitcnt"] + ["ds_read_b128"] * 17) * 2, (m.group(1), ops)
+        assert len(re.findall(r"\bv_add_f32 ", loop)) == 128 and len(re.findall(r"v_pk_mul_f32|v_pk_add_f32", loop)) == 0
+        found += 1
+    assert found == 2

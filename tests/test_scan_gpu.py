@@ -882,10 +882,10 @@ def test_search_device_leaves_results_on_the_device():
             assert np.all(gi[i, c:] == np.iinfo(np.int64).max) and np.all(np.isinf(gd[i, c:]))
 
 
-@pytest.mark.parametrize("qn", [0, 1, 2])
+@pytest.mark.parametrize("qn", [0, 1, 2, 4])
 @pytest.mark.parametrize("k", [100, 256])
 def test_coalesced_exhaustive_pass_vs_oracle(qn, k):
-    # k_scan_exact_co: 64-row tiles staged through LDS, QN queries per sweep; ragged last tile, odd query counts,
+    # k_scan_exact_co / k_scan_exact_co4: 64-row tiles staged through LDS, QN queries per sweep; ragged last tile, odd query counts,
     # k beyond 128 (the larger key buffers), duplicates of the query (ties broken by image_id)
     rng = np.random.default_rng(100 + qn)
     d, n = 256, 64 * 300 + 37
