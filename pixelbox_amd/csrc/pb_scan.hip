@@ -70,7 +70,7 @@ struct pb_index {
     uint64_t *d_dropkeys = nullptr; // Q_CHUNK * F_MAX_WG (byte / hamming pass: smallest key each workgroup dropped)
     uint64_t *d_xlists[2] = {nullptr, nullptr};  // exact pass ping-pong: Q_CHUNK * X_MAX_WG * PB_MAX_K
     uint32_t *d_xcounts[2] = {nullptr, nullptr};
-    uint32_t *d_qsel = nullptr;     // Q_CHUNK
+    uint32_t *d_qsel = nullptr;     // PIPE_Q (a chunk uses the first Q_CHUNK; the burst path's fallback lists all its uncertified queries)
     uint32_t *d_tail = nullptr;     // DYN_REGIONS ticket counters of the one-query filter launch (zero between launches)
     float *d_qf = nullptr;          // Q_CHUNK * 256: de-quantised queries of the coalesced exhaustive pass
     float *d_tau = nullptr;         // multi-query pass: per-query candidate threshold (PIPE_Q)
@@ -140,7 +140,7 @@ int alloc_workspace(pb_index *ix) {
         PB_HIP(hipMalloc(&ix->d_xlists[i], (size_t)Q_CHUNK * lists * PB_MAX_K * sizeof(uint64_t)));
         PB_HIP(hipMalloc(&ix->d_xcounts[i], (size_t)Q_CHUNK * lists * sizeof(uint32_t)));
     }
-    PB_HIP(hipMalloc(&ix->d_qsel, Q_CHUNK * sizeof(uint32_t)));
+    PB_HIP(hipMalloc(&ix->d_qsel, PIPE_Q * sizeof(uint32_t)));
     PB_HIP(hipMalloc(&ix->d_tail, (size_t)DYN_REGIONS * DYN_CTR_STRIDE * sizeof(uint32_t)));
     PB_HIP(hipMemset(ix->d_tail, 0, (size_t)DYN_REGIONS * DYN_CTR_STRIDE * sizeof(uint32_t)));
     PB_HIP(hipMalloc(&ix->d_qf, ((size_t)Q_CHUNK * 256 + 16) * sizeof(float)));  // + one piece of slack: k_scan_exact_co fetches one piece ahead
@@ -492,29 +492,30 @@ int run_fast_dist(pb_index *ix, uint32_t nq) {
 
 // exhaustive exact pass for the n_sel queries listed in d_qsel
 template <int QN, int MAXE>
-int launch_exact_co(pb_index *ix, int n_lists, uint32_t n_sel, uint32_t k) {
+int launch_exact_co(pb_index *ix, int n_lists, uint32_t n_sel, uint32_t k, const uint32_t *qsel) {
     const size_t cap = (size_t)k + WAVE;
     const size_t lds = (size_t)XC_WAVES * WAVE * XC_PITCH + (size_t)XC_WAVES * QN * cap * sizeof(uint64_t) + (size_t)XC_WAVES * QN * sizeof(int);
     auto kern = k_scan_exact_co<QN, MAXE>;
     PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(n_lists, (n_sel + QN - 1) / QN), dim3(XC_WAVES * WAVE), lds, ix->stream, ix->d_rows, ix->d_norms,
-                       ix->n_rows, ix->d_qf, ix->d_qp, ix->d_qsel, (int)n_sel, ix->d_lut, ix->d_xlists[0], ix->d_xcounts[0],
+                       ix->n_rows, ix->d_qf, ix->d_qp, qsel, (int)n_sel, ix->d_lut, ix->d_xlists[0], ix->d_xcounts[0],
                        (uint32_t)PB_MAX_K);
     return PB_OK;
 }
 
 template <int MAXE>
-int launch_exact_co4(pb_index *ix, int n_lists, uint32_t n_sel, uint32_t k) {
+int launch_exact_co4(pb_index *ix, int n_lists, uint32_t n_sel, uint32_t k, const uint32_t *qsel) {
     const size_t cap = (size_t)k + WAVE;
     const size_t lds = (size_t)XC_WAVES * XC4_IMAGE + (size_t)XC_WAVES * 4 * cap * sizeof(uint64_t) + (size_t)XC_WAVES * 4 * sizeof(int);
     auto kern = k_scan_exact_co4<MAXE>;
     PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(n_lists, (n_sel + 3) / 4), dim3(XC_WAVES * WAVE), lds, ix->stream, ix->d_rows, ix->d_norms, ix->n_rows,
-                       ix->d_qf, ix->d_qp, ix->d_qsel, (int)n_sel, ix->d_xlists[0], ix->d_xcounts[0], (uint32_t)PB_MAX_K);
+                       ix->d_qf, ix->d_qp, qsel, (int)n_sel, ix->d_xlists[0], ix->d_xcounts[0], (uint32_t)PB_MAX_K);
     return PB_OK;
 }
 
-int run_exact(pb_index *ix, uint32_t n_sel, uint32_t k) {
+int run_exact(pb_index *ix, uint32_t n_sel, uint32_t k, const uint32_t *qsel = nullptr) {
+    if (!qsel) qsel = ix->d_qsel;
     // cosine over 256-byte rows: the coalesced form, two queries per table sweep when there are two (k_scan_exact_co)
     const bool coalesced = ix->metric == 0 && ix->dim == 256 && !ix->env_exact_lane_rows;
     const uint64_t n_tiles = (ix->n_rows + WAVE - 1) / WAVE;
@@ -529,21 +530,27 @@ int run_exact(pb_index *ix, uint32_t n_sel, uint32_t k) {
         const uint64_t fat = std::max<uint64_t>(1, n_tiles / (32ull * XC_WAVES));
         const uint64_t fill = (2ull * ix->n_cu + groups - 1) / groups;  // workgroups per group that still fill 2 per CU
         n_lists = (int)std::min<uint64_t>((uint64_t)n_lists, std::max<uint64_t>(fat, fill));
+        // whole rounds of workgroups (2 per CU at a time): 122 lists x 16 groups = 3.8 rounds cost four
+        const uint64_t slots = 2ull * ix->n_cu, total = (uint64_t)n_lists * groups;
+        if (total > slots) {
+            const uint64_t rounds = total / slots;  // fewer, longer workgroups: each ends with its sorts
+            n_lists = (int)std::max<uint64_t>(1, rounds * slots / groups);
+        }
     }
     if (ix->opt_profile && ix->opt_path == 1) PB_HIP(hipEventRecord(ix->ev0, ix->stream));
     if (coalesced) {
-        hipLaunchKernelGGL(k_make_qf, dim3(n_sel), dim3(256), 0, ix->stream, ix->d_queries, ix->d_qsel, ix->d_lut, ix->d_qf);
+        hipLaunchKernelGGL(k_make_qf, dim3(n_sel), dim3(256), 0, ix->stream, ix->d_queries, qsel, ix->d_lut, ix->d_qf);
         PB_HIP(hipGetLastError());
         const int qn = ix->opt_exact_qn ? ix->opt_exact_qn : (n_sel >= 3 ? 4 : n_sel == 2 ? 2 : 1);
         int rc;
-        if (qn == 4) rc = k <= 128 ? launch_exact_co4<3>(ix, n_lists, n_sel, k) : launch_exact_co4<5>(ix, n_lists, n_sel, k);
-        else if (k <= 128) rc = qn == 2 ? launch_exact_co<2, 3>(ix, n_lists, n_sel, k) : launch_exact_co<1, 3>(ix, n_lists, n_sel, k);
-        else rc = qn == 2 ? launch_exact_co<2, 5>(ix, n_lists, n_sel, k) : launch_exact_co<1, 5>(ix, n_lists, n_sel, k);
+        if (qn == 4) rc = k <= 128 ? launch_exact_co4<3>(ix, n_lists, n_sel, k, qsel) : launch_exact_co4<5>(ix, n_lists, n_sel, k, qsel);
+        else if (k <= 128) rc = qn == 2 ? launch_exact_co<2, 3>(ix, n_lists, n_sel, k, qsel) : launch_exact_co<1, 3>(ix, n_lists, n_sel, k, qsel);
+        else rc = qn == 2 ? launch_exact_co<2, 5>(ix, n_lists, n_sel, k, qsel) : launch_exact_co<1, 5>(ix, n_lists, n_sel, k, qsel);
         if (rc) return rc;
     } else {
 #define PB_X(MV)                                                                                                   \
     hipLaunchKernelGGL((k_scan_exact<MV>), dim3(n_lists, n_sel), dim3(X_BLOCK), 0, ix->stream, ix->d_rows, ix->d_norms, \
-                       ix->n_rows, (int)ix->dim, ix->d_queries, ix->d_qp, ix->d_qsel, ix->d_lut, ix->d_xlists[0],  \
+                       ix->n_rows, (int)ix->dim, ix->d_queries, ix->d_qp, qsel, ix->d_lut, ix->d_xlists[0],  \
                        ix->d_xcounts[0], (uint32_t)PB_MAX_K)
     if (ix->metric == 1) PB_X(1);
     else if (ix->metric == 2) PB_X(2);
@@ -558,7 +565,7 @@ int run_exact(pb_index *ix, uint32_t n_sel, uint32_t k) {
         const int final_out = n_groups == 1;
         hipLaunchKernelGGL(k_merge_lists, dim3(n_groups, n_sel), dim3(M_BLOCK), 0, ix->stream, ix->d_xlists[cur],
                            ix->d_xcounts[cur], n_lists, (uint32_t)PB_MAX_K, k, ix->d_xlists[cur ^ 1],
-                           ix->d_xcounts[cur ^ 1], (uint32_t)PB_MAX_K, final_out, ix->d_ids, ix->d_qsel, ix->r_ids,
+                           ix->d_xcounts[cur ^ 1], (uint32_t)PB_MAX_K, final_out, ix->d_ids, qsel, ix->r_ids,
                            ix->r_dist, ix->r_hdr, (uint32_t)PB_MAX_K);
         PB_HIP(hipGetLastError());
         if (final_out) break;
@@ -937,7 +944,27 @@ int search_block_multi(pb_index *ix, const uint8_t *queries, uint32_t nq, uint32
     ix->stats.queries += nq;
     ix->stats.fast_path += nq - failed.size();
     ix->stats_multi += nq - failed.size();
-    // exhaustive pass for the uncertified ones, a chunk at a time (uses the chunk workspace at slot 0)
+    // Uncertified queries.  When the second chance is not worth trying (second_chance_pays) they all take the
+    // exhaustive pass at once: their queries and parameters are still on the device from the burst, the kernels are
+    // queued chunk after chunk with nothing waited for in between, and the final merge writes each result into ITS
+    // slot of the pinned host arrays (the burst's results for the other queries are already there).
+    const bool coalesced = ix->metric == 0 && ix->dim == 256 && !ix->env_exact_lane_rows;
+    if (!failed.empty() && coalesced &&
+        (ix->env_no_second_chance || ix->n_rows < 4096 || !second_chance_pays(ix, (uint32_t)std::min<size_t>(Q_CHUNK, failed.size())))) {
+        PB_HIP(hipMemcpyAsync(ix->d_qsel, failed.data(), failed.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ix->stream));
+        ix->r_ids = ix->h_res_ids;
+        ix->r_dist = ix->h_res_dist;
+        ix->r_hdr = ix->h_res_hdr;
+        for (size_t f0 = 0; f0 < failed.size(); f0 += Q_CHUNK) {
+            const uint32_t cq = (uint32_t)std::min<size_t>(Q_CHUNK, failed.size() - f0);
+            int rc = run_exact(ix, cq, k, ix->d_qsel + f0);
+            if (rc) return rc;
+        }
+        PB_HIP(hipStreamSynchronize(ix->stream));
+        ix->stats.fallback += failed.size();
+        return PB_OK;
+    }
+    // otherwise a chunk at a time through search_chunk (second chance, then the exhaustive pass; uses the chunk workspace at slot 0)
     std::vector<int64_t> keep_ids;
     std::vector<float> keep_dist;
     std::vector<ResultHdr> keep_hdr;
