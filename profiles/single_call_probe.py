@@ -5,7 +5,7 @@
 
 Runs N one-query pb_index_search calls over a 10M x 256 table and prints the median wall time per call; with
 --summarize it reads the kernel trace of such a run and prints, per call, the kernels' durations and the gaps between
-them (stage -> filter -> select), i.e. device time vs. everything else.
+them (filter -> select, and from one call's select to the next call's filter), i.e. device time vs. everything else.
 """
 import glob
 import os
@@ -50,29 +50,23 @@ def summarize(d):
                 rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
     calls = []
-    cur = []
-    for s, e, name in rows:
-        short = name.split("(")[0].split("::")[-1]
-        if "k_stage_query" in name:
-            cur = [(s, e, short)]
-            calls.append(cur)
-        elif cur is not None and cur:
-            cur.append((s, e, short))
+    for i, (s, e, name) in enumerate(rows[:-1]):  # a call = the filter launch and the select launch behind it
+        if "k_scan_filter" in name and "k_select_rescore" in rows[i + 1][2]:
+            calls.append([(s, e, "k_scan_filter"), (rows[i + 1][0], rows[i + 1][1], "k_select_rescore")])
     out = []
-    for c in calls[-30:]:
-        if len(c) < 3:
-            continue
-        names = [x[2][:22] for x in c[:3]]
-        durs = [(x[1] - x[0]) / 1e3 for x in c[:3]]
-        gaps = [(c[i + 1][0] - c[i][1]) / 1e3 for i in range(2)]
-        out.append((names, durs, gaps, (c[2][1] - c[0][0]) / 1e3))
+    for j in range(max(1, len(calls) - 30), len(calls)):
+        c = calls[j]
+        durs = [(x[1] - x[0]) / 1e3 for x in c]
+        gaps = [(c[1][0] - c[0][1]) / 1e3, (c[0][0] - calls[j - 1][1][1]) / 1e3]  # filter -> select, previous call's end -> this filter
+        out.append(([x[2] for x in c], durs, gaps, (c[1][1] - c[0][0]) / 1e3))
     if not out:
         print("no calls found")
         return
     med = lambda v: sorted(v)[len(v) // 2]
     print("kernels:", out[0][0])
-    print("durations us (median):", [round(med([o[1][i] for o in out]), 2) for i in range(3)])
-    print("gaps us (median):", [round(med([o[2][i] for o in out]), 2) for i in range(2)])
+    print("durations us (median):", [round(med([o[1][i] for o in out]), 2) for i in range(2)])
+    print("gap filter -> select, gap previous call's last kernel -> this call's filter (host turn-around), us (median):",
+          [round(med([o[2][i] for o in out]), 2) for i in range(2)])
     print("first kernel start -> last kernel end us (median):", round(med([o[3] for o in out]), 2))
 
 
