@@ -12,6 +12,9 @@ cd $R && python -m pytest tests -q -m gpu > $O/gpu_tests_full.txt 2>&1; grep -E 
 cd /tmp; export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/full -o full -- python3 $R/bench.py > $O/bench_under_rocprof.json 2> $O/full.err
+# the headline legs alone (default steps): the LOOPQ filter instance's average in this stats file is the 10M-row launches only
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/head -o head -- python3 $R/bench.py --no-embed --e2e-images 0 --no-sweep --no-cpu-baseline > $O/bench_headline_under_rocprof.json 2> $O/head.err
+cp $(find $O/head -name "head_kernel_stats.csv") $O/headline_kernel_stats.csv; rm -rf $O/head
 SCAN="--no-embed --e2e-images 0 --no-sweep --no-cpu-baseline --steps 2 --warmup 1"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 $R/bench.py $SCAN > /dev/null 2> $O/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 $R/bench.py $SCAN > /dev/null 2> $O/pmc_write.err
