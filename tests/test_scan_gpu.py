@@ -491,6 +491,69 @@ def test_second_chance_answers_tight_clusters_exactly(path):
         del os.environ["PB_NO_SECOND_CHANCE"]
 
 
+@pytest.mark.parametrize("k", [100, 256])
+def test_a_bursts_uncertified_queries_take_the_exhaustive_pass_in_one_queue(k):
+    # a collection like the end-to-end leg's: a few distinct rows repeated tens of thousands of times.  Queries at those
+    # rows tie with more rows than any list holds; the cost model sends all of them (more than one 64-query chunk, a
+    # ragged last group of four) to the exhaustive pass at once, results written straight into the host arrays
+    rng = np.random.default_rng(91 + k)
+    n = 300000
+    rows = rng.integers(0, 256, size=(n, 256), dtype=np.uint8)
+    protos = rng.integers(0, 256, size=(5, 256), dtype=np.uint8)
+    dup = rng.choice(n, size=200000, replace=False)
+    rows[dup] = protos[rng.integers(0, 5, size=len(dup))]
+    ids = np.arange(n, dtype=np.int64) * 2 + 7
+    nq = 150
+    q = rng.integers(0, 256, size=(nq, 256), dtype=np.uint8)
+    hot = rng.choice(nq, size=71, replace=False)  # 71 = 64 + 4 + 3
+    q[hot] = protos[rng.integers(0, 5, size=len(hot))]
+    q[hot[:20], 3] ^= 1  # near-duplicates of a prototype as well
+    ix = make_index(rows, ids, path=MULTI)
+    got = ix.search(q, k, 1e3)
+    st = ix.stats()
+    assert st.fallback >= 60 and st.second_chance == 0 and st.queries == nq == st.fast_path + st.fallback
+    ref = make_index(rows, ids, path=EXACT)
+    want = ref.search(q, k, 1e3)
+    cnt = want[2]
+    assert np.array_equal(got[2], cnt)
+    for i in range(nq):
+        c = int(cnt[i])
+        assert np.array_equal(got[0][i, :c], want[0][i, :c]) and np.array_equal(got[1][i, :c].view(np.uint32), want[1][i, :c].view(np.uint32))
+    check_against_oracle(ix, rows, ids, q[[hot[0], hot[25], hot[70]]], k=k)
+    # the device-result entry point patches the same queries through the host arrays before it emits
+    import torch
+
+    d_ids = torch.zeros((nq, k), dtype=torch.int64, device="cuda")
+    d_dist = torch.zeros((nq, k), dtype=torch.float32, device="cuda")
+    d_cnt = torch.zeros((nq,), dtype=torch.int32, device="cuda")
+    ix.search_device(q, k, 1e3, d_ids.data_ptr(), d_dist.data_ptr(), d_cnt.data_ptr())
+    assert np.array_equal(d_cnt.cpu().numpy().astype(np.uint32), cnt)
+    gi, gd = d_ids.cpu().numpy(), d_dist.cpu().numpy()
+    for i in range(nq):
+        c = int(cnt[i])
+        assert np.array_equal(gi[i, :c], want[0][i, :c]) and np.array_equal(gd[i, :c].view(np.uint32), want[1][i, :c].view(np.uint32))
+
+
+def test_cost_model_keeps_the_second_chance_for_large_tables_and_full_chunks():
+    # 2.2M rows, 64 queries inside a tight cluster: here one more MFMA sweep for the chunk is cheaper than 64 exhaustive
+    # passes, and it succeeds -- the default policy must still take it (PB_OPT_SECOND_CHANCE = 0)
+    rng = np.random.default_rng(97)
+    n = 2200000
+    rows, centre, where = _tight_cluster_table(rng, n, 9000)
+    ids = np.arange(n, dtype=np.int64) + 1
+    q = rows[where[:64]].copy()
+    ix = make_index(rows, ids, path=MULTI)
+    got = ix.search(q, 100, 1e3)
+    st = ix.stats()
+    assert st.second_chance >= 32 and st.queries == 64 == st.fast_path + st.second_chance + st.fallback
+    ix2 = make_index(rows, ids, path=MULTI)
+    ix2.set_option(capi.PB_OPT_SECOND_CHANCE, 2)
+    want = ix2.search(q, 100, 1e3)
+    assert ix2.stats().second_chance == 0
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    check_against_oracle(ix, rows, ids, q[:2])
+
+
 def test_second_chance_in_a_burst_and_list_overflow():
     rng = np.random.default_rng(73)
     n = 262144 + 3
