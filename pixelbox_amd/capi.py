@@ -246,6 +246,23 @@ class Index:
                                      _p(dist, C.c_float), _p(cnt, C.c_uint32)))
         return ids, dist, cnt
 
+    def prepared_search(self, queries, k: int = 100, max_dist: float = 1e3):
+        """-> (call, ids, dist, count): `call()` is the bare pb_index_search C call on pre-converted arguments, writing into
+        the returned arrays -- for timing the library call itself (what a compiled host pays), without this wrapper's
+        array allocations and pointer conversions."""
+        q = np.ascontiguousarray(queries, dtype=np.uint8).reshape(-1, self.dim)
+        nq = q.shape[0]
+        ids = np.zeros((nq, k), dtype=np.int64)
+        dist = np.zeros((nq, k), dtype=np.float32)
+        cnt = np.zeros(nq, dtype=np.uint32)
+        fn, h = lib().pb_index_search, self._h
+        args = (h, _p(q, C.c_uint8), nq, k, C.c_double(float(max_dist)), _p(ids, C.c_int64), _p(dist, C.c_float), _p(cnt, C.c_uint32))
+
+        def call(_keep=(q,)):
+            _check(fn(*args))
+
+        return call, ids, dist, cnt
+
     def search_one(self, query, k: int = 100, max_dist: float = 1e3):
         ids, dist, cnt = self.search(np.asarray(query).reshape(1, -1), k, max_dist)
         return ids[0, : cnt[0]].copy(), dist[0, : cnt[0]].copy()

@@ -4,6 +4,7 @@
 //
 // Reference: src/engine.rs:48,109 (table), :228-259 (insert), :363-396 (query), :572-588 (distance).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <limits>
 #include <mutex>
@@ -102,6 +103,10 @@ struct pb_index {
     int64_t *h_res_ids = nullptr;
     float *h_res_dist = nullptr;
     ResultHdr *h_res_hdr = nullptr;
+    uint32_t *h_done = nullptr;     // pinned: completion stamp of a one-query call, written last by k_select_rescore and polled by the host
+    uint32_t done_seq = 0;
+    bool poll_pending = false;      // the select launch of this call carries a stamp
+    bool env_no_poll = false;       // PB_NO_POLL: wait for the stream instead (comparison)
 
     bool env_static_tail = false;      // PB_STATIC_TAIL: the one-query filter launch without the ticketed tail (comparison)
     bool env_exact_lane_rows = false;  // PB_EXACT_LANE_ROWS: the lane-per-row exhaustive kernel also for 256-byte cosine rows (comparison)
@@ -162,6 +167,8 @@ int alloc_workspace(pb_index *ix) {
     PB_HIP(hipHostMalloc(&ix->h_res_ids, (size_t)PIPE_Q * PB_MAX_K * sizeof(int64_t), hipHostMallocDefault));
     PB_HIP(hipHostMalloc(&ix->h_res_dist, (size_t)PIPE_Q * PB_MAX_K * sizeof(float), hipHostMallocDefault));
     PB_HIP(hipHostMalloc(&ix->h_res_hdr, PIPE_Q * sizeof(ResultHdr), hipHostMallocDefault));
+    PB_HIP(hipHostMalloc(&ix->h_done, 64, hipHostMallocDefault));
+    memset(ix->h_done, 0, 64);
     return PB_OK;
 }
 
@@ -203,6 +210,7 @@ void free_all(pb_index *ix) {
     if (ix->h_res_ids) (void)hipHostFree(ix->h_res_ids);
     if (ix->h_res_dist) (void)hipHostFree(ix->h_res_dist);
     if (ix->h_res_hdr) (void)hipHostFree(ix->h_res_hdr);
+    if (ix->h_done) (void)hipHostFree(ix->h_done);
     if (ix->ev0) (void)hipEventDestroy(ix->ev0);
     if (ix->ev1) (void)hipEventDestroy(ix->ev1);
     if (ix->own_stream) (void)hipStreamDestroy(ix->own_stream);
@@ -445,7 +453,8 @@ int run_fast(pb_index *ix, uint32_t nq) {
     if (ix->opt_profile) PB_HIP(hipEventRecord(ix->ev1, ix->stream));
     hipLaunchKernelGGL(k_select_rescore, dim3(nq), dim3(SEL_BLOCK), 0, ix->stream, ix->d_rows, ix->d_ids, ix->d_norms,
                        (int)ix->dim, ix->d_queries, ix->d_qp, ix->d_lut, ix->d_lists, ix->d_hdrs, n_wg, ix->r_ids,
-                       ix->r_dist, ix->r_hdr, (uint32_t)PB_MAX_K, dyn ? ix->d_tail : nullptr);
+                       ix->r_dist, ix->r_hdr, (uint32_t)PB_MAX_K, dyn ? ix->d_tail : nullptr,
+                       ix->poll_pending ? ix->h_done : nullptr, ix->done_seq);
     PB_HIP(hipGetLastError());
     return PB_OK;
 }
@@ -769,6 +778,19 @@ int search_chunk(pb_index *ix, uint32_t cq, uint32_t k, double max_dist, const f
     ix->r_hdr = host_out ? ix->h_res_hdr : ix->d_res_hdr;
     auto wait_headers = [&]() -> int {
         if (!host_out) PB_HIP(hipMemcpyAsync(ix->h_res_hdr, ix->d_res_hdr, cq * sizeof(ResultHdr), hipMemcpyDeviceToHost, ix->stream));
+        if (ix->poll_pending) {
+            // one-query call: k_select_rescore stamps h_done after its results have reached host memory; seeing the stamp
+            // spares the end-of-kernel and stream-wait latency (the stream drains behind the caller's back; everything
+            // queued later is ordered after it).  A stamp that does not come within 20 ms falls back to the stream wait.
+            ix->poll_pending = false;
+            const uint32_t want = ix->done_seq;
+            const auto t0 = std::chrono::steady_clock::now();
+            for (uint32_t spins = 0;; ++spins) {
+                if (__atomic_load_n(&ix->h_done[0], __ATOMIC_ACQUIRE) == want) return PB_OK;
+                __builtin_ia32_pause();
+                if ((spins & 4095u) == 4095u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+            }
+        }
         PB_HIP(hipStreamSynchronize(ix->stream));
         return PB_OK;
     };
@@ -787,6 +809,10 @@ int search_chunk(pb_index *ix, uint32_t cq, uint32_t k, double max_dist, const f
         ix->argq.p = hp[0];
         memcpy(ix->argq.q, hq, 256);
         ix->argq_pending = true;
+        if (host_out && !ix->env_no_poll) {  // results go straight to pinned host memory: completion by stamp
+            ix->poll_pending = true;
+            if (++ix->done_seq == 0) ix->done_seq = 1;
+        }
     } else if (cq == 1) {
         // other single-query shapes: a one-wave staging kernel instead of two host-to-device copy commands
         QArg a;
@@ -1219,6 +1245,7 @@ int pb_index_create(pb_index **out, int device, uint32_t dim, uint64_t capacity_
     ix->env_trace_cert = getenv("PB_TRACE_CERT") != nullptr;
     ix->env_exact_lane_rows = getenv("PB_EXACT_LANE_ROWS") != nullptr;
     ix->env_static_tail = getenv("PB_STATIC_TAIL") != nullptr;
+    ix->env_no_poll = getenv("PB_NO_POLL") != nullptr;
     make_lut(ix->lut);
     auto body = [&]() -> int {
         hipDeviceProp_t prop;

@@ -705,7 +705,7 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
     int d, const uint8_t *__restrict__ queries, const QParams *__restrict__ qp,
     const float *__restrict__ lut, const uint64_t *__restrict__ lists, const ListHdr *__restrict__ hdrs,
     int n_lists, int64_t *__restrict__ out_ids, float *__restrict__ out_dist, ResultHdr *__restrict__ out_hdr,
-    uint32_t out_stride, uint32_t *tail_ctr = nullptr) {
+    uint32_t out_stride, uint32_t *tail_ctr = nullptr, uint32_t *done_flag = nullptr, uint32_t done_seq = 0) {
     // the filter launch before this one handed out its tail through these counters (k_scan_filter DYN): clear them
     if (tail_ctr && blockIdx.x == 0 && threadIdx.x < DYN_REGIONS) tail_ctr[threadIdx.x * DYN_CTR_STRIDE] = 0u;
     __shared__ float s_lut[256];
@@ -881,6 +881,9 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
     //      unexamined row could reach
     for (int off = 32; off >= 1; off >>= 1) ck = fminf(ck, __shfl_xor(ck, off));
     if ((tid & 63) == 0) s_ck[tid >> 6] = ck;
+    // done_flag (one-query calls): the host polls a word in pinned memory instead of waiting for the stream, so the
+    // result stores above must be visible there before the flag is: system-scope fence on every storing thread
+    if (done_flag) __threadfence_system();
     __syncthreads();
     if (tid == 0) {
         ck = 3.0f;
@@ -900,6 +903,10 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
         h.o_max = o_max;
         h.ck = n_out == P.k ? ck : -1.0f;
         out_hdr[q] = h;
+        if (done_flag) {
+            __threadfence_system();
+            __hip_atomic_store(&done_flag[q], done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 

@@ -35,6 +35,15 @@ def run():
         wall.append((time.perf_counter() - t0) * 1e3)
     wall.sort()
     print(f"rows {rows}: one-query call wall ms: median {wall[len(wall) // 2]:.4f} min {wall[0]:.4f} p90 {wall[int(len(wall) * 0.9)]:.4f}")
+    # the C call alone (arguments converted beforehand: what a compiled host pays)
+    bare = []
+    for i in range(n):
+        call, ids, dist, cnt = ix.prepared_search(q[i:i + 1], 100, 1e3)
+        t0 = time.perf_counter()
+        call()
+        bare.append((time.perf_counter() - t0) * 1e3)
+    bare.sort()
+    print(f"rows {rows}: bare pb_index_search call ms: median {bare[len(bare) // 2]:.4f} min {bare[0]:.4f} p90 {bare[int(len(bare) * 0.9)]:.4f}")
     st = ix.stats()
     print(f"certified {st.fast_path} of {st.queries}")
 
