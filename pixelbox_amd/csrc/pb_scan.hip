@@ -107,6 +107,7 @@ struct pb_index {
     uint32_t done_seq = 0;
     bool poll_pending = false;      // the select launch of this call carries a stamp
     bool env_no_poll = false;       // PB_NO_POLL: wait for the stream instead (comparison)
+    bool env_loop_static = false;   // PB_LOOP_STATIC: the looped filter launch with fixed tile strides per wave (comparison)
 
     bool env_static_tail = false;      // PB_STATIC_TAIL: the one-query filter launch without the ticketed tail (comparison)
     bool env_exact_lane_rows = false;  // PB_EXACT_LANE_ROWS: the lane-per-row exhaustive kernel also for 256-byte cosine rows (comparison)
@@ -348,11 +349,11 @@ void launch_filter_t(pb_index *ix, int n_wg, uint32_t q_base, uint32_t nq) {
                        (QParams *)nullptr, QArg256{});
 }
 // one launch, every workgroup answers the nq queries one after the other (k_scan_filter LOOPQ)
-template <int NW, int U = 8, int MAPB = 0>
+template <int NW, int U = 8, int MAPB = 0, bool WGT = false>
 void launch_filter_loop(pb_index *ix, int n_wg, uint32_t q_base, uint32_t nq) {
-    hipLaunchKernelGGL((k_scan_filter<16, U, true, NW, MAPB, true>), dim3(n_wg, 1), dim3(NW * 64), 0, ix->stream, ix->d_rows,
-                       ix->n_rows, ix->d_queries, ix->d_qp, ix->d_lists, ix->d_hdrs, (int)q_base, (int)nq, (uint8_t *)nullptr,
-                       (QParams *)nullptr, QArg256{});
+    hipLaunchKernelGGL((k_scan_filter<16, U, true, NW, MAPB, true, false, false, WGT>), dim3(n_wg, 1), dim3(NW * 64), 0, ix->stream,
+                       ix->d_rows, ix->n_rows, ix->d_queries, ix->d_qp, ix->d_lists, ix->d_hdrs, (int)q_base, (int)nq,
+                       (uint8_t *)nullptr, (QParams *)nullptr, QArg256{});
 }
 
 int filter_u(const pb_index *ix) {
@@ -439,7 +440,8 @@ int run_fast(pb_index *ix, uint32_t nq) {
         else if (v == 2) launch_filter_loop<8, 16, 0>(ix, n_wg, 0, nq);
         else if (v == 4) launch_filter_loop<8, 4, 0>(ix, n_wg, 0, nq);
         else if (ix->opt_waves == 4) launch_filter_loop<4>(ix, n_wg, 0, nq);
-        else launch_filter_loop<8>(ix, n_wg, 0, nq);
+        else if (ix->env_loop_static) launch_filter_loop<8>(ix, n_wg, 0, nq);
+        else launch_filter_loop<8, 8, 0, true>(ix, n_wg, 0, nq);
         PB_HIP(hipGetLastError());
     } else if (ix->opt_mode == 0 || ix->opt_mode == 2) {
         for (uint32_t q = 0; q < nq; ++q) {
@@ -1246,6 +1248,7 @@ int pb_index_create(pb_index **out, int device, uint32_t dim, uint64_t capacity_
     ix->env_exact_lane_rows = getenv("PB_EXACT_LANE_ROWS") != nullptr;
     ix->env_static_tail = getenv("PB_STATIC_TAIL") != nullptr;
     ix->env_no_poll = getenv("PB_NO_POLL") != nullptr;
+    ix->env_loop_static = getenv("PB_LOOP_STATIC") != nullptr;
     make_lut(ix->lut);
     auto body = [&]() -> int {
         hipDeviceProp_t prop;

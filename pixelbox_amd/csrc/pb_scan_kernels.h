@@ -331,7 +331,13 @@ constexpr int DYN_DEN = PB_DYN_DEN;  // k_scan_filter DYN: 1/DYN_DEN of the tabl
 constexpr int DYN_CH = PB_DYN_CH;    // super-tiles per ticket
 constexpr int DYN_REGIONS = 32;     // ticket counters
 constexpr int DYN_CTR_STRIDE = 64;  // uint32 between counters (256 B: different L2 channels)
-template <int LPR, int U = 8, bool NT = true, int NW = F_WAVES, int MAPB = 0, bool LOOPQ = false, bool ARGQ = false, bool DYN = false>
+// WGT (with LOOPQ): the waves of a workgroup take the workgroup's super-tiles by tickets from an LDS counter instead of
+// fixed strides, and the per-wave buffers are double-buffered by query parity.  The workgroup list of query i is merged
+// by wave 0 AFTER the barrier that ends query i while the other waves are already streaming query i + 1 -- wave 0 simply
+// takes fewer tickets of that query -- so the merge (and the second barrier that protected the buffers) leaves the
+// critical path: it is ~1 % of a pass over 10M rows but ~5 % of one over a 1.25M-row shard (8-GPU strong scaling).
+template <int LPR, int U = 8, bool NT = true, int NW = F_WAVES, int MAPB = 0, bool LOOPQ = false, bool ARGQ = false, bool DYN = false,
+          bool WGT = false>
 __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__restrict__ rows, uint64_t n_rows,
                                                          const uint8_t *queries, const QParams *qp,
                                                          uint64_t *__restrict__ lists,
@@ -340,23 +346,33 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
                                                          uint32_t *tail_ctr = nullptr) {
     static_assert(!ARGQ || (LPR == 16 && !LOOPQ), "ARGQ: one 256-byte query per launch");
     static_assert(!DYN || (ARGQ && MAPB == 0), "DYN: the one-query launch only");
+    static_assert(!WGT || (LOOPQ && MAPB == 0), "WGT: the looped launch only");
     constexpr int D = LPR * 16;
     constexpr int RPT = WAVE / LPR;                // rows per wave-instruction
     // U = loads in flight per lane (U KiB per wave); NT = non-temporal loads (the table is streamed once per query)
     constexpr int ROWS_IT = U * RPT;               // rows per wave-iteration
     constexpr int ROUNDS = (U + LPR - 1) / LPR;    // evaluation rounds (one row per lane each)
-    __shared__ uint64_t s_buf[NW][F_CAPW];
-    __shared__ int s_cnt[NW];
-    __shared__ float s_drop[NW];
+    constexpr int NPAR = WGT ? 2 : 1;
+    __shared__ uint64_t s_buf[NPAR][NW][F_CAPW];
+    __shared__ int s_cnt[NPAR][NW];
+    __shared__ float s_drop[NPAR][NW];
+    __shared__ uint32_t s_ticket[2];
 
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: loop bounds and LDS bases stay in SGPRs
     const int sub = lane % LPR;
     const int g = lane / LPR;
-    uint64_t *buf = s_buf[wave];
     constexpr int ME = NW * F_KW / WAVE;  // entries per lane (workgroup merge)
     __shared__ uint64_t s_merge[NW * F_KW];
+    if constexpr (WGT) {
+        if (threadIdx.x < 2) s_ticket[threadIdx.x] = 0u;
+        __syncthreads();
+    }
   for (int qi = 0; qi < (LOOPQ ? nq_loop : 1); ++qi) {
+    const int par = WGT ? (qi & 1) : 0;
+    uint64_t *buf = s_buf[par][wave];
+    // the other parity's counter served query qi - 1 (every wave is past that query's barrier) and serves qi + 1
+    if (WGT && threadIdx.x == 0) s_ticket[par ^ 1] = 0u;
     const int q = q_base + (LOOPQ ? qi : (int)blockIdx.y);
     QParams P;
     uint4 qv;
@@ -427,7 +443,15 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
             s = next_dyn();
         }
     }
+    uint32_t wg_pend = 0;
+    if constexpr (WGT) {
+        if (lane == 0) wg_pend = atomicAdd(&s_ticket[par], 1u);
+        s = (uint64_t)__builtin_amdgcn_readfirstlane(wg_pend) * gridDim.x + blockIdx.x;
+    }
     for (; DYN ? (s != ~0ull) : (s < n_super);) {
+        if constexpr (WGT) {
+            if (lane == 0) wg_pend = atomicAdd(&s_ticket[par], 1u);  // the next ticket, requested ahead of this tile's loads
+        }
         const uint64_t row0 = s * ROWS_IT;
         uint4 b[U];
 #pragma unroll
@@ -488,6 +512,8 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
             } else {
                 s = next_dyn();
             }
+        } else if constexpr (WGT) {
+            s = (uint64_t)__builtin_amdgcn_readfirstlane(wg_pend) * gridDim.x + blockIdx.x;
         } else {
             s += stride;
         }
@@ -498,8 +524,8 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
         dropped = filter_key_cos(kth);
     }
     if (lane == 0) {
-        s_cnt[wave] = cnt;
-        s_drop[wave] = dropped;
+        s_cnt[par][wave] = cnt;
+        s_drop[par][wave] = dropped;
     }
     __syncthreads();
     if (wave == 0) {
@@ -507,10 +533,10 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
         int total = 0;
         float drop = 0.0f;
         for (int w = 0; w < NW; ++w) {
-            const int c = s_cnt[w];
-            if (lane < c) s_merge[total + lane] = s_buf[w][lane];
+            const int c = s_cnt[par][w];
+            if (lane < c) s_merge[total + lane] = s_buf[par][w][lane];
             total += c;
-            drop = fmaxf(drop, s_drop[w]);
+            drop = fmaxf(drop, s_drop[par][w]);
         }
         if (total > F_KWG) {
             const uint64_t kth = wave_keep_smallest<ME>(s_merge, total, F_KWG);
@@ -533,7 +559,7 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
             hdrs[(size_t)q * gridDim.x + blockIdx.x] = h;
         }
     }
-    if constexpr (LOOPQ) __syncthreads();  // the wave buffers are reused by the next query
+    if constexpr (LOOPQ && !WGT) __syncthreads();  // the wave buffers are reused by the next query (WGT: the other parity's are)
   }
 }
 
