@@ -417,8 +417,19 @@ bool loop_mode(const pb_index *ix, uint32_t nq) {
 
 // fast path for nq staged queries; results + status land in d_res_*
 int run_fast(pb_index *ix, uint32_t nq) {
-    const int n_wg = filter_grid(ix);
+    int n_wg = filter_grid(ix);
     bool dyn = false;
+    // A table that (nearly) fits the 256 MiB Infinity Cache -- a 1.25M-row shard of the 8-GPU split is 320 MB -- is not an
+    // HBM stream any more: more loads in flight pay there.  Looped launch, nothing tuned by the caller: 16 loads per lane
+    // and two workgroups per CU (profiles/loop_ticket_probe.py: 6.29 -> 6.79 TB/s at 1.25M rows, 5.67 -> 6.59 at 625k; from
+    // 2.5M rows on the default shape wins, 6.84 vs 6.58)
+    const bool default_shape = ix->opt_variant == 0 && ix->opt_waves == F_WAVES && ix->opt_wg_per_cu == 1 && ix->opt_grid == 0;
+    const bool cache_sized = default_shape && !ix->argq_pending && loop_mode(ix, nq) && !ix->env_loop_static &&
+                             ix->n_rows * (uint64_t)ix->dim <= (400ull << 20);
+    if (cache_sized) {
+        const uint64_t n_super = (ix->n_rows + 63) / 64, want = (n_super + F_WAVES - 1) / F_WAVES;
+        n_wg = (int)std::max<uint64_t>(1, std::min<uint64_t>(want, std::min<uint64_t>(F_MAX_WG, 2ull * ix->n_cu)));
+    }
     if (ix->opt_profile) PB_HIP(hipEventRecord(ix->ev0, ix->stream));
     if (ix->argq_pending) {
         // one 256-byte query, default launch shape: the query rides in the kernel arguments (k_scan_filter ARGQ)
@@ -434,12 +445,15 @@ int run_fast(pb_index *ix, uint32_t nq) {
             dyn = true;
         }
         PB_HIP(hipGetLastError());
+    } else if (cache_sized) {
+        launch_filter_loop<8, 16, 0, true>(ix, n_wg, 0, nq);
+        PB_HIP(hipGetLastError());
     } else if (loop_mode(ix, nq)) {
         const int v = ix->opt_variant & 15;
         if (v == 8) launch_filter_loop<8, 8, 1>(ix, n_wg, 0, nq);
-        else if (v == 2) launch_filter_loop<8, 16, 0>(ix, n_wg, 0, nq);
-        else if (v == 4) launch_filter_loop<8, 4, 0>(ix, n_wg, 0, nq);
-        else if (ix->opt_waves == 4) launch_filter_loop<4>(ix, n_wg, 0, nq);
+        else if (v == 2) launch_filter_loop<8, 16, 0, true>(ix, n_wg, 0, nq);
+        else if (v == 4) launch_filter_loop<8, 4, 0, true>(ix, n_wg, 0, nq);
+        else if (ix->opt_waves == 4) launch_filter_loop<4, 8, 0, true>(ix, n_wg, 0, nq);
         else if (ix->env_loop_static) launch_filter_loop<8>(ix, n_wg, 0, nq);
         else launch_filter_loop<8, 8, 0, true>(ix, n_wg, 0, nq);
         PB_HIP(hipGetLastError());
