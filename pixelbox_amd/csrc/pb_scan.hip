@@ -848,7 +848,10 @@ int search_chunk(pb_index *ix, uint32_t cq, uint32_t k, double max_dist, const f
     const bool use_multi = use_fast && multi_eligible(ix, cq);
     if (use_fast) {
         int rc = use_dist ? run_fast_dist(ix, cq) : (use_multi ? run_multi(ix, cq, k) : run_fast(ix, cq));
-        if (rc) return rc;
+        if (rc) {
+            ix->poll_pending = ix->argq_pending = false;  // nothing was launched that would stamp / consume them
+            return rc;
+        }
         { int rcw = wait_headers(); if (rcw) return rcw; }
         if (ix->opt_profile) {
             int rc2 = use_multi ? account_profile(ix, 1, 1) : account_profile(ix, cq, (ix->opt_mode == 1 || loop_mode(ix, cq) || (use_dist && ix->opt_mode == 2)) ? 1 : cq);
