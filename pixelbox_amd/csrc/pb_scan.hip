@@ -110,6 +110,7 @@ struct pb_index {
     bool env_loop_static = false;   // PB_LOOP_STATIC: the looped filter launch with fixed tile strides per wave (comparison)
 
     bool env_static_tail = false;      // PB_STATIC_TAIL: the one-query filter launch without the ticketed tail (comparison)
+    bool env_force_tickets = false;    // PB_FORCE_TAIL_TICKETS: the ticketed tail also under 4M rows (tests)
     bool env_exact_lane_rows = false;  // PB_EXACT_LANE_ROWS: the lane-per-row exhaustive kernel also for 256-byte cosine rows (comparison)
     int opt_second_chance = 0;         // PB_OPT_SECOND_CHANCE: 0 = cost model, 1 = always, 2 = never
     float sc_success = 1.0f;           // running success rate of the second chance on this index (optimistic start)
@@ -434,7 +435,12 @@ int run_fast(pb_index *ix, uint32_t nq) {
     if (ix->argq_pending) {
         // one 256-byte query, default launch shape: the query rides in the kernel arguments (k_scan_filter ARGQ)
         ix->argq_pending = false;
-        if (ix->env_static_tail) {
+        // (a one-query launch over a cache-sized table does NOT gain from the looped launch's shape for such tables, with
+        // or without tickets: 55.4 us either way at 1M rows, of which ~19 us do not depend on the table size;
+        // profiles/small_table_probe.py)
+        // the ticketed tail pays from ~4M rows on (10M: -5..8 us per call); on a small table its 4-tile tickets are coarse
+        // against the ~2 tail tiles a wave would take (1M rows: 60.3 us ticketed, 55.8 us with static shares)
+        if (ix->env_static_tail || (ix->n_rows < (4ull << 20) && !ix->env_force_tickets)) {
             hipLaunchKernelGGL((k_scan_filter<16, 8, true, F_WAVES, 0, false, true>), dim3(n_wg, 1), dim3(F_WAVES * 64), 0,
                                ix->stream, ix->d_rows, ix->n_rows, ix->d_queries, ix->d_qp, ix->d_lists, ix->d_hdrs, 0, 1,
                                ix->d_queries, ix->d_qp, ix->argq, nullptr);
@@ -1264,6 +1270,7 @@ int pb_index_create(pb_index **out, int device, uint32_t dim, uint64_t capacity_
     ix->env_trace_cert = getenv("PB_TRACE_CERT") != nullptr;
     ix->env_exact_lane_rows = getenv("PB_EXACT_LANE_ROWS") != nullptr;
     ix->env_static_tail = getenv("PB_STATIC_TAIL") != nullptr;
+    ix->env_force_tickets = getenv("PB_FORCE_TAIL_TICKETS") != nullptr;
     ix->env_no_poll = getenv("PB_NO_POLL") != nullptr;
     ix->env_loop_static = getenv("PB_LOOP_STATIC") != nullptr;
     make_lut(ix->lut);

@@ -406,7 +406,7 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
     uint64_t s = first;
     uint64_t n_static = n_super, dyn_lo = 0, dyn_hi = 0, dyn_cur = 0;
     uint32_t dyn_left = 0, dyn_pend = 0;
-    bool dyn_on = false, dyn_done = false;
+    bool dyn_on = false, dyn_done = false, dyn_req = false;
     uint32_t *dyn_ctr = nullptr;
     if constexpr (DYN) {
         n_static = (n_super - n_super / DYN_DEN) / stride * stride;
@@ -417,7 +417,12 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
         dyn_lo = n_static + (uint64_t)reg * per_reg;
         dyn_hi = dyn_lo + per_reg < n_super ? dyn_lo + per_reg : n_super;
         dyn_ctr = tail_ctr + reg * DYN_CTR_STRIDE;
-        if (lane == 0) dyn_pend = atomicAdd(dyn_ctr, 1u);
+        // the first ticket is requested when the wave has ONE static tile left (below), not here: 2 048 waves asking 32
+        // counters at kernel start queue up for ~4.5 us, which a pass over a small table never earns back
+        if (s >= n_static || s + stride >= n_static) {
+            if (lane == 0) dyn_pend = atomicAdd(dyn_ctr, 1u);
+            dyn_req = true;
+        }
     }
     auto next_dyn = [&]() -> uint64_t {
         if (dyn_left) {
@@ -505,6 +510,10 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
         if constexpr (DYN) {
             if (!dyn_on) {
                 s += stride;
+                if (!dyn_req && s + stride >= n_static) {  // the tile about to be loaded is the last static one (or past it)
+                    if (lane == 0) dyn_pend = atomicAdd(dyn_ctr, 1u);
+                    dyn_req = true;
+                }
                 if (s >= n_static) {
                     dyn_on = true;
                     s = next_dyn();

@@ -117,9 +117,12 @@ def test_one_query_calls_hand_out_the_table_tail_by_tickets(n, monkeypatch):
     for j, r in enumerate(spots):
         rows[r] = q
         rows[r, j % 256] ^= np.uint8(1 + j % 7)
+    monkeypatch.setenv("PB_FORCE_TAIL_TICKETS", "1")  # tables under 4M rows take static shares by default
     ix = make_index(rows, ids)
     for _ in range(3):
         check_against_oracle(ix, rows, ids, q[None, :])
+    monkeypatch.delenv("PB_FORCE_TAIL_TICKETS")
+    check_against_oracle(make_index(rows, ids), rows, ids, q[None, :])  # the default for this size
     monkeypatch.setenv("PB_STATIC_TAIL", "1")
     check_against_oracle(make_index(rows, ids), rows, ids, q[None, :])
 
