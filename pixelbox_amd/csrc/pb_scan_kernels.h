@@ -1867,8 +1867,8 @@ __global__ __launch_bounds__(NWQ * WAVE) void k_scan_multi_wg(
     constexpr int QCAP = 1024;         // survivor queue entries
     static_assert(TR % 32 == 0 && TR <= NWQ * WAVE, "step shape");
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[2][TR * MQ_LDROW];
-    __shared__ __attribute__((aligned(16))) float s_iw[2][TR];  // 4 / W
-    __shared__ __attribute__((aligned(16))) float s_c2[2][TR];  // (cr - 4 * 12582912) / W
+    __shared__ float s_iw4[2][TR / 4];  // per group of 4 rows: 4 / min W
+    __shared__ float s_c24[2][TR / 4];  // (max cr - 4 * 12582912) / min W
     __shared__ i32x4 s_qacc[QCAP];  // survivor queue: accumulator quad, query, first row of the quad
     __shared__ uint32_t s_qq[QCAP], s_qrow[QCAP];
     __shared__ uint32_t s_qcnt;
@@ -1921,11 +1921,24 @@ __global__ __launch_bounds__(NWQ * WAVE) void k_scan_multi_wg(
             v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u;
             *reinterpret_cast<u32x4 *>(&s_tile[buf][(ld_row + j * 4 * NWQ) * MQ_LDROW + ld_col]) = v;
         }
-        if (tid < TR) {
+        if (tid < TR) {  // TR is a multiple of 64: whole waves
+            // the 4 rows a lane tests together (one accumulator quad) share ONE pair of factors: the smallest W and the
+            // largest cr of the group bound every row's t from above, (4 acc' + cr_r) / W_r <= (4 max acc' + max cr) / min W
+            // when the numerator is >= 0 (a negative one fails the test either way)
             const bool ok = stp * TR + (uint64_t)tid < n_rows;  // rows past the end can never pass
-            const double w = (double)(__builtin_amdgcn_sqrtf((float)db) * (1.0f - 1e-6f));
-            s_iw[buf][tid] = ok ? (float)(4.0 / w) : 0.0f;
-            s_c2[buf][tid] = ok ? (float)(((double)(2 * sb - 511 * D) - 50331648.0) / w) : -3.0e38f;
+            float w = ok ? __builtin_amdgcn_sqrtf((float)db) * (1.0f - 1e-6f) : 3.0e38f;
+            int cr = ok ? 2 * sb - 511 * D : -0x40000000;
+            w = fminf(w, __shfl_xor(w, 1));
+            w = fminf(w, __shfl_xor(w, 2));
+            const int c1 = __shfl_xor(cr, 1);
+            cr = cr > c1 ? cr : c1;
+            const int c2 = __shfl_xor(cr, 2);
+            cr = cr > c2 ? cr : c2;
+            if ((tid & 3) == 0) {
+                const bool any_ok = w < 1.0e38f;
+                s_iw4[buf][tid >> 2] = any_ok ? (float)(4.0 / (double)w) : 0.0f;
+                s_c24[buf][tid >> 2] = any_ok ? (float)(((double)cr - 50331648.0) / (double)w) : -3.0e38f;
+            }
         }
     };
     // exact integer re-test of one queued (row, query) and append to the query's candidate list
@@ -1941,36 +1954,48 @@ __global__ __launch_bounds__(NWQ * WAVE) void k_scan_multi_wg(
     auto mfma_tile = [&](const uint8_t *tile, i32x4 (&acc)[QT]) __attribute__((always_inline)) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
+#if defined(PB_MQ_ABL) && PB_MQ_ABL == 3  // ablation 3: no tests AND no LDS operand reads (a resident register instead)
+            const i32x4 a = bq[0][s];
+#else
             const i32x4 a = *reinterpret_cast<const i32x4 *>(tile + li * MQ_LDROW + 64 * s + 16 * kq);
+#endif
 #pragma unroll
-            for (int qt = 0; qt < QT; ++qt)
+            for (int qt = 0; qt < QT; ++qt) {
+#if defined(PB_MQ_ABL) && PB_MQ_ABL == 2  // ablation 2: no MFMAs (the operand reads stay)
+                acc[qt] = s == 0 ? cinit[qt] : (i32x4){acc[qt][0] + a[0], acc[qt][1], acc[qt][2], acc[qt][3]};
+#else
                 acc[qt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bq[qt][s], s == 0 ? cinit[qt] : acc[qt], 0, 0, 0);
+#endif
+            }
         }
     };
     auto test_tile = [&](const i32x4 (&acc)[QT], int buf, int tl, uint64_t stp) __attribute__((always_inline)) {
         // lane holds rows rbase + r (r = 0..3) of query column li
         const int rl = 16 * tl + 4 * kq;
-        const f32x4_t iw = *reinterpret_cast<const f32x4_t *>(&s_iw[buf][rl]);
-        const f32x4_t c2 = *reinterpret_cast<const f32x4_t *>(&s_c2[buf][rl]);
-        float t[QT][4], dq[QT];
+        const float iw = s_iw4[buf][rl >> 2], c2 = s_c24[buf][rl >> 2];
+        float dq[QT];
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) t[qt][r] = fma_plain(__int_as_float(acc[qt][r]), iw[r], c2[r]);
-            dq[qt] = max3_plain(max3_plain(t[qt][0], t[qt][1], t[qt][2]), t[qt][3], -3.0e38f) - gthr[qt];
+            // the accumulators read as floats are 12582912 + acc' (positive): their float order is their integer order, so
+            // the largest of the quad's four rows is picked first and tested ONCE with the group's factors
+            const float m = max3_plain(max3_plain(__int_as_float(acc[qt][0]), __int_as_float(acc[qt][1]), __int_as_float(acc[qt][2])),
+                                       __int_as_float(acc[qt][3]), 0.0f);
+            dq[qt] = fma_plain(m, iw, c2);
         }
-        const float any = max3_plain(max3_plain(dq[0], dq[1], dq[2]), dq[3], -1.0f);
+        // four compares whose masks are OR-ed on the scalar side (no subtractions, no max over the four)
+        const bool hit[QT] = {dq[0] >= gthr[0], dq[1] >= gthr[1], dq[2] >= gthr[2], dq[3] >= gthr[3]};
+        const bool any = hit[0] | hit[1] | hit[2] | hit[3];
         // ONE rarely-taken branch per tile.  It only QUEUES the lane's accumulator quad (4 rows of one query) in
         // LDS, in a handful of instructions: with 8 waves meeting at a barrier every step, and some wave of a
         // step's 64 wave-tiles nearly always holding a survivor, whatever this branch costs is paid by the whole
         // workgroup on almost every step.  The exact re-test (which also discards the quad's non-survivors: it
         // implies the test above) and the append to the candidate lists happen in drain().
-        if (any >= 0.0f) {
+        if (any) {
             const uint32_t row0 = (uint32_t)(stp * TR) + (uint32_t)rl;
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
                 const int q = qbase + qt * 16 + li;
-                if (dq[qt] >= 0.0f && q < n_q) {
+                if (hit[qt] && q < n_q) {
                     const uint32_t slot = atomicAdd(&s_qcnt, 1u);
                     if (slot < (uint32_t)QCAP) {
                         s_qacc[slot] = acc[qt];
@@ -2018,9 +2043,17 @@ __global__ __launch_bounds__(NWQ * WAVE) void k_scan_multi_wg(
 #pragma nounroll
             for (int tp = 0; tp < NT / 2; ++tp) {
                 mfma_tile(&s_tile[buf][(16 * (2 * tp + 1)) * MQ_LDROW], acc1);
+#if !defined(PB_MQ_ABL) || (PB_MQ_ABL != 1 && PB_MQ_ABL != 3)  // ablation 1 / 3: no survivor tests (timing only: nothing is collected)
                 test_tile(acc0, buf, 2 * tp, stp);
+#else
+                if ((acc0[0][0] ^ acc0[1][1] ^ acc0[2][2] ^ acc0[3][3]) == 0x7fffffff) s_qcnt = 1;
+#endif
                 if (tp + 1 < NT / 2) mfma_tile(&s_tile[buf][(16 * (2 * tp + 2)) * MQ_LDROW], acc0);
+#if !defined(PB_MQ_ABL) || (PB_MQ_ABL != 1 && PB_MQ_ABL != 3)
                 test_tile(acc1, buf, 2 * tp + 1, stp);
+#else
+                if ((acc1[0][0] ^ acc1[1][1] ^ acc1[2][2] ^ acc1[3][3]) == 0x7fffffff) s_qcnt = 1;
+#endif
             }
         } else if (s2 < n_steps) {
             issue(s2, ld_far, sb_far, db_far);
