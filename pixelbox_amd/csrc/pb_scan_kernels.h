@@ -1935,9 +1935,13 @@ __global__ __launch_bounds__(NWQ * WAVE) void k_scan_multi_wg(
             const int c2 = __shfl_xor(cr, 2);
             cr = cr > c2 ? cr : c2;
             if ((tid & 3) == 0) {
+                // correctly rounded f32 quotients (-fno-fast-math): |cr - 4 * 12582912| < 2^26 loses <= 2 units in the
+                // conversion, i.e. <= 2 / W <= 0.125 more in t -- with the 0.125 of the dropped remainder and <= 0.6 of
+                // roundings still inside the "- 1" of the threshold (the f64 divisions this replaces were ~13 % of a step
+                // on the two SIMDs that ran them)
                 const bool any_ok = w < 1.0e38f;
-                s_iw4[buf][tid >> 2] = any_ok ? (float)(4.0 / (double)w) : 0.0f;
-                s_c24[buf][tid >> 2] = any_ok ? (float)(((double)cr - 50331648.0) / (double)w) : -3.0e38f;
+                s_iw4[buf][tid >> 2] = any_ok ? 4.0f / w : 0.0f;
+                s_c24[buf][tid >> 2] = any_ok ? (float)(cr - 50331648) / w : -3.0e38f;
             }
         }
     };
