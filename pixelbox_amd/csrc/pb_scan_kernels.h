@@ -1867,6 +1867,8 @@ __global__ __launch_bounds__(NWQ * WAVE) void k_scan_multi_wg(
     constexpr int QCAP = 1024;         // survivor queue entries
     static_assert(TR % 32 == 0 && TR <= NWQ * WAVE, "step shape");
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[2][TR * MQ_LDROW];
+    __shared__ __attribute__((aligned(16))) float s_iw[2][TR];  // per row: 4 / W
+    __shared__ __attribute__((aligned(16))) float s_c2[2][TR];  // (cr - 4 * 12582912) / W
     __shared__ float s_iw4[2][TR / 4];  // per group of 4 rows: 4 / min W
     __shared__ float s_c24[2][TR / 4];  // (max cr - 4 * 12582912) / min W
     __shared__ i32x4 s_qacc[QCAP];  // survivor queue: accumulator quad, query, first row of the quad
@@ -1928,6 +1930,8 @@ __global__ __launch_bounds__(NWQ * WAVE) void k_scan_multi_wg(
             const bool ok = stp * TR + (uint64_t)tid < n_rows;  // rows past the end can never pass
             float w = ok ? __builtin_amdgcn_sqrtf((float)db) * (1.0f - 1e-6f) : 3.0e38f;
             int cr = ok ? 2 * sb - 511 * D : -0x40000000;
+            s_iw[buf][tid] = ok ? 4.0f / w : 0.0f;  // the row's own factors: the second, per-row stage of the test
+            s_c2[buf][tid] = ok ? (float)(cr - 50331648) / w : -3.0e38f;
             w = fminf(w, __shfl_xor(w, 1));
             w = fminf(w, __shfl_xor(w, 2));
             const int c1 = __shfl_xor(cr, 1);
@@ -1995,11 +1999,23 @@ __global__ __launch_bounds__(NWQ * WAVE) void k_scan_multi_wg(
         // workgroup on almost every step.  The exact re-test (which also discards the quad's non-survivors: it
         // implies the test above) and the append to the candidate lists happen in drain().
         if (any) {
+            // second stage, per row with the row's own factors (what the test was before the group bound): on a table whose
+            // neighbouring rows have very different norms the group bound alone would pass whole quads and flood the queue
             const uint32_t row0 = (uint32_t)(stp * TR) + (uint32_t)rl;
+            const f32x4_t iwr = *reinterpret_cast<const f32x4_t *>(&s_iw[buf][rl]);
+            const f32x4_t c2r = *reinterpret_cast<const f32x4_t *>(&s_c2[buf][rl]);
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
                 const int q = qbase + qt * 16 + li;
-                if (hit[qt] && q < n_q) {
+                bool pass = false;
+#ifdef PB_MQ_NO_STAGE2  // test-of-the-test build: the group bound alone
+                pass = hit[qt];
+#endif
+                if (hit[qt]) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pass = pass || fma_plain(__int_as_float(acc[qt][r]), iwr[r], c2r[r]) >= gthr[qt];
+                }
+                if (pass && q < n_q) {
                     const uint32_t slot = atomicAdd(&s_qcnt, 1u);
                     if (slot < (uint32_t)QCAP) {
                         s_qacc[slot] = acc[qt];

@@ -418,6 +418,31 @@ def test_multi_query_burst_vs_oracle(nq):
     check_against_oracle(ix, rows, ids, q[sel])
 
 
+def test_burst_certifies_on_a_table_whose_neighbouring_rows_have_very_different_norms():
+    # the burst's collect pass first tests a quad of four consecutive rows against the quad's loosest factors (smallest
+    # norm, largest byte sum) and only then row by row: with near-grey and full-range rows interleaved the first stage
+    # alone would pass whole quads, flood the survivor queue and send every query to the exhaustive pass (still the
+    # right answers, at 20x the cost) -- the path counters must say that did not happen
+    rng = np.random.default_rng(613)
+    n, nq = 400_000, 600
+    rows = rng.integers(0, 256, size=(n, 256), dtype=np.uint8)
+    grey = rng.integers(118, 138, size=(n // 2, 256), dtype=np.uint8)
+    rows[1::2] = grey[: len(rows[1::2])]
+    ids = np.arange(n, dtype=np.int64) + 1
+    q = rng.integers(0, 256, size=(nq, 256), dtype=np.uint8)
+    q[::7] = rows[rng.integers(0, n, size=len(q[::7]))]
+    ix = make_index(rows, ids, path=MULTI)
+    got = ix.search(q, 100, 1e3)
+    st = ix.stats()
+    assert st.queries == nq and st.fast_path >= int(0.9 * nq), (st.fast_path, st.second_chance, st.fallback)
+    sel = [0, 7, 14, 300, 599]
+    check_against_oracle(ix, rows, ids, q[sel])
+    ref = make_index(rows, ids, path=EXACT).search(q[sel], 100, 1e3)
+    for j, i in enumerate(sel):
+        c = int(ref[2][j])
+        assert np.array_equal(got[0][i, :c], ref[0][j, :c]) and np.array_equal(got[1][i, :c].view(np.uint32), ref[1][j, :c].view(np.uint32))
+
+
 def test_multi_query_pass_tail_rows_and_auto_switch():
     rng = np.random.default_rng(61)
     n = 65536 + 13  # not a multiple of the 16-row tile
