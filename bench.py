@@ -38,7 +38,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # f32-input MFMA (the parity-safe embed path)
 EMBED_FLOP_PER_IMAGE = 2 * 126_312_448  # SURVEY.md Appendix B, 128x128 -> 256
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -63,11 +63,140 @@ def parse():
     ap.add_argument("--cpu-sample-rows", type=int, default=2_000_000)
     ap.add_argument("--exact-path", action="store_true", help="force the exhaustive exact scan (diagnostic)")
     ap.add_argument("--concurrent-queries", type=int, default=1024, help="size of the concurrent-query burst (0: skip)")
-    return ap.parse_args()
+    ap.add_argument("--in-library-leg", action="store_true",
+                    help="(internal) run only the single-process product form: pb_sharded_* over --gpus devices, RCCL inside the library")
+    return ap.parse_args(argv)
+
+
+def _free_port() -> int:
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _last_json_line(text: str):
+    for line in reversed(text.splitlines()):
+        line = line.strip()
+        if line.startswith("{") and line.endswith("}"):
+            try:
+                return json.loads(line)
+            except ValueError:
+                continue
+    return None
+
+
+def needs_plain_launch(args, environ) -> bool:
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): this process becomes a parent
+    that NEVER touches the GPU and starts the ranks as a child (PIXELBOX_FORCE_SPAWN=1 takes the same route at N = 1, which
+    is how a one-GPU box exercises it)."""
+    if args.in_library_leg or environ.get("WORLD_SIZE") is not None:
+        return False
+    return args.gpus > 1 or environ.get("PIXELBOX_FORCE_SPAWN") == "1"
+
+
+def plain_launch_commands(args, argv, port: int):
+    """The two children of a plain launch: (1) the driver's own launch shape, one rank per GPU under torch.distributed.run;
+    (2) the product form, ONE process driving every GPU through pb_sharded_* (RCCL inside the library)."""
+    me = os.path.abspath(__file__)
+    ranks = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+             "--master-addr", "127.0.0.1", "--master-port", str(port), me] + list(argv)
+    single = [sys.executable, me] + list(argv) + ["--in-library-leg"]
+    return ranks, single
+
+
+def plain_launch(args, argv) -> int:
+    import subprocess
+
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this pool
+    env["PIXELBOX_SPAWNED"] = "1"
+    ranks_cmd, single_cmd = plain_launch_commands(args, argv, _free_port())
+    print("bench.py: no launcher around --gpus %d: starting the ranks as a child: %s" % (args.gpus, " ".join(ranks_cmd)), file=sys.stderr)
+    p = subprocess.run(ranks_cmd, stdout=subprocess.PIPE, env=env)
+    out = _last_json_line(p.stdout.decode(errors="replace"))
+    lib_leg, p2_rc = None, None
+    if os.environ.get("PIXELBOX_NO_IN_LIBRARY_LEG") != "1":
+        env2 = dict(env)
+        env2.pop("PIXELBOX_FORCE_DIST", None)
+        p2 = subprocess.run(single_cmd, stdout=subprocess.PIPE, env=env2)
+        p2_rc = p2.returncode
+        lib_leg = _last_json_line(p2.stdout.decode(errors="replace"))
+    if out is None and lib_leg is not None and "value" in lib_leg:
+        # the ranks did not produce a line (rendezvous / RCCL failure): the product form's measurement of the SAME step
+        # (64 batch-1 passes over the row-sharded table, RCCL all-gather, device merge) stands in, labelled
+        out = dict(lib_leg)
+        out["launch"] = {"form": "single process, pb_sharded_* (RCCL inside the library)",
+                         "note": "the torch.distributed.run child exited with code %d without a result line" % p.returncode}
+        lib_leg = None
+    if out is None:
+        print("bench.py: neither child produced a result line (rc %s / %s)" % (p.returncode, p2_rc), file=sys.stderr)
+        return p.returncode or 1
+    if lib_leg is not None:
+        out["in_library_sharded"] = lib_leg
+    sys.stdout.write(json.dumps(out) + "\n")
+    sys.stdout.flush()
+    return 0
+
+
+def in_library_leg(args) -> int:
+    """The product form of the multi-GPU step: ONE host process, `pb_sharded_create(device_ids, n, ...)`,
+    a worker thread per shard, ncclAllGather of the per-shard top-k inside the library, device merge.  Same step as the
+    headline (64 batch-1 passes per step over the row-sharded 10M-row table)."""
+    real_stdout = os.dup(1)
+    sys.stdout.flush()
+    os.dup2(2, 1)
+    from pixelbox_amd import capi, synth
+
+    n_dev = capi.device_count()
+    if n_dev < 1:
+        raise SystemExit("bench.py --in-library-leg needs a GPU")
+    # fewer devices than --gpus (a one-GPU box exercising the path): shards share devices, exchanged by copies
+    devs = [i % n_dev for i in range(args.gpus)]
+    d, k, B = args.dim, args.k, args.queries
+    sh = capi.ShardedIndexC(d, args.rows, devs)
+    sh.fill_synthetic(synth.SEED_INDEX, args.rows, 1)
+    sh.set_option(capi.PB_OPT_SEARCH_PATH, 2)
+    n_steps_total = args.warmup + args.steps
+    qbytes = synth.fill_synthetic(synth.SEED_QUERY, 0, n_steps_total * B * d).reshape(n_steps_total, B, d)
+    for s in range(args.warmup):
+        sh.search(qbytes[s], k, args.max_dist)
+    t0 = time.perf_counter()
+    last = None
+    for s in range(args.warmup, n_steps_total):
+        last = sh.search(qbytes[s], k, args.max_dist)
+    dt = time.perf_counter() - t0
+    info = sh.info()
+    total, per = sh.sizes()
+    out = {"metric": "similarity queries/sec over a 10M x 256-dim u8 index (cosine-distance top-100, batch-1 scans)",
+           "value": round(args.steps * B / dt, 2), "unit": "queries/s", "n_gpus": args.gpus, "devices": devs,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+           "form": "single process: pb_sharded_create / pb_sharded_search (worker thread per shard, one ncclAllGather per step, "
+                   "k_merge_packed on shard 0's device)",
+           "uses_rccl": bool(info["uses_rccl"]), "n_shards": int(info["n_shards"]), "n_exchanges": int(info["n_exchanges"]),
+           "rows_total": int(total), "shard_rows": [int(x) for x in per],
+           "check": {"first_result_id": int(last[0][0][0]) if last is not None and last[2][0] else None}}
+    if args.e2e_images > 0 and not args.no_embed:
+        try:
+            out["ingest"] = in_library_ingest(args, devs)
+        except Exception as e:  # the leg is additional evidence: a failure is reported, not fatal
+            out["ingest"] = {"error": str(e)}
+    os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    return 0
+
+
+def in_library_ingest(args, devs):
+    return {"skipped": "product-form ingest not built in this tree"}
 
 
 def main():
-    args = parse()
+    argv = sys.argv[1:]
+    args = parse(argv)
+    if needs_plain_launch(args, os.environ):
+        raise SystemExit(plain_launch(args, argv))
+    if args.in_library_leg:
+        raise SystemExit(in_library_leg(args))
     # stdout must carry exactly ONE line, the JSON: native libraries (RCCL prints a version banner on some builds)
     # write to fd 1 behind Python's back, so everything except the final line is sent to stderr
     real_stdout = os.dup(1)
@@ -79,8 +208,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
     # PIXELBOX_FORCE_DIST=1: run the collective path even at world size 1 (lets a 1-GPU box exercise the
     # nccl init / all-gather / merge code that the 2-, 4- and 8-GPU runs use)
     distributed = world > 1 or os.environ.get("PIXELBOX_FORCE_DIST") == "1"
@@ -145,10 +273,19 @@ def main():
         lat_wrapped.append((time.perf_counter() - t1) * 1e3)
     lat_wrapped_ms = sorted(lat_wrapped)[len(lat_wrapped) // 2]
     lat_ms = sorted(lat)[len(lat) // 2] if lat else lat_wrapped_ms
+    launch = {"form": "one process per GPU (torch.distributed.run)" if os.environ.get("WORLD_SIZE") is not None else "single process, one GPU",
+              "spawned_by_plain_launch": os.environ.get("PIXELBOX_SPAWNED") == "1", "uses_rccl": False, "n_ranks_seen": 1,
+              "shard_rows_per_rank": [len(sh.index)]}
     if distributed:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+        # what the collective layer itself reports: backend, ranks, and every rank's shard size (gathered over it)
+        mine = torch.tensor([len(sh.index)], dtype=torch.int64, device="cuda")
+        every = [torch.zeros_like(mine) for _ in range(torch.distributed.get_world_size())]
+        torch.distributed.all_gather(every, mine)
+        launch.update({"uses_rccl": torch.distributed.get_backend() == "nccl", "n_ranks_seen": torch.distributed.get_world_size(),
+                       "shard_rows_per_rank": [int(x.item()) for x in every]})
     qps = args.steps * B / dt
 
     # concurrent-query burst (BASELINE configs[4]: "serve 1k concurrent similarity queries"): the same API call
@@ -288,7 +425,7 @@ def main():
             "ms_per_query": round(dt / (args.steps * B) * 1e3, 4), "latency_ms_single_query_call": round(lat_ms, 4),
             "path_counts": {"queries": int(st.queries), "filter_certified": int(st.fast_path),
                             "second_chance": int(st.second_chance), "exhaustive": int(st.fallback)},
-            "roofline": roof, "roofline_single_call": roof_single, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_single_call": roof_single, "cpu_baseline": cpu, "launch": launch,
         }
         if sweep is not None:
             out["roofline"]["n_sweep"] = sweep["n_sweep"]
@@ -479,7 +616,7 @@ def bench_embed(args, torch, device, distributed):
         t0 = time.perf_counter()
         oracle.mlhash_batch(blob, sample, 256, nthreads=4, want_f32=False)
         dt = time.perf_counter() - t0
-        res["cpu_baseline"] = {"value": round(n / dt, 2), "unit": "images/s", "cores": 4, "kind": "port",
+        res["cpu_baseline"] = {"value": round(n / dt, 2), "unit": "images/s", "cores": 4, "host_cores": os.cpu_count(), "kind": "port",
                                "sample": f"{n} synthetic 128x128 images, batch-1 per call on 4 threads "
                                          "(PARALLEL_FILE_PROCESSORS = 4, engine.rs:22); naive f32 C port, not tract-onnx"}
     return res
@@ -632,13 +769,13 @@ def cpu_baseline(args, synth, queries):
         g_ids, g_d, g_c, secs = oracle.sqlite_scan(queries[:4], rows[:ns], ids[:ns], args.max_dist)
         w_ids, w_d = oracle.scan_topk(queries[0], rows[:ns], ids[:ns], args.k, args.max_dist)
         same = bool(args.k == 100 and np.array_equal(g_ids[0, : g_c[0]], w_ids) and np.array_equal(g_d[0, : g_c[0]].view(np.uint32), w_d.view(np.uint32)))
-        via_sqlite = {"value": round(1.0 / (secs * (args.rows / ns)), 4), "unit": "queries/s", "cores": 1, "kind": "port",
+        via_sqlite = {"value": round(1.0 / (secs * (args.rows / ns)), 4), "unit": "queries/s", "cores": 1, "host_cores": os.cpu_count(), "kind": "port",
                       "rows_per_sec": round(ns / secs, 1), "matches_the_bare_scan": same,
                       "sample": f"4 queries over the first {ns} rows in an in-memory SQLite (libsqlite3.so.0), scaled by {args.rows}/{ns}; "
                                 "cosine_distance registered as a UDF, the reference's literal SQL"}
     except Exception as e:  # no libsqlite3 on the box: the bare scan stands alone
         via_sqlite = {"error": str(e)}
-    return {"value": round(1.0 / per_full_query, 4), "unit": "queries/s", "cores": 1, "kind": "port",
+    return {"value": round(1.0 / per_full_query, 4), "unit": "queries/s", "cores": 1, "host_cores": os.cpu_count(), "kind": "port",
             "rows_per_sec": round(n / dt, 1), "through_sqlite": via_sqlite,
             "sample": f"{len(queries)} queries over the first {n} rows of the same index, scaled by {args.rows}/{n}; "
                       "single-thread C port of the reference algorithm (the Rust reference cannot be built here)"}

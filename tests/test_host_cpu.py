@@ -171,3 +171,40 @@ def test_option_constants_of_the_python_binding_match_the_header():
             assert defs[name] == value, (name, defs[name], value)
             checked += 1
     assert checked >= 8
+
+
+# ---- bench.py launch logic (`python bench.py --gpus 8` launched plainly must not exit) -------------
+def _bench():
+    import importlib
+
+    sys.path.insert(0, ROOT) if ROOT not in sys.path else None
+    return importlib.import_module("bench")
+
+
+def test_bench_plain_launch_decision_and_commands():
+    b = _bench()
+    a8, a1 = b.parse(["--gpus", "8"]), b.parse(["--gpus", "1"])
+    assert b.needs_plain_launch(a8, {})                                  # no launcher around it: become the parent
+    assert not b.needs_plain_launch(a8, {"WORLD_SIZE": "8"})             # a rank under torch.distributed.run
+    assert not b.needs_plain_launch(a1, {})                              # the N = 1 driver command runs in-process
+    assert b.needs_plain_launch(a1, {"PIXELBOX_FORCE_SPAWN": "1"})       # one-GPU pre-flight of the same route
+    assert not b.needs_plain_launch(b.parse(["--gpus", "8", "--in-library-leg"]), {})
+    ranks, single = b.plain_launch_commands(a8, ["--gpus", "8", "--steps", "3"], 29999)
+    assert ranks[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in ranks
+    assert ranks[ranks.index("--master-addr") + 1] == "127.0.0.1" and ranks[ranks.index("--master-port") + 1] == "29999"
+    assert ranks[-4:] == ["--gpus", "8", "--steps", "3"] and ranks[-5].endswith("bench.py")
+    assert single[-1] == "--in-library-leg" and single[1].endswith("bench.py")
+    assert b._last_json_line('RCCL banner\n{"a": 1}\ntrailing\n') == {"a": 1}
+    assert b._last_json_line("no json here") is None
+
+
+def test_bench_plain_launch_without_a_gpu_fails_loudly_not_silently(tmp_path):
+    # here (no GPU) both children refuse to run; the parent must relay that as a non-zero exit and an empty stdout --
+    # and must do so as a parent of CHILD processes (it never initialises the GPU itself, never execs)
+    env = dict(os.environ, PIXELBOX_NO_IN_LIBRARY_LEG="1")
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--rows", "1000"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=300)
+    assert p.returncode != 0
+    assert p.stdout.strip() == b""
+    assert b"starting the ranks as a child" in p.stderr and b"needs a GPU" in p.stderr
