@@ -12,6 +12,7 @@
 
 #include "pb_common.h"
 #include "pb_embed_kernels.h"
+#include "pb_front_band.h"
 
 using namespace pbe;
 
@@ -37,6 +38,7 @@ struct Block {
     bool has_expand, residual;
     Gemm expand, project;
     float *dw_w = nullptr, *dw_b = nullptr;            // [k*k][e], [e]
+    f32x4 *dw_wq = nullptr;                            // the same taps per channel quad: [e / 4][k*k] float4 (k_front_band)
     int sp = 0;                                        // sq rounded up to 8/16/32/48 (zero-padded rows)
     float *se_w1 = nullptr, *se_b1 = nullptr;          // [sp][e], [sp]
     float *se_w2t = nullptr, *se_b2 = nullptr;         // [sp][e], [e]
@@ -70,6 +72,9 @@ struct pb_embedder {
     int opt_async = 0;    // PB_OPT_EMBED_ASYNC
     int trace_tune = 0;   // PB_TRACE_TUNE (1: chosen forms, 2: every candidate), PB_NO_STEM_FUSION: read once at create
     bool no_stem_fusion = false;
+    unsigned *d_se_cnt = nullptr;  // [max_batch] arrival counters of the squeeze-excite tails (zero between launches)
+    bool fold_se = true;           // PB_NO_FOLD: the gates come from k_se launches of their own instead of the producing kernels' tails
+    bool no_band = false, force_band = false;  // PB_NO_BAND / PB_FORCE_BAND: leave out / always take the LDS-ring front kernel where it applies (A/B runs, bit comparisons)
     int tune_pick = 0;    // PB_TUNE_PICK: 0 fastest candidate (default); 1 slowest; 2 a pseudo-random one -- test hook: every form must give the same bits
     uint32_t tune_rng = 12345u;
     bool use_b3 = false;  // project / head / FC products from three bf16 pieces (k_gemm_b3) instead of the f32 MFMA chain
@@ -220,6 +225,14 @@ int load_weights(pb_embedder *e, const uint8_t *blob, size_t len) {
                 for (int c = 0; c < E; ++c)
                     for (int t = 0; t < KK; ++t) w[(size_t)t * E + c] = p[(size_t)c * KK + t];
                 if ((rc = upload(e, &bl.dw_w, w)) || (rc = upload(e, &bl.dw_b, b))) return rc;
+                if (E % 4 == 0) {
+                    std::vector<float> wq((size_t)KK * E);
+                    for (int c = 0; c < E; ++c)
+                        for (int t = 0; t < KK; ++t) wq[((size_t)(c / 4) * KK + t) * 4 + (c & 3)] = p[(size_t)c * KK + t];
+                    float *dq = nullptr;
+                    if ((rc = upload(e, &dq, wq))) return rc;
+                    bl.dw_wq = reinterpret_cast<f32x4 *>(dq);
+                }
                 p += (size_t)E * KK + E;
             }
             {
@@ -553,6 +566,16 @@ int launch_dw(pb_embedder *e, const Block &bl, const float *in, int B, int H, in
     return launch_dw_geom(e, bl, in, B, H, W, out, Ho, Wo, it->second);
 }
 
+// the squeeze-excite tail of a producing kernel (pb_embed_kernels.h SeTail); sp = 0 when the gates come from k_se
+SeTail se_tail(pb_embedder *e, const Block &bl, int Ho, int Wo) {
+    SeTail t;
+    t.w1 = bl.se_w1; t.b1 = bl.se_b1; t.w2t = bl.se_w2t; t.b2 = bl.se_b2;
+    t.gate = e->buf_gate; t.cnt = e->d_se_cnt;
+    t.inv_hw = 1.0f / (float)(Ho * Wo);
+    t.sp = (e->fold_se && bl.sp <= 16) ? bl.sp : 0;  // small excite weights only (see SeTail)
+    return t;
+}
+
 // ---- fused MBConv front (expand + depthwise in one kernel, expanded rows in registers) -------------------------
 bool front_eligible(const Block &bl) {
     const int kc = bl.expand.Kpad / 16;
@@ -655,13 +678,54 @@ int launch_small(pb_embedder *e, const Block &bl, int cfg, const float *x, int B
 #undef PB_SM2
 }
 
+// ---- fused MBConv front with the expanded rows in an LDS ring (k_front_band, pb_front_band.h): cfg = 0x2000 + n_bands
+struct BandShape {
+    int ks, s, cin, wt, rps;
+};
+// the instantiated shapes: EfficientNet-B0 blocks 1-5 at 128 x 128 input (maps 64 / 32 / 16 wide)
+const BandShape BAND_SHAPES[] = {{3, 2, 16, 4, 2}, {3, 1, 24, 2, 2}, {5, 2, 24, 2, 4}, {5, 1, 40, 1, 4}, {3, 2, 40, 1, 8}};
+
+const BandShape *band_shape(const Block &bl, int H, int W) {
+    if (!bl.has_expand || !bl.dw_wq || bl.e % 16 || H != W) return nullptr;
+    for (const BandShape &bs : BAND_SHAPES)
+        if (bs.ks == bl.k && bs.s == bl.stride && bs.cin == bl.cin && bs.wt * 16 == W) return &bs;
+    return nullptr;
+}
+
+template <int KS, int S, int CIN, int WT, int RPS>
+int launch_band_t(pb_embedder *e, const Block &bl, int n_bands, const float *x, int B, float *out) {
+    using G = FrontBandGeom<KS, S, WT, RPS>;
+    auto kern = k_front_band<KS, S, CIN, WT, RPS>;
+    if (G::LDS_BYTES > 48 * 1024)
+        PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
+    const unsigned n_items = (unsigned)B * (unsigned)n_bands;
+    hipLaunchKernelGGL(kern, dim3((n_items + 7) / 8 * 8 * (bl.e / 16)), dim3(256), G::LDS_BYTES, e->stream, x, bl.expand.wt, bl.expand.Npad,
+                       bl.expand.bias, bl.dw_wq, bl.dw_b, bl.e, out, e->buf_part, n_bands, G::Wo / n_bands, n_items,
+                       se_tail(e, bl, G::Wo, G::Wo));
+    PB_HIP(hipGetLastError());
+    return PB_OK;
+}
+
+int launch_band(pb_embedder *e, const Block &bl, const BandShape &bs, int n_bands, const float *x, int B, float *out) {
+#define PB_BD(KS, S, CIN, WT, RPS) \
+    if (bs.ks == KS && bs.s == S && bs.cin == CIN && bs.wt == WT) return launch_band_t<KS, S, CIN, WT, RPS>(e, bl, n_bands, x, B, out)
+    PB_BD(3, 2, 16, 4, 2);
+    PB_BD(3, 1, 24, 2, 2);
+    PB_BD(5, 2, 24, 2, 4);
+    PB_BD(5, 1, 40, 1, 4);
+    PB_BD(3, 2, 40, 1, 8);
+#undef PB_BD
+    return pb::fail(PB_ERR_INVALID, "launch_band: no kernel for k%d s%d", bs.ks, bs.s);
+}
+
 int launch_gemm(pb_embedder *e, const float *act, long M, const Gemm &g, const float *gate, int hw, const float *resid,
                 int do_silu, float *out);
 int launch_dw(pb_embedder *e, const Block &bl, const float *in, int B, int H, int W, float *out, int Ho, int Wo, DwGeom *used);
 
 // expand + depthwise of one block: the fused kernel (per row-band count) and the two-kernel path are timed on
 // the real buffers at first use per (block, batch); returns the number of SE partial tiles written to buf_part
-int run_front(pb_embedder *e, const Block &bl, const float *x, int n, int H, int W, int Ho, int Wo, int *n_part_tiles) {
+int run_front(pb_embedder *e, const Block &bl, const float *x, int n, int H, int W, int Ho, int Wo, int *n_part_tiles, bool *folded) {
+    *folded = false;
     const std::pair<const void *, long> key(bl.expand.wt, tune_bucket(n));
     auto separate = [&](int *tiles) -> int {
         int rc = launch_gemm(e, x, (long)n * H * W, bl.expand, nullptr, 1, nullptr, 1, e->buf_e);
@@ -731,7 +795,34 @@ int run_front(pb_embedder *e, const Block &bl, const float *x, int n, int H, int
                         best = cfg;
                     }
                 }
+        if (const BandShape *bs = band_shape(bl, H, W)) {
+            const int steps = Ho / bs->rps;
+            for (int nb : {1, 2, 4, 8, 16}) {
+                if (steps % nb || (size_t)nb * bl.e > e->part_floats_per_image || e->no_band) continue;
+                float ms = 0.f;
+                if ((rc = launch_band(e, bl, *bs, nb, x, n, e->buf_dw))) return rc;  // warm-up
+                PB_HIP(hipEventRecord(e0, e->stream));
+                for (int rep = 0; rep < 2; ++rep)
+                    if ((rc = launch_band(e, bl, *bs, nb, x, n, e->buf_dw))) return rc;
+                PB_HIP(hipEventRecord(e1, e->stream));
+                PB_HIP(hipEventSynchronize(e1));
+                PB_HIP(hipEventElapsedTime(&ms, e0, e1));
+                if (e->trace_tune)
+                    fprintf(stderr, "front k%d s%d e%d n%d: LDS-ring band kernel, bands %d %.1f us (separate %.1f)\n", bl.k, bl.stride, bl.e, n, nb,
+                            ms * 500.f, sep_ms * 500.f);
+                if (tune_take(e, ms, best_ms) || e->force_band) {
+                    if (e->force_band && best >= 0x2000 && ms >= best_ms) continue;
+                    best_ms = ms;
+                    best = 0x2000 + nb;
+                }
+            }
+        }
         it = e->front_cfg.emplace(key, best).first;
+    }
+    if (it->second >= 0x2000) {
+        *n_part_tiles = it->second - 0x2000;
+        *folded = e->fold_se && bl.sp <= 16;  // the band kernel's last workgroup per image has written the gate
+        return launch_band(e, bl, *band_shape(bl, H, W), it->second - 0x2000, x, n, e->buf_dw);
     }
     if (it->second >= 0x1000) {
         *n_part_tiles = 1;
@@ -747,6 +838,8 @@ int run_front(pb_embedder *e, const Block &bl, const float *x, int n, int H, int
 // forward for n images already on the device; results to device buffers
 int forward_device(pb_embedder *e, const uint8_t *d_rgb, int n, uint8_t *d_u8, float *d_f32) {
     int H = (int)e->H / 2, W = (int)e->W / 2;
+    // arrival counters of the squeeze-excite tails: every tail leaves them zero; cleared anyway (a failed launch must not poison the next forward)
+    if (e->fold_se) PB_HIP(hipMemsetAsync(e->d_se_cnt, 0, (size_t)n * sizeof(unsigned), e->stream));
     // the first block (no expansion, 3x3 stride 1, 32 channels, no residual) takes its depthwise conv fused into the
     // stem when the 3-row LDS ring fits (input width <= 320); identical bits either way
     const Block &b0 = e->blocks.front();
@@ -762,7 +855,7 @@ int forward_device(pb_embedder *e, const uint8_t *d_rgb, int n, uint8_t *d_u8, f
         if (fused_lds > 48 * 1024)
             PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stem_dw), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds));
         hipLaunchKernelGGL(k_stem_dw, dim3(stem_bands, n), dim3(256), fused_lds, e->stream, d_rgb, n, (int)e->H, (int)e->W, e->stem_w,
-                           e->stem_b, b0.dw_w, b0.dw_b, e->buf_dw, e->buf_part, stem_bands, rpb);
+                           e->stem_b, b0.dw_w, b0.dw_b, e->buf_dw, e->buf_part, stem_bands, rpb, se_tail(e, b0, H, W));
         PB_HIP(hipGetLastError());
     } else {
         // one block per output row, taps from LDS-staged input rows (W is a multiple of 32 and <= 1024: 37 KB at most)
@@ -777,10 +870,12 @@ int forward_device(pb_embedder *e, const uint8_t *d_rgb, int n, uint8_t *d_u8, f
         int rc;
         const int Ho = (H + bl.stride - 1) / bl.stride, Wo = (W + bl.stride - 1) / bl.stride;
         int part_tiles = 0;
+        bool folded = false;  // the gate was computed in the tail of the kernel that produced the pooled sums
         if (fuse_stem && &bl == &b0) {
             part_tiles = stem_bands;  // depthwise output and SE partials are already in buf_dw / buf_part
+            folded = e->fold_se && b0.sp <= 16;  // ... and the gate, written by the band that completed the image
         } else if (bl.has_expand) {
-            if ((rc = run_front(e, bl, x, n, H, W, Ho, Wo, &part_tiles))) return rc;
+            if ((rc = run_front(e, bl, x, n, H, W, Ho, Wo, &part_tiles, &folded))) return rc;
         } else {
             DwGeom g0;
             if ((rc = launch_dw(e, bl, x, n, H, W, e->buf_dw, Ho, Wo, &g0))) return rc;
@@ -796,7 +891,8 @@ int forward_device(pb_embedder *e, const uint8_t *d_rgb, int n, uint8_t *d_u8, f
         // the widest layers (2 x 48 x 1152 weights = 442 KB per block) run two images per block from 64 images
         // on: measured 24 -> 19 us per launch at batch 512; the narrower ones lose more parallelism than they
         // save traffic (9 -> 13 us) and keep one image per block
-        if (bl.sp == 8) PB_SE1(8, 1);
+        if (folded) {
+        } else if (bl.sp == 8) PB_SE1(8, 1);
         else if (bl.sp == 16) PB_SE1(16, 1);
         else if (bl.sp == 32) PB_SE1(32, 1);
         else if (n >= 64) PB_SE1(48, 2);
@@ -904,6 +1000,9 @@ int pb_embed_create(pb_embedder **out, int device, const void *weights_blob, siz
     if (const char *tp = getenv("PB_TUNE_PICK")) e->tune_pick = atoi(tp);
     if (const char *tt = getenv("PB_TRACE_TUNE")) e->trace_tune = tt[0] == '2' ? 2 : 1;
     e->no_stem_fusion = getenv("PB_NO_STEM_FUSION") != nullptr;
+    e->fold_se = getenv("PB_NO_FOLD") == nullptr;
+    e->no_band = getenv("PB_NO_BAND") != nullptr;
+    e->force_band = getenv("PB_FORCE_BAND") != nullptr;
     auto body = [&]() -> int {
         hipDeviceProp_t prop;
         PB_HIP(hipGetDeviceProperties(&prop, device));
@@ -935,6 +1034,8 @@ int pb_embed_create(pb_embedder **out, int device, const void *weights_blob, siz
         e->part_floats_per_image = max_part;
         if ((rc = dalloc(e, &e->buf_part, B * max_part)) || (rc = dalloc(e, &e->buf_gate, B * std::max<size_t>(1152, e->D)))) return rc;
         if ((rc = dalloc(e, &e->buf_pool, B * 1280))) return rc;
+        if ((rc = dalloc(e, &e->d_se_cnt, B))) return rc;
+        PB_HIP(hipMemset(e->d_se_cnt, 0, B * sizeof(unsigned)));
         if ((rc = dalloc(e, &e->d_out_f32, B * e->D)) || (rc = dalloc(e, &e->d_out_u8, B * e->D))) return rc;
         return PB_OK;
     };

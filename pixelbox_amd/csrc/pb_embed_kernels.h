@@ -84,6 +84,130 @@ __device__ __forceinline__ uint8_t quantize_u8(float f) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// The squeeze-excite gate computed in the TAIL of the kernel that produced the pooled sums, by the workgroup that finishes an
+// image last -- for the blocks whose excite weights are small (squeeze width <= 16: the stem-fused first block and the five
+// LDS-ring fronts, 2 * SP * E * 4 B <= 31 KB per image; the late blocks' 123-442 KB per image would make the tail a long
+// serial piece of one workgroup, and stay with k_se, which shares the loads between images) (-6 dependent launches per forward; the reference evaluates the same layers inside one `MODEL.run`,
+// src/image_hashes/efficientnet.rs:34).  Same arithmetic, in the same order, as k_se above -- the order is defined on channel
+// quads, not on threads: FC1 sums a unit's products per quad (x, y, z, w in sequence), then over the 64 quads of a block by
+// the xor butterfly of a wave, then over the blocks in order; FC2 sums the units in groups of 16 in sequence and the groups
+// in order behind the bias -- so a forward gives the same bits whether a layer's gate comes from k_se or from here.
+//
+// Hand-off (guide: inter-workgroup communication, the counter form): every workgroup stores its pooled sums WRITE-THROUGH
+// (8-byte agent-scope atomic stores: se_part_store), each storing wave drains its stores (s_waitcnt vmcnt(0)), the workgroup
+// meets at a barrier, ONE lane adds 1 to the image's counter (agent-scope atomic); the workgroup whose add returns
+// total - 1 is the last: one lane runs an agent-scope acquire, the workgroup meets again, and every load of another
+// workgroup's sums is an 8-byte agent-scope atomic load (L1 bypassed).  No placement or dispatch order is assumed.  The last
+// workgroup zeroes the counter for the next launch (the host also clears the counters at the start of every forward).
+struct SeTail {
+    const float *w1, *b1, *w2t, *b2;  // as k_se: [SP][E], [SP], [SP][E], [E]
+    float *gate;                      // [B][E]
+    unsigned *cnt;                    // [B] arrival counters, zero between launches
+    float inv_hw;
+    int sp;                           // 0: no tail (k_se runs as a kernel of its own); else 8 / 16 / 32 / 48
+};
+
+__device__ __forceinline__ void se_part_store(long long *p, const ll4 &v) {
+    __hip_atomic_store(p + 0, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p + 2, v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p + 3, v.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ ll4 se_part_load(const long long *p) {
+    ll4 v;
+    v.x = __hip_atomic_load(p + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v.y = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v.z = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v.w = __hip_atomic_load(p + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return v;
+}
+
+// Arrival of this workgroup for one counter; true in the workgroup that arrives last (uniform over the workgroup).  Every
+// wave that stored sums must call it (all threads of the workgroup do).  `s_flag`: one LDS word nobody else uses meanwhile.
+__device__ __forceinline__ bool se_arrive(unsigned *cnt, unsigned total, unsigned *s_flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have left
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool last = old == total - 1u;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+        }
+        *s_flag = last ? 1u : 0u;
+    }
+    __syncthreads();
+    return *s_flag != 0u;
+}
+
+// Gate of ONE image by the calling workgroup (NT threads, a multiple of 64): part = the image's [n_tiles][E] pooled sums,
+// gate = its [E] output, scr = (E / 256 + 1) * SP + SP floats of LDS scratch (16-byte aligned).
+template <int SP, int NT>
+__device__ __forceinline__ void se_gate_image(const long long *__restrict__ part, int n_tiles, int E, const SeTail &se,
+                                              float *__restrict__ gate, float *scr) {
+    constexpr int JG = SP < 16 ? SP : 16, G = SP / JG;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_quads = E >> 2, n_blocks = (n_quads + 63) >> 6;
+    float *s_p = scr;                  // [n_blocks][SP]
+    float *s_s = scr + n_blocks * SP;  // [SP]
+    const double sc = (1.0 / 16777216.0) * (double)se.inv_hw;
+    // ---- FC1: block of 64 quads per wave turn
+    for (int blk = wave; blk < n_blocks; blk += NT / 64) {
+        const int cq = blk * 64 + lane;
+        const bool on = cq < n_quads;
+        const int c = on ? 4 * cq : 0;
+        ll4 t = {0, 0, 0, 0};
+        for (int tl = 0; tl < n_tiles; ++tl) se_add(t, se_part_load(part + (size_t)tl * E + c));
+        f32x4 m = {(float)((double)t.x * sc), (float)((double)t.y * sc), (float)((double)t.z * sc), (float)((double)t.w * sc)};
+        if (!on) m = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int jj = 0; jj < SP; ++jj) {
+            const f32x4 wv = *reinterpret_cast<const f32x4 *>(se.w1 + (size_t)jj * E + c);
+            float a = m.x * wv.x;
+            a = a + m.y * wv.y; a = a + m.z * wv.z; a = a + m.w * wv.w;
+            for (int off = 32; off >= 1; off >>= 1) a = a + __shfl_xor(a, off);
+            if (lane == 0) s_p[blk * SP + jj] = a;
+        }
+    }
+    __syncthreads();
+    if (tid < SP) {
+        float v = s_p[tid];
+        for (int blk = 1; blk < n_blocks; ++blk) v = v + s_p[blk * SP + tid];
+        s_s[tid] = silu_f(v + se.b1[tid]);
+    }
+    __syncthreads();
+    // ---- FC2 + sigmoid, a channel quad per thread turn
+    for (int cq = tid; cq < n_quads; cq += NT) {
+        const int c = 4 * cq;
+        f32x4 v = *reinterpret_cast<const f32x4 *>(se.b2 + c);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+            for (int j = 0; j < JG; ++j) {
+                const f32x4 wv = *reinterpret_cast<const f32x4 *>(se.w2t + (size_t)(g * JG + j) * E + c);
+                const float sj = s_s[g * JG + j];
+                acc.x = acc.x + sj * wv.x; acc.y = acc.y + sj * wv.y; acc.z = acc.z + sj * wv.z; acc.w = acc.w + sj * wv.w;
+            }
+            v.x = v.x + acc.x; v.y = v.y + acc.y; v.z = v.z + acc.z; v.w = v.w + acc.w;
+        }
+        const f32x4 r = {sigmoid_f(v.x), sigmoid_f(v.y), sigmoid_f(v.z), sigmoid_f(v.w)};
+        *reinterpret_cast<f32x4 *>(gate + c) = r;
+    }
+    __syncthreads();  // scr may be reused by the caller (next image)
+}
+
+template <int NT>
+__device__ __forceinline__ void se_gate_image_sp(const long long *part, int n_tiles, int E, const SeTail &se, float *gate, float *scr) {
+    if (se.sp == 8) se_gate_image<8, NT>(part, n_tiles, E, se, gate, scr);
+    else if (se.sp == 16) se_gate_image<16, NT>(part, n_tiles, E, se, gate, scr);
+    else if (se.sp == 32) se_gate_image<32, NT>(part, n_tiles, E, se, gate, scr);
+    else se_gate_image<48, NT>(part, n_tiles, E, se, gate, scr);
+}
+
+// ------------------------------------------------------------------------------------------------
 // stem: u8 NHWC [B,H,W,3] -> f32 NHWC [B,H/2,W/2,32]; 3x3 stride 2 pad 1, + bias, SiLU, as an im2col GEMM on the
 // f32 matrix cores: K = 27 taps (padded to 32), N = 32 channels, M = output pixels.  A block owns one output row
 // (b, y): its three input rows are loaded as dwords (coalesced), converted through the v/255 table (the px/255 of
@@ -177,7 +301,7 @@ __global__ __launch_bounds__(256) void k_stem_dw(const uint8_t *__restrict__ img
                                                  const float *__restrict__ w, const float *__restrict__ bias,
                                                  const float *__restrict__ dw_w, const float *__restrict__ dw_b,
                                                  float *__restrict__ out, long long *__restrict__ part, int n_bands,
-                                                 int rows_per_band) {
+                                                 int rows_per_band, SeTail se) {
     extern __shared__ __attribute__((aligned(16))) float s_sd[];
     __shared__ float s_px[256];
     __shared__ f32x4 s_dww[9 * 8];
@@ -284,7 +408,12 @@ __global__ __launch_bounds__(256) void k_stem_dw(const uint8_t *__restrict__ img
     if (tid < 8) {
         ll4 t = s_red[tid];
         for (int j = 1; j < 32; ++j) se_add(t, s_red[j * 8 + tid]);
-        *reinterpret_cast<ll4 *>(part + ((size_t)b * n_bands + band) * 32 + 4 * tid) = t;
+        se_part_store(part + ((size_t)b * n_bands + band) * 32 + 4 * tid, t);
+    }
+    // the band that completes the image computes the first block's squeeze-excite gate (se_gate_image; the ring is free by now)
+    if (se.sp) {
+        if (se_arrive(se.cnt + b, (unsigned)n_bands, reinterpret_cast<unsigned *>(s_sd)))
+            se_gate_image_sp<256>(part + (size_t)b * n_bands * 32, n_bands, 32, se, se.gate + (size_t)b * 32, s_sd + 4);
     }
 }
 
