@@ -32,6 +32,7 @@ struct Gemm {  // 1x1 conv as GEMM
     float *wt = nullptr;    // [Kpad][Npad]
     float *bias = nullptr;  // [Npad]
     uint2 *wt3 = nullptr;   // three-bf16-piece form for k_gemm_b3: [3][Kpad / 4][Npad] x (4 consecutive k as bf16); null = f32 path only
+    float *wt2 = nullptr;   // fragment order for k_gemm_t: [chunk of 64 k][Npad / 16][kk][li][s][e] = w[64 chunk + 16 s + 4 kk + e][16 tile + li]; null when K % 16
 };
 struct Block {
     int cin, cout, e, sq, k, stride;
@@ -73,7 +74,9 @@ struct pb_embedder {
     int trace_tune = 0;   // PB_TRACE_TUNE (1: chosen forms, 2: every candidate), PB_NO_STEM_FUSION: read once at create
     bool no_stem_fusion = false;
     unsigned *d_se_cnt = nullptr;  // [max_batch] arrival counters of the squeeze-excite tails (zero between launches)
-    bool fold_se = true;           // PB_NO_FOLD: the gates come from k_se launches of their own instead of the producing kernels' tails
+    bool fold_se = false;          // PB_FOLD_SE=1: the gates of the first six blocks come from the producing kernels' tails instead of k_se
+                                   // launches (measured: +0.04 ms per batch-512 forward and per batch-1 forward -- see SeTail; off by default)
+    bool no_gemm_t = false;        // PB_NO_GEMM_T: leave k_gemm_t out of the per-layer timing loops (A/B runs)
     bool no_band = false, force_band = false;  // PB_NO_BAND / PB_FORCE_BAND: leave out / always take the LDS-ring front kernel where it applies (A/B runs, bit comparisons)
     int tune_pick = 0;    // PB_TUNE_PICK: 0 fastest candidate (default); 1 slowest; 2 a pseudo-random one -- test hook: every form must give the same bits
     uint32_t tune_rng = 12345u;
@@ -140,6 +143,16 @@ int make_gemm(pb_embedder *e, Gemm *g, const float *w, const float *b, int N, in
     for (int n = 0; n < N; ++n) bp[n] = b[n];
     int rc = upload(e, &g->wt, wt);
     if (!rc) rc = upload(e, &g->bias, bp);
+    if (!rc && K % 16 == 0) {
+        const int chunks = (K + 63) / 64, t16 = g->Npad / 16;
+        std::vector<float> w2((size_t)chunks * t16 * 1024, 0.0f);
+        for (int k = 0; k < K; ++k)
+            for (int n = 0; n < N; ++n) {
+                const int ch = k / 64, s2 = (k % 64) / 16, kk = (k % 16) / 4, e2 = k % 4;
+                w2[((((size_t)ch * t16 + n / 16) * 4 + kk) * 16 + n % 16) * 16 + s2 * 4 + e2] = w[(size_t)n * K + k];
+            }
+        rc = upload(e, &g->wt2, w2);
+    }
     if (rc || !pieces) return rc;
     // w = hi + mid + lo exactly, each piece a bf16 (truncation split: 8 + 8 + 8 significand bits)
     const int KQ = g->Kpad / 4;
@@ -260,12 +273,12 @@ int load_weights(pb_embedder *e, const uint8_t *blob, size_t len) {
     return PB_OK;
 }
 
-template <int MR, bool GATE, int NW = 4>
+template <int MR, bool GATE, int NW = 4, int PDX = 0>
 void launch_gemm_mr(int nr, dim3 grid, hipStream_t st, const float *act, int M, const Gemm &g, const float *gate, int hw,
                     const float *resid, int do_silu, float *out) {
 #define PB_G(NRV)                                                                                                    \
     case NRV:                                                                                                        \
-        hipLaunchKernelGGL((k_gemm1x1<MR, NRV, GATE, NW>), grid, dim3(64 * NW), 0, st, act, M, g.K, g.wt, g.Kpad, g.Npad, g.bias, \
+        hipLaunchKernelGGL((k_gemm1x1<MR, NRV, GATE, NW, PDX>), grid, dim3(64 * NW), 0, st, act, M, g.K, g.wt, g.Kpad, g.Npad, g.bias, \
                            g.N, gate, hw, resid, do_silu, out);                                                      \
         break;
     switch (nr) {
@@ -307,6 +320,21 @@ int launch_gemm_b3(int nr, int nw, hipStream_t st, const float *act, long M, con
 #undef PB_B3
 }
 
+template <bool GATE, int NW>
+void launch_gemm_t(int nr, hipStream_t st, const float *act, long M, const Gemm &g, const float *gate, int hw, const float *resid,
+                   int do_silu, float *out) {
+    const dim3 grid((unsigned)((M + 16 * NW - 1) / (16 * NW)), (unsigned)(g.Npad / 16 / nr));
+#define PB_G(NRV)                                                                                                              \
+    case NRV:                                                                                                                  \
+        hipLaunchKernelGGL((k_gemm_t<NRV, GATE, NW>), grid, dim3(64 * NW), 0, st, act, (int)M, g.K, g.wt2, g.Npad / 16, g.bias, g.N, gate, hw, \
+                           resid, do_silu, out);                                                                               \
+        break;
+    switch (nr) {
+        PB_G(1) PB_G(2) PB_G(3) PB_G(4) PB_G(5) PB_G(6) PB_G(7) PB_G(8)
+    }
+#undef PB_G
+}
+
 // Tile choice.  NR (16-column tiles per wave) must divide Npad/16; MR in {4,2,1} (64*MR rows per block).
 // The best (MR, NR) depends on the layer shape and on the batch (memory-bound thin layers want big tiles,
 // small-M late layers want many small blocks), so it is measured: the first forward with a given row count
@@ -314,6 +342,8 @@ int launch_gemm_b3(int nr, int nw, hipStream_t st, const float *act, long M, con
 // simply overwritten with identical values) and the winner is cached per (layer, M).
 struct GemmCfg {
     int mr, nr, nw;  // nw = 8: eight waves per block (MR = 1 only), else four
+    int pd = 0;      // eight-wave form only: activation prefetch distance 8 / 16 k-steps (0: the default of 4)
+    int tform = 0;   // 1: k_gemm_t (fragment-ordered weights, pipelined fragment reads, no masks in the loop), nw = 4 or 8
 };
 
 void launch_gemm_cfg(pb_embedder *e, GemmCfg c, const float *act, long M, const Gemm &g, const float *gate, int hw,
@@ -322,6 +352,16 @@ void launch_gemm_cfg(pb_embedder *e, GemmCfg c, const float *act, long M, const 
     const long rows_per_block = 16L * c.nw * c.mr;
     dim3 grid((unsigned)((M + rows_per_block - 1) / rows_per_block), (unsigned)(tiles / c.nr));
     const int nr = c.nr;
+    if (c.tform) {
+        if (gate) {
+            if (c.nw == 8) launch_gemm_t<true, 8>(nr, e->stream, act, M, g, gate, hw, resid, do_silu, out);
+            else launch_gemm_t<true, 4>(nr, e->stream, act, M, g, gate, hw, resid, do_silu, out);
+        } else {
+            if (c.nw == 8) launch_gemm_t<false, 8>(nr, e->stream, act, M, g, gate, hw, resid, do_silu, out);
+            else launch_gemm_t<false, 4>(nr, e->stream, act, M, g, gate, hw, resid, do_silu, out);
+        }
+        return;
+    }
     if (c.nw == 1) {  // one wave per 16 x 16 tile, weights from global (a few pixel rows: small batches of the late layers)
         const dim3 tg((unsigned)((M + 15) / 16), (unsigned)tiles);
         if (gate)
@@ -331,8 +371,11 @@ void launch_gemm_cfg(pb_embedder *e, GemmCfg c, const float *act, long M, const 
         return;
     }
     if (c.nw == 8) {
-        if (gate) launch_gemm_mr<1, true, 8>(nr, grid, e->stream, act, (int)M, g, gate, hw, resid, do_silu, out);
-        else launch_gemm_mr<1, false, 8>(nr, grid, e->stream, act, (int)M, g, gate, hw, resid, do_silu, out);
+#define PB_L8(PDV)                                                                                                      \
+    (gate ? launch_gemm_mr<1, true, 8, PDV>(nr, grid, e->stream, act, (int)M, g, gate, hw, resid, do_silu, out)          \
+          : launch_gemm_mr<1, false, 8, PDV>(nr, grid, e->stream, act, (int)M, g, gate, hw, resid, do_silu, out))
+        PB_L8(0);  // (prefetch distances 8 / 16 were measured on the late layers: no gain)
+#undef PB_L8
         return;
     }
 #define PB_L(MRV)                                                                                                    \
@@ -394,11 +437,13 @@ int launch_gemm(pb_embedder *e, const float *act, long M, const Gemm &g, const f
         const hipEvent_t e0 = e->tune_e0, e1 = e->tune_e1;  // the embedder's own pair: nothing to release on an early return
         for (int nr = 8; nr >= 1; --nr) {
             if (tiles % nr) continue;
-            for (int mr : {4, 2, 1, 0, -1}) {  // 0: the eight-wave form of MR = 1; -1: the one-wave form (k_gemm_thin)
+            // 0: the eight-wave form of MR = 1; -1: the one-wave form (k_gemm_thin); -104 / -108: k_gemm_t with 4 / 8 waves
+            for (int mr : {4, 2, 1, 0, -104, -108, -1}) {
                 if (mr > 1 && M <= 64L * (mr / 2)) continue;  // tile taller than the problem
-                if (mr == 0 && M <= 64) continue;
+                if ((mr == 0 || mr == -108) && M <= 64) continue;
+                if (mr <= -100 && (!g.wt2 || e->no_gemm_t)) continue;
                 if (mr == -1 && (nr != 1 || M > 1024)) continue;
-                const GemmCfg c{mr > 0 ? mr : 1, nr, mr > 0 ? 4 : (mr == 0 ? 8 : 1)};
+                const GemmCfg c{mr > 0 ? mr : 1, nr, mr > 0 ? 4 : (mr == -1 ? 1 : (mr == -104 ? 4 : 8)), 0, mr <= -100 ? 1 : 0};
                 launch_gemm_cfg(e, c, act, M, g, gate, hw, resid, do_silu, out);
                 PB_HIP(hipEventRecord(e0, e->stream));
                 launch_gemm_cfg(e, c, act, M, g, gate, hw, resid, do_silu, out);
@@ -409,7 +454,7 @@ int launch_gemm(pb_embedder *e, const float *act, long M, const Gemm &g, const f
                 float ms = 0.f;
                 PB_HIP(hipEventElapsedTime(&ms, e0, e1));
                 if (e->trace_tune >= 2)
-                    fprintf(stderr, "  gemm M%ld K%d N%d: MR%d NR%d NW%d %.1f us\n", M, g.K, g.N, c.mr, c.nr, c.nw, ms * 500.f);
+                    fprintf(stderr, "  gemm M%ld K%d N%d: MR%d NR%d NW%d%s %.1f us\n", M, g.K, g.N, c.mr, c.nr, c.nw, c.tform ? " t-form" : "", ms * 500.f);
                 if (tune_take(e, ms, best_ms)) {
                     best_ms = ms;
                     best = c;
@@ -417,13 +462,14 @@ int launch_gemm(pb_embedder *e, const float *act, long M, const Gemm &g, const f
             }
         }
         if (e->trace_tune)
-            fprintf(stderr, "gemm M%ld K%d N%d%s: best MR%d NR%d NW%d %.1f us = %.1f TFLOP/s\n", M, g.K, g.N, gate ? " gated" : "", best.mr,
-                    best.nr, best.nw, best_ms * 500.f, 2.0 * (double)M * g.K * g.N / (best_ms * 0.5e-3) / 1e12);
-        it = e->gemm_cfg.emplace(key, std::make_pair(best.nw == 1 ? 100 : best.mr * (best.nw == 8 ? -1 : 1), best.nr)).first;
+            fprintf(stderr, "gemm M%ld K%d N%d%s: best MR%d NR%d NW%d%s %.1f us = %.1f TFLOP/s\n", M, g.K, g.N, gate ? " gated" : "", best.mr,
+                    best.nr, best.nw, best.tform ? " t-form" : "", best_ms * 500.f, 2.0 * (double)M * g.K * g.N / (best_ms * 0.5e-3) / 1e12);
+        // encoding: 100 one-wave form; -1 eight-wave form; 304 / 308 k_gemm_t with 4 / 8 waves; else MR of the four-wave form
+        it = e->gemm_cfg.emplace(key, std::make_pair(best.tform ? 300 + best.nw : (best.nw == 1 ? 100 : (best.nw == 8 ? -1 : best.mr)), best.nr)).first;
     }
-    const int enc = it->second.first;  // 100: one-wave form; negative: eight-wave form
-    launch_gemm_cfg(e, GemmCfg{enc == 100 ? 1 : std::abs(enc), it->second.second, enc == 100 ? 1 : (enc < 0 ? 8 : 4)}, act, M, g, gate, hw,
-                    resid, do_silu, out);
+    const int enc = it->second.first;
+    launch_gemm_cfg(e, GemmCfg{(enc >= 100 || enc < 0) ? 1 : enc, it->second.second, enc >= 300 ? enc - 300 : (enc == 100 ? 1 : (enc < 0 ? 8 : 4)), 0, enc >= 300 ? 1 : 0},
+                    act, M, g, gate, hw, resid, do_silu, out);
     PB_HIP(hipGetLastError());
     return PB_OK;
 }
@@ -1000,7 +1046,8 @@ int pb_embed_create(pb_embedder **out, int device, const void *weights_blob, siz
     if (const char *tp = getenv("PB_TUNE_PICK")) e->tune_pick = atoi(tp);
     if (const char *tt = getenv("PB_TRACE_TUNE")) e->trace_tune = tt[0] == '2' ? 2 : 1;
     e->no_stem_fusion = getenv("PB_NO_STEM_FUSION") != nullptr;
-    e->fold_se = getenv("PB_NO_FOLD") == nullptr;
+    e->fold_se = getenv("PB_FOLD_SE") != nullptr;
+    e->no_gemm_t = getenv("PB_NO_GEMM_T") != nullptr;
     e->no_band = getenv("PB_NO_BAND") != nullptr;
     e->force_band = getenv("PB_FORCE_BAND") != nullptr;
     auto body = [&]() -> int {

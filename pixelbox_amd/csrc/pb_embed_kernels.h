@@ -435,7 +435,11 @@ constexpr int G_KC = 64;  // K chunk staged in LDS (double-buffered: one barrier
 // written to the other LDS buffer afterwards (one barrier per chunk); (b) the activation operand of k-step
 // t+PD is requested before the MFMAs of k-step t (register ring), so the global-load latency of the streamed
 // operand hides behind 4*MR*NR MFMAs per step times PD steps.
-template <int MR, int NR, bool GATE, int NW = 4>
+// PDX: activation prefetch distance in k-steps (0: the default, 2 for MR = 4 and 4 otherwise; 8 / 16: the eight-wave form of
+// the late layers, whose operand arrives from beyond the XCD's L2 -- with 1 KiB per wave and k-step, 8 waves x 4 steps
+// keep 32 KiB per CU in flight, which at ~1.5 us of loaded latency is ~20 GB/s per CU, the rate those layers ran at; the
+// ring is registers, and an eight-wave workgroup per CU has 256 of them per lane).
+template <int MR, int NR, bool GATE, int NW = 4, int PDX = 0>
 __global__ __launch_bounds__(64 * NW) void k_gemm1x1(const float *__restrict__ act, int M, int K,
                                                  const float *__restrict__ wt, int Kpad, int Npad,
                                                  const float *__restrict__ bias, int N,
@@ -444,7 +448,10 @@ __global__ __launch_bounds__(64 * NW) void k_gemm1x1(const float *__restrict__ a
                                                  float *__restrict__ out) {
     constexpr int NT = 16 * NR;
     constexpr int LDW = NT + 4;  // +4: rows k and k+4 land 16 banks apart (conflict-free ds_read_b32)
-    constexpr int PD = MR == 4 ? 2 : 4;  // activation prefetch distance in k-steps; must divide G_KC/16 = 4 (ring slot = step % PD)
+    constexpr int PD = PDX ? PDX : (MR == 4 ? 2 : 4);  // activation prefetch distance in k-steps: divides, or is a multiple of, the
+                                                        // G_KC/16 = 4 steps of a chunk (ring slot = step % PD, a compile-time index)
+    constexpr int CPG = PD > 4 ? PD / 4 : 1;            // chunks per turn of the main loop (the slots repeat after PD steps)
+    static_assert(PD == 2 || PD == 4 || PD == 8 || PD == 16, "prefetch distance");
     constexpr int NTHR = 64 * NW;  // NW = 8: the same 16*MR rows per wave, twice the waves per block (the late layers have
                                    // few row tiles: more waves per CU hide the operand latency without changing the k order)
     constexpr int WREGS = (G_KC * (NT / 4) + NTHR - 1) / NTHR;  // float4 per thread per weight chunk
@@ -519,7 +526,8 @@ __global__ __launch_bounds__(64 * NW) void k_gemm1x1(const float *__restrict__ a
 
     // The full chunks run in a loop of their own and the tail chunk (Kpad % 64 != 0) after it: with both forms in ONE
     // loop body the ring slots are phis of two paths and hipcc copies all of them at the back edge behind vmcnt(0).
-    auto do_chunk = [&](int chunk, auto full) __attribute__((always_inline)) {
+    auto do_chunk = [&](int chunk, auto full, auto cpos) __attribute__((always_inline)) {
+        constexpr int SLOT0 = (4 * decltype(cpos)::value) % PD;  // ring slot of the chunk's first step
         const int k0 = chunk * G_KC;
         const int kc = (Kpad - k0) < G_KC ? (Kpad - k0) : G_KC;
         // full chunks fetch and stage the next weight chunk unconditionally (after the last one: the same chunk again, into
@@ -570,18 +578,45 @@ __global__ __launch_bounds__(64 * NW) void k_gemm1x1(const float *__restrict__ a
         };
         if constexpr (decltype(full)::value) {  // four unguarded steps
 #pragma unroll
-            for (int q = 0; q < G_KC / 16; ++q) k_step(16 * q, q % PD);
+            for (int q = 0; q < G_KC / 16; ++q) k_step(16 * q, (SLOT0 + q) % PD);
         } else {  // tail chunk, once per kernel
 #pragma unroll
             for (int q = 0; q < G_KC / 16; ++q)
-                if (16 * q < kc) k_step(16 * q, q % PD);
+                if (16 * q < kc) k_step(16 * q, (SLOT0 + q) % PD);
         }
         if constexpr (decltype(full)::value) store_w((chunk + 1) & 1);
         __syncthreads();
     };
     const int n_full = Kpad / G_KC;
-    for (int chunk = 0; chunk < n_full; ++chunk) do_chunk(chunk, std::true_type{});
-    if (n_full < n_chunks) do_chunk(n_full, std::false_type{});
+    if constexpr (CPG == 1) {
+        for (int chunk = 0; chunk < n_full; ++chunk) do_chunk(chunk, std::true_type{}, std::integral_constant<int, 0>{});
+        if (n_full < n_chunks) do_chunk(n_full, std::false_type{}, std::integral_constant<int, 0>{});
+    } else {
+        int chunk = 0;
+        for (; chunk + CPG <= n_full; chunk += CPG) {
+            do_chunk(chunk, std::true_type{}, std::integral_constant<int, 0>{});
+            do_chunk(chunk + 1, std::true_type{}, std::integral_constant<int, 1>{});
+            if constexpr (CPG == 4) {
+                do_chunk(chunk + 2, std::true_type{}, std::integral_constant<int, 2>{});
+                do_chunk(chunk + 3, std::true_type{}, std::integral_constant<int, 3>{});
+            }
+        }
+        // the chunks left over (fewer than CPG, once per kernel): the same bodies at their positions in the turn
+        const int rem = n_full - chunk;
+        if (rem > 0) do_chunk(chunk, std::true_type{}, std::integral_constant<int, 0>{});
+        if constexpr (CPG == 4) {
+            if (rem > 1) do_chunk(chunk + 1, std::true_type{}, std::integral_constant<int, 1>{});
+            if (rem > 2) do_chunk(chunk + 2, std::true_type{}, std::integral_constant<int, 2>{});
+        }
+        if (n_full < n_chunks) {
+            if (rem == 0) do_chunk(n_full, std::false_type{}, std::integral_constant<int, 0>{});
+            else if (rem == 1) do_chunk(n_full, std::false_type{}, std::integral_constant<int, 1>{});
+            else if constexpr (CPG == 4) {
+                if (rem == 2) do_chunk(n_full, std::false_type{}, std::integral_constant<int, 2>{});
+                else do_chunk(n_full, std::false_type{}, std::integral_constant<int, 3>{});
+            }
+        }
+    }
     // epilogue: lane holds channels n0 + 16c + 4kk .. +3 of pixel mrow[r]
 #pragma unroll
     for (int r = 0; r < MR; ++r) {
@@ -600,6 +635,174 @@ __global__ __launch_bounds__(64 * NW) void k_gemm1x1(const float *__restrict__ a
             }
             *reinterpret_cast<f32x4 *>(out + mrow[r] * N + n) = v;
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_gemm_t: the same product as k_gemm1x1<MR = 1> -- same operand maps, same k order, bit-identical results -- with the
+// per-k-step overhead taken out of the loop.  In k_gemm1x1 a k-step of 4 NR MFMAs also issues ~20 vector and ~8 scalar
+// instructions (row / k masks and clamped 64-bit addresses under saveexec, the gate multiplies, 2 NR two-dword LDS reads that
+// the first MFMA waits for), and on this chip vector instructions do not hide under f32 MFMAs (profiles/micro/
+// mfma_f32_rate.hip: the two share the SIMD's f32 datapath).  Here:
+//  * the weights arrive pre-arranged for the fragment reads: wt2[chunk of 64 k][16-column tile][kk][li][s][e] holds
+//    w[k = 64 chunk + 16 s + 4 kk + e][n = 16 tile + li] (zero beyond K / N), so a lane's four e-values of a k-step are ONE
+//    ds_read_b128 (NR per k-step instead of 4 NR dwords) and the staging is a straight 16-byte copy; LDS rows of 5 slots
+//    (80 B) per (kk, li) make both the staging stores and the fragment reads conflict-free;
+//  * the fragments of k-step s + 1 are read while the MFMAs of step s run (two register sets);
+//  * rows beyond M are clamped ONCE (they compute on row M - 1 and store nothing), k-steps beyond K exist only in the last
+//    chunk (a uniform trip count), so the loop carries no masks; the activation / gate addresses of a chunk's four steps are
+//    immediates off one pointer that advances 256 B per chunk.
+// Needs K % 16 == 0 (every project / head / FC layer of EfficientNet-B0; the thin expand layers keep k_gemm1x1).
+// grid = (ceil(M / (16 NW)), Npad / (16 NR)); block = 64 NW.
+template <int NR, bool GATE, int NW>
+__global__ __launch_bounds__(64 * NW) void k_gemm_t(const float *__restrict__ act, int M, int K, const float *__restrict__ wt2,
+                                                   int tiles16, const float *__restrict__ bias, int N,
+                                                   const float *__restrict__ gate, int hw, const float *__restrict__ resid,
+                                                   int do_silu, float *__restrict__ out) {
+    constexpr int NTHR = 64 * NW;
+    constexpr int CH4 = NR * 256;                         // float4 per weight chunk of this block (NR tiles x 4 kk x 16 li x 4 s)
+    constexpr int WREGS = NR;                             // staged by the first 256 threads, NR float4 each (whole waves: no lane predicate)
+    constexpr int BUF = NR * 64 * 5;                      // float4 slots per LDS buffer
+    __shared__ __attribute__((aligned(16))) f32x4 s_w[2 * BUF];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 15, kk = lane >> 4;
+    const int c0 = blockIdx.y * NR;  // first 16-column tile
+    const long mrow = (long)blockIdx.x * (16 * NW) + wave * 16 + li;
+    const bool mval = mrow < M;
+    const long mc = mval ? mrow : (long)M - 1;
+    const float *ap = act + mc * K + 4 * kk;                             // + 16 floats per k-step
+    const float *gp = GATE ? gate + (mc / hw) * K + 4 * kk : nullptr;
+    const int n_steps = K >> 4, n_chunks = (n_steps + 3) >> 2;
+    f32x4 acc[NR];
+#pragma unroll
+    for (int c = 0; c < NR; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // two operand sets of four k-steps each: the MFMAs of chunk c read one set while the steps of chunk c + 1 are requested
+    // into the other (a single set, each slot re-requested once read, makes the new value, the old one and their gated
+    // product overlap in time: hipcc rotates registers and copies the ring at the loop's back edge behind near-complete
+    // waits for the loads just issued -- seen in the ISA)
+    f32x4 ar[2][4], gr[2][GATE ? 4 : 1];
+    // steps of the first chunk (a chunk shorter than 4 steps re-reads its last step: in bounds, never used)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int tc = q < n_steps ? q : n_steps - 1;
+        ar[0][q] = *reinterpret_cast<const f32x4 *>(ap + 16 * tc);
+        if constexpr (GATE) gr[0][q] = *reinterpret_cast<const f32x4 *>(gp + 16 * tc);
+    }
+
+    f32x4 wreg[WREGS];
+    const float *wsrc = wt2 + (size_t)c0 * 1024;  // + chunk * tiles16 * 1024 floats
+    const int stg = threadIdx.x & 255;
+    auto load_w = [&](int chunk) __attribute__((always_inline)) {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(wsrc + (size_t)chunk * tiles16 * 1024);
+        if (NW == 4 || wave < 4) {  // wave-uniform
+#pragma unroll
+            for (int j = 0; j < WREGS; ++j) wreg[j] = src[stg + j * 256];
+        }
+    };
+    auto store_w = [&](int buf) __attribute__((always_inline)) {
+        if (NW == 4 || wave < 4) {
+#pragma unroll
+            for (int j = 0; j < WREGS; ++j) {
+                const int i = stg + j * 256;  // = (c * 64 + kk * 16 + li) * 4 + s
+                s_w[buf * BUF + (i >> 2) * 5 + (i & 3)] = wreg[j];
+            }
+        }
+    };
+    load_w(0);
+    store_w(0);
+    __syncthreads();
+    const unsigned rd0 = (unsigned)((kk * 16 + li) * 5);  // + c * 320 + s, + buf * BUF
+    f32x4 wa[NR], wb[NR];
+#pragma unroll
+    for (int c = 0; c < NR; ++c) wa[c] = s_w[rd0 + c * 320];
+    // One chunk of STEPS k-steps.  The full chunks run in a loop of their own and the short last chunk (K % 64 != 0) after
+    // it: with both in ONE loop body the ring slots are phis of two paths, and hipcc resolves them by loading into
+    // temporaries that it copies into the slots behind s_waitcnt vmcnt(0) -- every chunk would wait for the loads it has
+    // just issued (seen in the ISA of the first version of this kernel, as in k_gemm1x1).
+    auto do_chunk = [&](int chunk, auto steps_c, auto set_c) __attribute__((always_inline)) {
+        constexpr int STEPS = decltype(steps_c)::value;
+        constexpr int CUR = decltype(set_c)::value, NXT = CUR ^ 1;
+        const unsigned rb = rd0 + (unsigned)(chunk & 1) * BUF, rn = rd0 + (unsigned)((chunk + 1) & 1) * BUF;
+        load_w(chunk + 1 < n_chunks ? chunk + 1 : chunk);  // unconditional (a conditional fetch makes hipcc drain every outstanding load per chunk)
+        // one k-step: operands of step q from ring slot q, the same step of the NEXT chunk requested into that slot (past
+        // the end: the last step again, never used), the fragments of step q + 1 read into the other register set, then
+        // 4 NR MFMAs from this one
+        auto k_step = [&](auto qc, f32x4 (&wcur)[NR], f32x4 (&wnxt)[NR]) __attribute__((always_inline)) {
+            constexpr int q = decltype(qc)::value;
+            f32x4 a = ar[CUR][q];
+            if constexpr (GATE) {
+                const f32x4 g = gr[CUR][q];
+                a.x = a.x * g.x; a.y = a.y * g.y; a.z = a.z * g.z; a.w = a.w * g.w;
+            }
+            {
+                const int tn = 4 * chunk + 4 + q;  // global k-step requested
+                const int tc = tn < n_steps ? tn : n_steps - 1;
+                ar[NXT][q] = *reinterpret_cast<const f32x4 *>(ap + 16 * tc);
+                if constexpr (GATE) gr[NXT][q] = *reinterpret_cast<const f32x4 *>(gp + 16 * tc);
+            }
+            if constexpr (q + 1 < STEPS) {
+#pragma unroll
+                for (int c = 0; c < NR; ++c) wnxt[c] = s_w[rb + c * 320 + q + 1];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float av = e == 0 ? a.x : (e == 1 ? a.y : (e == 2 ? a.z : a.w));
+#pragma unroll
+                for (int c = 0; c < NR; ++c) {
+                    const float wv = e == 0 ? wcur[c].x : (e == 1 ? wcur[c].y : (e == 2 ? wcur[c].z : wcur[c].w));
+                    acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, av, acc[c], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        k_step(std::integral_constant<int, 0>{}, wa, wb);
+        if constexpr (STEPS > 1) k_step(std::integral_constant<int, 1>{}, wb, wa);
+        if constexpr (STEPS > 2) k_step(std::integral_constant<int, 2>{}, wa, wb);
+        if constexpr (STEPS > 3) k_step(std::integral_constant<int, 3>{}, wb, wa);
+        store_w((chunk + 1) & 1);
+        __syncthreads();
+        // first fragments of the next chunk (after the barrier: the buffer has just been written)
+#pragma unroll
+        for (int c = 0; c < NR; ++c) wa[c] = s_w[rn + c * 320];
+    };
+    const int n_full = n_steps >> 2;
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I4 = std::integral_constant<int, 4>;
+    int chunk = 0;
+    for (; chunk + 2 <= n_full; chunk += 2) {
+        do_chunk(chunk, I4{}, I0{});
+        do_chunk(chunk + 1, I4{}, I1{});
+    }
+    {   // once per kernel: an odd full chunk, then the short last chunk (K % 64 != 0) -- on whichever set holds its steps
+        const int rem = n_steps & 3;
+        if (chunk < n_full) {
+            do_chunk(chunk, I4{}, I0{});
+            if (rem == 1) do_chunk(n_full, std::integral_constant<int, 1>{}, I1{});
+            else if (rem == 2) do_chunk(n_full, std::integral_constant<int, 2>{}, I1{});
+            else if (rem == 3) do_chunk(n_full, std::integral_constant<int, 3>{}, I1{});
+        } else {
+            if (rem == 1) do_chunk(n_full, std::integral_constant<int, 1>{}, I0{});
+            else if (rem == 2) do_chunk(n_full, std::integral_constant<int, 2>{}, I0{});
+            else if (rem == 3) do_chunk(n_full, std::integral_constant<int, 3>{}, I0{});
+        }
+    }
+    if (!mval) return;
+#pragma unroll
+    for (int c = 0; c < NR; ++c) {
+        const int n = (c0 + c) * 16 + kk * 4;
+        if (n >= N) continue;  // N % 4 == 0
+        const f32x4 b = *reinterpret_cast<const f32x4 *>(bias + n);
+        f32x4 v = acc[c];
+        v.x = v.x + b.x; v.y = v.y + b.y; v.z = v.z + b.z; v.w = v.w + b.w;
+        if (do_silu) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+        if (resid) {
+            const f32x4 rv = *reinterpret_cast<const f32x4 *>(resid + mrow * N + n);
+            v.x = rv.x + v.x; v.y = rv.y + v.y; v.z = rv.z + v.z; v.w = rv.w + v.w;
+        }
+        *reinterpret_cast<f32x4 *>(out + mrow * N + n) = v;
     }
 }
 
