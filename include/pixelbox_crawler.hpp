@@ -1,4 +1,4 @@
-// pixelbox_crawler.hpp -- the crawler -> embed stage re-built for a GPU, mirroring
+// pixelbox_crawler.hpp -- the crawler -> embed stage re-built for GPUs, mirroring
 // src/crawler.rs:10-123 + the hashing half of IndexedImage::from_memory (src/indexed_image.rs:47-91).
 //
 // Reference: one glob thread walks "<folder>/**/*.*" and keeps the files whose extension is one of twelve (crawler.rs:7,
@@ -7,18 +7,30 @@
 // channel that the insert thread drains (crawler.rs:27-28, engine.rs:186-203).
 //
 // Here the workers only READ and DECODE (CPU codecs; the decoder is the host's callback, PNM built in) and hand the
-// decoded pixels, at whatever size, to ONE embed thread, which gathers up to `max_batch` (512) of them and runs
-// `resize_to_fill(W, H, Triangle)` + the network for the whole batch on the GPU (pb_embed_batch_images) and `phash` per
-// image (pb_phash_image); the finished IndexedImages go into the same bounded channel, which the caller drains with
-// recv() exactly as engine.rs:189-200 drains its Receiver.  Same 12-extension allow-list, same "undecodable files are
+// decoded pixels, at whatever size, to the EMBED THREADS -- one per pb_embedder, i.e. one per GPU -- each of which gathers
+// up to `max_batch` (512) of them and runs `resize_to_fill(W, H, Triangle)` + the network for the whole batch on its GPU and
+// `phash` per image (pb_phash_image); the finished IndexedImages go into the same bounded channel, which the caller drains
+// with recv() exactly as engine.rs:189-200 drains its Receiver.  Same 12-extension allow-list, same "undecodable files are
 // skipped" rule (crawler.rs:78), same back-pressure (a full channel stalls the producers).
+//
+// Multi-GPU ingest (BASELINE configs[4]): with a BatchSink the embed thread of GPU g hands every finished batch -- records
+// AND a pointer to the batch's hashes in that GPU's memory -- to the sink before the records enter the channel; ShardedEngine
+// (pixelbox_sharded.hpp) uses it to assign image ids and store the hashes on shard g device-to-device
+// (pb_sharded_append_device), so that N GPUs embed and insert concurrently with no host hop for the hashes.
+//
+// Shutdown: like the reference's detached workers, which stop when the Receiver is dropped (`TrySendError::Disconnected`,
+// crawler.rs:97-101), every thread here leaves as soon as the stage is cancelled -- by the destructor, by cancel(), or by an
+// embed thread that failed.  A failure (a pb_* call returning an error throws pixelbox::Error on the embed thread) is
+// caught there, recorded, closes the channel and is reported by error(); nothing terminates the process.
 #pragma once
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <deque>
 #include <filesystem>
+#include <functional>
 #include <mutex>
+#include <string>
 #include <thread>
 
 #include "pixelbox_host.hpp"
@@ -31,27 +43,63 @@ class Crawler {
     static inline const char *const SUPPORTED_IMAGE_EXTENSIONS[12] = {"png", "bmp", "jpg",  "jpeg", "jfif", "gif",
                                                                       "tiff", "pnm", "webp", "ico",  "tga",  "exr"};  // crawler.rs:7
 
+    // records of one finished batch + its hashes in the memory of embedder `model_index`'s GPU (uint8[batch][dim], valid for
+    // the duration of the call); may set IndexedImage::id.  Runs on that embedder's thread: sinks of different embedders
+    // run concurrently.  Throwing pixelbox::Error stops the stage.
+    using BatchSink = std::function<void(size_t model_index, std::vector<IndexedImage> &batch, const uint8_t *d_hashes)>;
+
     Crawler(const Embedder &model, const PHasher *hasher, Decoder decode = decode_pnm, uint32_t max_batch = 512)
-        : model_(model), hasher_(hasher), decode_(std::move(decode)), max_batch_(max_batch) {}
-    ~Crawler() { join(); }
+        : models_{&model}, hasher_(hasher), decode_(std::move(decode)), max_batch_(max_batch) {}
+    // one embed thread per model (one model per GPU); `hasher` (optional) must be usable from all of them
+    Crawler(std::vector<const Embedder *> models, const PHasher *hasher, Decoder decode = decode_pnm, uint32_t max_batch = 512,
+            BatchSink sink = nullptr)
+        : models_(std::move(models)), hasher_(hasher), decode_(std::move(decode)), max_batch_(max_batch), sink_(std::move(sink)) {
+        if (models_.empty()) throw Error(PB_ERR_INVALID, "Crawler: no embedder");
+    }
+    ~Crawler() {
+        cancel();
+        join();
+    }
     Crawler(const Crawler &) = delete;
+
+    // stop everything: waiting threads wake up and leave, recv() returns false once the channel is empty
+    void cancel() {
+        std::lock_guard<std::mutex> lk(mu_);
+        cancelled_ = true;
+        cv_files_.notify_all();
+        cv_decoded_.notify_all();
+        cv_out_.notify_all();
+        cv_space_.notify_all();
+    }
+    // message of the first failure on an embed thread ("" = none); the stage is cancelled when one occurs
+    std::string error() const {
+        std::lock_guard<std::mutex> lk(mu_);
+        return error_;
+    }
 
     // crawler.rs:21-122.  Returns at once; the IndexedImages arrive through recv().
     void start_indexing(std::vector<std::string> folders, size_t num_workers) {
+        cancel();
         join();
+        files_.clear();
+        decoded_.clear();
+        out_.clear();
+        cancelled_ = false;
+        error_.clear();
         files_done_ = false;
         decoders_left_ = num_workers;
+        embedders_left_ = models_.size();
         out_closed_ = false;
         stats_ = Stats{};
         threads_.emplace_back([this, folders] { glob_thread(folders); });
         for (size_t i = 0; i < num_workers; ++i) threads_.emplace_back([this] { decode_worker(); });
-        threads_.emplace_back([this] { embed_thread(); });
+        for (size_t m = 0; m < models_.size(); ++m) threads_.emplace_back([this, m] { embed_thread(m); });
     }
 
     // the Receiver<IndexedImage>: blocks for the next image; false once every file has been processed
     bool recv(IndexedImage &out) {
         std::unique_lock<std::mutex> lk(mu_);
-        cv_out_.wait(lk, [&] { return !out_.empty() || out_closed_; });
+        cv_out_.wait(lk, [&] { return !out_.empty() || out_closed_ || cancelled_; });
         if (out_.empty()) return false;
         out = std::move(out_.front());
         out_.pop_front();
@@ -96,6 +144,7 @@ class Crawler {
             for (fs::recursive_directory_iterator it(dir, fs::directory_options::skip_permission_denied, ec), end; !ec && it != end; it.increment(ec)) {
                 if (!it->is_regular_file(ec)) continue;
                 std::lock_guard<std::mutex> lk(mu_);
+                if (cancelled_) break;
                 ++stats_.files_seen;
                 if (!is_image_file(it->path())) continue;
                 ++stats_.files_matched;
@@ -113,8 +162,8 @@ class Crawler {
             std::string path;
             {
                 std::unique_lock<std::mutex> lk(mu_);
-                cv_files_.wait(lk, [&] { return !files_.empty() || files_done_; });
-                if (files_.empty()) break;
+                cv_files_.wait(lk, [&] { return !files_.empty() || files_done_ || cancelled_; });
+                if (files_.empty() || cancelled_) break;
                 path = std::move(files_.front());
                 files_.pop_front();
             }
@@ -127,7 +176,8 @@ class Crawler {
             }
             ++stats_.decoded;
             // back-pressure: decoded pixels are the big items; hold at most two batches of them
-            cv_space_.wait(lk, [&] { return decoded_.size() < 2 * (size_t)max_batch_; });
+            cv_space_.wait(lk, [&] { return decoded_.size() < 2 * (size_t)max_batch_ * models_.size() || cancelled_; });
+            if (cancelled_) break;
             Decoded d;
             d.path = path;
             const size_t slash = path.find_last_of('/');
@@ -140,13 +190,32 @@ class Crawler {
         if (--decoders_left_ == 0) cv_decoded_.notify_all();
     }
 
-    void embed_thread() {  // the GPU half: whatever is pending, up to max_batch images per forward pass
+    void embed_thread(size_t m) {  // the GPU half: whatever is pending, up to max_batch images per forward pass
+        try {
+            embed_loop(m);
+        } catch (const std::exception &ex) {  // pixelbox::Error from a pb_* call, bad_alloc, ...: never out of a std::thread
+            std::lock_guard<std::mutex> lk(mu_);
+            if (error_.empty()) error_ = ex.what();
+            cancelled_ = true;
+            cv_files_.notify_all();
+            cv_decoded_.notify_all();
+            cv_space_.notify_all();
+        }
+        std::lock_guard<std::mutex> lk(mu_);
+        if (--embedders_left_ == 0 || cancelled_) {
+            out_closed_ = true;
+            cv_out_.notify_all();
+        }
+    }
+
+    void embed_loop(size_t m) {
+        const Embedder &model = *models_[m];
         for (;;) {
             std::vector<Decoded> batch;
             {
                 std::unique_lock<std::mutex> lk(mu_);
-                cv_decoded_.wait(lk, [&] { return !decoded_.empty() || decoders_left_ == 0; });
-                if (decoded_.empty()) break;
+                cv_decoded_.wait(lk, [&] { return !decoded_.empty() || decoders_left_ == 0 || cancelled_; });
+                if (decoded_.empty() || cancelled_) break;
                 while (!decoded_.empty() && batch.size() < max_batch_) {
                     batch.push_back(std::move(decoded_.front()));
                     decoded_.pop_front();
@@ -158,36 +227,42 @@ class Crawler {
             std::vector<RgbImage> imgs;
             imgs.reserve(batch.size());
             for (Decoded &d : batch) imgs.push_back(std::move(d.img));
-            const std::vector<std::vector<uint8_t>> hashes = image_hashes::mlhash_batch(model_, imgs);  // resize_to_fill + network, one batch
+            // resize_to_fill + network, one batch; the hashes stay on the GPU as well (for the sink)
+            const uint8_t *d_hashes = nullptr;
+            const std::vector<std::vector<uint8_t>> hashes = image_hashes::mlhash_batch(model, imgs, sink_ ? &d_hashes : nullptr);
+            std::vector<IndexedImage> recs(batch.size());
             for (size_t i = 0; i < batch.size(); ++i) {
-                IndexedImage r;
+                IndexedImage &r = recs[i];
                 r.filename = batch[i].filename;
                 r.path = batch[i].path;
                 r.resolution = {imgs[i].width, imgs[i].height};
                 if (hasher_) r.phash = image_hashes::phash(*hasher_, imgs[i]);
                 r.visual_hash = hashes[i];
+            }
+            if (sink_) sink_(m, recs, d_hashes);
+            for (IndexedImage &r : recs) {
                 std::unique_lock<std::mutex> lk(mu_);
-                cv_space_.wait(lk, [&] { return out_.size() < MAX_PENDING_TX; });  // bounded(128): a slow consumer stalls the stage
+                cv_space_.wait(lk, [&] { return out_.size() < MAX_PENDING_TX || cancelled_; });  // bounded(128): a slow consumer stalls the stage
+                if (cancelled_) return;
                 out_.push_back(std::move(r));
                 cv_out_.notify_one();
             }
         }
-        std::lock_guard<std::mutex> lk(mu_);
-        out_closed_ = true;
-        cv_out_.notify_all();
     }
 
-    const Embedder &model_;
+    std::vector<const Embedder *> models_;
     const PHasher *hasher_;
     Decoder decode_;
     uint32_t max_batch_;
+    BatchSink sink_;
     mutable std::mutex mu_;
     std::condition_variable cv_files_, cv_decoded_, cv_out_, cv_space_;
     std::deque<std::string> files_;
     std::deque<Decoded> decoded_;
     std::deque<IndexedImage> out_;
-    bool files_done_ = true, out_closed_ = true;
-    size_t decoders_left_ = 0;
+    bool files_done_ = true, out_closed_ = true, cancelled_ = false;
+    size_t decoders_left_ = 0, embedders_left_ = 0;
+    std::string error_;
     Stats stats_;
     std::vector<std::thread> threads_;
 };

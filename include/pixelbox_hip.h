@@ -207,6 +207,14 @@ int pb_sharded_load(pb_sharded *s, const int64_t *image_ids, const uint8_t *rows
 /* INSERT OR IGNORE (engine.rs:251-256) over all shards: a pair whose image_id is stored on ANY shard is skipped; the new
  * pairs of a call go to the least-full shard (spilling to the next when it fills up). */
 int pb_sharded_append(pb_sharded *s, const int64_t *image_ids, const uint8_t *rows, uint64_t n, uint64_t *n_inserted);
+/* The multi-GPU form of the crawler -> embed -> insert pipeline (engine.rs:177-205,228-259; crawler.rs:68-119): rows that are
+ * already in the DEVICE memory of shard `shard`'s GPU -- the hashes a pb_embedder on that device has just written -- are
+ * stored on that shard with no host round trip (pb_index_append_device).  image_ids: HOST array of fresh ids (strictly
+ * ascending, greater than every id of that shard, stored on no other shard: last_insert_rowid() values).  Calls for
+ * DIFFERENT shards may run concurrently from different host threads (one embed thread per device); pb_sharded_shard_device
+ * tells which device a shard lives on, so that an embedder can be created beside it. */
+int pb_sharded_append_device(pb_sharded *s, int shard, const int64_t *image_ids, const uint8_t *d_rows, uint64_t n);
+int pb_sharded_shard_device(const pb_sharded *s, int shard, int *device);
 /* Engine::query_by_image_hash_from_image (engine.rs:363-396) over all shards; arguments as pb_index_search */
 int pb_sharded_search(pb_sharded *s, const uint8_t *queries, uint32_t nq, uint32_t k, double max_dist, int64_t *out_ids,
                       float *out_dist, uint32_t *out_count);
@@ -246,6 +254,14 @@ int pb_embed_batch_device(pb_embedder *e, const uint8_t *d_rgb, uint32_t n, uint
 
 /* mlhash(img) -> Vec<u8> for one image: writes D bytes to out (out_len must be >= D). */
 int pb_mlhash(pb_embedder *e, const uint8_t *rgb, uint8_t *out, size_t out_len);
+
+/* pb_embed_batch_images for n <= max_batch images whose hashes are wanted IN DEVICE MEMORY as well: *d_out_u8 receives a
+ * pointer to the embedder's own output buffer on its GPU (uint8[n][D], valid until the next call on this embedder) -- what
+ * pb_index_append_device / pb_sharded_append_device take, so the crawler -> embed -> insert pipeline (crawler.rs:68-119,
+ * engine.rs:186-203) stores a batch without uploading its hashes again.  out_u8 (HOST, optional) receives a copy for the
+ * record (IndexedImage.visual_hash, the write-through to SQLite).  The call returns with the forward pass complete. */
+int pb_embed_batch_images_device(pb_embedder *e, const uint8_t *const *rgb, const uint32_t *widths, const uint32_t *heights, uint32_t n,
+                                 uint8_t *out_u8, const uint8_t **d_out_u8);
 
 /* The same for images of ANY size: efficientnet.rs:19-29 `image_to_tensor` in full -- the image crate's
  * `resize_to_fill(W, H, FilterType::Triangle)` (scale to cover, separable triangle filter through an f32
@@ -292,6 +308,10 @@ int pb_fill_synthetic(int device, uint64_t seed, uint64_t byte_offset, uint64_t 
  * configuration (BASELINE.json configs[4]: embed + insert 1M synthetic images) run without staging 49 GB of
  * pixels through the host. */
 int pb_fill_synthetic_images(int device, uint64_t seed, uint64_t start, uint64_t n, uint32_t h, uint32_t w, uint8_t *d_out);
+/* The STRUCTURED synthetic stream (pixelbox_amd/synth.py:synthetic_scenes): a brightness window per (image, cell of a
+ * grid x grid partition, channel) instead of one per (image, channel), so that a million images give a million different
+ * hashes (the end-to-end leg of bench.py; with pb_fill_synthetic_images ~40 % of them are exact duplicates). */
+int pb_fill_synthetic_scenes(int device, uint64_t seed, uint64_t start, uint64_t n, uint32_t h, uint32_t w, uint32_t grid, uint8_t *d_out);
 
 #ifdef __cplusplus
 }

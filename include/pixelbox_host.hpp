@@ -107,7 +107,10 @@ inline std::vector<uint8_t> mlhash(const Embedder &model, const RgbImage &img) {
     return out;
 }
 // batched form used by a re-built crawler stage
-inline std::vector<std::vector<uint8_t>> mlhash_batch(const Embedder &model, const std::vector<RgbImage> &imgs) {
+// d_hashes (optional): the batch (at most the embedder's max_batch images) is run by pb_embed_batch_images_device and
+// *d_hashes receives the hashes' address in the GPU's memory (valid until the next call on this embedder)
+inline std::vector<std::vector<uint8_t>> mlhash_batch(const Embedder &model, const std::vector<RgbImage> &imgs,
+                                                      const uint8_t **d_hashes = nullptr) {
     std::vector<uint8_t> out(imgs.size() * model.dim());
     std::vector<const uint8_t *> ptrs(imgs.size());
     std::vector<uint32_t> ws(imgs.size()), hs(imgs.size());
@@ -117,7 +120,8 @@ inline std::vector<std::vector<uint8_t>> mlhash_batch(const Embedder &model, con
         ws[i] = imgs[i].width;
         hs[i] = imgs[i].height;
     }
-    check(pb_embed_batch_images(model.raw(), ptrs.data(), ws.data(), hs.data(), (uint32_t)imgs.size(), out.data(), nullptr));
+    if (d_hashes) check(pb_embed_batch_images_device(model.raw(), ptrs.data(), ws.data(), hs.data(), (uint32_t)imgs.size(), out.data(), d_hashes));
+    else check(pb_embed_batch_images(model.raw(), ptrs.data(), ws.data(), hs.data(), (uint32_t)imgs.size(), out.data(), nullptr));
     std::vector<std::vector<uint8_t>> res(imgs.size());
     for (size_t i = 0; i < imgs.size(); ++i) res[i].assign(out.begin() + i * model.dim(), out.begin() + (i + 1) * model.dim());
     return res;
@@ -262,7 +266,7 @@ class Engine {
         // The reference's INNER JOIN runs BEFORE `LIMIT 100`: a hash whose image row is missing does not use up a result
         // slot.  Ask the index for more than 100 when orphans turn up (PB_MAX_K at most) and cut after the join.
         std::vector<IndexedImage> out;
-        for (uint32_t k = RESULT_LIMIT;; k = PB_MAX_K) {
+        for (uint32_t k = RESULT_LIMIT;; k = (2 * k < PB_MAX_K ? 2 * k : PB_MAX_K)) {
             std::vector<int64_t> ids(k);
             std::vector<float> dist(k);
             uint32_t count = 0;

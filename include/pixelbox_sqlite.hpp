@@ -12,6 +12,7 @@
 // dlopen and the few entry points are declared by hand (the image ships the library without headers).
 // Schema strings are the reference's (engine.rs:30-48), with IF NOT EXISTS.
 #pragma once
+#include <algorithm>
 #include <dlfcn.h>
 
 #include <cstring>
@@ -81,6 +82,7 @@ class PersistentEngine {
     }
     // hashes in `semantic_hashes` whose length differs from the index dimension (left out of the device table)
     uint64_t num_skipped_hashes() const { return skipped_hashes_; }
+    uint64_t num_orphan_hashes() const { return orphan_hashes_; }  // hashes without an images row: left out of the device index at open
 
   private:
     void close_all() {
@@ -103,7 +105,17 @@ class PersistentEngine {
         check(pb_index_create(&h, device, hash_dim, capacity_rows));
         idx_.reset(h);
         // bulk load in image_id order, chunked (hashes of another length are skipped: fixed dim per index)
-        void *st = prepare("SELECT image_id, hash FROM semantic_hashes ORDER BY image_id");
+        // the reference's query JOINs semantic_hashes with images BEFORE its LIMIT (engine.rs:375-381): a hash whose image
+        // row is missing can never be a result.  Loading only the joined rows keeps such orphans out of the device index
+        // altogether, so a query's first 100 device results ARE the first 100 joined rows however many orphans the file
+        // holds (the over-fetch in query_by_image_hash_from_image only has to cover rows deleted AFTER the load)
+        void *st = prepare("SELECT semantic_hashes.image_id, semantic_hashes.hash FROM semantic_hashes INNER JOIN images ON images.id = "
+                           "semantic_hashes.image_id ORDER BY semantic_hashes.image_id");
+        {
+            void *cnt = prepare("SELECT COUNT(*) FROM semantic_hashes WHERE image_id NOT IN (SELECT id FROM images)");
+            if (S.step(cnt) == 100) orphan_hashes_ = (uint64_t)S.column_int64(cnt, 0);
+            S.finalize(cnt);
+        }
         struct Fin {  // the statement is finalised however this scope is left
             const SqliteApi &S;
             void *st;
@@ -172,7 +184,7 @@ class PersistentEngine {
         // INNER JOIN before LIMIT 100 (engine.rs:377-381): hashes without an `images` row must not use up result slots, so
         // the index is asked for more (PB_MAX_K at most) when orphans turn up
         std::vector<IndexedImage> out;
-        for (uint32_t k = RESULT_LIMIT;; k = PB_MAX_K) {
+        for (uint32_t k = RESULT_LIMIT;; k = std::min<uint32_t>(2 * k, PB_MAX_K)) {
             std::vector<int64_t> ids(k);
             std::vector<float> dist(k);
             uint32_t count = 0;
@@ -230,7 +242,7 @@ class PersistentEngine {
     std::unique_ptr<pb_index, Del> idx_;
     void *ins_img_ = nullptr, *ins_hash_ = nullptr, *sel_img_ = nullptr, *sel_hash_ = nullptr;
     std::optional<std::vector<IndexedImage>> cached_;
-    uint64_t skipped_hashes_ = 0;
+    uint64_t skipped_hashes_ = 0, orphan_hashes_ = 0;
 };
 
 }  // namespace pixelbox

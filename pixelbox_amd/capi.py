@@ -36,12 +36,12 @@ SYMBOLS = [
     "pb_last_error", "pb_version", "pb_device_count",
     "pb_index_create", "pb_index_create_metric", "pb_index_destroy", "pb_index_size", "pb_index_dim", "pb_index_contains",
     "pb_sharded_create", "pb_sharded_destroy", "pb_sharded_info", "pb_sharded_size", "pb_sharded_load", "pb_sharded_append",
-    "pb_sharded_search", "pb_sharded_fill_synthetic", "pb_sharded_set_option", "pb_sharded_get_stats", "pb_topk_merge_packed_device", "pb_index_append", "pb_index_append_device", "pb_index_load",
+    "pb_sharded_search", "pb_sharded_append_device", "pb_sharded_shard_device", "pb_sharded_fill_synthetic", "pb_sharded_set_option", "pb_sharded_get_stats", "pb_topk_merge_packed_device", "pb_index_append", "pb_index_append_device", "pb_index_load",
     "pb_index_search", "pb_index_search_device", "pb_index_search_packed", "pb_topk_merge_packed", "pb_topk_merge", "pb_index_read", "pb_index_fill_synthetic",
     "pb_index_set_option", "pb_index_get_stats",
     "pb_embed_create", "pb_embed_destroy", "pb_embed_info", "pb_embed_batch", "pb_embed_batch_device", "pb_mlhash",
-    "pb_mlhash_image", "pb_embed_batch_images", "pb_resize_to_fill",
-    "pb_embed_set_option", "pb_fill_synthetic", "pb_fill_synthetic_images",
+    "pb_mlhash_image", "pb_embed_batch_images", "pb_embed_batch_images_device", "pb_resize_to_fill",
+    "pb_embed_set_option", "pb_fill_synthetic", "pb_fill_synthetic_images", "pb_fill_synthetic_scenes",
     "pb_phash_create", "pb_phash_destroy", "pb_phash_image", "pb_phash_small_image",
 ]
 
@@ -103,6 +103,8 @@ def lib():
         L.pb_sharded_load.argtypes = [vp, i64p, u8p, C.c_uint64]
         L.pb_sharded_append.argtypes = [vp, i64p, u8p, C.c_uint64, u64p]
         L.pb_sharded_search.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, C.c_double, i64p, f32p, u32p]
+        L.pb_sharded_append_device.argtypes = [vp, C.c_int, i64p, vp, C.c_uint64]
+        L.pb_sharded_shard_device.argtypes = [vp, C.c_int, C.POINTER(C.c_int)]
         L.pb_sharded_fill_synthetic.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int64]
         L.pb_sharded_set_option.argtypes = [vp, C.c_int, C.c_int64]
         L.pb_sharded_get_stats.argtypes = [vp, C.POINTER(ScanStats), C.c_int]
@@ -127,6 +129,7 @@ def lib():
         L.pb_phash_small_image.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, u8p, u32p, u32p]
         L.pb_fill_synthetic.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, vp]
         L.pb_fill_synthetic_images.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, vp]
+        L.pb_fill_synthetic_scenes.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, vp]
         _lib = L
     return _lib
 
@@ -332,6 +335,16 @@ class ShardedIndexC:
         _check(lib().pb_sharded_append(self._h, _p(ids, C.c_int64), _p(rows, C.c_uint8), ids.shape[0], C.byref(stored)))
         return stored.value
 
+    def append_device(self, shard: int, image_ids, d_rows_ptr: int):
+        """rows already in the memory of the shard's GPU (an embedder's output): no host round trip"""
+        ids = np.ascontiguousarray(image_ids, dtype=np.int64)
+        _check(lib().pb_sharded_append_device(self._h, shard, _p(ids, C.c_int64), C.c_void_p(d_rows_ptr), ids.shape[0]))
+
+    def shard_device(self, shard: int) -> int:
+        d = C.c_int(-1)
+        _check(lib().pb_sharded_shard_device(self._h, shard, C.byref(d)))
+        return d.value
+
     def fill_synthetic(self, seed: int, n: int, first_id: int = 1):
         _check(lib().pb_sharded_fill_synthetic(self._h, seed, n, first_id))
 
@@ -474,6 +487,10 @@ class PHasher:
 
 def fill_synthetic_device(device: int, seed: int, byte_offset: int, nbytes: int, d_ptr: int):
     _check(lib().pb_fill_synthetic(device, seed, byte_offset, nbytes, C.c_void_p(d_ptr)))
+
+
+def fill_synthetic_scenes_device(device: int, seed: int, start: int, n: int, h: int, w: int, d_ptr: int, grid: int = 4):
+    _check(lib().pb_fill_synthetic_scenes(device, seed, start, n, h, w, grid, C.c_void_p(d_ptr)))
 
 
 def fill_synthetic_images_device(device: int, seed: int, start: int, n: int, h: int, w: int, d_ptr: int):

@@ -1185,6 +1185,29 @@ int pb_embed_batch_images(pb_embedder *e, const uint8_t *const *rgb, const uint3
     return PB_OK;
 }
 
+int pb_embed_batch_images_device(pb_embedder *e, const uint8_t *const *rgb, const uint32_t *widths, const uint32_t *heights, uint32_t n,
+                                 uint8_t *out_u8, const uint8_t **d_out_u8) {
+    PB_CHECK(e, PB_ERR_INVALID, "pb_embed_batch_images_device: null embedder");
+    PB_CHECK(d_out_u8, PB_ERR_INVALID, "pb_embed_batch_images_device: null device-pointer output");
+    PB_CHECK(n <= e->max_batch, PB_ERR_INVALID, "pb_embed_batch_images_device: n = %u > max_batch %u", n, e->max_batch);
+    PB_CHECK(n == 0 || (rgb && widths && heights), PB_ERR_INVALID, "pb_embed_batch_images_device: null buffer");
+    *d_out_u8 = e->d_out_u8;
+    if (n == 0) return PB_OK;
+    std::lock_guard<std::mutex> lock(e->mu);
+    pb::DeviceGuard guard(e->device);
+    const size_t img_bytes = (size_t)e->H * e->W * 3;
+    for (uint32_t i = 0; i < n; ++i) {
+        int rc = resize_to_slot(e, rgb[i], widths[i], heights[i], e->d_img + (size_t)i * img_bytes);
+        if (rc) return rc;
+        PB_HIP(hipStreamSynchronize(e->stream));  // the source scratch is reused by the next image
+    }
+    int rc = forward_device(e, e->d_img, (int)n, e->d_out_u8, e->d_out_f32);
+    if (rc) return rc;
+    if (out_u8) PB_HIP(hipMemcpyAsync(out_u8, e->d_out_u8, (size_t)n * e->D, hipMemcpyDeviceToHost, e->stream));
+    PB_HIP(hipStreamSynchronize(e->stream));
+    return PB_OK;
+}
+
 int pb_mlhash_image(pb_embedder *e, const uint8_t *rgb, uint32_t width, uint32_t height, uint8_t *out, size_t out_len) {
     PB_CHECK(e, PB_ERR_INVALID, "pb_mlhash_image: null embedder");
     PB_CHECK(out_len >= e->D, PB_ERR_INVALID, "pb_mlhash_image: out_len %zu < D = %u", out_len, e->D);

@@ -1691,6 +1691,26 @@ int pb_fill_synthetic_images(int device, uint64_t seed, uint64_t start, uint64_t
     return PB_OK;
 }
 
+int pb_fill_synthetic_scenes(int device, uint64_t seed, uint64_t start, uint64_t n, uint32_t h, uint32_t w, uint32_t grid, uint8_t *d_out) {
+    PB_CHECK(d_out || n == 0, PB_ERR_INVALID, "pb_fill_synthetic_scenes: null output");
+    const uint64_t per = (uint64_t)h * w * 3;
+    PB_CHECK(per > 0 && per % 8 == 0, PB_ERR_INVALID, "pb_fill_synthetic_scenes: h*w*3 = %llu must be a positive multiple of 8",
+             (unsigned long long)per);
+    PB_CHECK(grid >= 1 && h % grid == 0 && w % grid == 0, PB_ERR_INVALID, "pb_fill_synthetic_scenes: %u x %u is not a multiple of the %u x %u grid", h, w,
+             grid, grid);
+    if (n == 0) return PB_OK;
+    pb::DeviceGuard guard(device);
+    PB_CHECK(guard.ok, PB_ERR_HIP, "hipSetDevice(%d) failed", device);
+    const uint64_t n_words = n * per / 8;
+    const int block = 256;
+    const int blocks = (int)std::min<uint64_t>((n_words + block - 1) / block, 65536);
+    hipLaunchKernelGGL(k_fill_synth_scenes, dim3(blocks), dim3(block), 0, nullptr, seed, start, per, n_words, w * 3, h / grid, w / grid, grid,
+                       reinterpret_cast<uint64_t *>(d_out));
+    PB_HIP(hipGetLastError());
+    PB_HIP(hipStreamSynchronize(nullptr));
+    return PB_OK;
+}
+
 #ifdef PB_MQ_STAMP
 int pb_debug_mq_stamps(unsigned long long *out, int reset) {
     PB_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mq_stamp), 8 * sizeof(unsigned long long)));

@@ -2448,6 +2448,32 @@ __global__ void k_fill_synth_images(uint64_t seed, uint64_t start, uint64_t per,
         out[i] = o;
     }
 }
+// structured synthetic RGB8 images (pixelbox_amd/synth.py:synthetic_scenes): the same noise stream, a brightness window per
+// (image, cell of a grid x grid partition, channel); w3 = w * 3 bytes per image row, ch / cw = cell height / width in pixels
+__global__ void k_fill_synth_scenes(uint64_t seed, uint64_t start, uint64_t per, uint64_t n_words, uint32_t w3, uint32_t ch, uint32_t cw,
+                                    uint32_t grid, uint64_t *__restrict__ out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t g0 = start * per + 8 * i;
+        const uint64_t noise = splitmix64_at(seed, g0 >> 3);
+        uint64_t o = 0;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const uint64_t g = g0 + b;
+            const uint64_t img = g / per;
+            const uint32_t r = (uint32_t)(g - img * per);  // byte inside the image
+            const uint32_t y = r / w3, xc = r - y * w3, x = xc / 3, c = xc - 3 * x;
+            const uint64_t cell = ((img * grid + y / ch) * grid + x / cw) * 3 + c;
+            const uint64_t z = splitmix64_at(seed ^ 0xC0FFEEull, cell);
+            const uint32_t lo = (uint32_t)(z & 0xFF) * 3 / 4;
+            const uint32_t span = (uint32_t)((z >> 8) & 0xFF) / 4 + 1;
+            const uint32_t nz = (uint32_t)(noise >> (8 * b)) & 0xFF;
+            uint32_t px = lo + ((nz * span) >> 8);
+            px = px > 255 ? 255 : px;
+            o |= (uint64_t)px << (8 * b);
+        }
+        out[i] = o;
+    }
+}
 // out[i] = src[perm[i]] for i < n: the gather step of an out-of-order insert (rows of `elt` bytes, 16-byte pieces when
 // elt % 16 == 0, else 4-byte or single bytes); perm holds positions relative to `src`
 __global__ void k_gather_elts(const uint8_t *__restrict__ src, const uint32_t *__restrict__ perm, uint64_t n, uint32_t elt,

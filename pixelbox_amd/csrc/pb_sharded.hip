@@ -444,6 +444,41 @@ int pb_sharded_append(pb_sharded *s, const int64_t *image_ids, const uint8_t *ro
 }
 
 // synthetic table for benchmarks: rows [0, n) of stream `seed`, contiguous ranges per shard, generated on the devices
+int pb_sharded_shard_device(const pb_sharded *s, int shard, int *device) {
+    PB_CHECK(s && device, PB_ERR_INVALID, "pb_sharded_shard_device: null argument");
+    PB_CHECK(shard >= 0 && shard < s->n, PB_ERR_INVALID, "pb_sharded_shard_device: shard %d of %d", shard, s->n);
+    *device = s->devices[shard];
+    return PB_OK;
+}
+
+int pb_sharded_append_device(pb_sharded *s, int shard, const int64_t *image_ids, const uint8_t *d_rows, uint64_t n) {
+    PB_CHECK(s, PB_ERR_INVALID, "pb_sharded_append_device: null handle");
+    PB_CHECK(shard >= 0 && shard < s->n, PB_ERR_INVALID, "pb_sharded_append_device: shard %d of %d", shard, s->n);
+    PB_CHECK(n == 0 || (image_ids && d_rows), PB_ERR_INVALID, "pb_sharded_append_device: null ids/rows");
+    if (n == 0) return PB_OK;
+    {
+        // bookkeeping under the table's lock (the device copy below runs under the SHARD's lock only, so the embed threads
+        // of different devices insert concurrently): capacity, and the ids must be new to EVERY shard -- fresh
+        // last_insert_rowid() values (engine.rs:233,249); an update or a re-insert goes through pb_sharded_append
+        std::lock_guard<std::mutex> lock(s->mu);
+        uint64_t total = 0;
+        for (int g = 0; g < s->n; ++g) total += shard_size(s, g);
+        PB_CHECK(total + n <= s->capacity, PB_ERR_CAPACITY, "pb_sharded_append_device: %llu rows + %llu > capacity %llu",
+                 (unsigned long long)total, (unsigned long long)n, (unsigned long long)s->capacity);
+        PB_CHECK(shard_size(s, shard) + n <= s->shard_cap[shard], PB_ERR_CAPACITY, "pb_sharded_append_device: shard %d is full (%llu of %llu rows)",
+                 shard, (unsigned long long)shard_size(s, shard), (unsigned long long)s->shard_cap[shard]);
+        for (uint64_t i = 0; i < n; ++i)
+            for (int g = 0; g < s->n; ++g) {
+                if (g == shard) continue;  // the shard itself checks its own ids (ascending, beyond everything stored)
+                int found = 0;
+                int rc = pb_index_contains(s->shards[g], image_ids[i], &found);
+                if (rc) return rc;
+                PB_CHECK(!found, PB_ERR_INVALID, "pb_sharded_append_device: image_id %lld is already stored on shard %d", (long long)image_ids[i], g);
+            }
+    }
+    return pb_index_append_device(s->shards[shard], image_ids, d_rows, n);
+}
+
 int pb_sharded_fill_synthetic(pb_sharded *s, uint64_t seed, uint64_t n, int64_t first_id) {
     PB_CHECK(s, PB_ERR_INVALID, "pb_sharded_fill_synthetic: null handle");
     PB_CHECK(n <= s->capacity, PB_ERR_CAPACITY, "pb_sharded_fill_synthetic: %llu rows > capacity", (unsigned long long)n);

@@ -48,3 +48,24 @@ def synthetic_images(seed: int, start: int, n: int, h: int, w: int) -> np.ndarra
     lo = (z & np.uint64(0xFF)).astype(np.uint32) * 3 // 4  # 0..191
     span = ((z >> np.uint64(8)) & np.uint64(0xFF)).astype(np.uint32) // 4 + 1  # 1..64
     return np.minimum(lo + ((noise * span) >> 8), 255).astype(np.uint8)
+
+
+def synthetic_scenes(seed: int, start: int, n: int, h: int, w: int, grid: int = 4) -> np.ndarray:
+    """uint8[n, h, w, 3]: images start..start+n of the STRUCTURED synthetic stream (bench.py's end-to-end leg).
+
+    `synthetic_images` gives an image 6 numbers of its own (a brightness window per channel), so a million of them fall onto
+    a six-dimensional family of hashes with ~40 % exact duplicates.  Here every cell of a grid x grid partition of the image
+    has its own window per channel (grid * grid * 6 numbers per image: 96 at grid 4): px = lo + ((noise * span) >> 8) with
+    (lo, span) drawn per (image, cell, channel) from stream seed ^ 0xC0FFEE at index ((image * grid + cy) * grid + cx) * 3 + c.
+    Same noise stream as synthetic_images; integer arithmetic only (the device generator pb_fill_synthetic_scenes and this
+    function give identical bytes).  h and w must be multiples of grid.
+    """
+    per = h * w * 3
+    noise = fill_synthetic(seed, start * per, n * per).reshape(n, h, w, 3).astype(np.uint32)
+    cells = grid * grid
+    z = splitmix64_at(seed ^ 0xC0FFEE, np.arange(start * cells * 3, (start + n) * cells * 3, dtype=np.uint64)).reshape(n, grid, grid, 3)
+    lo = (z & np.uint64(0xFF)).astype(np.uint32) * 3 // 4  # 0..191
+    span = ((z >> np.uint64(8)) & np.uint64(0xFF)).astype(np.uint32) // 4 + 1  # 1..64
+    lo = np.repeat(np.repeat(lo, h // grid, axis=1), w // grid, axis=2)
+    span = np.repeat(np.repeat(span, h // grid, axis=1), w // grid, axis=2)
+    return np.minimum(lo + ((noise * span) >> 8), 255).astype(np.uint8)

@@ -118,8 +118,13 @@ _CALIB: list[float] | None = [
 ]
 
 
-def synthetic_blob(seed: int = 0x5EED0005, h: int = 128, w: int = 128, d: int = 256) -> bytes:
-    """Deterministic (integer PRNG) random-init weights in PBXW0001 format."""
+def synthetic_blob(seed: int = 0x5EED0005, h: int = 128, w: int = 128, d: int = 256, fc_gain: float = 1.0) -> bytes:
+    """Deterministic (integer PRNG) random-init weights in PBXW0001 format.
+
+    fc_gain multiplies the final Linear's weights (one exact f32 multiply per weight; 1.0 = the blob every fixture uses).
+    The end-to-end leg of bench.py uses the structured `synth.synthetic_scenes` images, whose pooled features vary less
+    from image to image than the brightness-window images the calibration was made on; a gain of 3 restores outputs that
+    fill (-1, 1) (a trained, BN-folded model does this by itself)."""
     specs = tensor_specs(d)
     total = n_floats(d)
     out = np.empty(total, dtype=np.float32)
@@ -142,6 +147,8 @@ def synthetic_blob(seed: int = 0x5EED0005, h: int = 128, w: int = 128, d: int = 
                 t = t.reshape(-1)
             if _CALIB is not None:
                 t = (t * np.float32(_CALIB[wi])).astype(np.float32)
+            if role == "fc" and fc_gain != 1.0:
+                t = (t * np.float32(fc_gain)).astype(np.float32)
             wi += 1
         out[pos : pos + n] = t.astype(np.float32)
         pos += n

@@ -16,8 +16,8 @@ int main(int argc, char **argv) {
         const int n_new = atoi(argv[4]);
         FILE *out = fopen(argv[5], "w");
         pixelbox::PersistentEngine engine(argv[1], dim, 100000);
-        fprintf(out, "loaded %llu skipped %llu\n", (unsigned long long)engine.get_num_indexed_images(),
-                (unsigned long long)engine.num_skipped_hashes());
+        fprintf(out, "loaded %llu skipped %llu orphans %llu\n", (unsigned long long)engine.get_num_indexed_images(),
+                (unsigned long long)engine.num_skipped_hashes(), (unsigned long long)engine.num_orphan_hashes());
         std::vector<pixelbox::IndexedImage> fresh;
         for (int i = 0; i < n_new; ++i) {
             pixelbox::IndexedImage rec;

@@ -208,3 +208,15 @@ def test_bench_plain_launch_without_a_gpu_fails_loudly_not_silently(tmp_path):
     assert p.returncode != 0
     assert p.stdout.strip() == b""
     assert b"starting the ranks as a child" in p.stderr and b"needs a GPU" in p.stderr
+
+
+def test_structured_synthetic_images_are_deterministic_windows_over_the_same_noise():
+    a = synth.synthetic_scenes(synth.SEED_IMAGES, 5, 3, 32, 64, 4)
+    b = synth.synthetic_scenes(synth.SEED_IMAGES, 0, 8, 32, 64, 4)[5:8]
+    assert a.shape == (3, 32, 64, 3) and a.dtype == np.uint8 and np.array_equal(a, b)  # image i does not depend on the call's range
+    # inside one cell the pixels of a channel stay inside that cell's window (lo .. lo + span), windows differ between cells
+    cell = a[0, :8, :16, 0].astype(int)
+    assert cell.max() - cell.min() <= 64
+    assert len({(int(a[0, 8 * cy:8 * cy + 8, 16 * cx:16 * cx + 16, 0].min())) for cy in range(4) for cx in range(4)}) > 8
+    # grid 1 = one window per (image, channel), drawn from another position of the window stream than synthetic_images uses
+    assert synth.synthetic_scenes(synth.SEED_IMAGES, 0, 1, 32, 32, 1).shape == (1, 32, 32, 3)

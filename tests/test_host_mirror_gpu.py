@@ -70,12 +70,18 @@ def test_sqlite_persistence_bridge(tmp_path):
         conn.execute("INSERT INTO images (id, filename, path, image_width, image_height) VALUES (?, ?, ?, 10, 10)",
                      (int(i), f"f{i}.png", f"/old/f{i}.png"))
         conn.execute("INSERT INTO semantic_hashes (image_id, hash) VALUES (?, ?)", (int(i), r.tobytes()))
-    conn.execute("INSERT INTO semantic_hashes (image_id, hash) VALUES (?, ?)", (5001, rows[0].tobytes()))  # orphan: no images row
-    conn.execute("INSERT INTO semantic_hashes (image_id, hash) VALUES (?, ?)", (5003, b"short"))  # wrong length: skipped
-    conn.commit()
-    conn.close()
     new = rng.integers(0, 256, size=(3, d), dtype=np.uint8)
     new[0] = rows[7]  # duplicate of an existing hash
+    conn.execute("INSERT INTO semantic_hashes (image_id, hash) VALUES (?, ?)", (5001, rows[0].tobytes()))  # orphan: no images row
+    conn.execute("INSERT INTO semantic_hashes (image_id, hash) VALUES (?, ?)", (5003, b"short"))  # orphan of the wrong length
+    # 300 more orphans, every one an exact copy of query 1: with the reference's JOIN-before-LIMIT (engine.rs:377-381) none of
+    # them is a result; a device index that held them would spend its 256 result slots on them
+    for i in range(300):
+        conn.execute("INSERT INTO semantic_hashes (image_id, hash) VALUES (?, ?)", (6000 + i, new[1].tobytes()))
+    conn.execute("INSERT INTO images (id, filename, path, image_width, image_height) VALUES (7001, 'w.png', '/old/w.png', 10, 10)")
+    conn.execute("INSERT INTO semantic_hashes (image_id, hash) VALUES (7001, ?)", (b"short",))  # joined row of the wrong length: skipped, counted
+    conn.commit()
+    conn.close()
     (tmp_path / "new.u8").write_bytes(new.tobytes())
     exe = tmp_path / "bridge"
     libdir = os.path.dirname(capi.LIB_PATH)
@@ -85,13 +91,14 @@ def test_sqlite_persistence_bridge(tmp_path):
     out = tmp_path / "out.txt"
     subprocess.check_call([str(exe), str(db), str(d), str(tmp_path / "new.u8"), "3", str(out)])
     lines = out.read_text().splitlines()
-    assert lines[0] == f"loaded {n + 1} skipped 1"  # 400 + the orphan; the short blob is left out and counted
+    # only rows of semantic_hashes JOIN images reach the device table; the 302 hashes without an images row are counted
+    assert lines[0] == f"loaded {n} skipped 1 orphans 302"
     new_ids = [int(x.split()[1]) for x in lines[1:4]]
-    assert new_ids == [801, 802, 803]  # rowids continue after max(images.id) = 800; they sort BEFORE the orphan 5001
-    assert lines[4] == f"indexed {n + 4}"  # the re-insert of a known path changed nothing
-    # expected table on the device: old rows + orphan + 3 new, in image_id order
-    all_ids = np.concatenate([ids, [5001], new_ids]).astype(np.int64)
-    all_rows = np.concatenate([rows, rows[:1], new])
+    assert new_ids == [7002, 7003, 7004]  # rowids continue after max(images.id) = 7001
+    assert lines[4] == f"indexed {n + 3}"  # the re-insert of a known path changed nothing
+    # expected table on the device: old rows + 3 new, in image_id order
+    all_ids = np.concatenate([ids, new_ids]).astype(np.int64)
+    all_rows = np.concatenate([rows, new])
     order = np.argsort(all_ids)
     all_ids, all_rows = all_ids[order], all_rows[order]
     pos = 5
@@ -101,24 +108,22 @@ def test_sqlite_persistence_bridge(tmp_path):
         cnt = int(hdr[3])
         # the reference's INNER JOIN runs before LIMIT 100 (engine.rs:377-381): the orphan hash (no images row) does not
         # use up a result slot, the 100 results are the best 100 among the joined rows
-        want_ids, want_d = oracle.scan_topk(new[qi], all_rows, all_ids, 256, 1e3)
-        keep = want_ids != 5001
-        want_ids, want_d = want_ids[keep][:100], want_d[keep][:100]
+        want_ids, want_d = oracle.scan_topk(new[qi], all_rows, all_ids, 100, 1e3)
         assert len(want_ids) == 100
         assert cnt == len(want_ids)
         for j in range(cnt):
             rid, dist, path, hlen = lines[pos + 1 + j].split()
             assert int(rid) == want_ids[j] and np.float32(float(dist)) == want_d[j] and int(hlen) == d
-            assert path == (f"/new/new{int(rid) - 801}.png" if int(rid) in new_ids else f"/old/f{int(rid)}.png")
+            assert path == (f"/new/new{int(rid) - 7002}.png" if int(rid) in new_ids else f"/old/f{int(rid)}.png")
         pos += 1 + cnt
     # query 0 is a duplicate of old row 7 (id 16): both tie at the reference's self-distance, smaller id first
     first = [ln.split() for ln in lines[6:8]]
-    assert [int(first[0][0]), int(first[1][0])] == [16, 801]
+    assert [int(first[0][0]), int(first[1][0])] == [16, 7002]
     # SQLite is the system of record: the new hashes are in the file
     conn = sqlite3.connect(db)
-    got = dict(conn.execute("SELECT image_id, hash FROM semantic_hashes WHERE image_id >= 801 AND image_id <= 803").fetchall())
+    got = dict(conn.execute("SELECT image_id, hash FROM semantic_hashes WHERE image_id >= 7002 AND image_id <= 7004").fetchall())
     assert [bytes(got[i]) for i in new_ids] == [r.tobytes() for r in new]
-    assert conn.execute("SELECT COUNT(*) FROM images").fetchone()[0] == n + 3
+    assert conn.execute("SELECT COUNT(*) FROM images").fetchone()[0] == n + 4
     conn.close()
 
 
@@ -206,3 +211,66 @@ def test_crawler_stage_and_query_by_file(tmp_path):
     dists = [float(r[2]) for r in res]
     assert dists == sorted(dists) and len(res) == 37
     assert lines[-1] == "missing 0"
+
+
+@pytest.mark.parametrize("devices", ["0", "0,0", "0,0,0"])
+def test_sharded_engine_ingests_device_to_device_with_an_embed_thread_per_shard(tmp_path, devices):
+    """VERDICT r2 row x1 (BASELINE configs[4], product form): ONE process, a shard + an embedder per entry of the device list,
+    the crawler's decode workers feeding one embed thread per shard, every batch stored on its shard straight from the
+    embedder's device buffer (pb_sharded_append_device), then the query over all shards -- against the oracle.  One GPU
+    here, so the shards share device 0 (copy exchange); the same code runs N devices.  Reference: engine.rs:177-205,
+    228-259, 352-396; crawler.rs:68-119."""
+    rng = np.random.default_rng(11)
+    h, w, d = 64, 64, 32
+    blob = W.synthetic_blob(synth.SEED_WEIGHTS, h, w, d)
+    (tmp_path / "w.pbxw").write_bytes(blob)
+    root = tmp_path / "pics"
+    (root / "sub").mkdir(parents=True)
+    imgs = {}
+    sizes = [(64, 64), (80, 100), (64, 64), (130, 70)]
+    for i in range(75):  # 75 images in batches of <= 16: several batches per shard
+        hh, ww = sizes[i % len(sizes)]
+        img = rng.integers(0, 256, size=(hh, ww, 3), dtype=np.uint8)
+        name = f"p{i:03d}.pnm"
+        _write_pnm((root if i % 2 else root / "sub") / name, img)
+        imgs[name] = img
+    (root / "broken.jpg").write_bytes(b"not a jpeg")
+    query_name = "p042.pnm"
+    exe = tmp_path / "sharded_ingest_demo"
+    libdir = os.path.dirname(capi.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "sharded_ingest_demo.cpp"), "-o", str(exe),
+                           "-L", libdir, "-lpixelbox_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
+    out = tmp_path / "out.txt"
+    subprocess.run([str(exe), str(tmp_path / "w.pbxw"), str(root), str(next(root.rglob(query_name))), str(out), "3", devices],
+                   check=True, timeout=600)
+    lines = out.read_text().splitlines()
+    assert lines[0] == "dropped_early 1"  # the stage that was dropped mid-run neither hung nor crashed
+    head_tok = lines[1].split()
+    head = dict(zip(head_tok[:16:2], map(int, head_tok[1:16:2])))
+    n_shards = len(devices.split(","))
+    per_shard = list(map(int, head_tok[16:]))
+    assert head["decoded"] == 75 and head["skipped"] == 1 and head["indexed"] == 75 and head["shards"] == n_shards
+    assert len(per_shard) == n_shards and sum(per_shard) == 75 and head["largest"] <= 16 and head["batches"] >= 5
+    got = {}
+    for ln in lines[2:77]:
+        _, name, iid, vh = ln.split()
+        got[name] = (int(iid), bytes.fromhex(vh))
+    assert set(got) == set(imgs)
+    assert sorted(v[0] for v in got.values()) == list(range(1, 76))  # ids = last_insert_rowid(): 1..75, each once
+    from embed_tol import assert_bytes_match
+
+    names = sorted(imgs)
+    pre = np.stack([oracle.resize_to_fill(imgs[n], w, h) for n in names])
+    ref_u8, ref_f = oracle.mlhash_batch(blob, pre, d, nthreads=4)
+    have = np.stack([np.frombuffer(got[n][1], dtype=np.uint8) for n in names])
+    assert_bytes_match(have, ref_u8, ref_f)
+    assert [ln for ln in lines if ln.startswith("reindexed ")] == ["reindexed 75 total 75"]  # every path known: nothing stored twice
+    # the query over all shards = the oracle's scan over the stored (id, hash) pairs
+    res = [ln.split() for ln in lines if ln.startswith("res ")]
+    ids = np.array([got[n][0] for n in names], dtype=np.int64)
+    order = np.argsort(ids)
+    want_ids, want_d = oracle.scan_topk(have[names.index(query_name)], have[order], ids[order], 100, 1e3)
+    assert [int(r[2]) for r in res] == list(want_ids)
+    assert np.array_equal(np.array([float(r[3]) for r in res], dtype=np.float32), want_d)  # %.9g round-trips an f32
+    assert res[0][1] == query_name
