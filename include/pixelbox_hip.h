@@ -130,7 +130,9 @@ int pb_topk_merge(const int64_t *ids, const float *dist, const uint32_t *counts,
 /* The same merge on the GPU: d_gathered is the all-gathered message block in DEVICE memory of `device` (one rank's receive
  * buffer); results to HOST buffers.  One workgroup per query ranks every listed entry by binary searches over the other
  * lists (pb_merge_kernels.h).  This is the merge pb_sharded_search runs internally; it is exported for hosts that run
- * their own exchange (bench.py under torchrun: one process per GPU). */
+ * their own exchange (bench.py under torchrun: one process per GPU).  STREAM CONTRACT: the kernel runs on the device's NULL
+ * stream; the caller must have synchronised whatever stream produced d_gathered (e.g. the collective's) before the call.
+ * Calls are serialised by a process-wide lock; the scratch buffers are cached per device for the life of the process. */
 int pb_topk_merge_packed_device(int device, const int64_t *d_gathered, uint32_t n_lists, uint32_t nq, uint32_t k,
                                 int64_t *out_ids, float *out_dist, uint32_t *out_count);
 

@@ -106,7 +106,9 @@ struct pb_index {
     uint32_t *h_done = nullptr;     // pinned: completion stamp of a one-query call, written last by k_select_rescore and polled by the host
     uint32_t done_seq = 0;
     bool poll_pending = false;      // the select launch of this call carries a stamp
-    bool env_no_poll = false;       // PB_NO_POLL: wait for the stream instead (comparison)
+    bool env_no_poll = false;       // PB_NO_POLL: wait for the stream instead (comparison); also set after a stamp time-out
+    uint64_t stamp_timeouts = 0;
+    bool tail_dirty = false;        // a ticketed (DYN) filter launch was queued without the k_select_rescore that clears d_tail
     bool env_loop_static = false;   // PB_LOOP_STATIC: the looped filter launch with fixed tile strides per wave (comparison)
 
     bool env_static_tail = false;      // PB_STATIC_TAIL: the one-query filter launch without the ticketed tail (comparison)
@@ -166,10 +168,13 @@ int alloc_workspace(pb_index *ix) {
     PB_HIP(hipMalloc(&ix->d_res_hdr, PIPE_Q * sizeof(ResultHdr)));
     PB_HIP(hipHostMalloc(&ix->h_stage, Q_CHUNK * (d + sizeof(QParams) + sizeof(uint32_t)), hipHostMallocDefault));
     PB_HIP(hipHostMalloc(&ix->h_pipe, PIPE_Q * (d + sizeof(QParams)), hipHostMallocDefault));
-    PB_HIP(hipHostMalloc(&ix->h_res_ids, (size_t)PIPE_Q * PB_MAX_K * sizeof(int64_t), hipHostMallocDefault));
-    PB_HIP(hipHostMalloc(&ix->h_res_dist, (size_t)PIPE_Q * PB_MAX_K * sizeof(float), hipHostMallocDefault));
-    PB_HIP(hipHostMalloc(&ix->h_res_hdr, PIPE_Q * sizeof(ResultHdr), hipHostMallocDefault));
-    PB_HIP(hipHostMalloc(&ix->h_done, 64, hipHostMallocDefault));
+    // kernels store results and the completion stamp here and the host reads them while the stream is still busy: the memory
+    // must be fine-grained COHERENT whatever HIP_HOST_COHERENT says (with non-coherent memory every one-query call would spin
+    // for the stamp's whole time-out before it falls back to the stream wait)
+    PB_HIP(hipHostMalloc(&ix->h_res_ids, (size_t)PIPE_Q * PB_MAX_K * sizeof(int64_t), hipHostMallocCoherent));
+    PB_HIP(hipHostMalloc(&ix->h_res_dist, (size_t)PIPE_Q * PB_MAX_K * sizeof(float), hipHostMallocCoherent));
+    PB_HIP(hipHostMalloc(&ix->h_res_hdr, PIPE_Q * sizeof(ResultHdr), hipHostMallocCoherent));
+    PB_HIP(hipHostMalloc(&ix->h_done, 64, hipHostMallocCoherent));
     memset(ix->h_done, 0, 64);
     return PB_OK;
 }
@@ -445,6 +450,11 @@ int run_fast(pb_index *ix, uint32_t nq) {
                                ix->stream, ix->d_rows, ix->n_rows, ix->d_queries, ix->d_qp, ix->d_lists, ix->d_hdrs, 0, 1,
                                ix->d_queries, ix->d_qp, ix->argq, nullptr);
         } else {
+            if (ix->tail_dirty) {  // an earlier call failed between its ticketed launch and the launch that resets the tickets
+                PB_HIP(hipMemsetAsync(ix->d_tail, 0, (size_t)DYN_REGIONS * DYN_CTR_STRIDE * sizeof(uint32_t), ix->stream));
+                ix->tail_dirty = false;
+            }
+            ix->tail_dirty = true;
             hipLaunchKernelGGL((k_scan_filter<16, 8, true, F_WAVES, 0, false, true, true>), dim3(n_wg, 1), dim3(F_WAVES * 64),
                                0, ix->stream, ix->d_rows, ix->n_rows, ix->d_queries, ix->d_qp, ix->d_lists, ix->d_hdrs, 0, 1,
                                ix->d_queries, ix->d_qp, ix->argq, ix->d_tail);
@@ -478,6 +488,7 @@ int run_fast(pb_index *ix, uint32_t nq) {
                        ix->r_dist, ix->r_hdr, (uint32_t)PB_MAX_K, dyn ? ix->d_tail : nullptr,
                        ix->poll_pending ? ix->h_done : nullptr, ix->done_seq);
     PB_HIP(hipGetLastError());
+    if (dyn) ix->tail_dirty = false;  // k_select_rescore is queued: it leaves the ticket counters zero
     return PB_OK;
 }
 
@@ -812,6 +823,9 @@ int search_chunk(pb_index *ix, uint32_t cq, uint32_t k, double max_dist, const f
                 __builtin_ia32_pause();
                 if ((spins & 4095u) == 4095u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
             }
+            // the stamp did not arrive in time (it has never been seen to happen): do not spin 20 ms on every later call
+            ++ix->stamp_timeouts;
+            ix->env_no_poll = true;
         }
         PB_HIP(hipStreamSynchronize(ix->stream));
         return PB_OK;

@@ -2155,7 +2155,11 @@ __global__ void k_mq_pick_tau(const uint32_t *__restrict__ ghist, const QParams 
     }
     if (lane == 0) {
         float t = found >= 0 ? (float)found / (float)MQ_BINS - 2e-6f : 0.0f;
-        t = fmaxf(t, qp[q].thr0);
+        // never <= 0: the collect pass's group bound (4 max acc' + max cr) / min W bounds a row's value only while that
+        // numerator is non-negative, i.e. for thresholds above zero (thr0 is >= 2 M + 2e-6 by construction, make_qparams;
+        // the clamp states it here: a query that needs rows with a cosine below it ends in the exhaustive pass through
+        // its failed certificate)
+        t = fmaxf(t, fmaxf(qp[q].thr0, 1e-6f));
         if ((uint64_t)cum * MQ_SAMPLE > (uint64_t)MQ_CAP) {
             float h = found_k >= 0 ? (float)found_k / (float)MQ_BINS - 4e-6f - qp[q].m : 0.0f;
             h = h > 0.0f && h < 0.999f ? h : 0.0f;

@@ -95,7 +95,14 @@ struct Worker {
                 j = std::move(job);
                 has_job = false;
             }
-            const int r = j();
+            int r;
+            try {  // a throw out of a std::thread terminates the host process: bad_alloc and friends become status codes
+                r = j();
+            } catch (const std::bad_alloc &) {
+                r = pb::fail(PB_ERR_NOMEM, "shard worker: out of host memory");
+            } catch (const std::exception &ex) {
+                r = pb::fail(PB_ERR_INTERNAL, "shard worker: %s", ex.what());
+            }
             {
                 std::lock_guard<std::mutex> lk(mu);
                 rc = r;

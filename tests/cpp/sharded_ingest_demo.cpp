@@ -65,8 +65,10 @@ int main(int argc, char **argv) {
         std::fprintf(out, "reindexed %llu total %llu\n", (unsigned long long)again, (unsigned long long)engine.get_num_indexed_images());
         const bool ok = engine.query_by_image_hash_from_file(argv[3], &hasher);
         std::fprintf(out, "query %d\n", (int)ok);
-        if (ok)
-            for (const pixelbox::IndexedImage &r : *engine.get_query_results()) std::fprintf(out, "res %s %lld %.9g\n", r.filename.c_str(), (long long)r.id, *r.distance_from_query);
+        if (ok) {
+            const auto res = engine.get_query_results();  // Option<Vec<IndexedImage>>, cloned like engine.rs:398-400 (kept alive for the loop)
+            for (const pixelbox::IndexedImage &r : *res) std::fprintf(out, "res %s %lld %.9g\n", r.filename.c_str(), (long long)r.id, *r.distance_from_query);
+        }
         std::fclose(out);
     } catch (const pixelbox::Error &e) {
         std::fprintf(stderr, "error %d: %s\n", e.code, e.what());
