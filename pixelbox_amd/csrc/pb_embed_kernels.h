@@ -25,6 +25,10 @@ __device__ __forceinline__ float sigmoid_f(float x) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
 }
 __device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
+// the value held by the previous lane of the 16-lane row (lane 0 of a row: 0)
+__device__ __forceinline__ float dpp_shr1(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111 /* row_shr:1 */, 0xF, 0xF, true));
+}
 
 // Squeeze-excite pooling sums are accumulated in 64-bit fixed point (2^-24 resolution): integer addition is
 // associative, so the pooled mean -- and with it the whole embedding -- is bit-identical whatever the batch size,
@@ -654,11 +658,19 @@ __global__ __launch_bounds__(64 * NW) void k_gemm1x1(const float *__restrict__ a
 //    immediates off one pointer that advances 256 B per chunk.
 // Needs K % 16 == 0 (every project / head / FC layer of EfficientNet-B0; the thin expand layers keep k_gemm1x1).
 // grid = (ceil(M / (16 NW)), Npad / (16 NR)); block = 64 NW.
-template <int NR, bool GATE, int NW>
+// EPI selects the epilogue: 0 bias (+ SiLU) (+ residual), store the [M][N] result;
+//   1 (the head conv of a 4 x 4 map: hw = 16, a wave's 16 rows are ONE image): bias + SiLU, then the global average pool in
+//     the accumulators -- the 16 pixels summed in pixel order across the lanes (v_add_f32 with a row_shr:1 DPP source, the
+//     order of k_avgpool's loop), times `scale` = 1/16 -- and only the pooled [M / 16][N] row is stored: the head's
+//     [M][1280] activation (42 MB per 512 images) is neither written nor read back, and k_avgpool's launch is gone;
+//   2 (the final Linear): bias, tanh, the u8 quantiser of efficientnet.rs:39, stored to out (f32, optional) and out_u8:
+//     k_tanh_quant's launch is gone.
+template <int NR, bool GATE, int NW, int EPI = 0>
 __global__ __launch_bounds__(64 * NW) void k_gemm_t(const float *__restrict__ act, int M, int K, const float *__restrict__ wt2,
                                                    int tiles16, const float *__restrict__ bias, int N,
                                                    const float *__restrict__ gate, int hw, const float *__restrict__ resid,
-                                                   int do_silu, float *__restrict__ out) {
+                                                   int do_silu, float *__restrict__ out, float scale = 0.f,
+                                                   uint8_t *__restrict__ out_u8 = nullptr) {
     constexpr int NTHR = 64 * NW;
     constexpr int CH4 = NR * 256;                         // float4 per weight chunk of this block (NR tiles x 4 kk x 16 li x 4 s)
     constexpr int WREGS = NR;                             // staged by the first 256 threads, NR float4 each (whole waves: no lane predicate)
@@ -789,6 +801,30 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_t(const float *__restrict__ ac
             else if (rem == 3) do_chunk(n_full, std::integral_constant<int, 3>{}, I0{});
         }
     }
+    if constexpr (EPI == 1) {
+        // M is a multiple of 16 here (whole images), so a tile is valid or not as a whole: no lane leaves before the shifts
+#pragma unroll
+        for (int c = 0; c < NR; ++c) {
+            const int n = (c0 + c) * 16 + kk * 4;
+            const int nc = n < N ? n : 0;
+            const f32x4 b = *reinterpret_cast<const f32x4 *>(bias + nc);
+            f32x4 v = acc[c];
+            v.x = silu_f(v.x + b.x); v.y = silu_f(v.y + b.y); v.z = silu_f(v.z + b.z); v.w = silu_f(v.w + b.w);
+            // t = 0; for p in 0..15: t = t + v[p]  (k_avgpool's order): after step j lane j of the 16-lane row holds the sum of
+            // pixels 0..j; lane 0 keeps 0 + v[0]
+            f32x4 t = {0.0f + v.x, 0.0f + v.y, 0.0f + v.z, 0.0f + v.w};
+#pragma unroll
+            for (int j = 1; j < 16; ++j) {
+                const float px = dpp_shr1(t.x), py = dpp_shr1(t.y), pz = dpp_shr1(t.z), pw = dpp_shr1(t.w);
+                if (li >= j) { t.x = px + v.x; t.y = py + v.y; t.z = pz + v.z; t.w = pw + v.w; }
+            }
+            if (mval && li == 15 && n < N) {
+                const f32x4 r = {t.x * scale, t.y * scale, t.z * scale, t.w * scale};
+                *reinterpret_cast<f32x4 *>(out + (mrow >> 4) * N + n) = r;
+            }
+        }
+        return;
+    }
     if (!mval) return;
 #pragma unroll
     for (int c = 0; c < NR; ++c) {
@@ -797,6 +833,14 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_t(const float *__restrict__ ac
         const f32x4 b = *reinterpret_cast<const f32x4 *>(bias + n);
         f32x4 v = acc[c];
         v.x = v.x + b.x; v.y = v.y + b.y; v.z = v.z + b.z; v.w = v.w + b.w;
+        if constexpr (EPI == 2) {
+            const f32x4 y = {tanhf(v.x), tanhf(v.y), tanhf(v.z), tanhf(v.w)};
+            if (out) *reinterpret_cast<f32x4 *>(out + mrow * N + n) = y;
+            const uint32_t pk = (uint32_t)quantize_u8(y.x) | ((uint32_t)quantize_u8(y.y) << 8) | ((uint32_t)quantize_u8(y.z) << 16) |
+                                ((uint32_t)quantize_u8(y.w) << 24);
+            *reinterpret_cast<uint32_t *>(out_u8 + mrow * N + n) = pk;
+            continue;
+        }
         if (do_silu) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
         if (resid) {
             const f32x4 rv = *reinterpret_cast<const f32x4 *>(resid + mrow * N + n);
