@@ -1,0 +1,438 @@
+// A WHOLE MBConv block of a small map in one kernel (included by pb_embed.hip after pb_embed_kernels.h).
+//
+// For the 4 x 4 maps of EfficientNet-B0's last stage (blocks 12-15: 192 -> 1152 -> 192 / 320 channels) the 6x-expanded
+// activation of two images is 32 pixel rows x 1152 channels x 4 B = 144 KB: it fits the 160 KB of LDS of one CU.  One
+// workgroup of eight waves therefore runs, for its G images,
+//   1. expand 1x1 + bias + SiLU on the f32 MFMA, one group of 16 GC channels at a time, into a small LDS window,
+//   2. the depthwise KS x KS filter + bias + SiLU from that window into the LDS-resident depthwise output `dwo`,
+//   3. squeeze-excite: pooled means (the same 2^-24 fixed-point sums as se_acc / k_se), FC1 + SiLU, FC2 + sigmoid, and the
+//      gate multiplied into `dwo` in place,
+//   4. project 1x1 + bias (+ residual) on the f32 MFMA with `dwo` as the activation operand,
+// and only the block's [P][COUT] output goes back to memory.  Against k_mbconv_small + k_se + k_gemm_t this removes the
+// depthwise output's HBM/L2 round trip (2 x 37.7 MB per 512 images and layer), the pooled-sum and gate round trips and two
+// dependent launches per block.  Every value is produced by the SAME operations in the SAME order as the unfused kernels
+// (MFMA operand maps and k order of k_gemm1x1 / k_gemm_t, tap order of k_dwconv, k_se's reduction order; gate * activation is
+// one rounding whether it happens in the project GEMM's operand fetch or in place here), so the block's output is
+// bit-identical -- tests/test_embed_gpu.py compares the kernel forms.
+//
+// Rows: R = G * P pixel rows (P = HW * HW), PT = R / 16 row tiles; a channel group has GC = 8 / PT 16-channel tiles.
+//  * expand: the eight waves own one (row tile, channel tile) accumulator each; a lane's weight fragments come straight
+//    from memory into registers (Gemm::wt4: a k-step's 64 lanes contiguous, one KB per wave request), the next group's
+//    while the filter phase runs; the block input x stays in registers for the whole kernel;
+//  * depthwise: wave = (image, output row), lane = channel of the group; a lane keeps ITS channel's taps in registers and
+//    reads single floats of the window; rows / columns of the filter that fall outside the map are skipped (see below);
+//  * squeeze-excite: wave w owns the units w, w + 8, ...; FC2 is a channel quad per thread;
+//  * project: every wave takes ALL the row tiles and a share of the output tiles (a weight fragment is requested once).
+// What sets the time (profiles/micro/block_small_bench.hip, in-kernel stamps): the vector-memory instructions -- a
+// 16-byte-per-lane load occupies the CU's address path for 16 cycles whatever it hits, and at 32 pixel rows per workgroup
+// every MFMA operand fragment is used for only two row tiles -- then the MFMAs, then the squeeze-excite phase (no MFMA work
+// to hide it: one workgroup per CU).  Measured per 512 images: 116 us (5 x 5 blocks; front + k_se + project GEMM: 125) and
+// 131 us (the 3 x 3 / 320-column block; 138).  At small batches the unfused kernels win (a workgroup here takes ~110 us
+// however few images there are), so the host times both forms per (block, batch bucket).
+// LDS (floats): dwo [R][E + 8] (pitch = 8 mod 64 dwords: the project phase's 16-byte fragment reads are conflict-free in
+// ds_read_b128's lane groups) | the expand window [R][16 GC + 4], later the pooled means [G][E], FC1 partial sums
+// [G][NB][SP] and squeezed units [G][SP].
+#pragma once
+
+namespace pbe {
+
+struct BlockW {
+    const float *we2;   // expand weights, fragments by k-step (Gemm::wt4): [CIN / 16][E / 16][64 lanes][4 e]
+    const float *be;    // [E] expand bias
+    const float *dwc;   // [E][KS * KS rounded up to 4] depthwise taps per channel
+    const float *bd;    // [E] depthwise bias
+    const float *w1, *b1, *w2t, *b2;  // squeeze-excite, as k_se: [SP][E], [SP], [SP][E], [E]
+    const float *wp2;   // project weights, fragments by k-step: [E / 16][NT16][64 lanes][4 e]
+    const float *bp;    // [16 NT16] project bias
+    int nt16;           // 16-column tiles of the project weights' padded width
+    unsigned long long *dbg;  // ABL 32 (stamped diagnostic build): [workgroup][wave][16] cycle sums per phase; else unused
+};
+
+template <int KS, int CIN, int E, int COUT, int HW, int G, int SP>
+struct BlockGeom {
+    static constexpr int P = HW * HW, R = G * P, PT = R / 16, GC = 8 / PT, QG = 4 * GC, NG = E / (16 * GC);
+    static constexpr int KC = CIN / 16, NT = COUT / 16, NGR = 8 / PT, NRP = (NT + NGR - 1) / NGR;
+    static constexpr int WP = 16 * GC + 4, DP = E + 8, KK = KS * KS, KKP = (KK + 3) / 4 * 4, PAD = (KS - 1) / 2;
+    static constexpr int NQ = E / 4, NB = (NQ + 63) / 64, KSP = E / 16;
+    static constexpr int WIN = R * WP, SEF = G * E + G * NB * SP + G * SP, SCR = (WIN > SEF ? WIN : SEF);
+    static constexpr int LDS_FLOATS = R * DP + SCR;
+    static constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * 4;
+    static_assert(R % 16 == 0 && (PT == 2 || PT == 4), "two or four row tiles");
+    static_assert(E % (16 * GC) == 0 && CIN % 16 == 0 && COUT % 16 == 0, "whole tiles");
+    static_assert(G * HW == 8 && (HW == 4 || HW == 8), "a wave per (image, output row)");
+};
+
+// ABL (timing experiments only, results invalid): 1 no expand MFMAs, 2 no filter taps, 4 no squeeze-excite, 8 no project MFMAs,
+// 16 the expand / project weights of the first group / chunk re-read throughout (no L2 traffic for them)
+template <int KS, int CIN, int E, int COUT, int HW, int G, int SP, bool RESID, int ABL = 0>
+__global__ __launch_bounds__(512) void k_block_small(const float *__restrict__ x, BlockW w, float *__restrict__ out, int n_img) {
+    using GEO = BlockGeom<KS, CIN, E, COUT, HW, G, SP>;
+    constexpr int P = GEO::P, R = GEO::R, PT = GEO::PT, GC = GEO::GC, QG = GEO::QG, NG = GEO::NG, KC = GEO::KC, NT = GEO::NT;
+    constexpr int NRP = GEO::NRP, WP = GEO::WP, DP = GEO::DP, KK = GEO::KK, PAD = GEO::PAD, NQ = GEO::NQ, NB = GEO::NB;
+    constexpr int KSP = GEO::KSP, ET = E / 16;
+    extern __shared__ __attribute__((aligned(16))) float s_blk[];
+    float *s_dwo = s_blk;                    // [R][DP]
+    float *s_scr = s_dwo + R * DP;           // window [R][WP], later means [G][E] | FC1 partial sums | squeezed units
+    float *s_p = s_scr + G * E;              // [G][NB][SP]
+    float *s_s = s_p + G * NB * SP;          // [G][SP]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kk = lane >> 4;
+    const int b0 = blockIdx.x * G;
+    unsigned long long st_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0;
+    auto stamp = [&](int i) __attribute__((always_inline)) {
+        if constexpr ((ABL & 32) != 0) {
+            unsigned long long t;
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (i >= 0) st_[i] += t - st_t;
+            st_t = t;
+        }
+    };
+    stamp(-1);
+    // ---- expand role: accumulator (row tile ept, channel tile ect of the group)
+    const int ept = wave % PT, ect = wave / PT;
+    const int erow = 16 * ept + li;
+    int eimg = b0 + erow / P;
+    if (eimg >= n_img) eimg = n_img - 1;  // a padded slot repeats the last image, stores nothing
+    const float *xrow = x + ((size_t)eimg * P + erow % P) * CIN + 4 * kk;
+    f32x4 xb[KC];
+#pragma unroll
+    for (int s = 0; s < KC; ++s) xb[s] = *reinterpret_cast<const f32x4 *>(xrow + 16 * s);
+    f32x4 aw[KC], bev;
+    auto load_a = [&](int g) __attribute__((always_inline)) {
+        const int tile = ((ABL & 16) ? 0 : g) * GC + ect;  // ABL 16: every group re-reads the first group's weights (L1 hits)
+#pragma unroll
+        for (int s = 0; s < KC; ++s)
+            aw[s] = *reinterpret_cast<const f32x4 *>(w.we2 + (((size_t)s * ET + tile) * 64 + lane) * 4);
+        bev = *reinterpret_cast<const f32x4 *>(w.be + 16 * tile + 4 * kk);
+    };
+    load_a(0);
+    // ---- depthwise role: wave = (image dimg, output row dpy), lane = (channel dc of the group, strip dh of 4 output pixels).
+    // A lane holds ITS channel's taps in registers (KKP floats, 16-byte loads of the [E][KKP] table) and reads single
+    // floats of the window (64 lanes = consecutive channels: conflict-free).  Filter rows that fall outside the map are
+    // skipped by a wave-uniform branch and, on the 4-wide maps, columns outside it at compile time: on a 4 x 4 map 51 %
+    // of a 5 x 5 filter's taps are padding.  (A skipped tap is fma(0, w, o) = o in the unfused kernels.)
+    constexpr int CH = 16 * GC, KKP = GEO::KKP, NIN = 4 + 2 * PAD;
+    const int dimg = wave / HW, dpy = wave % HW;
+    const int dc = lane % CH, dh = lane / CH;
+    const float *dwin = s_scr + (dimg * P) * WP + dc;  // + (iy * HW + ix) * WP
+    float *ddst = s_dwo + (dimg * P + dpy * HW + 4 * dh) * DP + dc;  // + px * DP + CH * g
+    float *ewin = s_scr + erow * WP + 16 * ect + 4 * kk;
+    stamp(0);
+    for (int g = 0; g < NG; ++g) {
+        f32x4 tq[KKP / 4];
+        float bdv;
+        {
+            const f32x4 *tp = reinterpret_cast<const f32x4 *>(w.dwc + (size_t)(g * CH + dc) * KKP);
+#pragma unroll
+            for (int t = 0; t < KKP / 4; ++t) tq[t] = tp[t];
+            bdv = w.bd[g * CH + dc];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        stamp(1);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < ((ABL & 1) ? 1 : KC); ++s) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[s].x, xb[s].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[s].y, xb[s].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[s].z, xb[s].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[s].w, xb[s].w, acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        stamp(2);
+        {
+            f32x4 v = acc;
+            const f32x4 bq = bev;
+            v.x = silu_f(v.x + bq.x); v.y = silu_f(v.y + bq.y); v.z = silu_f(v.z + bq.z); v.w = silu_f(v.w + bq.w);
+            *reinterpret_cast<f32x4 *>(ewin) = v;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        load_a(g + 1 < NG ? g + 1 : g);  // the next group's weight fragments: in flight under the filter phase
+        stamp(3);
+        __syncthreads();
+        stamp(4);
+        float o[4] = {bdv, bdv, bdv, bdv};
+#pragma unroll
+        for (int ky = 0; ky < ((ABL & 2) ? 1 : KS); ++ky) {
+            const int iy = dpy + ky - PAD;
+            if (iy >= 0 && iy < HW) {  // wave-uniform
+                float in[NIN];
+#pragma unroll
+                for (int j = 0; j < NIN; ++j) {
+                    if constexpr (HW == 4) {
+                        const int ix = j - PAD;  // dh = 0
+                        in[j] = (ix >= 0 && ix < HW) ? dwin[(iy * HW + ix) * WP] : 0.f;
+                    } else {
+                        const int ix = 4 * dh + j - PAD;
+                        const bool ok = ix >= 0 && ix < HW;
+                        const float v = dwin[(iy * HW + (ok ? ix : 0)) * WP];
+                        in[j] = ok ? v : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int px = 0; px < 4; ++px)
+#pragma unroll
+                    for (int kx = 0; kx < KS; ++kx) {
+                        if (HW == 4 && (px + kx - PAD < 0 || px + kx - PAD >= HW)) continue;
+                        const int t = ky * KS + kx;
+                        const f32x4 q = tq[t >> 2];
+                        const float wv = (t & 3) == 0 ? q.x : ((t & 3) == 1 ? q.y : ((t & 3) == 2 ? q.z : q.w));
+                        o[px] = __builtin_fmaf(in[px + kx], wv, o[px]);
+                    }
+            }
+        }
+#pragma unroll
+        for (int px = 0; px < 4; ++px) ddst[px * DP + CH * g] = silu_f(o[px]);
+        stamp(5);
+        __syncthreads();
+        stamp(6);
+    }
+    // ---- squeeze-excite (k_se's arithmetic and order).  Wave w owns the units jj = w, w + 8, ...: their FC1 weights for every
+    // block of 64 quads are requested before the pooled means are formed (one L2 round trip under that pass).
+    if constexpr (!(ABL & 4)) {
+        float *s_m = s_scr;  // [G][E] pooled means
+        constexpr int JW = (SP + 7) / 8;  // units per wave
+        f32x4 w1v[NB][JW];
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) {
+            const int cq = blk * 64 + lane;
+            const int c = cq < NQ ? 4 * cq : 0;
+#pragma unroll
+            for (int j = 0; j < JW; ++j) {
+                const int jj = wave + 8 * j;
+                w1v[blk][j] = *reinterpret_cast<const f32x4 *>(w.w1 + (size_t)(jj < SP ? jj : 0) * E + c);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const double sc = (1.0 / 16777216.0) * (double)(1.0f / (float)P);  // k_se: 2^-24 * (double)inv_hw
+        for (int it = tid; it < G * NQ; it += 512) {
+            const int im = it / NQ, cq = it - im * NQ;
+            ll4 t = {0, 0, 0, 0};
+#pragma unroll 8
+            for (int p = 0; p < P; ++p) se_acc(t, *reinterpret_cast<const f32x4 *>(s_dwo + (im * P + p) * DP + 4 * cq));
+            const f32x4 m = {(float)((double)t.x * sc), (float)((double)t.y * sc), (float)((double)t.z * sc), (float)((double)t.w * sc)};
+            *reinterpret_cast<f32x4 *>(s_m + im * E + 4 * cq) = m;
+        }
+        __syncthreads();
+        stamp(7);
+        // FC1: per unit jj the products of a quad summed x, y, z, w, then the 64 quads of a block by the xor butterfly
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) {
+            const int cq = blk * 64 + lane;
+            const bool on = cq < NQ;
+            const int c = on ? 4 * cq : 0;
+            f32x4 m[G];
+#pragma unroll
+            for (int im = 0; im < G; ++im) {
+                m[im] = *reinterpret_cast<const f32x4 *>(s_m + im * E + c);
+                if (!on) m[im] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            float a[JW][G];
+#pragma unroll
+            for (int j = 0; j < JW; ++j)
+#pragma unroll
+                for (int im = 0; im < G; ++im) {
+                    const f32x4 wv = w1v[blk][j];
+                    float t = m[im].x * wv.x;
+                    t = t + m[im].y * wv.y; t = t + m[im].z * wv.z; t = t + m[im].w * wv.w;
+                    a[j][im] = t;
+                }
+            // the JW * G butterflies side by side: a level's cross-lane reads are independent of each other
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+                for (int j = 0; j < JW; ++j)
+#pragma unroll
+                    for (int im = 0; im < G; ++im) a[j][im] = a[j][im] + __shfl_xor(a[j][im], off);
+#pragma unroll
+            for (int j = 0; j < JW; ++j) {
+                const int jj = wave + 8 * j;
+#pragma unroll
+                for (int im = 0; im < G; ++im)
+                    if (lane == 0 && jj < SP) s_p[(im * NB + blk) * SP + jj] = a[j][im];
+            }
+        }
+        stamp(8);
+        // FC2 weights of the first 16 units: requested before the squeezed units exist
+        constexpr int JG = SP < 16 ? SP : 16, GG = SP / JG;
+        static_assert(NQ <= 512, "one quad per thread in FC2");
+        const int cq2 = tid < NQ ? tid : 0, c2 = 4 * cq2;
+        f32x4 w2v[JG];
+#pragma unroll
+        for (int j = 0; j < JG; ++j) w2v[j] = *reinterpret_cast<const f32x4 *>(w.w2t + (size_t)j * E + c2);
+        __syncthreads();
+        if (tid < G * SP) {
+            const int im = tid / SP, jj = tid - im * SP;
+            float v = s_p[(im * NB) * SP + jj];
+            for (int blk = 1; blk < NB; ++blk) v = v + s_p[(im * NB + blk) * SP + jj];
+            s_s[im * SP + jj] = silu_f(v + w.b1[jj]);
+        }
+        __syncthreads();
+        stamp(9);
+        // FC2 + sigmoid, then the gate multiplied into the quad's column of dwo
+        if (tid < NQ) {
+            const f32x4 bv = *reinterpret_cast<const f32x4 *>(w.b2 + c2);
+            f32x4 v[G];
+#pragma unroll
+            for (int im = 0; im < G; ++im) v[im] = bv;
+#pragma unroll
+            for (int gg = 0; gg < GG; ++gg) {
+                f32x4 wn[JG];
+                if (gg + 1 < GG) {
+#pragma unroll
+                    for (int j = 0; j < JG; ++j) wn[j] = *reinterpret_cast<const f32x4 *>(w.w2t + (size_t)((gg + 1) * JG + j) * E + c2);
+                }
+                f32x4 a2[G];
+#pragma unroll
+                for (int im = 0; im < G; ++im) a2[im] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < JG; ++j) {
+                    const f32x4 wv = w2v[j];
+#pragma unroll
+                    for (int im = 0; im < G; ++im) {
+                        const float sj = s_s[im * SP + gg * JG + j];
+                        a2[im].x = a2[im].x + sj * wv.x; a2[im].y = a2[im].y + sj * wv.y;
+                        a2[im].z = a2[im].z + sj * wv.z; a2[im].w = a2[im].w + sj * wv.w;
+                    }
+                }
+#pragma unroll
+                for (int im = 0; im < G; ++im) {
+                    v[im].x = v[im].x + a2[im].x; v[im].y = v[im].y + a2[im].y;
+                    v[im].z = v[im].z + a2[im].z; v[im].w = v[im].w + a2[im].w;
+                }
+                if (gg + 1 < GG) {
+#pragma unroll
+                    for (int j = 0; j < JG; ++j) w2v[j] = wn[j];
+                }
+            }
+#pragma unroll
+            for (int im = 0; im < G; ++im) {
+                const f32x4 gt = {sigmoid_f(v[im].x), sigmoid_f(v[im].y), sigmoid_f(v[im].z), sigmoid_f(v[im].w)};
+#pragma unroll 8
+                for (int p = 0; p < P; ++p) {
+                    f32x4 *d = reinterpret_cast<f32x4 *>(s_dwo + (im * P + p) * DP + c2);
+                    f32x4 a = *d;
+                    a.x = a.x * gt.x; a.y = a.y * gt.y; a.z = a.z * gt.z; a.w = a.w * gt.w;
+                    *d = a;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    stamp(10);
+    // ---- project: every wave takes ALL the row tiles and a share of the 16-column output tiles, so that a weight fragment is
+    // requested by exactly one wave (with a wave per row tile the PT waves of a column group each requested it: twice the
+    // vector-memory instructions and L1 fills, and those, not the MFMAs, set the phase's time).  Waves 0-3 take TA tiles each,
+    // waves 4-7 TB (waves w and w + 4 share a SIMD, so the four SIMDs get TA + TB tiles each).
+    {
+        constexpr int TA = (NT / 4 + 1) / 2, TB = NT / 4 - TA;
+        static_assert(NT % 4 == 0 && TB >= 0, "output tiles split over four SIMDs");
+        auto project = [&](auto cntc, int tile0) __attribute__((always_inline)) {
+            constexpr int CNT = decltype(cntc)::value;
+            if constexpr (CNT > 0) {
+                constexpr int CS = (KSP % 8 == 0 && CNT * PT <= 4) ? 4 : 2;  // k-steps per weight request
+                constexpr int NCH = KSP / CS;
+                static_assert(KSP % CS == 0 && NCH % 3 == 0, "whole rounds of three weight requests");
+                const float *brow = s_dwo + li * DP + 4 * kk;  // + 16 pt * DP + 16 s
+                const float *wl = w.wp2 + ((size_t)tile0 * 64 + lane) * 4;
+                f32x4 acc[PT][CNT];
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+                    for (int c = 0; c < CNT; ++c) acc[pt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                // three weight sets: the requests run two chunks ahead of the MFMAs
+                f32x4 wa[3][CS][CNT];
+                auto load_w = [&](int s0, auto setc) __attribute__((always_inline)) {
+                    constexpr int SET = decltype(setc)::value;
+                    s0 = s0 < KSP ? s0 : KSP - CS;  // past the end: the last chunk again, never used
+                    if (ABL & 16) s0 = 0;
+#pragma unroll
+                    for (int j = 0; j < CS; ++j)
+#pragma unroll
+                        for (int c = 0; c < CNT; ++c)
+                            wa[SET][j][c] = *reinterpret_cast<const f32x4 *>(wl + ((size_t)(s0 + j) * w.nt16 + c) * 256);
+                };
+                f32x4 b[CS][PT], bn[CS][PT];
+                auto comp = [&](int s0, auto setc) __attribute__((always_inline)) {
+                    constexpr int SET = decltype(setc)::value;
+                    const int sn = s0 + CS < KSP ? s0 + CS : s0;
+#pragma unroll
+                    for (int j = 0; j < CS; ++j)
+#pragma unroll
+                        for (int pt = 0; pt < PT; ++pt) bn[j][pt] = *reinterpret_cast<const f32x4 *>(brow + 16 * pt * DP + 16 * (sn + j));
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < CS; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+#pragma unroll
+                            for (int c = 0; c < CNT; ++c) {
+                                const f32x4 wq = wa[SET][j][c];
+                                const float wv = e == 0 ? wq.x : (e == 1 ? wq.y : (e == 2 ? wq.z : wq.w));
+#pragma unroll
+                                for (int pt = 0; pt < PT; ++pt) {
+                                    const f32x4 bq = b[j][pt];
+                                    const float bv = e == 0 ? bq.x : (e == 1 ? bq.y : (e == 2 ? bq.z : bq.w));
+                                    acc[pt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, bv, acc[pt][c], 0, 0, 0);
+                                }
+                            }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < CS; ++j)
+#pragma unroll
+                        for (int pt = 0; pt < PT; ++pt) b[j][pt] = bn[j][pt];
+                };
+                using I0 = std::integral_constant<int, 0>;
+                using I1 = std::integral_constant<int, 1>;
+                using I2 = std::integral_constant<int, 2>;
+                load_w(0, I0{});
+                load_w(CS, I1{});
+#pragma unroll
+                for (int j = 0; j < CS; ++j)
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt) b[j][pt] = *reinterpret_cast<const f32x4 *>(brow + 16 * pt * DP + 16 * j);
+                for (int s0 = 0; s0 < ((ABL & 8) ? 3 * CS : KSP); s0 += 3 * CS) {
+                    load_w(s0 + 2 * CS, I2{});
+                    comp(s0, I0{});
+                    load_w(s0 + 3 * CS, I0{});
+                    comp(s0 + CS, I1{});
+                    load_w(s0 + 4 * CS, I1{});
+                    comp(s0 + 2 * CS, I2{});
+                }
+                stamp(11);
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) {
+                    const int prow = 16 * pt + li;
+                    const int pimg = b0 + prow / P;
+                    if (pimg >= n_img) continue;
+                    const size_t orow = (size_t)pimg * P + prow % P;
+#pragma unroll
+                    for (int c = 0; c < CNT; ++c) {
+                        const int n = 16 * (tile0 + c) + 4 * kk;
+                        const f32x4 bq = *reinterpret_cast<const f32x4 *>(w.bp + n);
+                        f32x4 v = acc[pt][c];
+                        v.x = v.x + bq.x; v.y = v.y + bq.y; v.z = v.z + bq.z; v.w = v.w + bq.w;
+                        if constexpr (RESID) {
+                            const f32x4 rv = *reinterpret_cast<const f32x4 *>(x + orow * CIN + n);
+                            v.x = rv.x + v.x; v.y = rv.y + v.y; v.z = rv.z + v.z; v.w = rv.w + v.w;
+                        }
+                        *reinterpret_cast<f32x4 *>(out + orow * COUT + n) = v;
+                    }
+                }
+                stamp(12);
+            }
+        };
+        if (wave < 4) project(std::integral_constant<int, TA>{}, wave * TA);
+        else project(std::integral_constant<int, TB>{}, 4 * TA + (wave - 4) * TB);
+    }
+    if constexpr ((ABL & 32) != 0) {
+        if (lane == 0) {
+            unsigned long long *d = w.dbg + ((size_t)blockIdx.x * 8 + wave) * 16;
+            for (int i = 0; i < 16; ++i) d[i] = st_[i];
+        }
+    }
+}
+
+}  // namespace pbe

@@ -13,6 +13,7 @@
 #include "pb_common.h"
 #include "pb_embed_kernels.h"
 #include "pb_front_band.h"
+#include "pb_block_small.h"
 
 using namespace pbe;
 
@@ -32,6 +33,7 @@ struct Gemm {  // 1x1 conv as GEMM
     float *wt = nullptr;    // [Kpad][Npad]
     float *bias = nullptr;  // [Npad]
     uint2 *wt3 = nullptr;   // three-bf16-piece form for k_gemm_b3: [3][Kpad / 4][Npad] x (4 consecutive k as bf16); null = f32 path only
+    float *wt4 = nullptr;   // fragments by k-step for k_block_small: [K / 16][Npad / 16][kk * 16 + li][e]; null unless asked for
     float *wt2 = nullptr;   // fragment order for k_gemm_t: [chunk of 64 k][Npad / 16][kk][li][s][e] = w[64 chunk + 16 s + 4 kk + e][16 tile + li]; null when K % 16
 };
 struct Block {
@@ -40,6 +42,7 @@ struct Block {
     Gemm expand, project;
     float *dw_w = nullptr, *dw_b = nullptr;            // [k*k][e], [e]
     f32x4 *dw_wq = nullptr;                            // the same taps per channel quad: [e / 4][k*k] float4 (k_front_band)
+    float *dw_wc = nullptr;                            // the same taps per channel: [e][k*k rounded up to 4] (k_block_small)
     int sp = 0;                                        // sq rounded up to 8/16/32/48 (zero-padded rows)
     float *se_w1 = nullptr, *se_b1 = nullptr;          // [sp][e], [sp]
     float *se_w2t = nullptr, *se_b2 = nullptr;         // [sp][e], [e]
@@ -76,6 +79,7 @@ struct pb_embedder {
     unsigned *d_se_cnt = nullptr;  // [max_batch] arrival counters of the squeeze-excite tails (zero between launches)
     bool fold_se = false;          // PB_FOLD_SE=1: the gates of the first six blocks come from the producing kernels' tails instead of k_se
                                    // launches (measured: +0.04 ms per batch-512 forward and per batch-1 forward -- see SeTail; off by default)
+    bool no_block_fusion = false;  // PB_NO_BLOCK_FUSION: the 4 x 4 blocks as front + k_se + project GEMM (A/B runs)
     bool no_tail_fusion = false;   // PB_NO_TAIL_FUSION: head conv, k_avgpool, FC GEMM and k_tanh_quant as four launches (A/B runs)
     bool no_gemm_t = false;        // PB_NO_GEMM_T: leave k_gemm_t out of the per-layer timing loops (A/B runs)
     bool no_band = false, force_band = false;  // PB_NO_BAND / PB_FORCE_BAND: leave out / always take the LDS-ring front kernel where it applies (A/B runs, bit comparisons)
@@ -133,7 +137,7 @@ bool tune_take(pb_embedder *e, float ms, float best_ms) {
 }
 
 // torch [N][K] (OI) -> k-major zero-padded [Kpad][Npad] + padded bias
-int make_gemm(pb_embedder *e, Gemm *g, const float *w, const float *b, int N, int K, bool pieces = false) {
+int make_gemm(pb_embedder *e, Gemm *g, const float *w, const float *b, int N, int K, bool pieces = false, bool fragments_by_step = false) {
     g->K = K;
     g->N = N;
     g->Kpad = round_up(K, 16);
@@ -153,6 +157,16 @@ int make_gemm(pb_embedder *e, Gemm *g, const float *w, const float *b, int N, in
                 w2[((((size_t)ch * t16 + n / 16) * 4 + kk) * 16 + n % 16) * 16 + s2 * 4 + e2] = w[(size_t)n * K + k];
             }
         rc = upload(e, &g->wt2, w2);
+        if (!rc && fragments_by_step) {
+            // the same fragments with a k-step's 64 lanes contiguous: [k / 16][tile][kk * 16 + li][e] -- for kernels whose lanes
+            // load their fragment straight into registers (k_block_small): a wave's request is one contiguous KB
+            const int steps = K / 16;
+            std::vector<float> w4((size_t)steps * t16 * 256, 0.0f);
+            for (int k = 0; k < K; ++k)
+                for (int n = 0; n < N; ++n)
+                    w4[(((size_t)(k / 16) * t16 + n / 16) * 64 + ((k % 16) / 4) * 16 + n % 16) * 4 + k % 4] = w[(size_t)n * K + k];
+            rc = upload(e, &g->wt4, w4);
+        }
     }
     if (rc || !pieces) return rc;
     // w = hi + mid + lo exactly, each piece a bf16 (truncation split: 8 + 8 + 8 significand bits)
@@ -231,7 +245,7 @@ int load_weights(pb_embedder *e, const uint8_t *blob, size_t len) {
             bl.residual = bl.stride == 1 && bl.cin == bl.cout;
             const int E = bl.e, S = bl.sq, KK = st.k * st.k;
             if (bl.has_expand) {
-                if ((rc = make_gemm(e, &bl.expand, p, p + (size_t)E * bl.cin, E, bl.cin))) return rc;
+                if ((rc = make_gemm(e, &bl.expand, p, p + (size_t)E * bl.cin, E, bl.cin, false, bl.stride == 1))) return rc;
                 p += (size_t)E * bl.cin + E;
             }
             {  // dw [E][k][k] -> [k*k][E]
@@ -246,6 +260,13 @@ int load_weights(pb_embedder *e, const uint8_t *blob, size_t len) {
                     float *dq = nullptr;
                     if ((rc = upload(e, &dq, wq))) return rc;
                     bl.dw_wq = reinterpret_cast<f32x4 *>(dq);
+                }
+                {  // [E][k*k rounded up to 4]: a channel's taps as 16-byte pieces (k_block_small)
+                    const int KKP = (KK + 3) / 4 * 4;
+                    std::vector<float> wc((size_t)E * KKP, 0.0f);
+                    for (int c = 0; c < E; ++c)
+                        for (int t = 0; t < KK; ++t) wc[(size_t)c * KKP + t] = p[(size_t)c * KK + t];
+                    if ((rc = upload(e, &bl.dw_wc, wc))) return rc;
                 }
                 p += (size_t)E * KK + E;
             }
@@ -263,7 +284,7 @@ int load_weights(pb_embedder *e, const uint8_t *blob, size_t len) {
                 if ((rc = upload(e, &bl.se_w2t, w2t)) || (rc = upload(e, &bl.se_b2, b2))) return rc;
                 p += (size_t)E * S + E;
             }
-            if ((rc = make_gemm(e, &bl.project, p, p + (size_t)bl.cout * E, bl.cout, E, true))) return rc;
+            if ((rc = make_gemm(e, &bl.project, p, p + (size_t)bl.cout * E, bl.cout, E, true, bl.stride == 1))) return rc;
             p += (size_t)bl.cout * E + bl.cout;
             e->blocks.push_back(bl);
         }
@@ -883,6 +904,38 @@ int run_front(pb_embedder *e, const Block &bl, const float *x, int n, int H, int
 }
 
 // forward for n images already on the device; results to device buffers
+// ---- a whole MBConv block of a 4 x 4 map in one kernel (k_block_small, pb_block_small.h)
+template <int KS, int CIN, int E, int COUT, int HW, int G, int SP, bool RESID>
+int launch_block_t(pb_embedder *e, const Block &bl, const float *x, int n, float *out) {
+    using GEO = BlockGeom<KS, CIN, E, COUT, HW, G, SP>;
+    auto kern = k_block_small<KS, CIN, E, COUT, HW, G, SP, RESID>;
+    static_assert(GEO::LDS_BYTES <= 160 * 1024, "one CU's LDS");
+    PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEO::LDS_BYTES));
+    BlockW w{};
+    w.we2 = bl.expand.wt4; w.be = bl.expand.bias; w.dwc = bl.dw_wc; w.bd = bl.dw_b;
+    w.w1 = bl.se_w1; w.b1 = bl.se_b1; w.w2t = bl.se_w2t; w.b2 = bl.se_b2;
+    w.wp2 = bl.project.wt4; w.bp = bl.project.bias; w.nt16 = bl.project.Npad / 16;
+    hipLaunchKernelGGL(kern, dim3((n + G - 1) / G), dim3(512), GEO::LDS_BYTES, e->stream, x, w, out, n);
+    PB_HIP(hipGetLastError());
+    return PB_OK;
+}
+
+// 0: not a shape the fused kernel is built for
+int block_shape(const pb_embedder *e, const Block &bl, int H, int W) {
+    if (e->no_block_fusion || !bl.has_expand || bl.stride != 1 || !bl.expand.wt4 || !bl.project.wt4 || !bl.dw_wc) return 0;
+    if (H == 4 && W == 4 && bl.cin == 192 && bl.e == 1152 && bl.sp == 48) {
+        if (bl.k == 5 && bl.cout == 192 && bl.residual) return 1;
+        if (bl.k == 3 && bl.cout == 320 && !bl.residual) return 2;
+    }
+    return 0;
+}
+
+int launch_block(pb_embedder *e, const Block &bl, int shape, const float *x, int n, float *out) {
+    if (shape == 1) return launch_block_t<5, 192, 1152, 192, 4, 2, 48, true>(e, bl, x, n, out);
+    if (shape == 2) return launch_block_t<3, 192, 1152, 320, 4, 2, 48, false>(e, bl, x, n, out);
+    return PB_ERR_INTERNAL;
+}
+
 int forward_device(pb_embedder *e, const uint8_t *d_rgb, int n, uint8_t *d_u8, float *d_f32) {
     int H = (int)e->H / 2, W = (int)e->W / 2;
     // arrival counters of the squeeze-excite tails: every tail leaves them zero; cleared anyway (a failed launch must not poison the next forward)
@@ -914,42 +967,77 @@ int forward_device(pb_embedder *e, const uint8_t *d_rgb, int n, uint8_t *d_u8, f
     int cur = 0;
     for (const Block &bl : e->blocks) {
         const float *x = e->buf_x[cur];
-        int rc;
         const int Ho = (H + bl.stride - 1) / bl.stride, Wo = (W + bl.stride - 1) / bl.stride;
-        int part_tiles = 0;
-        bool folded = false;  // the gate was computed in the tail of the kernel that produced the pooled sums
-        if (fuse_stem && &bl == &b0) {
-            part_tiles = stem_bands;  // depthwise output and SE partials are already in buf_dw / buf_part
-            folded = e->fold_se && b0.sp <= 16;  // ... and the gate, written by the band that completed the image
-        } else if (bl.has_expand) {
-            if ((rc = run_front(e, bl, x, n, H, W, Ho, Wo, &part_tiles, &folded))) return rc;
-        } else {
-            DwGeom g0;
-            if ((rc = launch_dw(e, bl, x, n, H, W, e->buf_dw, Ho, Wo, &g0))) return rc;
-            part_tiles = g0.n_tiles;
-        }
-        struct { int n_tiles; } g{part_tiles};
-        // block = (channel quads rounded up to a wave multiple) x (groups of 16 squeeze units)
-        const int se_qp = ((bl.e / 4 + 63) / 64) * 64;
+        // the unfused form of the block: front (expand + depthwise + pooled sums), squeeze-excite gates, project GEMM
+        auto run_unfused = [&]() -> int {
+            int rc;
+            int part_tiles = 0;
+            bool folded = false;  // the gate was computed in the tail of the kernel that produced the pooled sums
+            if (fuse_stem && &bl == &b0) {
+                part_tiles = stem_bands;  // depthwise output and SE partials are already in buf_dw / buf_part
+                folded = e->fold_se && b0.sp <= 16;  // ... and the gate, written by the band that completed the image
+            } else if (bl.has_expand) {
+                if ((rc = run_front(e, bl, x, n, H, W, Ho, Wo, &part_tiles, &folded))) return rc;
+            } else {
+                DwGeom g0;
+                if ((rc = launch_dw(e, bl, x, n, H, W, e->buf_dw, Ho, Wo, &g0))) return rc;
+                part_tiles = g0.n_tiles;
+            }
+            struct { int n_tiles; } g{part_tiles};
+            // block = (channel quads rounded up to a wave multiple) x (groups of 16 squeeze units)
+            const int se_qp = ((bl.e / 4 + 63) / 64) * 64;
 #define PB_SE1(SPV, IMGV)                                                                                                  \
-    hipLaunchKernelGGL((k_se<SPV, IMGV>), dim3((n + (IMGV) - 1) / (IMGV)), dim3(se_qp * ((SPV) < 16 ? 1 : (SPV) / 16)), 0, e->stream, \
-                       e->buf_part, g.n_tiles, bl.e, 1.0f / (float)(Ho * Wo), bl.se_w1, bl.se_b1, bl.se_w2t, bl.se_b2,     \
-                       e->buf_gate, se_qp, n)
-        // the widest layers (2 x 48 x 1152 weights = 442 KB per block) run two images per block from 64 images
-        // on: measured 24 -> 19 us per launch at batch 512; the narrower ones lose more parallelism than they
-        // save traffic (9 -> 13 us) and keep one image per block
-        if (folded) {
-        } else if (bl.sp == 8) PB_SE1(8, 1);
-        else if (bl.sp == 16) PB_SE1(16, 1);
-        else if (bl.sp == 32) PB_SE1(32, 1);
-        else if (n >= 64) PB_SE1(48, 2);
-        else PB_SE1(48, 1);
+        hipLaunchKernelGGL((k_se<SPV, IMGV>), dim3((n + (IMGV) - 1) / (IMGV)), dim3(se_qp * ((SPV) < 16 ? 1 : (SPV) / 16)), 0, e->stream, \
+                           e->buf_part, g.n_tiles, bl.e, 1.0f / (float)(Ho * Wo), bl.se_w1, bl.se_b1, bl.se_w2t, bl.se_b2,     \
+                           e->buf_gate, se_qp, n)
+            // the widest layers (2 x 48 x 1152 weights = 442 KB per block) run two images per block from 64 images
+            // on: measured 24 -> 19 us per launch at batch 512; the narrower ones lose more parallelism than they
+            // save traffic (9 -> 13 us) and keep one image per block
+            if (folded) {
+            } else if (bl.sp == 8) PB_SE1(8, 1);
+            else if (bl.sp == 16) PB_SE1(16, 1);
+            else if (bl.sp == 32) PB_SE1(32, 1);
+            else if (n >= 64) PB_SE1(48, 2);
+            else PB_SE1(48, 1);
 #undef PB_SE1
-        PB_HIP(hipGetLastError());
-        const long Mo = (long)n * Ho * Wo;
-        if ((rc = launch_gemm(e, e->buf_dw, Mo, bl.project, e->buf_gate, Ho * Wo, bl.residual ? x : nullptr, 0,
-                              e->buf_x[cur ^ 1])))
+            PB_HIP(hipGetLastError());
+            const long Mo = (long)n * Ho * Wo;
+            if ((rc = launch_gemm(e, e->buf_dw, Mo, bl.project, e->buf_gate, Ho * Wo, bl.residual ? x : nullptr, 0,
+                                  e->buf_x[cur ^ 1])))
+                return rc;
+            return PB_OK;
+        };
+        int rc;
+        if (const int shape = block_shape(e, bl, H, W)) {
+            // one kernel for the whole block, or the unfused form -- identical bits; which is faster depends on the batch (the
+            // fused kernel runs two images per CU at a fixed ~110 us: it wins from about one workgroup per CU on), so both are
+            // timed once per (block, batch bucket)
+            const std::pair<const void *, long> key(&bl, tune_bucket(n));
+            auto it = e->front_cfg.find(key);
+            if (it == e->front_cfg.end()) {
+                if ((rc = run_unfused())) return rc;  // lets the unfused kernels pick their own forms first
+                float best_ms = 1e30f;
+                int best = 0;
+                for (int cand = 0; cand < 2; ++cand) {
+                    PB_HIP(hipEventRecord(e->tune_e0, e->stream));
+                    for (int rep = 0; rep < 2; ++rep)
+                        if ((rc = cand ? launch_block(e, bl, shape, x, n, e->buf_x[cur ^ 1]) : run_unfused())) return rc;
+                    PB_HIP(hipEventRecord(e->tune_e1, e->stream));
+                    PB_HIP(hipEventSynchronize(e->tune_e1));
+                    float ms = 0.f;
+                    PB_HIP(hipEventElapsedTime(&ms, e->tune_e0, e->tune_e1));
+                    if (e->trace_tune) fprintf(stderr, "block e%d k%d n%d: %s %.1f us\n", bl.e, bl.k, n, cand ? "one kernel" : "front + se + project", ms * 500.f);
+                    if (tune_take(e, ms, best_ms)) {
+                        best_ms = ms;
+                        best = cand;
+                    }
+                }
+                it = e->front_cfg.emplace(key, best).first;
+            }
+            if ((rc = it->second ? launch_block(e, bl, shape, x, n, e->buf_x[cur ^ 1]) : run_unfused())) return rc;
+        } else if ((rc = run_unfused())) {
             return rc;
+        }
         cur ^= 1;
         H = Ho;
         W = Wo;
@@ -1094,6 +1182,7 @@ int pb_embed_create(pb_embedder **out, int device, const void *weights_blob, siz
     e->fold_se = getenv("PB_FOLD_SE") != nullptr;
     e->no_gemm_t = getenv("PB_NO_GEMM_T") != nullptr;
     e->no_tail_fusion = getenv("PB_NO_TAIL_FUSION") != nullptr;
+    e->no_block_fusion = getenv("PB_NO_BLOCK_FUSION") != nullptr;
     e->no_band = getenv("PB_NO_BAND") != nullptr;
     e->force_band = getenv("PB_FORCE_BAND") != nullptr;
     auto body = [&]() -> int {
