@@ -218,40 +218,51 @@ __global__ __launch_bounds__(512) void k_block_small(const float *__restrict__ x
         __syncthreads();
         stamp(7);
         // FC1: per unit jj the products of a quad summed x, y, z, w, then the 64 quads of a block by the xor butterfly
+        // (a + shfl_xor(a, 32), then 16, 8, 4, 2, 1 -- k_se's order).  The wave has NV = NB * JW * G such sums to form; run one
+        // by one that is 6 NV cross-lane steps.  They are formed TRANSPOSED instead: at the level of offset `off`, sums k and
+        // k + off share a register -- the lanes with bit `off` clear keep their element of sum k and hand over their element of
+        // sum k + off, the other half the reverse -- so each level halves the registers and all NV sums take 63 steps; every
+        // addition has the same two operands in the same order (own element + partner's) as in the one-by-one butterfly, and at
+        // the end lane L holds sum number L.
+        {
+            constexpr int NV = NB * JW * G;
+            static_assert(NV <= 64, "one finished sum per lane");
+            float v[64];
 #pragma unroll
-        for (int blk = 0; blk < NB; ++blk) {
-            const int cq = blk * 64 + lane;
-            const bool on = cq < NQ;
-            const int c = on ? 4 * cq : 0;
-            f32x4 m[G];
+            for (int k = NV; k < 64; ++k) v[k] = 0.f;
 #pragma unroll
-            for (int im = 0; im < G; ++im) {
-                m[im] = *reinterpret_cast<const f32x4 *>(s_m + im * E + c);
-                if (!on) m[im] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-            float a[JW][G];
-#pragma unroll
-            for (int j = 0; j < JW; ++j)
+            for (int blk = 0; blk < NB; ++blk) {
+                const int cq = blk * 64 + lane;
+                const bool on = cq < NQ;
+                const int c = on ? 4 * cq : 0;
 #pragma unroll
                 for (int im = 0; im < G; ++im) {
-                    const f32x4 wv = w1v[blk][j];
-                    float t = m[im].x * wv.x;
-                    t = t + m[im].y * wv.y; t = t + m[im].z * wv.z; t = t + m[im].w * wv.w;
-                    a[j][im] = t;
+                    f32x4 m = *reinterpret_cast<const f32x4 *>(s_m + im * E + c);
+                    if (!on) m = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < JW; ++j) {
+                        const f32x4 wv = w1v[blk][j];
+                        float t = m.x * wv.x;
+                        t = t + m.y * wv.y; t = t + m.z * wv.z; t = t + m.w * wv.w;
+                        v[(blk * JW + j) * G + im] = t;
+                    }
                 }
-            // the JW * G butterflies side by side: a level's cross-lane reads are independent of each other
+            }
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1)
+            for (int off = 32; off >= 1; off >>= 1) {
+                const bool hi = (lane & off) != 0;
+                const int src = (lane ^ off) << 2;
 #pragma unroll
-                for (int j = 0; j < JW; ++j)
-#pragma unroll
-                    for (int im = 0; im < G; ++im) a[j][im] = a[j][im] + __shfl_xor(a[j][im], off);
-#pragma unroll
-            for (int j = 0; j < JW; ++j) {
+                for (int k = 0; k < off; ++k) {
+                    const float keep = hi ? v[k + off] : v[k];
+                    const float send = hi ? v[k] : v[k + off];
+                    v[k] = keep + __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(send)));
+                }
+            }
+            if (lane < NV) {
+                const int im = lane % G, j = (lane / G) % JW, blk = lane / (G * JW);
                 const int jj = wave + 8 * j;
-#pragma unroll
-                for (int im = 0; im < G; ++im)
-                    if (lane == 0 && jj < SP) s_p[(im * NB + blk) * SP + jj] = a[j][im];
+                if (jj < SP) s_p[(im * NB + blk) * SP + jj] = v[0];
             }
         }
         stamp(8);

@@ -30,7 +30,7 @@ def main():
             continue
         extra = " ".join(f"{k}={v:.4g}" for k, v in d.items() if k not in ("name", "grid"))
         print(f"{d['name'][:34]:34s} grid={d['grid']:>9s} {extra}")
-        if "k_tanh_quant" in d["name"]:
+        if "k_tanh_quant" in d["name"] or ("k_gemm_t" in d["name"] and d["name"].rstrip(">").endswith(", 2")):
             break
 
 

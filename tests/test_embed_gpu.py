@@ -279,3 +279,18 @@ def test_stem_fused_with_first_depthwise_gives_the_same_bits(monkeypatch):
     monkeypatch.setenv("PB_NO_STEM_FUSION", "1")  # k_stem + k_dwconv instead of k_stem_dw
     _, f = capi.Embedder(blob, max_batch=8).embed(imgs)
     assert np.array_equal(f.view(np.uint32), f_ref.view(np.uint32))
+
+
+def test_host_buffer_call_larger_than_max_batch_pipelines_its_chunks():
+    # pb_embed_batch with n > max_batch: chunks go through the two-slot pipeline (input copy, forward and output copy of
+    # consecutive chunks on three streams); every image must come out as from a one-chunk call, ragged last chunk included
+    blob = W.synthetic_blob(synth.SEED_WEIGHTS, 128, 128, 256)
+    imgs = synth.synthetic_images(synth.SEED_IMAGES, 900, 27, 128, 128)
+    u8_ref, f_ref = capi.Embedder(blob, max_batch=32).embed(imgs)
+    small = capi.Embedder(blob, max_batch=4)
+    for _ in range(2):  # the slots are reused across calls
+        u8, f = small.embed(imgs)
+        assert np.array_equal(f.view(np.uint32), f_ref.view(np.uint32))
+        assert np.array_equal(u8, u8_ref)
+    u8, _ = small.embed(imgs[:9], want_f32=False)
+    assert np.array_equal(u8, u8_ref[:9])
