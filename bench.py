@@ -36,7 +36,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s is the measured copy rate
 MFMA_F32_PEAK_TFLOPS = 157.3  # f32-input MFMA (the parity-safe embed path)
 EMBED_FLOP_PER_IMAGE = 2 * 126_312_448  # SURVEY.md Appendix B, 128x128 -> 256
-E2E_FC_GAIN = 3.0  # end-to-end legs: structured synthetic images (synth.synthetic_scenes) + a final Linear scaled to fill (-1, 1)
+E2E_FC_GAIN = float(os.environ.get("PIXELBOX_E2E_FC_GAIN", "3.0"))  # end-to-end legs: structured synthetic images (synth.synthetic_scenes) + a final Linear scaled to fill (-1, 1)
 
 
 def parse(argv=None):

@@ -91,24 +91,31 @@ __global__ __launch_bounds__(512) void k_block_small(const float *__restrict__ x
         }
     };
     stamp(-1);
-    // ---- expand role: accumulator (row tile ept, channel tile ect of the group)
-    const int ept = wave % PT, ect = wave / PT;
-    const int erow = 16 * ept + li;
-    int eimg = b0 + erow / P;
-    if (eimg >= n_img) eimg = n_img - 1;  // a padded slot repeats the last image, stores nothing
-    const float *xrow = x + ((size_t)eimg * P + erow % P) * CIN + 4 * kk;
-    f32x4 xb[KC];
+    // ---- expand role: waves 0-3 (one per SIMD: a single MFMA stream per SIMD runs closer to the pipe's rate than two waves
+    // taking turns) own channel tile ect of the group for PTW = 2 row tiles each -- two accumulator chains per weight fragment,
+    // so a fragment is requested once; waves 4-7 have no MFMA work in this phase.  A fragment register is re-requested for the
+    // NEXT group right after its last MFMA of this group (in place: the requests spread over the MFMA phase and have the
+    // epilogue, both barriers and the filter phase to land).
+    constexpr int PTW = PT * GC / 4;
+    const bool ew = wave < 4;
+    const int ect = wave % GC, ept0 = (wave % 4) / GC * PTW;
+    f32x4 xb[PTW][KC];
 #pragma unroll
-    for (int s = 0; s < KC; ++s) xb[s] = *reinterpret_cast<const f32x4 *>(xrow + 16 * s);
+    for (int pt = 0; pt < PTW; ++pt) {
+        const int erow = 16 * (ept0 + pt) + li;
+        int eimg = b0 + erow / P;
+        if (eimg >= n_img) eimg = n_img - 1;  // a padded slot repeats the last image, stores nothing
+        const float *xrow = x + ((size_t)eimg * P + erow % P) * CIN + 4 * kk;
+#pragma unroll
+        for (int s = 0; s < KC; ++s) xb[pt][s] = *reinterpret_cast<const f32x4 *>(xrow + 16 * s);
+    }
     f32x4 aw[KC], bev;
-    auto load_a = [&](int g) __attribute__((always_inline)) {
-        const int tile = ((ABL & 16) ? 0 : g) * GC + ect;  // ABL 16: every group re-reads the first group's weights (L1 hits)
+    const float *awp = w.we2 + ((size_t)ect * 64 + lane) * 4;  // + (s * ET + g * GC) * 256
+    if (ew) {
 #pragma unroll
-        for (int s = 0; s < KC; ++s)
-            aw[s] = *reinterpret_cast<const f32x4 *>(w.we2 + (((size_t)s * ET + tile) * 64 + lane) * 4);
-        bev = *reinterpret_cast<const f32x4 *>(w.be + 16 * tile + 4 * kk);
-    };
-    load_a(0);
+        for (int s = 0; s < KC; ++s) aw[s] = *reinterpret_cast<const f32x4 *>(awp + (size_t)s * ET * 256);
+        bev = *reinterpret_cast<const f32x4 *>(w.be + 16 * ect + 4 * kk);
+    }
     // ---- depthwise role: wave = (image dimg, output row dpy), lane = (channel dc of the group, strip dh of 4 output pixels).
     // A lane holds ITS channel's taps in registers (KKP floats, 16-byte loads of the [E][KKP] table) and reads single
     // floats of the window (64 lanes = consecutive channels: conflict-free).  Filter rows that fall outside the map are
@@ -119,7 +126,7 @@ __global__ __launch_bounds__(512) void k_block_small(const float *__restrict__ x
     const int dc = lane % CH, dh = lane / CH;
     const float *dwin = s_scr + (dimg * P) * WP + dc;  // + (iy * HW + ix) * WP
     float *ddst = s_dwo + (dimg * P + dpy * HW + 4 * dh) * DP + dc;  // + px * DP + CH * g
-    float *ewin = s_scr + erow * WP + 16 * ect + 4 * kk;
+    float *ewin = s_scr + (16 * ept0 + li) * WP + 16 * ect + 4 * kk;  // + 16 pt * WP
     stamp(0);
     for (int g = 0; g < NG; ++g) {
         f32x4 tq[KKP / 4];
@@ -132,24 +139,37 @@ __global__ __launch_bounds__(512) void k_block_small(const float *__restrict__ x
         }
         __builtin_amdgcn_sched_barrier(0);
         stamp(1);
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (ew) {
+            const int gn = ((ABL & 16) ? 0 : (g + 1 < NG ? g + 1 : g)) * GC;  // ABL 16: every group re-reads the first group's weights
+            f32x4 acc[PTW];
 #pragma unroll
-        for (int s = 0; s < ((ABL & 1) ? 1 : KC); ++s) {
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[s].x, xb[s].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[s].y, xb[s].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[s].z, xb[s].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[s].w, xb[s].w, acc, 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        stamp(2);
-        {
-            f32x4 v = acc;
+            for (int pt = 0; pt < PTW; ++pt) acc[pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < ((ABL & 1) ? 1 : KC); ++s) {
+#pragma unroll
+                for (int e2 = 0; e2 < 4; ++e2) {
+                    const float av = e2 == 0 ? aw[s].x : (e2 == 1 ? aw[s].y : (e2 == 2 ? aw[s].z : aw[s].w));
+#pragma unroll
+                    for (int pt = 0; pt < PTW; ++pt) {
+                        const f32x4 xq = xb[pt][s];
+                        const float xv = e2 == 0 ? xq.x : (e2 == 1 ? xq.y : (e2 == 2 ? xq.z : xq.w));
+                        acc[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xv, acc[pt], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                aw[s] = *reinterpret_cast<const f32x4 *>(awp + ((size_t)s * ET + gn) * 256);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            stamp(2);
             const f32x4 bq = bev;
-            v.x = silu_f(v.x + bq.x); v.y = silu_f(v.y + bq.y); v.z = silu_f(v.z + bq.z); v.w = silu_f(v.w + bq.w);
-            *reinterpret_cast<f32x4 *>(ewin) = v;
+            bev = *reinterpret_cast<const f32x4 *>(w.be + 16 * (gn + ect) + 4 * kk);
+#pragma unroll
+            for (int pt = 0; pt < PTW; ++pt) {
+                f32x4 v = acc[pt];
+                v.x = silu_f(v.x + bq.x); v.y = silu_f(v.y + bq.y); v.z = silu_f(v.z + bq.z); v.w = silu_f(v.w + bq.w);
+                *reinterpret_cast<f32x4 *>(ewin + 16 * pt * WP) = v;
+            }
         }
-        __builtin_amdgcn_sched_barrier(0);
-        load_a(g + 1 < NG ? g + 1 : g);  // the next group's weight fragments: in flight under the filter phase
         stamp(3);
         __syncthreads();
         stamp(4);
@@ -338,7 +358,11 @@ __global__ __launch_bounds__(512) void k_block_small(const float *__restrict__ x
     // vector-memory instructions and L1 fills, and those, not the MFMAs, set the phase's time).  Waves 0-3 take TA tiles each,
     // waves 4-7 TB (waves w and w + 4 share a SIMD, so the four SIMDs get TA + TB tiles each).
     {
+#ifdef PB_BLK_SPLIT8
         constexpr int TA = (NT / 4 + 1) / 2, TB = NT / 4 - TA;
+#else
+        constexpr int TA = NT / 4, TB = 0;
+#endif
         static_assert(NT % 4 == 0 && TB >= 0, "output tiles split over four SIMDs");
         auto project = [&](auto cntc, int tile0) __attribute__((always_inline)) {
             constexpr int CNT = decltype(cntc)::value;
