@@ -25,13 +25,14 @@ def run():
     from pixelbox_amd import capi, synth, weights
 
     n, nb, d = int(os.environ.get("PB_PROBE_IMAGES", "1000000")), 512, 256
-    emb = capi.Embedder(weights.synthetic_blob(synth.SEED_WEIGHTS, 128, 128, d), max_batch=nb, device=0)
+    gain = float(os.environ.get("PIXELBOX_E2E_FC_GAIN", "3.0"))  # as bench.py's end-to-end leg: structured scenes, scaled final Linear
+    emb = capi.Embedder(weights.synthetic_blob(synth.SEED_WEIGHTS, 128, 128, d, fc_gain=gain), max_batch=nb, device=0)
     ix = capi.Index(d, n)
     imgs = torch.empty((nb, 128, 128, 3), dtype=torch.uint8, device="cuda:0")
     out = torch.empty((nb, d), dtype=torch.uint8, device="cuda:0")
     for first in range(0, n, nb):
         count = min(nb, n - first)
-        capi.fill_synthetic_images_device(0, synth.SEED_IMAGES, first, count, 128, 128, imgs.data_ptr())
+        capi.fill_synthetic_scenes_device(0, synth.SEED_IMAGES, first, count, 128, 128, imgs.data_ptr(), 4)
         emb.embed_device(imgs.data_ptr(), count, out.data_ptr())
         ix.append_device(np.arange(first + 1, first + count + 1, dtype=np.int64), out.data_ptr())
     nq = 1000
