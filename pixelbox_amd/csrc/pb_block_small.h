@@ -16,18 +16,21 @@
 // bit-identical -- tests/test_embed_gpu.py compares the kernel forms.
 //
 // Rows: R = G * P pixel rows (P = HW * HW), PT = R / 16 row tiles; a channel group has GC = 8 / PT 16-channel tiles.
-//  * expand: the eight waves own one (row tile, channel tile) accumulator each; a lane's weight fragments come straight
-//    from memory into registers (Gemm::wt4: a k-step's 64 lanes contiguous, one KB per wave request), the next group's
-//    while the filter phase runs; the block input x stays in registers for the whole kernel;
+//  * expand: waves 0-3 own one 16-channel tile of the group for two row tiles each (two accumulator chains per weight
+//    fragment); a lane's fragments come straight from memory into registers (Gemm::wt4: a k-step's 64 lanes contiguous,
+//    one KB per wave request) and each register is re-requested for the NEXT group right after its last MFMA; the block
+//    input x stays in registers for the whole kernel;
 //  * depthwise: wave = (image, output row), lane = channel of the group; a lane keeps ITS channel's taps in registers and
 //    reads single floats of the window; rows / columns of the filter that fall outside the map are skipped (see below);
-//  * squeeze-excite: wave w owns the units w, w + 8, ...; FC2 is a channel quad per thread;
-//  * project: every wave takes ALL the row tiles and a share of the output tiles (a weight fragment is requested once).
-// What sets the time (profiles/micro/block_small_bench.hip, in-kernel stamps): the vector-memory instructions -- a
+//  * squeeze-excite: wave w owns the units w, w + 8, ...; FC1's butterflies are formed transposed; FC2 is a quad per thread;
+//  * project: waves 0-3 take ALL the row tiles and a quarter of the output tiles each (a weight fragment is requested once).
+// Both MFMA phases run as ONE instruction stream per SIMD (waves 0-3 sit on the four SIMDs): two waves taking turns on a
+// SIMD's matrix pipe ran the project phase at 75 % of the bare MFMA rate, one wave with 6 or 10 accumulator chains at 96 %.
+// What else sets the time (profiles/micro/block_small_bench.hip, in-kernel stamps): the vector-memory instructions -- a
 // 16-byte-per-lane load occupies the CU's address path for 16 cycles whatever it hits, and at 32 pixel rows per workgroup
-// every MFMA operand fragment is used for only two row tiles -- then the MFMAs, then the squeeze-excite phase (no MFMA work
-// to hide it: one workgroup per CU).  Measured per 512 images: 116 us (5 x 5 blocks; front + k_se + project GEMM: 125) and
-// 131 us (the 3 x 3 / 320-column block; 138).  At small batches the unfused kernels win (a workgroup here takes ~110 us
+// every MFMA operand fragment is used for only two row tiles -- and the phases without MFMA work (filter, squeeze-excite:
+// one workgroup per CU, nothing to hide them under).  Per 512 images: 94 us (5 x 5 blocks; front + k_se + project GEMM: 128)
+// and 113 us (the 3 x 3 / 320-column block; 139).  At small batches the unfused kernels win (a workgroup here takes ~95 us
 // however few images there are), so the host times both forms per (block, batch bucket).
 // LDS (floats): dwo [R][E + 8] (pitch = 8 mod 64 dwords: the project phase's 16-byte fragment reads are conflict-free in
 // ds_read_b128's lane groups) | the expand window [R][16 GC + 4], later the pooled means [G][E], FC1 partial sums
@@ -353,12 +356,13 @@ __global__ __launch_bounds__(512) void k_block_small(const float *__restrict__ x
         __syncthreads();
     }
     stamp(10);
-    // ---- project: every wave takes ALL the row tiles and a share of the 16-column output tiles, so that a weight fragment is
+    // ---- project: a wave takes ALL the row tiles and a share of the 16-column output tiles, so that a weight fragment is
     // requested by exactly one wave (with a wave per row tile the PT waves of a column group each requested it: twice the
-    // vector-memory instructions and L1 fills, and those, not the MFMAs, set the phase's time).  Waves 0-3 take TA tiles each,
-    // waves 4-7 TB (waves w and w + 4 share a SIMD, so the four SIMDs get TA + TB tiles each).
+    // vector-memory instructions and L1 fills).  Waves 0-3 take TA = NT / 4 tiles each and waves 4-7 none: ONE MFMA stream per
+    // SIMD (2 TA accumulator chains) runs at 96 % of the bare MFMA rate where waves w and w + 4 sharing a SIMD's pipe with
+    // TA + TB tiles between them ran at 75 % (-DPB_BLK_SPLIT8 restores that split).
     {
-#ifdef PB_BLK_SPLIT8
+#ifdef PB_BLK_SPLIT8  // comparison build: the output tiles over all eight waves (two waves per SIMD)
         constexpr int TA = (NT / 4 + 1) / 2, TB = NT / 4 - TA;
 #else
         constexpr int TA = NT / 4, TB = 0;
