@@ -34,9 +34,10 @@ def main(path, batch):
     stem_fl = 2 * 64 * 64 * 27 * 32
     bi = 0
     tail_gemms = 0
-    tot_us = tot_fl = 0.0
+    tot_us = tot_fl = tot_gap = 0.0
     by = {}
-    print(f"{'kernel':38s} {'block':>5s} {'us':>8s} {'GFLOP':>8s} {'TFLOP/s':>8s} {'of peak':>7s}")
+    print(f"{'kernel':38s} {'block':>5s} {'us':>8s} {'GFLOP':>8s} {'TFLOP/s':>8s} {'of peak':>7s} {'gap us':>7s}")
+    prev_end = None
     for r in rows[s : s + 90]:
         n = r["Kernel_Name"]
         if "pbe::" not in n:
@@ -82,11 +83,14 @@ def main(path, batch):
         tot_fl += fl
         by[fam] = by.get(fam, 0.0) + dur
         tf = fl / dur / 1e6 if dur > 0 else 0.0
-        print(f"{short[:38]:38s} {label:>5s} {dur:8.1f} {fl / 1e9:8.2f} {tf:8.1f} {tf / PEAK_TF:7.3f}")
+        gap = (int(r["Start_Timestamp"]) - prev_end) / 1000 if prev_end is not None else 0.0  # idle time since the previous kernel ended
+        prev_end = int(r["End_Timestamp"])
+        tot_gap += gap
+        print(f"{short[:38]:38s} {label:>5s} {dur:8.1f} {fl / 1e9:8.2f} {tf:8.1f} {tf / PEAK_TF:7.3f} {gap:7.1f}")
         if "k_tanh_quant" in n or ("k_gemm_t" in n and short.rstrip(">").endswith(", 2")):
             break
     tf = tot_fl / tot_us / 1e6
-    print(f"{'total':38s} {'':>5s} {tot_us:8.1f} {tot_fl / 1e9:8.2f} {tf:8.1f} {tf / PEAK_TF:7.3f}   (sum of kernel durations; batch {batch})")
+    print(f"{'total':38s} {'':>5s} {tot_us:8.1f} {tot_fl / 1e9:8.2f} {tf:8.1f} {tf / PEAK_TF:7.3f}   (sum of kernel durations; gaps between them {tot_gap:.1f} us; batch {batch})")
     print("per kernel family, us:", {k: round(v, 1) for k, v in sorted(by.items(), key=lambda kv: -kv[1])})
 
 

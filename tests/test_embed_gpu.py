@@ -294,3 +294,22 @@ def test_host_buffer_call_larger_than_max_batch_pipelines_its_chunks():
         assert np.array_equal(u8, u8_ref)
     u8, _ = small.embed(imgs[:9], want_f32=False)
     assert np.array_equal(u8, u8_ref[:9])
+
+
+@pytest.mark.parametrize("switch", ["PB_NO_BLOCK_FUSION", "PB_NO_TAIL_FUSION", "PB_NO_GEMM_T", "PB_NO_BAND", "PB_FORCE_BAND", "PB_FOLD_SE"])
+def test_round3_kernel_forms_give_the_same_bits(monkeypatch, switch):
+    # Each switch (read at pb_embed_create) takes one of round 3's kernel forms out of -- or forces it into -- the forward:
+    # the whole-block kernel of the 4 x 4 maps, the pooling / tanh + quantiser epilogues, the fragment-ordered GEMM, the
+    # LDS-ring front kernel, the squeeze-excite tails.  At a batch where the forms are in use (512: one workgroup of the
+    # whole-block kernel per CU) and at small ones the embedding must not change in a single bit.
+    blob = W.synthetic_blob(synth.SEED_WEIGHTS, 128, 128, 256)
+    imgs = synth.synthetic_scenes(synth.SEED_IMAGES, 4000, 512, 128, 128)
+    ref = capi.Embedder(blob, max_batch=512)
+    u8_ref, f_ref = ref.embed(imgs)
+    assert len(np.unique(u8_ref, axis=0)) > 500  # a real table, not one repeated hash
+    monkeypatch.setenv(switch, "1")
+    other = capi.Embedder(blob, max_batch=512)
+    for n in (512, 65, 2):
+        u8, f = other.embed(imgs[:n])
+        assert np.array_equal(f.view(np.uint32), f_ref[:n].view(np.uint32)), (switch, n)
+        assert np.array_equal(u8, u8_ref[:n])
