@@ -84,8 +84,10 @@ struct pb_embedder {
     unsigned *d_se_cnt = nullptr;  // [max_batch] arrival counters of the squeeze-excite tails (zero between launches)
     bool fold_se = false;          // PB_FOLD_SE=1: the gates of the first six blocks come from the producing kernels' tails instead of k_se
                                    // launches (measured: +0.04 ms per batch-512 forward and per batch-1 forward -- see SeTail; off by default)
+    bool block_attr_set[2] = {false, false};  // k_block_small's LDS size attribute requested (5 x 5 residual form, 3 x 3 / 320 form)
     bool no_block_fusion = false;  // PB_NO_BLOCK_FUSION: the 4 x 4 blocks as front + k_se + project GEMM (A/B runs)
     bool no_tail_fusion = false;   // PB_NO_TAIL_FUSION: head conv, k_avgpool, FC GEMM and k_tanh_quant as four launches (A/B runs)
+    bool no_gemm_stream = false;   // PB_NO_GEMM_STREAM: leave k_gemm_stream out of the per-layer timing loops (A/B runs)
     bool no_gemm_t = false;        // PB_NO_GEMM_T: leave k_gemm_t out of the per-layer timing loops (A/B runs)
     bool no_band = false, force_band = false;  // PB_NO_BAND / PB_FORCE_BAND: leave out / always take the LDS-ring front kernel where it applies (A/B runs, bit comparisons)
     int tune_pick = 0;    // PB_TUNE_PICK: 0 fastest candidate (default); 1 slowest; 2 a pseudo-random one -- test hook: every form must give the same bits
@@ -289,7 +291,7 @@ int load_weights(pb_embedder *e, const uint8_t *blob, size_t len) {
                 if ((rc = upload(e, &bl.se_w2t, w2t)) || (rc = upload(e, &bl.se_b2, b2))) return rc;
                 p += (size_t)E * S + E;
             }
-            if ((rc = make_gemm(e, &bl.project, p, p + (size_t)bl.cout * E, bl.cout, E, true, bl.stride == 1))) return rc;
+            if ((rc = make_gemm(e, &bl.project, p, p + (size_t)bl.cout * E, bl.cout, E, true, true))) return rc;
             p += (size_t)bl.cout * E + bl.cout;
             e->blocks.push_back(bl);
         }
@@ -370,8 +372,16 @@ void launch_gemm_t(int nr, hipStream_t st, const float *act, long M, const Gemm 
 struct GemmCfg {
     int mr, nr, nw;  // nw = 8: eight waves per block (MR = 1 only), else four
     int pd = 0;      // eight-wave form only: activation prefetch distance 8 / 16 k-steps (0: the default of 4)
-    int tform = 0;   // 1: k_gemm_t (fragment-ordered weights, pipelined fragment reads, no masks in the loop), nw = 4 or 8
+    int tform = 0;   // 1: k_gemm_t (fragment-ordered weights, pipelined fragment reads, no masks in the loop), nw = 4 or 8;
+                     // 2: k_gemm_stream (whole weight matrix in registers, a wave streams `mr` 16-row tiles of one image), nr = all tiles
 };
+
+// k_gemm_stream is built for the gated, thin project layers of the early blocks (K x Npad: 32 x 16, 96 x 32, 144 x 32, 144 x 48, 240 x 48)
+bool stream_eligible(const pb_embedder *e, const Gemm &g, long M, const float *gate, int hw, int do_silu) {
+    if (e->no_gemm_stream || !g.wt4 || !gate || do_silu || g.K % 16 || M % 16 || hw % 16 || g.N % 4) return false;
+    const int ks = g.K / 16, t = g.Npad / 16;
+    return (ks == 2 && t == 1) || (ks == 6 && t == 2) || (ks == 9 && (t == 2 || t == 3)) || (ks == 15 && t == 3);
+}
 
 void launch_gemm_cfg(pb_embedder *e, GemmCfg c, const float *act, long M, const Gemm &g, const float *gate, int hw,
                      const float *resid, int do_silu, float *out) {
@@ -379,6 +389,22 @@ void launch_gemm_cfg(pb_embedder *e, GemmCfg c, const float *act, long M, const 
     const long rows_per_block = 16L * c.nw * c.mr;
     dim3 grid((unsigned)((M + rows_per_block - 1) / rows_per_block), (unsigned)(tiles / c.nr));
     const int nr = c.nr;
+    if (c.tform == 2) {
+        const int ks = g.K / 16;
+        const unsigned n_wg = (unsigned)((M / 16 + 4L * c.mr - 1) / (4L * c.mr));
+#define PB_GS(KSV, NTV)                                                                                                            \
+    do {                                                                                                                           \
+        if (resid) hipLaunchKernelGGL((k_gemm_stream<KSV, NTV, true>), dim3(n_wg), dim3(256), 0, e->stream, act, M, g.wt4, tiles, g.bias, g.N, gate, hw, resid, out, c.mr); \
+        else hipLaunchKernelGGL((k_gemm_stream<KSV, NTV, false>), dim3(n_wg), dim3(256), 0, e->stream, act, M, g.wt4, tiles, g.bias, g.N, gate, hw, resid, out, c.mr);    \
+    } while (0)
+        if (ks == 2 && tiles == 1) PB_GS(2, 1);
+        else if (ks == 6 && tiles == 2) PB_GS(6, 2);
+        else if (ks == 9 && tiles == 2) PB_GS(9, 2);
+        else if (ks == 9 && tiles == 3) PB_GS(9, 3);
+        else if (ks == 15 && tiles == 3) PB_GS(15, 3);
+#undef PB_GS
+        return;
+    }
     if (c.tform) {
         if (gate) {
             if (c.nw == 8) launch_gemm_t<true, 8>(nr, e->stream, act, M, g, gate, hw, resid, do_silu, out);
@@ -465,7 +491,27 @@ int launch_gemm(pb_embedder *e, const float *act, long M, const Gemm &g, const f
         for (int nr = 8; nr >= 1; --nr) {
             if (tiles % nr) continue;
             // 0: the eight-wave form of MR = 1; -1: the one-wave form (k_gemm_thin); -104 / -108: k_gemm_t with 4 / 8 waves
-            for (int mr : {4, 2, 1, 0, -104, -108, -1}) {
+            for (int mr : {4, 2, 1, 0, -104, -108, -1, -208, -216, -232, -264}) {
+                if (mr <= -200) {  // k_gemm_stream with 8 / 16 / 32 / 64 tiles per wave
+                    const int tpw = -mr - 200;
+                    if (nr != tiles || !stream_eligible(e, g, M, gate, hw, do_silu) || hw % (16 * tpw) || M / 16 / tpw < 2L * e->n_cu) continue;
+                    const GemmCfg c{tpw, nr, 4, 0, 2};
+                    launch_gemm_cfg(e, c, act, M, g, gate, hw, resid, do_silu, out);
+                    PB_HIP(hipEventRecord(e0, e->stream));
+                    launch_gemm_cfg(e, c, act, M, g, gate, hw, resid, do_silu, out);
+                    launch_gemm_cfg(e, c, act, M, g, gate, hw, resid, do_silu, out);
+                    PB_HIP(hipEventRecord(e1, e->stream));
+                    PB_HIP(hipEventSynchronize(e1));
+                    PB_HIP(hipGetLastError());
+                    float ms = 0.f;
+                    PB_HIP(hipEventElapsedTime(&ms, e0, e1));
+                    if (e->trace_tune >= 2) fprintf(stderr, "  gemm M%ld K%d N%d: stream form, %d tiles per wave %.1f us\n", M, g.K, g.N, tpw, ms * 500.f);
+                    if (tune_take(e, ms, best_ms)) {
+                        best_ms = ms;
+                        best = c;
+                    }
+                    continue;
+                }
                 if (mr > 1 && M <= 64L * (mr / 2)) continue;  // tile taller than the problem
                 if ((mr == 0 || mr == -108) && M <= 64) continue;
                 if (mr <= -100 && (!g.wt2 || e->no_gemm_t)) continue;
@@ -489,12 +535,18 @@ int launch_gemm(pb_embedder *e, const float *act, long M, const Gemm &g, const f
             }
         }
         if (e->trace_tune)
-            fprintf(stderr, "gemm M%ld K%d N%d%s: best MR%d NR%d NW%d%s %.1f us = %.1f TFLOP/s\n", M, g.K, g.N, gate ? " gated" : "", best.mr,
-                    best.nr, best.nw, best.tform ? " t-form" : "", best_ms * 500.f, 2.0 * (double)M * g.K * g.N / (best_ms * 0.5e-3) / 1e12);
+            fprintf(stderr, "gemm M%ld K%d N%d%s: best %s%d NR%d NW%d%s %.1f us = %.1f TFLOP/s\n", M, g.K, g.N, gate ? " gated" : "",
+                    best.tform == 2 ? "stream form, tiles per wave " : "MR", best.mr, best.nr, best.nw, best.tform == 1 ? " t-form" : "", best_ms * 500.f,
+                    2.0 * (double)M * g.K * g.N / (best_ms * 0.5e-3) / 1e12);
         // encoding: 100 one-wave form; -1 eight-wave form; 304 / 308 k_gemm_t with 4 / 8 waves; else MR of the four-wave form
-        it = e->gemm_cfg.emplace(key, std::make_pair(best.tform ? 300 + best.nw : (best.nw == 1 ? 100 : (best.nw == 8 ? -1 : best.mr)), best.nr)).first;
+        it = e->gemm_cfg.emplace(key, std::make_pair(best.tform == 2 ? 1000 + best.mr : (best.tform ? 300 + best.nw : (best.nw == 1 ? 100 : (best.nw == 8 ? -1 : best.mr))), best.nr)).first;
     }
     const int enc = it->second.first;
+    if (enc >= 1000) {  // k_gemm_stream, enc - 1000 tiles per wave
+        launch_gemm_cfg(e, GemmCfg{enc - 1000, it->second.second, 4, 0, 2}, act, M, g, gate, hw, resid, do_silu, out);
+        PB_HIP(hipGetLastError());
+        return PB_OK;
+    }
     launch_gemm_cfg(e, GemmCfg{(enc >= 100 || enc < 0) ? 1 : enc, it->second.second, enc >= 300 ? enc - 300 : (enc == 100 ? 1 : (enc < 0 ? 8 : 4)), 0, enc >= 300 ? 1 : 0},
                     act, M, g, gate, hw, resid, do_silu, out);
     PB_HIP(hipGetLastError());
@@ -915,7 +967,10 @@ int launch_block_t(pb_embedder *e, const Block &bl, const float *x, int n, float
     using GEO = BlockGeom<KS, CIN, E, COUT, HW, G, SP>;
     auto kern = k_block_small<KS, CIN, E, COUT, HW, G, SP, RESID>;
     static_assert(GEO::LDS_BYTES <= 160 * 1024, "one CU's LDS");
-    PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEO::LDS_BYTES));
+    if (!e->block_attr_set[RESID ? 0 : 1]) {  // once per embedder and instantiation (the attribute is per device function and context)
+        PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEO::LDS_BYTES));
+        e->block_attr_set[RESID ? 0 : 1] = true;
+    }
     BlockW w{};
     w.we2 = bl.expand.wt4; w.be = bl.expand.bias; w.dwc = bl.dw_wc; w.bd = bl.dw_b;
     w.w1 = bl.se_w1; w.b1 = bl.se_b1; w.w2t = bl.se_w2t; w.b2 = bl.se_b2;
@@ -1198,6 +1253,7 @@ int pb_embed_create(pb_embedder **out, int device, const void *weights_blob, siz
     e->no_gemm_t = getenv("PB_NO_GEMM_T") != nullptr;
     e->no_tail_fusion = getenv("PB_NO_TAIL_FUSION") != nullptr;
     e->no_block_fusion = getenv("PB_NO_BLOCK_FUSION") != nullptr;
+    e->no_gemm_stream = getenv("PB_NO_GEMM_STREAM") != nullptr;
     e->no_band = getenv("PB_NO_BAND") != nullptr;
     e->force_band = getenv("PB_FORCE_BAND") != nullptr;
     auto body = [&]() -> int {

@@ -851,6 +851,100 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_t(const float *__restrict__ ac
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_gemm_stream: the gated project GEMMs of the EARLY blocks (K = 32 ... 240, N <= 48, hundreds of thousands of pixel rows)
+// as a stream.  Those layers are memory-bound -- 0.25-0.4 GB read per launch for 2-4 GFLOP -- and the tiled kernels above pay
+// a workgroup's set-up (weight staging, barrier, gate pointers) for every 64 rows.  Here a wave keeps the WHOLE weight matrix
+// as MFMA fragments in registers (KS * NT float4 per lane, from Gemm::wt4), walks `tiles_per_wave` consecutive 16-row tiles
+// of one image with the next tile's activation (and residual) fragments requested before the current tile's MFMAs, and holds
+// the image's squeeze-excite gate in registers; no LDS, no barrier.  Same operand maps, same k order, gate multiplied into
+// the activation fragment at use: bit-identical to k_gemm1x1 / k_gemm_t.
+// Needs K = 16 KS, hw % (16 tiles_per_wave) == 0 (a wave never straddles two images), M % 16 == 0.
+// grid = ceil(M / 16 / tiles_per_wave / 4); block = 256.
+template <int KS, int NT, bool RESID>
+__global__ __launch_bounds__(256) void k_gemm_stream(const float *__restrict__ act, long M, const float *__restrict__ wt4, int nt16,
+                                                     const float *__restrict__ bias, int N, const float *__restrict__ gate, int hw,
+                                                     const float *__restrict__ resid, float *__restrict__ out, int tiles_per_wave) {
+    constexpr int K = 16 * KS;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 15, kk = lane >> 4;
+    const long n_tiles = M >> 4;
+    const long t0 = ((long)blockIdx.x * 4 + wave) * tiles_per_wave;
+    if (t0 >= n_tiles) return;
+    const long t1 = t0 + tiles_per_wave < n_tiles ? t0 + tiles_per_wave : n_tiles;
+    f32x4 wf[KS][NT], bq[NT], g[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int c = 0; c < NT; ++c) wf[s][c] = *reinterpret_cast<const f32x4 *>(wt4 + (((size_t)s * nt16 + c) * 64 + lane) * 4);
+#pragma unroll
+    for (int c = 0; c < NT; ++c) bq[c] = *reinterpret_cast<const f32x4 *>(bias + 16 * c + 4 * kk);
+    {
+        const float *gp = gate + ((t0 * 16) / hw) * K + 4 * kk;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) g[s] = *reinterpret_cast<const f32x4 *>(gp + 16 * s);
+    }
+    const float *ap = act + (t0 * 16 + li) * K + 4 * kk;  // + 16 K floats per tile
+    const float *rp = RESID ? resid + (t0 * 16 + li) * N + 4 * kk : nullptr;
+    float *op = out + (t0 * 16 + li) * N + 4 * kk;
+    f32x4 a[2][KS], rv[2][RESID ? NT : 1];
+    auto request = [&](long t, auto setc) __attribute__((always_inline)) {
+        constexpr int SET = decltype(setc)::value;
+        const long d = (t < t1 ? t : t1 - 1) - t0;  // past the end: the last tile again, never used
+#pragma unroll
+        for (int s = 0; s < KS; ++s) a[SET][s] = *reinterpret_cast<const f32x4 *>(ap + d * 16 * K + 16 * s);
+        if constexpr (RESID) {
+#pragma unroll
+            for (int c = 0; c < NT; ++c) {
+                const int n = 16 * c + 4 * kk;
+                rv[SET][c] = *reinterpret_cast<const f32x4 *>(rp + d * 16 * N + (n < N ? 16 * c : 0));
+            }
+        }
+    };
+    auto tile = [&](long t, auto setc) __attribute__((always_inline)) {
+        constexpr int SET = decltype(setc)::value;
+        request(t + 1, std::integral_constant<int, SET ^ 1>{});
+        f32x4 acc[NT];
+#pragma unroll
+        for (int c = 0; c < NT; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            f32x4 v = a[SET][s];
+            v.x = v.x * g[s].x; v.y = v.y * g[s].y; v.z = v.z * g[s].z; v.w = v.w * g[s].w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float av = e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w));
+#pragma unroll
+                for (int c = 0; c < NT; ++c) {
+                    const f32x4 wq = wf[s][c];
+                    const float wv = e == 0 ? wq.x : (e == 1 ? wq.y : (e == 2 ? wq.z : wq.w));
+                    acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, av, acc[c], 0, 0, 0);
+                }
+            }
+        }
+        const long d = t - t0;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+            const int n = 16 * c + 4 * kk;
+            if (n >= N) continue;  // N % 4 == 0
+            f32x4 v = acc[c];
+            v.x = v.x + bq[c].x; v.y = v.y + bq[c].y; v.z = v.z + bq[c].z; v.w = v.w + bq[c].w;
+            if constexpr (RESID) {
+                const f32x4 r = rv[SET][c];
+                v.x = r.x + v.x; v.y = r.y + v.y; v.z = r.z + v.z; v.w = r.w + v.w;
+            }
+            *reinterpret_cast<f32x4 *>(op + d * 16 * N + 16 * c) = v;
+        }
+    };
+    request(t0, std::integral_constant<int, 0>{});
+    for (long t = t0; t < t1; t += 2) {
+        tile(t, std::integral_constant<int, 0>{});
+        if (t + 1 < t1) tile(t + 1, std::integral_constant<int, 1>{});
+        else break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // The 1x1 convolution with f32 products assembled from bf16 pieces on the bf16 matrix cores ("3 x bf16").
 // Every f32 value is EXACTLY hi + mid + lo with three bf16 (8 + 8 + 8 significand bits, split by truncation);
 // a product a * w is the sum of nine piece products, each exact in f32; the six leading ones

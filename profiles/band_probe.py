@@ -17,7 +17,7 @@ blob = W.synthetic_blob(synth.SEED_WEIGHTS, 128, 128, 256)
 
 
 def make(env):
-    for k in ("PB_NO_BAND", "PB_FORCE_BAND", "PB_FOLD_SE", "PB_NO_GEMM_T", "PB_NO_TAIL_FUSION", "PB_NO_BLOCK_FUSION"):
+    for k in ("PB_NO_BAND", "PB_FORCE_BAND", "PB_FOLD_SE", "PB_NO_GEMM_T", "PB_NO_TAIL_FUSION", "PB_NO_BLOCK_FUSION", "PB_NO_GEMM_STREAM"):
         os.environ.pop(k, None)
     os.environ.update(env)
     e = capi.Embedder(blob, max_batch=batch)
@@ -26,7 +26,7 @@ def make(env):
     return e
 
 
-variants = {"old": {"PB_NO_BAND": "1", "PB_NO_GEMM_T": "1", "PB_NO_TAIL_FUSION": "1", "PB_NO_BLOCK_FUSION": "1"}, "no_block_fusion": {"PB_NO_BLOCK_FUSION": "1"}, "tuned": {}}
+variants = {"old": {"PB_NO_BAND": "1", "PB_NO_GEMM_T": "1", "PB_NO_TAIL_FUSION": "1", "PB_NO_BLOCK_FUSION": "1", "PB_NO_GEMM_STREAM": "1"}, "no_block_fusion": {"PB_NO_BLOCK_FUSION": "1"}, "no_gemm_stream": {"PB_NO_GEMM_STREAM": "1"}, "tuned": {}}
 only = os.environ.get("PB_PROBE_VARIANTS")
 if only:
     variants = {k: v for k, v in variants.items() if k in only.split(",")}
