@@ -68,7 +68,7 @@ def main(path, batch):
                 fl = f_dw
             elif fam == "k_se":
                 fl = f_se
-            elif fam in ("k_gemm1x1", "k_gemm_t", "k_gemm_b3", "k_gemm_thin") and gated:
+            elif fam == "k_gemm_stream" or (fam in ("k_gemm1x1", "k_gemm_t", "k_gemm_b3", "k_gemm_thin") and gated):
                 fl = f_proj
                 bi += 1
             elif fam in ("k_gemm1x1", "k_gemm_t", "k_gemm_b3", "k_gemm_thin"):
