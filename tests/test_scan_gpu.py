@@ -443,6 +443,37 @@ def test_burst_certifies_on_a_table_whose_neighbouring_rows_have_very_different_
         assert np.array_equal(got[0][i, :c], ref[0][j, :c]) and np.array_equal(got[1][i, :c].view(np.uint32), ref[1][j, :c].view(np.uint32))
 
 
+def test_burst_with_queries_anti_correlated_to_the_whole_table():
+    # every row lies on the bright side of 128 and every query on the dark side: all cosines are negative, the sample pass of
+    # the burst finds no positive threshold (k_mq_pick_tau clamps it at a small positive value instead of returning <= 0,
+    # where the collect pass's group bound -- (4 max acc + max cr) / min W, an upper bound only for a non-negative numerator
+    # -- could reject a quad holding a row that passes its own test: ADVICE r2).  engine.rs:587 maps every cosine <= 1e-6
+    # to the distance 1 / 1e-6 - 1: with the default threshold nothing qualifies (count 0), with max_dist = 2e6 EVERY row
+    # does, all at the same distance, and ORDER BY dist, image_id LIMIT 100 is the 100 smallest ids.  Whatever path each
+    # query takes, the results must be the reference's.
+    rng = np.random.default_rng(977)
+    n, nq = 300_000, 130
+    rows = (140 + rng.integers(0, 110, size=(n, 256))).astype(np.uint8)
+    ids = np.arange(n, dtype=np.int64) * 3 + 5  # ascending, as pb_index_load requires (the table is read ORDER BY image_id)
+    q = (116 - rng.integers(0, 110, size=(nq, 256))).astype(np.uint8)
+    ix = make_index(rows, ids, path=MULTI)
+    ex = make_index(rows, ids, path=EXACT)
+    for max_dist in (1e3, 2e6):
+        got = ix.search(q, 100, max_dist)
+        want = ex.search(q, 100, max_dist)
+        assert np.array_equal(got[2], want[2])
+        for i in range(nq):
+            c = int(got[2][i])
+            assert np.array_equal(got[0][i, :c], want[0][i, :c]) and np.array_equal(got[1][i, :c].view(np.uint32), want[1][i, :c].view(np.uint32)), i
+        if max_dist < 1e6:
+            assert (got[2] == 0).all()
+        else:
+            assert (got[2] == 100).all() and (got[1][:, 0] > 9e5).all()
+            assert np.array_equal(got[0][0], ids[:100])
+        check_against_oracle(ix, rows, ids, q[[0, 64, 129]], max_dist=max_dist)
+    assert ix.stats().queries == 2 * (nq + 3)
+
+
 def test_multi_query_pass_tail_rows_and_auto_switch():
     rng = np.random.default_rng(61)
     n = 65536 + 13  # not a multiple of the 16-row tile
