@@ -233,7 +233,8 @@ typedef struct pb_embedder pb_embedder;
 
 /* Replaces the lazy-static tract model (efficientnet.rs:10-14).  weights_blob: PBXW0001 blob
  * (pixelbox_amd/weights.py; BN-folded EfficientNet-B0 + Linear(1280, D), resources/train.py:30-46)
- * in HOST memory; it fixes H, W and D.  max_batch bounds the images per pb_embed_batch call. */
+ * in HOST memory; it fixes H, W and D.  max_batch is the number of images one forward pass takes (the workspace is sized
+ * for it); pb_embed_batch accepts any n and runs larger calls as chunks of max_batch. */
 int pb_embed_create(pb_embedder **out, int device, const void *weights_blob, size_t blob_len,
                     uint32_t max_batch);
 int pb_embed_destroy(pb_embedder *e);
@@ -242,7 +243,11 @@ int pb_embed_info(const pb_embedder *e, uint32_t *h, uint32_t *w, uint32_t *d, u
 /* Replaces mlhash (efficientnet.rs:31-42) for n images at once.  rgb: HOST uint8[n][H][W][3]
  * (what `resize_to_fill(W,H,Triangle).to_rgb8()` yields, efficientnet.rs:20); the px/255 NCHW
  * conversion of efficientnet.rs:21-28 is fused into the first kernel.  out_u8: HOST uint8[n][D], the
- * quantised hash of efficientnet.rs:39 (bit-exact quantiser).  out_f32 (optional): the D tanh outputs. */
+ * quantised hash of efficientnet.rs:39 (bit-exact quantiser).  out_f32 (optional): the D tanh outputs.
+ * n may exceed max_batch: the call then runs as chunks of max_batch through a two-slot pipeline (the input copy of the next
+ * chunk and the output copy of the previous one beside the current forward pass; pageable input is staged through pinned
+ * buffers, pinned / registered caller memory is transferred directly).  An image's hash does not depend on the chunking.
+ * The call returns with all of its device work finished and nothing reading or writing the caller's buffers. */
 int pb_embed_batch(pb_embedder *e, const uint8_t *rgb, uint32_t n, uint8_t *out_u8, float *out_f32);
 
 /* Same with DEVICE input/output pointers (no PCIe in the timed region; bench.py uses this).

@@ -1435,19 +1435,20 @@ int pb_embed_batch(pb_embedder *e, const uint8_t *rgb, uint32_t n, uint8_t *out_
         count[slot] = 0;
         return PB_OK;
     };
-    int slot = 0, rc = PB_OK;
-    for (uint32_t i0 = 0; i0 < n && !rc; i0 += chunk, slot ^= 1) {
-        const uint32_t c = std::min(chunk, n - i0);
-        if ((rc = hand_over(slot))) break;  // the slot's previous outputs have arrived (its input was consumed before them)
+    // one chunk's share of the pipeline; a failing call leaves through the drain below (a transfer may still be reading the
+    // caller's buffer: the call must not return while it does)
+    auto run_chunk = [&](int slot, uint32_t i0, uint32_t c) -> int {
+        int rc = hand_over(slot);  // the slot's previous outputs have arrived (its input was consumed before them)
+        if (rc) return rc;
         const uint8_t *src = rgb + i0 * img_bytes;
-        if (stage) {  // pageable caller memory: into the slot's pinned buffer first (its previous transfer ended before the outputs handed over above)
+        if (stage) {  // pageable caller memory: into the slot's pinned buffer first
             parallel_copy(e->h_in[slot], src, c * img_bytes);
             src = e->h_in[slot];
         }
         PB_HIP(hipMemcpyAsync(d_in[slot], src, c * img_bytes, hipMemcpyHostToDevice, e->h2d_stream));
         PB_HIP(hipEventRecord(e->ev_in[slot], e->h2d_stream));
         PB_HIP(hipStreamWaitEvent(e->stream, e->ev_in[slot], 0));
-        if ((rc = forward_device(e, d_in[slot], (int)c, d_u8[slot], d_f[slot]))) break;
+        if ((rc = forward_device(e, d_in[slot], (int)c, d_u8[slot], d_f[slot]))) return rc;
         PB_HIP(hipEventRecord(e->ev_fwd[slot], e->stream));
         PB_HIP(hipStreamWaitEvent(e->d2h_stream, e->ev_fwd[slot], 0));
         PB_HIP(hipMemcpyAsync(e->h_out_u8[slot], d_u8[slot], (size_t)c * e->D, hipMemcpyDeviceToHost, e->d2h_stream));
@@ -1456,14 +1457,18 @@ int pb_embed_batch(pb_embedder *e, const uint8_t *rgb, uint32_t n, uint8_t *out_
         PB_HIP(hipEventRecord(e->ev_out[slot], e->d2h_stream));
         first[slot] = i0;
         count[slot] = c;
-    }
-    if (rc) {
+        return PB_OK;
+    };
+    int slot = 0, rc = PB_OK;
+    for (uint32_t i0 = 0; i0 < n && !rc; i0 += chunk, slot ^= 1) rc = run_chunk(slot, i0, std::min(chunk, n - i0));
+    if (!rc) rc = hand_over(slot);
+    if (!rc) rc = hand_over(slot ^ 1);
+    if (rc) {  // drain: nothing of this call may still be in flight when it returns
+        (void)hipStreamSynchronize(e->h2d_stream);
         (void)hipStreamSynchronize(e->stream);
         (void)hipStreamSynchronize(e->d2h_stream);
-        return rc;
     }
-    if ((rc = hand_over(slot)) || (rc = hand_over(slot ^ 1))) return rc;
-    return PB_OK;
+    return rc;
 }
 
 int pb_mlhash(pb_embedder *e, const uint8_t *rgb, uint8_t *out, size_t out_len) {
