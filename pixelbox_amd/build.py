@@ -22,8 +22,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpixelbox_hip.so")
 STAMP = LIB + ".stamp"
-SOURCES = ["pb_scan.hip", "pb_embed.hip", "pb_sharded.hip", "pb_phash.hip"]
-HEADERS = ["pb_common.h", "pb_scan_kernels.h", "pb_embed_kernels.h", "pb_front_band.h", "pb_block_small.h", "pb_phash_kernels.h", "pb_merge_kernels.h",
+SOURCES = ["pb_scan.hip", "pb_embed.hip", "pb_gemm_p3.hip", "pb_sharded.hip", "pb_phash.hip"]
+HEADERS = ["pb_common.h", "pb_scan_kernels.h", "pb_embed_common.h", "pb_embed_kernels.h", "pb_gemm_p3.h", "pb_gemm_p3_launch.h", "pb_front_band.h", "pb_block_small.h", "pb_phash_kernels.h", "pb_merge_kernels.h",
            os.path.join("..", "..", "include", "pixelbox_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall",
          "-Wno-unused-function"]
@@ -76,7 +76,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         print(f"pixelbox_amd.build: {os.path.basename(LIB)} is up to date with the sources (sha256 {want[:16]})", file=sys.stderr)
         return LIB
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    with ThreadPoolExecutor(max_workers=min(4, len(srcs))) as ex:
+    with ThreadPoolExecutor(max_workers=min(5, len(srcs))) as ex:
         objs = list(ex.map(lambda s: _compile(s, verbose), srcs))
     cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + LINK
     if verbose:

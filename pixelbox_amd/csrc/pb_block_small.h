@@ -46,16 +46,20 @@ struct BlockW {
     const float *bd;    // [E] depthwise bias
     const float *w1, *b1, *w2t, *b2;  // squeeze-excite, as k_se: [SP][E], [SP], [SP][E], [E]
     const float *wp2;   // project weights, fragments by k-step: [E / 16][NT16][64 lanes][4 e]
+    const void *wp3;    // P3 project layers (pb_gemm_p3.h): the three bf16 planes in fragment order, [E / 32][NT16][3][64 lanes] x 16 B; else null
     const float *bp;    // [16 NT16] project bias
     int nt16;           // 16-column tiles of the project weights' padded width
     unsigned long long *dbg;  // ABL 32 (stamped diagnostic build): [workgroup][wave][16] cycle sums per phase; else unused
 };
 
-template <int KS, int CIN, int E, int COUT, int HW, int G, int SP>
+// P3: the project phase runs on the bf16 matrix cores from three pieces per operand (the layer's arithmetic when the tiled
+// GEMM computes it: pb_gemm_p3.h); a lane then reads 8 consecutive k of its pixel row, and the dwo pitch is 4 mod 64 dwords
+// (16 lanes x 16 bytes of one k-slot land on 16 different bank quads) instead of 8 mod 64.
+template <int KS, int CIN, int E, int COUT, int HW, int G, int SP, bool P3 = false>
 struct BlockGeom {
     static constexpr int P = HW * HW, R = G * P, PT = R / 16, GC = 8 / PT, QG = 4 * GC, NG = E / (16 * GC);
     static constexpr int KC = CIN / 16, NT = COUT / 16, NGR = 8 / PT, NRP = (NT + NGR - 1) / NGR;
-    static constexpr int WP = 16 * GC + 4, DP = E + 8, KK = KS * KS, KKP = (KK + 3) / 4 * 4, PAD = (KS - 1) / 2;
+    static constexpr int WP = 16 * GC + 4, DP = E + (P3 ? 4 : 8), KK = KS * KS, KKP = (KK + 3) / 4 * 4, PAD = (KS - 1) / 2;
     static constexpr int NQ = E / 4, NB = (NQ + 63) / 64, KSP = E / 16;
     static constexpr int WIN = R * WP, SEF = G * E + G * NB * SP + G * SP, SCR = (WIN > SEF ? WIN : SEF);
     static constexpr int LDS_FLOATS = R * DP + SCR;
@@ -67,9 +71,9 @@ struct BlockGeom {
 
 // ABL (timing experiments only, results invalid): 1 no expand MFMAs, 2 no filter taps, 4 no squeeze-excite, 8 no project MFMAs,
 // 16 the expand / project weights of the first group / chunk re-read throughout (no L2 traffic for them)
-template <int KS, int CIN, int E, int COUT, int HW, int G, int SP, bool RESID, int ABL = 0>
+template <int KS, int CIN, int E, int COUT, int HW, int G, int SP, bool RESID, int ABL = 0, bool P3 = false>
 __global__ __launch_bounds__(512) void k_block_small(const float *__restrict__ x, BlockW w, float *__restrict__ out, int n_img) {
-    using GEO = BlockGeom<KS, CIN, E, COUT, HW, G, SP>;
+    using GEO = BlockGeom<KS, CIN, E, COUT, HW, G, SP, P3>;
     constexpr int P = GEO::P, R = GEO::R, PT = GEO::PT, GC = GEO::GC, QG = GEO::QG, NG = GEO::NG, KC = GEO::KC, NT = GEO::NT;
     constexpr int NRP = GEO::NRP, WP = GEO::WP, DP = GEO::DP, KK = GEO::KK, PAD = GEO::PAD, NQ = GEO::NQ, NB = GEO::NB;
     constexpr int KSP = GEO::KSP, ET = E / 16;
@@ -463,8 +467,112 @@ __global__ __launch_bounds__(512) void k_block_small(const float *__restrict__ x
                 stamp(12);
             }
         };
-        if (wave < 4) project(std::integral_constant<int, TA>{}, wave * TA);
-        else project(std::integral_constant<int, TB>{}, 4 * TA + (wave - 4) * TB);
+        // The same phase for a P3 project layer: per k-step of 32 a lane reads its 8 values of each row tile from dwo (two
+        // ds_read_b128), splits them into the three bf16 planes (p3_split8 -- the gate is already multiplied in: one rounding,
+        // as in the tiled GEMM's operand fetch) and runs the six passes of p3_step on CNT x PT accumulators; the weight
+        // fragments (three planes per tile, 16 bytes per lane each) come straight from memory three k-steps deep.  The split
+        // of step s + 1 is issued among the MFMAs of step s (one wave per SIMD: nothing else would fill the gaps).
+        auto project3 = [&](auto cntc, int tile0) __attribute__((always_inline)) {
+            constexpr int CNT = decltype(cntc)::value;
+            if constexpr (CNT > 0 && P3) {
+                constexpr int KS32 = E / 32;
+                static_assert(E % 32 == 0 && KS32 % 3 == 0, "whole rounds of three weight requests");
+                const float *brow = s_dwo + li * DP + 8 * kk;  // + 16 pt * DP + 32 s
+                const u32x4 *wl = reinterpret_cast<const u32x4 *>(w.wp3) + (size_t)tile0 * 192 + lane;
+                f32x4 acc[PT][CNT];
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+                    for (int c = 0; c < CNT; ++c) acc[pt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                u32x4 wa[3][CNT][3];
+                auto load_w = [&](int s0, auto setc) __attribute__((always_inline)) {
+                    constexpr int SET = decltype(setc)::value;
+                    s0 = s0 < KS32 ? s0 : KS32 - 1;  // past the end: the last step again, never used
+                    if (ABL & 16) s0 = 0;
+                    const u32x4 *src = wl + (size_t)s0 * w.nt16 * 192;
+#pragma unroll
+                    for (int c = 0; c < CNT; ++c)
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) wa[SET][c][p] = src[(c * 3 + p) * 64];
+                };
+                P3Act pb[PT];
+                auto read_b = [&](int s, f32x4 (&rb)[PT][2]) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt) {
+                        rb[pt][0] = *reinterpret_cast<const f32x4 *>(brow + 16 * pt * DP + 32 * s);
+                        rb[pt][1] = *reinterpret_cast<const f32x4 *>(brow + 16 * pt * DP + 32 * s + 4);
+                    }
+                };
+                auto comp = [&](int s, auto setc) __attribute__((always_inline)) {
+                    constexpr int SET = decltype(setc)::value;
+                    f32x4 rb[PT][2];
+                    read_b(s + 1 < KS32 ? s + 1 : s, rb);
+                    __builtin_amdgcn_sched_barrier(0);
+#define PB_BLK_PASS(WP_, AP_)                                                                        \
+    _Pragma("unroll") for (int c = 0; c < CNT; ++c) _Pragma("unroll") for (int pt = 0; pt < PT; ++pt) \
+        acc[pt][c] = p3_mfma(wa[SET][c][WP_], pb[pt].AP_, acc[pt][c]);
+                    PB_BLK_PASS(2, h)
+                    PB_BLK_PASS(1, m)
+                    PB_BLK_PASS(1, h)
+                    PB_BLK_PASS(0, l)
+                    PB_BLK_PASS(0, m)
+                    PB_BLK_PASS(0, h)
+#undef PB_BLK_PASS
+                    P3Act pn[PT];
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt) pn[pt] = p3_split8(rb[pt][0], rb[pt][1]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt) pb[pt] = pn[pt];
+                };
+                using I0 = std::integral_constant<int, 0>;
+                using I1 = std::integral_constant<int, 1>;
+                using I2 = std::integral_constant<int, 2>;
+                load_w(0, I0{});
+                load_w(1, I1{});
+                {
+                    f32x4 rb[PT][2];
+                    read_b(0, rb);
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt) pb[pt] = p3_split8(rb[pt][0], rb[pt][1]);
+                }
+                for (int s0 = 0; s0 < ((ABL & 8) ? 3 : KS32); s0 += 3) {
+                    load_w(s0 + 2, I2{});
+                    comp(s0, I0{});
+                    load_w(s0 + 3, I0{});
+                    comp(s0 + 1, I1{});
+                    load_w(s0 + 4, I1{});
+                    comp(s0 + 2, I2{});
+                }
+                stamp(11);
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) {
+                    const int prow = 16 * pt + li;
+                    const int pimg = b0 + prow / P;
+                    if (pimg >= n_img) continue;
+                    const size_t orow = (size_t)pimg * P + prow % P;
+#pragma unroll
+                    for (int c = 0; c < CNT; ++c) {
+                        const int n = 16 * (tile0 + c) + 4 * kk;
+                        const f32x4 bq = *reinterpret_cast<const f32x4 *>(w.bp + n);
+                        f32x4 v = acc[pt][c];
+                        v.x = v.x + bq.x; v.y = v.y + bq.y; v.z = v.z + bq.z; v.w = v.w + bq.w;
+                        if constexpr (RESID) {
+                            const f32x4 rv = *reinterpret_cast<const f32x4 *>(x + orow * CIN + n);
+                            v.x = rv.x + v.x; v.y = rv.y + v.y; v.z = rv.z + v.z; v.w = rv.w + v.w;
+                        }
+                        *reinterpret_cast<f32x4 *>(out + orow * COUT + n) = v;
+                    }
+                }
+                stamp(12);
+            }
+        };
+        if constexpr (P3) {
+            if (wave < 4) project3(std::integral_constant<int, TA>{}, wave * TA);
+        } else {
+            if (wave < 4) project(std::integral_constant<int, TA>{}, wave * TA);
+            else project(std::integral_constant<int, TB>{}, 4 * TA + (wave - 4) * TB);
+        }
     }
     if constexpr ((ABL & 32) != 0) {
         if (lane == 0) {

@@ -14,6 +14,8 @@
 #include "pb_common.h"
 #include "pb_embed_kernels.h"
 #include "pb_front_band.h"
+#include "pb_gemm_p3.h"
+#include "pb_gemm_p3_launch.h"
 #include "pb_block_small.h"
 
 using namespace pbe;
@@ -33,7 +35,9 @@ struct Gemm {  // 1x1 conv as GEMM
     int K = 0, N = 0, Kpad = 0, Npad = 0;
     float *wt = nullptr;    // [Kpad][Npad]
     float *bias = nullptr;  // [Npad]
-    uint2 *wt3 = nullptr;   // three-bf16-piece form for k_gemm_b3: [3][Kpad / 4][Npad] x (4 consecutive k as bf16); null = f32 path only
+    void *wt3 = nullptr;    // P3 layers (pb_gemm_p3.h): the weights as three bf16 planes in MFMA fragment order, [ceil(K / 32)][Npad / 16][3][64 lanes] x 16 B
+    bool p3 = false;        // the layer's ARITHMETIC: products from bf16 pieces on the bf16 matrix cores (every kernel form of this layer, every
+                            // batch size) instead of the f32 MFMA chain; decided by the layer's shape alone when the weights are loaded
     float *wt4 = nullptr;   // fragments by k-step for k_block_small: [K / 16][Npad / 16][kk * 16 + li][e]; null unless asked for
     float *wt2 = nullptr;   // fragment order for k_gemm_t: [chunk of 64 k][Npad / 16][kk][li][s][e] = w[64 chunk + 16 s + 4 kk + e][16 tile + li]; null when K % 16
 };
@@ -96,7 +100,7 @@ struct pb_embedder {
     bool no_band = false, force_band = false;  // PB_NO_BAND / PB_FORCE_BAND: leave out / always take the LDS-ring front kernel where it applies (A/B runs, bit comparisons)
     int tune_pick = 0;    // PB_TUNE_PICK: 0 fastest candidate (default); 1 slowest; 2 a pseudo-random one -- test hook: every form must give the same bits
     uint32_t tune_rng = 12345u;
-    bool use_b3 = false;  // project / head / FC products from three bf16 pieces (k_gemm_b3) instead of the f32 MFMA chain
+    int p3_min_k = 240;   // layers with K >= this (project of blocks 4-15, head, Linear) are P3 layers (pb_gemm_p3.h); PB_P3_MIN_K, PB_NO_P3
     std::map<std::pair<const void *, long>, std::pair<int, int>> gemm_cfg;  // (layer weights, rows) -> (MR, NR), measured; MR < 0: eight-wave form
     std::map<std::pair<const void *, long>, DwGeom> dw_cfg;
     std::map<std::pair<const void *, long>, int> front_cfg;  // (block, batch) -> 0: expand GEMM + depthwise kernels, else fused kernel config 16 * bands + nc
@@ -180,27 +184,28 @@ int make_gemm(pb_embedder *e, Gemm *g, const float *w, const float *b, int N, in
         }
     }
     if (rc || !pieces) return rc;
-    // w = hi + mid + lo exactly, each piece a bf16 (truncation split: 8 + 8 + 8 significand bits)
-    const int KQ = g->Kpad / 4;
-    std::vector<uint32_t> w3((size_t)3 * KQ * g->Npad * 2, 0u);
+    // P3 layer: w = hi + mid + lo exactly, each piece a bf16 (truncation split: 8 + 8 + 8 significand bits), stored as the MFMA
+    // fragments of pb_gemm_p3.h: [k-step of 32][16-column tile][plane][lane = kk * 16 + li][j] = piece of w[k = 32 s + 8 kk + j][n = 16 t + li]
+    const int steps = (K + 31) / 32, t16 = g->Npad / 16;
+    std::vector<uint16_t> w3((size_t)steps * t16 * 3 * 64 * 8, 0);
     auto bits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
     auto flt = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
-    for (int k = 0; k < g->Kpad; ++k)
-        for (int n = 0; n < g->Npad; ++n) {
-            const float x = wt[(size_t)k * g->Npad + n];
+    for (int k = 0; k < K; ++k)
+        for (int n = 0; n < N; ++n) {
+            const float x = w[(size_t)n * K + k];
             const float r1 = x - flt(bits(x) & 0xFFFF0000u);
             const float r2 = r1 - flt(bits(r1) & 0xFFFF0000u);
-            const uint32_t piece[3] = {bits(x) >> 16, bits(r1) >> 16, bits(r2) >> 16};
-            for (int pl = 0; pl < 3; ++pl) {
-                uint32_t &d = w3[(((size_t)pl * KQ + k / 4) * g->Npad + n) * 2 + ((k & 3) >> 1)];
-                d |= piece[pl] << (16 * (k & 1));
-            }
+            const uint16_t piece[3] = {(uint16_t)(bits(x) >> 16), (uint16_t)(bits(r1) >> 16), (uint16_t)(bits(r2) >> 16)};
+            const size_t frag = ((size_t)(k / 32) * t16 + n / 16) * 3;
+            const int lane = ((k % 32) / 8) * 16 + n % 16, j = k % 8;
+            for (int pl = 0; pl < 3; ++pl) w3[((frag + pl) * 64 + lane) * 8 + j] = piece[pl];
         }
-    uint32_t *dw = nullptr;
+    uint16_t *dw = nullptr;
     rc = dalloc(e, &dw, w3.size());
     if (rc) return rc;
-    PB_HIP(hipMemcpy(dw, w3.data(), w3.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    g->wt3 = reinterpret_cast<uint2 *>(dw);
+    PB_HIP(hipMemcpy(dw, w3.data(), w3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    g->wt3 = dw;
+    g->p3 = true;
     return PB_OK;
 }
 
@@ -295,14 +300,14 @@ int load_weights(pb_embedder *e, const uint8_t *blob, size_t len) {
                 if ((rc = upload(e, &bl.se_w2t, w2t)) || (rc = upload(e, &bl.se_b2, b2))) return rc;
                 p += (size_t)E * S + E;
             }
-            if ((rc = make_gemm(e, &bl.project, p, p + (size_t)bl.cout * E, bl.cout, E, true, true))) return rc;
+            if ((rc = make_gemm(e, &bl.project, p, p + (size_t)bl.cout * E, bl.cout, E, E >= e->p3_min_k && E % 8 == 0, true))) return rc;
             p += (size_t)bl.cout * E + bl.cout;
             e->blocks.push_back(bl);
         }
-    if ((rc = make_gemm(e, &e->head, p, p + 1280 * 320, 1280, 320, true))) return rc;
+    if ((rc = make_gemm(e, &e->head, p, p + 1280 * 320, 1280, 320, 320 >= e->p3_min_k))) return rc;
     p += 1280 * 320 + 1280;
     PB_CHECK(e->D % 4 == 0, PB_ERR_FORMAT, "weight blob: D = %u must be a multiple of 4", e->D);
-    if ((rc = make_gemm(e, &e->fc, p, p + (size_t)e->D * 1280, (int)e->D, 1280, true))) return rc;
+    if ((rc = make_gemm(e, &e->fc, p, p + (size_t)e->D * 1280, (int)e->D, 1280, 1280 >= e->p3_min_k))) return rc;
     return PB_OK;
 }
 
@@ -318,39 +323,6 @@ void launch_gemm_mr(int nr, dim3 grid, hipStream_t st, const float *act, int M, 
         PB_G(1) PB_G(2) PB_G(3) PB_G(4) PB_G(5) PB_G(6) PB_G(7) PB_G(8)
     }
 #undef PB_G
-}
-
-template <bool GATE, int NW, int KC>
-int launch_gemm_b3_t(int nr, hipStream_t st, const float *act, int M, const Gemm &g, const float *gate, int hw, const float *resid,
-                     int do_silu, float *out) {
-    const dim3 grid((unsigned)((M + 16 * NW - 1) / (16 * NW)), (unsigned)(g.Npad / 16 / nr));
-#define PB_G(NRV)                                                                                                        \
-    case NRV: {                                                                                                          \
-        constexpr int NT = 16 * NRV, LDP = NT + (NT % 32 == 0 ? 16 : 0);                                                 \
-        constexpr size_t lds = (size_t)2 * 3 * (KC / 4) * LDP * 8;                                                       \
-        auto kern = k_gemm_b3<NRV, GATE, NW, KC>;                                                                        \
-        if (lds > 48 * 1024)                                                                                             \
-            PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, act, M, g.K, g.wt3, g.Kpad, g.Npad, g.bias, g.N, gate, hw, resid, \
-                           do_silu, out);                                                                                \
-    } break;
-    switch (nr) {
-        PB_G(1) PB_G(2) PB_G(3) PB_G(4) PB_G(5) PB_G(6) PB_G(7) PB_G(8)
-    }
-#undef PB_G
-    return PB_OK;
-}
-// nw: 4 or 8 waves per block; + 100: the 128-deep chunk form (eight k-steps of activations in flight)
-int launch_gemm_b3(int nr, int nw, hipStream_t st, const float *act, long M, const Gemm &g, const float *gate, int hw,
-                   const float *resid, int do_silu, float *out) {
-#define PB_B3(NWV, KCV)                                                                                          \
-    (gate ? launch_gemm_b3_t<true, NWV, KCV>(nr, st, act, (int)M, g, gate, hw, resid, do_silu, out)              \
-          : launch_gemm_b3_t<false, NWV, KCV>(nr, st, act, (int)M, g, gate, hw, resid, do_silu, out))
-    if (nw == 108) return PB_B3(8, 128);
-    if (nw == 104) return PB_B3(4, 128);
-    if (nw == 8) return PB_B3(8, 64);
-    return PB_B3(4, 64);
-#undef PB_B3
 }
 
 template <bool GATE, int NW, int EPI = 0>
@@ -444,50 +416,71 @@ void launch_gemm_cfg(pb_embedder *e, GemmCfg c, const float *act, long M, const 
 #undef PB_L
 }
 
+// ---- P3 layers (pb_gemm_p3.h): one arithmetic, several tile shapes; the shape is measured per (layer, row bucket) like the
+// f32 forms' (the shapes give identical bits, so the pick only affects speed).  enc = 4096 * nw + 16 * mr + nr.
+P3Args p3_args(const float *act, long M, const Gemm &g, const float *gate, int hw, const float *resid, int do_silu, float *out, float scale = 0.f,
+               uint8_t *out_u8 = nullptr) {
+    P3Args a;
+    a.act = act; a.M = M; a.K = g.K; a.wt3 = g.wt3; a.tiles16 = g.Npad / 16; a.bias = g.bias; a.N = g.N; a.gate = gate; a.hw = hw;
+    a.resid = resid; a.do_silu = do_silu; a.out = out; a.scale = scale; a.out_u8 = out_u8;
+    return a;
+}
+
+int launch_p3_tuned(pb_embedder *e, int epi, const P3Args &a, const void *key_ptr, const char *what) {
+    const std::pair<const void *, long> key(key_ptr, tune_bucket(a.M));
+    auto it = e->gemm_cfg.find(key);
+    if (it == e->gemm_cfg.end()) {
+        int best = 0;
+        float best_ms = 1e30f;
+        const bool gate = a.gate != nullptr, kt = (a.K & 31) != 0;
+        for (int nw : {8, 4, 1})
+            for (int mr : {1, 2})
+                for (int nr = 8; nr >= 1; --nr) {
+                    if (a.tiles16 % nr || !p3_has(nr, mr, nw, epi, gate, kt)) continue;
+                    if (nw == 1 && a.M > 1024) continue;             // the one-wave form: a few pixel rows
+                    if (nw > 1 && a.M <= 16L * (nw / 2) * mr) continue;  // more than half of the workgroup's rows would be padding
+                    p3_launch(nr, mr, nw, epi, e->stream, a);
+                    PB_HIP(hipEventRecord(e->tune_e0, e->stream));
+                    p3_launch(nr, mr, nw, epi, e->stream, a);
+                    p3_launch(nr, mr, nw, epi, e->stream, a);
+                    PB_HIP(hipEventRecord(e->tune_e1, e->stream));
+                    PB_HIP(hipEventSynchronize(e->tune_e1));
+                    PB_HIP(hipGetLastError());
+                    float ms = 0.f;
+                    PB_HIP(hipEventElapsedTime(&ms, e->tune_e0, e->tune_e1));
+                    if (e->trace_tune >= 2) fprintf(stderr, "  %s M%ld K%d N%d: P3 NR%d MR%d NW%d %.1f us\n", what, a.M, a.K, a.N, nr, mr, nw, ms * 500.f);
+                    if (tune_take(e, ms, best_ms)) {
+                        best_ms = ms;
+                        best = 4096 * nw + 16 * mr + nr;
+                    }
+                }
+        if (!best) {  // tiny problems: whatever shape exists
+            for (int nw : {1, 4, 8})
+                for (int nr = 1; nr <= 8 && !best; ++nr)
+                    if (a.tiles16 % nr == 0 && p3_has(nr, 1, nw, epi, gate, kt)) best = 4096 * nw + 16 + nr;
+            PB_CHECK(best, PB_ERR_INTERNAL, "no P3 GEMM shape for %d column tiles (epilogue %d)", a.tiles16, epi);
+        }
+        if (e->trace_tune)
+            fprintf(stderr, "%s M%ld K%d N%d%s: P3 best NR%d MR%d NW%d %.1f us = %.1f TFLOP/s\n", what, a.M, a.K, a.N, gate ? " gated" : "", best & 15, (best >> 4) & 15,
+                    best >> 12, best_ms * 500.f, 2.0 * (double)a.M * a.K * a.N / (best_ms * 0.5e-3) / 1e12);
+        it = e->gemm_cfg.emplace(key, std::make_pair(best, 0)).first;
+    }
+    const int enc = it->second.first;
+    PB_CHECK(p3_launch(enc & 15, (enc >> 4) & 15, enc >> 12, epi, e->stream, a), PB_ERR_INTERNAL, "P3 GEMM shape %d not built", enc);
+    PB_HIP(hipGetLastError());
+    return PB_OK;
+}
+
+int launch_gemm_p3(pb_embedder *e, const float *act, long M, const Gemm &g, const float *gate, int hw, const float *resid, int do_silu, float *out) {
+    return launch_p3_tuned(e, 0, p3_args(act, M, g, gate, hw, resid, do_silu, out), g.wt, "gemm");
+}
+
 int launch_gemm(pb_embedder *e, const float *act, long M, const Gemm &g, const float *gate, int hw, const float *resid,
                 int do_silu, float *out) {
     const int tiles = g.Npad / 16;
     const std::pair<const void *, long> key(g.wt, tune_bucket(M));
     auto it = e->gemm_cfg.find(key);
-    if (g.wt3 && e->use_b3) {
-        // project / head / FC: the three-bf16-piece form for EVERY batch size (its numerics differ from the f32 chain,
-        // so the choice must not depend on M); only the tile shape (NR, NW) is measured
-        if (it == e->gemm_cfg.end()) {
-            int best_nr = 1, best_nw = 4;
-            float best_ms = 1e30f;
-            const hipEvent_t e0 = e->tune_e0, e1 = e->tune_e1;  // the embedder's own pair: nothing to release on an early return
-            for (int nr = 8; nr >= 1; --nr) {
-                if (tiles % nr) continue;
-                for (int nw : {8, 4, 108, 104}) {
-                    if (nw % 100 == 8 && M <= 64) continue;
-                    if (nw > 100 && (g.Kpad < 256 || nr > 5)) continue;  // 128-deep chunks: LDS 2 x 96 rows x (16 nr + pad) x 8 B <= 150 KB
-                    int rc = launch_gemm_b3(nr, nw, e->stream, act, M, g, gate, hw, resid, do_silu, out);
-                    if (rc) return rc;
-                    PB_HIP(hipEventRecord(e0, e->stream));
-                    launch_gemm_b3(nr, nw, e->stream, act, M, g, gate, hw, resid, do_silu, out);
-                    launch_gemm_b3(nr, nw, e->stream, act, M, g, gate, hw, resid, do_silu, out);
-                    PB_HIP(hipEventRecord(e1, e->stream));
-                    PB_HIP(hipEventSynchronize(e1));
-                    PB_HIP(hipGetLastError());
-                    float ms = 0.f;
-                    PB_HIP(hipEventElapsedTime(&ms, e0, e1));
-                    if (tune_take(e, ms, best_ms)) {
-                        best_ms = ms;
-                        best_nr = nr;
-                        best_nw = nw;
-                    }
-                }
-            }
-            if (e->trace_tune)
-                fprintf(stderr, "gemm M%ld K%d N%d%s: bf16 pieces, best NR%d NW%d (+100: 128-deep chunks) %.1f us = %.1f TFLOP/s\n", M, g.K, g.N, gate ? " gated" : "",
-                        best_nr, best_nw, best_ms * 500.f, 2.0 * (double)M * g.K * g.N / (best_ms * 0.5e-3) / 1e12);
-            it = e->gemm_cfg.emplace(key, std::make_pair(200 + best_nw, best_nr)).first;
-        }
-        int rc = launch_gemm_b3(it->second.second, it->second.first - 200, e->stream, act, M, g, gate, hw, resid, do_silu, out);
-        if (rc) return rc;
-        PB_HIP(hipGetLastError());
-        return PB_OK;
-    }
+    if (g.p3) return launch_gemm_p3(e, act, M, g, gate, hw, resid, do_silu, out);
     if (it == e->gemm_cfg.end()) {
         GemmCfg best{1, 1, 4};
         float best_ms = 1e30f;
@@ -966,10 +959,10 @@ int run_front(pb_embedder *e, const Block &bl, const float *x, int n, int H, int
 
 // forward for n images already on the device; results to device buffers
 // ---- a whole MBConv block of a 4 x 4 map in one kernel (k_block_small, pb_block_small.h)
-template <int KS, int CIN, int E, int COUT, int HW, int G, int SP, bool RESID>
+template <int KS, int CIN, int E, int COUT, int HW, int G, int SP, bool RESID, bool P3>
 int launch_block_t(pb_embedder *e, const Block &bl, const float *x, int n, float *out) {
-    using GEO = BlockGeom<KS, CIN, E, COUT, HW, G, SP>;
-    auto kern = k_block_small<KS, CIN, E, COUT, HW, G, SP, RESID>;
+    using GEO = BlockGeom<KS, CIN, E, COUT, HW, G, SP, P3>;
+    auto kern = k_block_small<KS, CIN, E, COUT, HW, G, SP, RESID, 0, P3>;
     static_assert(GEO::LDS_BYTES <= 160 * 1024, "one CU's LDS");
     if (!e->block_attr_set[RESID ? 0 : 1]) {  // once per embedder and instantiation (the attribute is per device function and context)
         PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEO::LDS_BYTES));
@@ -978,7 +971,7 @@ int launch_block_t(pb_embedder *e, const Block &bl, const float *x, int n, float
     BlockW w{};
     w.we2 = bl.expand.wt4; w.be = bl.expand.bias; w.dwc = bl.dw_wc; w.bd = bl.dw_b;
     w.w1 = bl.se_w1; w.b1 = bl.se_b1; w.w2t = bl.se_w2t; w.b2 = bl.se_b2;
-    w.wp2 = bl.project.wt4; w.bp = bl.project.bias; w.nt16 = bl.project.Npad / 16;
+    w.wp2 = bl.project.wt4; w.wp3 = bl.project.wt3; w.bp = bl.project.bias; w.nt16 = bl.project.Npad / 16;
     hipLaunchKernelGGL(kern, dim3((n + G - 1) / G), dim3(512), GEO::LDS_BYTES, e->stream, x, w, out, n);
     PB_HIP(hipGetLastError());
     return PB_OK;
@@ -987,6 +980,7 @@ int launch_block_t(pb_embedder *e, const Block &bl, const float *x, int n, float
 // 0: not a shape the fused kernel is built for
 int block_shape(const pb_embedder *e, const Block &bl, int H, int W) {
     if (e->no_block_fusion || !bl.has_expand || bl.stride != 1 || !bl.expand.wt4 || !bl.project.wt4 || !bl.dw_wc) return 0;
+    if (bl.expand.p3) return 0;  // the whole-block kernel expands on the f32 MFMA
     if (H == 4 && W == 4 && bl.cin == 192 && bl.e == 1152 && bl.sp == 48) {
         if (bl.k == 5 && bl.cout == 192 && bl.residual) return 1;
         if (bl.k == 3 && bl.cout == 320 && !bl.residual) return 2;
@@ -995,8 +989,11 @@ int block_shape(const pb_embedder *e, const Block &bl, int H, int W) {
 }
 
 int launch_block(pb_embedder *e, const Block &bl, int shape, const float *x, int n, float *out) {
-    if (shape == 1) return launch_block_t<5, 192, 1152, 192, 4, 2, 48, true>(e, bl, x, n, out);
-    if (shape == 2) return launch_block_t<3, 192, 1152, 320, 4, 2, 48, false>(e, bl, x, n, out);
+    // the project phase follows the layer's arithmetic (P3 or the f32 chain)
+    if (shape == 1) return bl.project.p3 ? launch_block_t<5, 192, 1152, 192, 4, 2, 48, true, true>(e, bl, x, n, out)
+                                         : launch_block_t<5, 192, 1152, 192, 4, 2, 48, true, false>(e, bl, x, n, out);
+    if (shape == 2) return bl.project.p3 ? launch_block_t<3, 192, 1152, 320, 4, 2, 48, false, true>(e, bl, x, n, out)
+                                         : launch_block_t<3, 192, 1152, 320, 4, 2, 48, false, false>(e, bl, x, n, out);
     return PB_ERR_INTERNAL;
 }
 
@@ -1110,7 +1107,13 @@ int forward_device(pb_embedder *e, const uint8_t *d_rgb, int n, uint8_t *d_u8, f
         W = Wo;
     }
     const long M = (long)n * H * W;
-    if (H * W == 16 && e->head.wt2 && e->fc.wt2 && !e->no_tail_fusion) {
+    if (H * W == 16 && e->head.p3 && e->fc.p3 && !e->no_tail_fusion) {
+        // P3 head + Linear with the same fused epilogues (pool in the head's accumulators; tanh + quantiser behind the Linear)
+        int rc = launch_p3_tuned(e, 1, p3_args(e->buf_x[cur], M, e->head, nullptr, 16, nullptr, 1, e->buf_pool, 1.0f / 16.0f), e->head.wt2, "head + pool");
+        if (rc) return rc;
+        return launch_p3_tuned(e, 2, p3_args(e->buf_pool, n, e->fc, nullptr, 1, nullptr, 0, d_f32, 0.f, d_u8), e->fc.wt2, "linear + tanh + quantiser");
+    }
+    if (H * W == 16 && e->head.wt2 && e->fc.wt2 && !e->head.p3 && !e->fc.p3 && !e->no_tail_fusion) {
         // 4 x 4 final map: the head conv pools in its epilogue (a wave's 16 rows are one image) and the Linear finishes with
         // tanh + the u8 quantiser: three launches (k_avgpool, the FC GEMM's own pass, k_tanh_quant) and the head's [M][1280]
         // round trip less; same arithmetic in the same order (bit-identical)
@@ -1254,7 +1257,8 @@ int pb_embed_create(pb_embedder **out, int device, const void *weights_blob, siz
     PB_CHECK(e, PB_ERR_NOMEM, "out of host memory");
     e->device = device;
     e->max_batch = max_batch;
-    e->use_b3 = getenv("PB_GEMM_B3") != nullptr;  // experiment switch
+    if (const char *pk = getenv("PB_P3_MIN_K")) e->p3_min_k = atoi(pk);  // A/B runs; the default is part of the arithmetic's definition
+    if (getenv("PB_NO_P3")) e->p3_min_k = 1 << 30;
     if (const char *tp = getenv("PB_TUNE_PICK")) e->tune_pick = atoi(tp);
     if (const char *tt = getenv("PB_TRACE_TUNE")) e->trace_tune = tt[0] == '2' ? 2 : 1;
     e->no_stem_fusion = getenv("PB_NO_STEM_FUSION") != nullptr;

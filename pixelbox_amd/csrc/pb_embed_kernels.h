@@ -8,84 +8,9 @@
 // (bit-for-bit an fmaf chain), the only MFMA dtype that keeps the embedding within 1e-5 of an f32 CPU
 // implementation.  Depthwise convolutions, squeeze-excite and the head are HBM/latency-bound VALU kernels.
 #pragma once
-#include <type_traits>
-#include <hip/hip_runtime.h>
-#include <stdint.h>
+#include "pb_embed_common.h"
 
 namespace pbe {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-// SiLU / sigmoid in 5 VALU instructions: e^-x = v_exp_f32(x * -log2 e) (1 ulp on the exponential, plus
-// |x| * 7e-8 relative from the rounded argument), reciprocal through v_rcp_f32 (1 ulp).  Absolute error on
-// SiLU ~1e-7 * |x|, the same scale as the f32 rounding of the convolution sum feeding it; ocml expf plus a
-// correctly rounded divide costs ~25 instructions per element and made the epilogues VALU-bound.  The
-// embedding floats are compared at 1e-5 (tests/embed_tol.py).
-__device__ __forceinline__ float sigmoid_f(float x) {
-    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
-}
-__device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
-// the value held by the previous lane of the 16-lane row (lane 0 of a row: 0)
-__device__ __forceinline__ float dpp_shr1(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111 /* row_shr:1 */, 0xF, 0xF, true));
-}
-
-// Squeeze-excite pooling sums are accumulated in 64-bit fixed point (2^-24 resolution): integer addition is
-// associative, so the pooled mean -- and with it the whole embedding -- is bit-identical whatever the batch size,
-// tiling or kernel form that produced the partial sums.  (f32 partial sums made an image's hash depend, in the
-// last bit, on how many images shared its batch.)
-struct ll4 {
-    long long x, y, z, w;
-};
-__device__ __forceinline__ void se_acc(ll4 &s, const f32x4 &o) {
-    const float a = o.x * 16777216.0f, b = o.y * 16777216.0f, c = o.z * 16777216.0f, d = o.w * 16777216.0f;
-    // |o| < 128 (every activation seen in practice): the scaled value fits an i32, and rndne + cvt_i32 is a fifth
-    // of the instructions of the generic f32 -> i64 conversion; both give rint() exactly
-    if (fmaxf(fmaxf(fabsf(a), fabsf(b)), fmaxf(fabsf(c), fabsf(d))) < 2147483648.0f) {
-        s.x += (long long)__float2int_rn(a);
-        s.y += (long long)__float2int_rn(b);
-        s.z += (long long)__float2int_rn(c);
-        s.w += (long long)__float2int_rn(d);
-    } else {
-        s.x += __float2ll_rn(a);
-        s.y += __float2ll_rn(b);
-        s.z += __float2ll_rn(c);
-        s.w += __float2ll_rn(d);
-    }
-}
-__device__ __forceinline__ void se_add(ll4 &s, const ll4 &o) {
-    s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
-}
-
-// One depthwise filter tap on a channel quad: acc += v * w, as ONE fused multiply-add per channel (v_fma_f32 /
-// v_pk_fma_f32 / v_fmac_f32_dpp) in EVERY depthwise form (strip, rolling, LDS, fused fronts, stem), so that all forms
-// still give identical bits.  The unfused mul + add of the CPU restatement costs twice the VALU issue slots, and the
-// depthwise phases are VALU-issue-bound; the fused form differs from it by at most half an ulp of the sum per tap
-// (it is the more accurate of the two) -- far inside the 1e-5 bar the parity tests hold the embedding to.
-// -DPB_DW_UNFUSED restores the two-instruction form for comparison.
-__device__ __forceinline__ void dw_tap(f32x4 &acc, const f32x4 &v, const f32x4 &w) {
-#ifdef PB_DW_UNFUSED
-    const float p0 = v.x * w.x, p1 = v.y * w.y, p2 = v.z * w.z, p3 = v.w * w.w;
-    acc.x = acc.x + p0; acc.y = acc.y + p1; acc.z = acc.z + p2; acc.w = acc.w + p3;
-#else
-    acc.x = __builtin_fmaf(v.x, w.x, acc.x); acc.y = __builtin_fmaf(v.y, w.y, acc.y);
-    acc.z = __builtin_fmaf(v.z, w.z, acc.z); acc.w = __builtin_fmaf(v.w, w.w, acc.w);
-#endif
-}
-
-// efficientnet.rs:39 -- 128u8.saturating_add_signed((f*128).max(-128).min(128) as i8), bit-exact
-__device__ __forceinline__ uint8_t quantize_u8(float f) {
-    float t = f * 128.0f;
-    t = (t != t) ? -128.0f : (t > -128.0f ? t : -128.0f);  // f32::max(NaN, x) = x
-    t = t < 128.0f ? t : 128.0f;
-    int i;
-    if (t >= 127.0f) i = 127;        // `as i8` saturates
-    else if (t <= -128.0f) i = -128;
-    else i = (int)t;                 // truncation toward zero
-    int u = 128 + i;
-    u = u < 0 ? 0 : (u > 255 ? 255 : u);
-    return (uint8_t)u;
-}
 
 // ------------------------------------------------------------------------------------------------
 // The squeeze-excite gate computed in the TAIL of the kernel that produced the pooled sums, by the workgroup that finishes an
@@ -941,174 +866,6 @@ __global__ __launch_bounds__(256) void k_gemm_stream(const float *__restrict__ a
         tile(t, std::integral_constant<int, 0>{});
         if (t + 1 < t1) tile(t + 1, std::integral_constant<int, 1>{});
         else break;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// The 1x1 convolution with f32 products assembled from bf16 pieces on the bf16 matrix cores ("3 x bf16").
-// Every f32 value is EXACTLY hi + mid + lo with three bf16 (8 + 8 + 8 significand bits, split by truncation);
-// a product a * w is the sum of nine piece products, each exact in f32; the six leading ones
-//     w_lo a_hi, w_hi a_lo, w_mid a_mid, w_mid a_hi, w_hi a_mid, w_hi a_hi
-// are accumulated (smallest first) by v_mfma_f32_16x16x16_bf16, the three dropped ones are <= 2^-24 |a w|.
-// One bf16 MFMA covers 16 k in 8 cycles where the f32 path needs four MFMAs of 32: six of them are 2.7x the f32 rate.
-// The result is a deterministic function of the operands (same pieces, same order for every batch size and tile
-// shape) but NOT the fmaf chain of k_gemm1x1: it is used only for layers that no fused kernel also computes
-// (project, head, FC), for all batch sizes alike.
-// Weights arrive pre-split: wt3[plane][Kpad / 4][Npad] of 8-byte units holding 4 consecutive k as bf16.  Lane (li, kk)
-// owns, exactly as in k_gemm1x1, k = 16 s + 4 kk .. + 3 of pixel row li (activation, split in registers: and / sub /
-// and / sub per element + three v_perm_b32 per pair) and of channel n0 + 16 c + li (weights, one ds_read_b64 per
-// plane and tile).  Same chunking (64 k per LDS buffer, one barrier per chunk), operand ring and epilogue.
-// dynamic LDS: 2 buffers x 3 planes x 16 x LDP 8-byte units.
-typedef short bf16x4 __attribute__((ext_vector_type(4)));
-// KC = k per LDS chunk (64 or 128); the activation ring is KC / 16 k-steps deep: a bf16 k-step is ~5x shorter than an f32
-// one, so the four steps in flight that cover the memory latency of k_gemm1x1 do not cover it here
-template <int NR, bool GATE, int NW, int KC = 64>
-__global__ __launch_bounds__(64 * NW) void k_gemm_b3(const float *__restrict__ act, int M, int K, const uint2 *__restrict__ wt3,
-                                                   int Kpad, int Npad, const float *__restrict__ bias, int N,
-                                                   const float *__restrict__ gate, int hw, const float *__restrict__ resid,
-                                                   int do_silu, float *__restrict__ out) {
-    constexpr int NT = 16 * NR;
-    constexpr int LDP = NT + (NT % 32 == 0 ? 16 : 0);  // row pitch (8-byte units): rows kk and kk + 1 land on opposite bank halves
-    constexpr int PD = KC / 16;
-    constexpr int KQC = KC / 4;                         // k-quads per chunk
-    constexpr int NTHR = 64 * NW;
-    constexpr int ROWS = 3 * KQC;                       // (plane, k-quad) rows of a chunk
-    constexpr int W4 = ROWS * (NT / 2);                 // 16-byte pieces per chunk
-    constexpr int WREGS = (W4 + NTHR - 1) / NTHR;
-    extern __shared__ __attribute__((aligned(16))) uint2 s_w3[];  // [2][ROWS][LDP]
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int li = lane & 15, kk = lane >> 4;
-    const int n0 = blockIdx.y * NT;
-    const long mrow = (long)blockIdx.x * (16 * NW) + wave * 16 + li;
-    const bool mval = mrow < M;
-    const long mc = mval ? mrow : 0;
-    const float *arow = act + mc * K;
-    const float *grow = GATE ? gate + (mc / hw) * K : nullptr;
-    const int KQ = Kpad / 4;
-    f32x4 acc[NR];
-#pragma unroll
-    for (int c = 0; c < NR; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int n_steps = Kpad / 16;
-    const int n_chunks = (Kpad + KC - 1) / KC;
-    f32x4 aring[PD], gring[GATE ? PD : 1];
-    auto load_act = [&](int t, int slot) __attribute__((always_inline)) {
-        const int kbase = t * 16 + 4 * kk;
-        const int kb = (mval && kbase < K) ? kbase : 0;
-        aring[slot] = *reinterpret_cast<const f32x4 *>(arow + kb);
-        if constexpr (GATE) gring[slot] = *reinterpret_cast<const f32x4 *>(grow + kb);
-    };
-#pragma unroll
-    for (int t = 0; t < PD; ++t) load_act(t < n_steps ? t : n_steps - 1, t);
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 wreg[WREGS];
-    auto load_w = [&](int chunk) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < WREGS; ++j) {
-            const int i = threadIdx.x + j * NTHR;
-            const int ic = i < W4 ? i : 0;
-            const int row = ic / (NT / 2), c2 = ic % (NT / 2);
-            const int pl = row / KQC, r = row % KQC;
-            int kq = chunk * KQC + r;
-            kq = kq < KQ ? kq : KQ - 1;  // clamp: k-quads beyond Kpad are never used
-            wreg[j] = *reinterpret_cast<const u32x4 *>(wt3 + ((size_t)pl * KQ + kq) * Npad + n0 + 2 * c2);
-        }
-    };
-    auto store_w = [&](int buf) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < WREGS; ++j) {
-            const int i = threadIdx.x + j * NTHR;
-            if (i < W4) {
-                const int row = i / (NT / 2), c2 = i % (NT / 2);
-                *reinterpret_cast<u32x4 *>(s_w3 + ((size_t)buf * ROWS + row) * LDP + 2 * c2) = wreg[j];
-            }
-        }
-    };
-    load_w(0);
-    store_w(0);
-    __syncthreads();
-    auto do_chunk = [&](int chunk, auto full) __attribute__((always_inline)) {
-        const int k0 = chunk * KC;
-        const int kc = (Kpad - k0) < KC ? (Kpad - k0) : KC;
-        if constexpr (decltype(full)::value) load_w(chunk + 1 < n_chunks ? chunk + 1 : n_chunks - 1);
-        const uint2 *sw = s_w3 + (size_t)(chunk & 1) * ROWS * LDP + li;
-        auto k_step = [&](int q, int u) __attribute__((always_inline)) {
-            const int t = k0 / 16 + q;
-            const int kbase = t * 16 + 4 * kk;
-            f32x4 a = aring[u];
-            if constexpr (GATE) {
-                const f32x4 g = gring[u];
-                a.x = a.x * g.x; a.y = a.y * g.y; a.z = a.z * g.z; a.w = a.w * g.w;
-            }
-            if (!(mval && kbase < K)) a = (f32x4){0.f, 0.f, 0.f, 0.f};
-            load_act((t + PD < n_steps) ? (t + PD) : (n_steps - 1), u);
-            // weight pieces of the step: 3 NR 8-byte LDS reads, all issued before the split arithmetic and the MFMAs
-            uint2 wq[3][NR];
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-                for (int c = 0; c < NR; ++c) wq[pl][c] = sw[(size_t)(pl * KQC + 4 * q + kk) * LDP + 16 * c];
-            // split the four activations: hi = top 16 bits, r1 = a - hi (exact), mid = top 16 bits of r1, lo = r1 - mid
-            uint32_t hb[4], mb[4], lb[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float x = e == 0 ? a.x : (e == 1 ? a.y : (e == 2 ? a.z : a.w));
-                const uint32_t xb = __float_as_uint(x);
-                hb[e] = xb;
-                const float r1 = x - __uint_as_float(xb & 0xFFFF0000u);
-                const uint32_t rb = __float_as_uint(r1);
-                mb[e] = rb;
-                lb[e] = __float_as_uint(r1 - __uint_as_float(rb & 0xFFFF0000u));
-            }
-            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-            const u32x2 ph = {__builtin_amdgcn_perm(hb[1], hb[0], 0x07060302u), __builtin_amdgcn_perm(hb[3], hb[2], 0x07060302u)};
-            const u32x2 pm = {__builtin_amdgcn_perm(mb[1], mb[0], 0x07060302u), __builtin_amdgcn_perm(mb[3], mb[2], 0x07060302u)};
-            const u32x2 pl2 = {__builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u), __builtin_amdgcn_perm(lb[3], lb[2], 0x07060302u)};
-            const bf16x4 ah = __builtin_bit_cast(bf16x4, ph), am = __builtin_bit_cast(bf16x4, pm), al = __builtin_bit_cast(bf16x4, pl2);
-            __builtin_amdgcn_sched_barrier(0);
-            // piece products outermost, column tiles innermost: consecutive MFMAs write DIFFERENT accumulators (six in a row
-            // on one accumulator is a dependent chain that runs at the MFMA's result latency, not its issue rate); every
-            // accumulator still receives its six products in the same order, smallest first
-#define PB_B3_PASS(WP, AP)                                                                                          \
-    _Pragma("unroll") for (int c = 0; c < NR; ++c)                                                                  \
-        acc[c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(bf16x4, wq[WP][c]), AP, acc[c], 0, 0, 0);
-            PB_B3_PASS(2, ah)
-            PB_B3_PASS(0, al)
-            PB_B3_PASS(1, am)
-            PB_B3_PASS(1, ah)
-            PB_B3_PASS(0, am)
-            PB_B3_PASS(0, ah)
-#undef PB_B3_PASS
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        if constexpr (decltype(full)::value) {
-#pragma unroll
-            for (int q = 0; q < KC / 16; ++q) k_step(q, q % PD);
-        } else {
-#pragma unroll
-            for (int q = 0; q < KC / 16; ++q)
-                if (16 * q < kc) k_step(q, q % PD);
-        }
-        if constexpr (decltype(full)::value) store_w((chunk + 1) & 1);
-        __syncthreads();
-    };
-    const int n_full = Kpad / KC;
-    for (int chunk = 0; chunk < n_full; ++chunk) do_chunk(chunk, std::true_type{});
-    if (n_full < n_chunks) do_chunk(n_full, std::false_type{});
-    if (!mval) return;
-#pragma unroll
-    for (int c = 0; c < NR; ++c) {
-        const int n = n0 + c * 16 + kk * 4;
-        if (n >= N) continue;  // N % 4 == 0
-        const f32x4 b = *reinterpret_cast<const f32x4 *>(bias + n);
-        f32x4 v = acc[c];
-        v.x = v.x + b.x; v.y = v.y + b.y; v.z = v.z + b.z; v.w = v.w + b.w;
-        if (do_silu) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
-        if (resid) {
-            const f32x4 rv = *reinterpret_cast<const f32x4 *>(resid + mrow * N + n);
-            v.x = rv.x + v.x; v.y = rv.y + v.y; v.z = rv.z + v.z; v.w = rv.w + v.w;
-        }
-        *reinterpret_cast<f32x4 *>(out + mrow * N + n) = v;
     }
 }
 

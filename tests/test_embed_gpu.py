@@ -236,11 +236,12 @@ def test_other_input_sizes_and_latent_dims_vs_oracle(h, w, d, n):
     assert np.array_equal(fb[:n].view(np.uint32), f.view(np.uint32)) and np.array_equal(fb[-n:].view(np.uint32), f.view(np.uint32))
 
 
-def test_bf16_piece_gemm_form_stays_within_tolerance(monkeypatch):
-    # PB_GEMM_B3=1 (read at pb_embed_create) routes the project / head / FC products through k_gemm_b3: f32 values split
-    # exactly into three bf16 pieces, six leading cross products on the bf16 matrix cores.  Off by default (measured: not
-    # faster in the present loop structure); the form must still meet the same bars.
-    monkeypatch.setenv("PB_GEMM_B3", "1")
+def test_piece_arithmetic_layers_meet_the_bars_and_are_what_runs(monkeypatch):
+    # The project layers of blocks 4-15, the head conv and the Linear are P3 layers (pixelbox_amd/csrc/pb_gemm_p3.h): f32 operands
+    # split exactly into three bf16 pieces, the six leading piece products accumulated in f32 by v_mfma_f32_16x16x32_bf16, in one
+    # fixed order in every kernel form (tiled GEMM in all its shapes, one-wave form, the whole-block kernel's project phase).
+    # The bars are those of the f32 forms; PB_NO_P3 (A/B switch, read at pb_embed_create) puts every layer back on the f32 MFMA
+    # chain: that arithmetic meets the bars too, and its bits differ -- i.e. the default embedder really runs the piece arithmetic.
     blob = W.synthetic_blob(synth.SEED_WEIGHTS, 128, 128, 256)
     imgs = synth.synthetic_images(synth.SEED_IMAGES, 300, 24, 128, 128)
     emb = capi.Embedder(blob, max_batch=32)
@@ -252,6 +253,12 @@ def test_bf16_piece_gemm_form_stays_within_tolerance(monkeypatch):
     for i in (0, 7, 23):  # the same bits for every batch size
         _, f1 = one.embed(imgs[i:i + 1])
         assert np.array_equal(f1.view(np.uint32), f[i:i + 1].view(np.uint32))
+    monkeypatch.setenv("PB_NO_P3", "1")
+    u8c, fc = capi.Embedder(blob, max_batch=32).embed(imgs)
+    assert_embeddings_close(fc, ref_f)
+    assert_bytes_match(u8c, ref_u8, ref_f)
+    assert not np.array_equal(fc.view(np.uint32), f.view(np.uint32))
+    assert np.abs(fc - f).max() < 1e-5
 
 
 @pytest.mark.parametrize("pick", ["1", "2"])

@@ -220,3 +220,92 @@ def test_structured_synthetic_images_are_deterministic_windows_over_the_same_noi
     assert len({(int(a[0, 8 * cy:8 * cy + 8, 16 * cx:16 * cx + 16, 0].min())) for cy in range(4) for cx in range(4)}) > 8
     # grid 1 = one window per (image, channel), drawn from another position of the window stream than synthetic_images uses
     assert synth.synthetic_scenes(synth.SEED_IMAGES, 0, 1, 32, 32, 1).shape == (1, 32, 32, 3)
+
+
+# ---- INTEGRATION.md's Rust `extern "C"` block against include/pixelbox_hip.h (the block declared
+# pb_sharded_shard_device with the wrong arity and nothing parsed it) ---------------------------------------------------
+_RUST_SCALARS = {"c_int": "int", "c_char": "char", "c_void": "void", "u8": "uint8_t", "u32": "uint32_t", "u64": "uint64_t",
+                 "i64": "int64_t", "f32": "float", "f64": "double", "usize": "size_t", "PbIndex": "pb_index",
+                 "PbSharded": "pb_sharded", "PbEmbedder": "pb_embedder", "PbPhasher": "pb_phasher", "PbScanStats": "pb_scan_stats"}
+
+
+def _rust_type(t):
+    """`*const *mut u8` -> ('ptr', True, ('ptr', False, 'uint8_t')): pointer levels with the constness of the pointee"""
+    t = t.strip()
+    m = re.match(r"\*(const|mut)\s+(.*)$", t, flags=re.S)
+    if m:
+        return ("ptr", m.group(1) == "const", _rust_type(m.group(2)))
+    assert t in _RUST_SCALARS, f"unknown Rust type {t!r}"
+    return _RUST_SCALARS[t]
+
+
+def _c_type(t):
+    """`const uint8_t *const *` -> the same canonical form (east-const reading, right to left)"""
+    toks = re.findall(r"[A-Za-z_][A-Za-z0-9_]*|\*", t)
+    toks = [x for x in toks if x not in ("struct", "enum")]
+    # base: everything before the first '*'; const may sit on either side of the type name
+    n_base = toks.index("*") if "*" in toks else len(toks)
+    base = [x for x in toks[:n_base] if x != "const"]
+    assert len(base) == 1, (t, toks)
+    cur, cur_const = base[0], "const" in toks[:n_base]
+    i = n_base
+    while i < len(toks):
+        assert toks[i] == "*", (t, toks)
+        cur = ("ptr", cur_const, cur)
+        cur_const = i + 1 < len(toks) and toks[i + 1] == "const"
+        i += 2 if cur_const else 1
+    return cur
+
+
+def _c_prototypes():
+    hdr = open(os.path.join(ROOT, "include", "pixelbox_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    hdr = re.sub(r"^\s*#.*?(?<!\\)$", "", hdr, flags=re.M | re.S)  # directives (with continuation lines)
+    protos = {}
+    for ret, name, args in re.findall(r"([A-Za-z_][A-Za-z0-9_ \*]*?)\b(pb_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", hdr):
+        params = []
+        if args.strip() != "void":
+            for a in args.split(","):
+                m = re.match(r"(.*?)([A-Za-z_][A-Za-z0-9_]*)\s*$", a.strip(), flags=re.S)  # strip the parameter name
+                params.append(_c_type(m.group(1)))
+        protos[name] = (_c_type(ret), params)
+    return protos, hdr
+
+
+def _rust_prototypes():
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r'^extern "C" \{\n(.*?)^\}', md, flags=re.M | re.S)
+    assert m, 'no extern "C" block in INTEGRATION.md'
+    body = re.sub(r"//[^\n]*", "", m.group(1))
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    protos = {}
+    for name, args, ret in re.findall(r"pub fn (pb_[a-z0-9_]+)\s*\(([^)]*)\)\s*(?:->\s*([^;]+?))?\s*;", body, flags=re.S):
+        params = [_rust_type(a.split(":", 1)[1]) for a in args.split(",") if a.strip()]
+        protos[name] = (_rust_type(ret) if ret else "void", params)
+    return protos, md
+
+
+def test_integration_md_extern_block_matches_the_header():
+    c, hdr = _c_prototypes()
+    r, md = _rust_prototypes()
+    assert len(c) > 40 and set(c) == set(capi.SYMBOLS)  # the parser saw the whole header
+    assert set(r) == set(c), f"only in INTEGRATION.md: {sorted(set(r) - set(c))}; only in the header: {sorted(set(c) - set(r))}"
+    for name in sorted(c):
+        assert r[name][0] == c[name][0], f"{name}: return type {r[name][0]} (Rust) vs {c[name][0]} (C)"
+        assert len(r[name][1]) == len(c[name][1]), f"{name}: {len(r[name][1])} parameters in INTEGRATION.md, {len(c[name][1])} in the header"
+        for i, (a, b) in enumerate(zip(r[name][1], c[name][1])):
+            assert a == b, f"{name}: parameter {i} is {a} in INTEGRATION.md, {b} in the header"
+    # the one by-value struct of the ABI: field order and widths
+    cs = re.search(r"typedef struct pb_scan_stats \{(.*?)\}", hdr, flags=re.S).group(1)
+    c_fields = [(_c_type(t), n) for t, n in re.findall(r"([A-Za-z_][A-Za-z0-9_ ]*?)\s+([a-z_]+)\s*;", cs)]
+    rs = re.search(r"pub struct PbScanStats \{(.*?)\}", md, flags=re.S).group(1)
+    r_fields = [(_rust_type(t), n) for n, t in re.findall(r"pub ([a-z_]+)\s*:\s*([A-Za-z0-9_]+)", rs)]
+    assert r_fields == c_fields and len(c_fields) >= 7, (r_fields, c_fields)
+
+
+def test_the_abi_type_parsers_agree_on_known_spellings():
+    assert _c_type("const uint8_t *const *") == _rust_type("*const *const u8") == ("ptr", True, ("ptr", True, "uint8_t"))
+    assert _c_type("const uint8_t **") == _rust_type("*mut *const u8")
+    assert _c_type("pb_index **") == _rust_type("*mut *mut PbIndex")
+    assert _c_type("const pb_sharded *") == _rust_type("*const PbSharded") != _rust_type("*mut PbSharded")
+    assert _c_type("int") == _rust_type("c_int") and _c_type("size_t") == _rust_type("usize") != _rust_type("u32")
