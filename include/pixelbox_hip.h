@@ -182,6 +182,9 @@ typedef struct pb_scan_stats {
     uint64_t profiled_bytes;  /* algorithmic bytes those launches streamed (rows * dim per query) */
     uint64_t second_chance;   /* no certificate at first, answered exactly by the second-chance pass: every row within
                                  the error margin of the first attempt's k-th cosine listed and re-scored */
+    uint64_t stamp_timeouts;  /* one-query calls whose completion stamp did not arrive within 20 ms and that fell back to the
+                                 stream wait (a GPU shared with ingest or another process); after 3 in a row the index waits
+                                 on the stream for its next 256 one-query calls, then tries the stamp again */
 } pb_scan_stats;                /* queries = fast_path + second_chance + fallback */
 int pb_index_get_stats(pb_index *idx, pb_scan_stats *out, int reset);
 
@@ -285,6 +288,19 @@ int pb_resize_to_fill(pb_embedder *e, const uint8_t *rgb, uint32_t width, uint32
 #define PB_OPT_EMBED_STREAM 3 /* value = hipStream_t the forward pass is launched on (0 = the embedder's own stream) */
 #define PB_OPT_EMBED_ASYNC 4  /* 1: pb_embed_batch_device returns with the forward pass queued (see its stream contract); default 0 */
 int pb_embed_set_option(pb_embedder *e, int option, int64_t value);
+
+/* The embedder picks a kernel form per (layer, batch-size bucket) by timing the candidates at first use (all forms give the
+ * same bits; only speed depends on the pick).  The reference creates its model lazily and runs the first mlhash on whatever
+ * thread asks (efficientnet.rs:10-14; the UI thread for a query, engine.rs:352-361), so that first-use cost is user-visible:
+ *   pb_embed_tune_ms     host milliseconds spent in those timing loops so far on this embedder;
+ *   pb_embed_get_tuning  serialises the picks made so far: *len receives the size; the bytes are written when out != NULL and
+ *                        cap >= *len (call once with out = NULL to size the buffer);
+ *   pb_embed_set_tuning  restores picks saved by an embedder created from a blob of the same H, W, D (any max_batch, any
+ *                        process, any MI355X): calls at batch sizes they cover start without a timing loop.  Picks for
+ *                        layers this embedder does not have, or of another library build, are rejected (PB_ERR_FORMAT) whole. */
+int pb_embed_tune_ms(pb_embedder *e, double *ms);
+int pb_embed_get_tuning(pb_embedder *e, uint8_t *out, size_t cap, size_t *len);
+int pb_embed_set_tuning(pb_embedder *e, const uint8_t *data, size_t len);
 
 /* ======================================================================================
  *  image_hashes::phash (src/image_hashes/phash.rs:3-22) -- the reference's other hash, stored in `phashes`

@@ -41,7 +41,7 @@ SYMBOLS = [
     "pb_index_set_option", "pb_index_get_stats",
     "pb_embed_create", "pb_embed_destroy", "pb_embed_info", "pb_embed_batch", "pb_embed_batch_device", "pb_mlhash",
     "pb_mlhash_image", "pb_embed_batch_images", "pb_embed_batch_images_device", "pb_resize_to_fill",
-    "pb_embed_set_option", "pb_fill_synthetic", "pb_fill_synthetic_images", "pb_fill_synthetic_scenes",
+    "pb_embed_set_option", "pb_embed_tune_ms", "pb_embed_get_tuning", "pb_embed_set_tuning", "pb_fill_synthetic", "pb_fill_synthetic_images", "pb_fill_synthetic_scenes",
     "pb_phash_create", "pb_phash_destroy", "pb_phash_image", "pb_phash_small_image",
 ]
 
@@ -55,7 +55,7 @@ class PixelboxError(RuntimeError):
 class ScanStats(C.Structure):
     _fields_ = [("queries", C.c_uint64), ("fast_path", C.c_uint64), ("fallback", C.c_uint64),
                 ("profiled_launches", C.c_uint64), ("profiled_ms", C.c_double), ("profiled_bytes", C.c_uint64),
-                ("second_chance", C.c_uint64)]
+                ("second_chance", C.c_uint64), ("stamp_timeouts", C.c_uint64)]
 
 
 _lib = None
@@ -123,6 +123,9 @@ def lib():
         L.pb_embed_batch_images.argtypes = [vp, C.POINTER(u8p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint32, u8p, C.POINTER(C.c_float)]
         L.pb_resize_to_fill.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, u8p]
         L.pb_embed_set_option.argtypes = [vp, C.c_int, C.c_int64]
+        L.pb_embed_tune_ms.argtypes = [vp, C.POINTER(C.c_double)]
+        L.pb_embed_get_tuning.argtypes = [vp, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.pb_embed_set_tuning.argtypes = [vp, u8p, C.c_size_t]
         L.pb_phash_create.argtypes = [C.POINTER(vp), C.c_int]
         L.pb_phash_destroy.argtypes = [vp]
         L.pb_phash_image.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, u8p, C.c_size_t, u32p]
@@ -412,6 +415,23 @@ class Embedder:
     def embed_device(self, d_rgb_ptr: int, n: int, d_out_u8_ptr: int, d_out_f32_ptr: int = 0):
         _check(lib().pb_embed_batch_device(self._h, C.c_void_p(d_rgb_ptr), n, C.c_void_p(d_out_u8_ptr),
                                            C.c_void_p(d_out_f32_ptr) if d_out_f32_ptr else None))
+
+    def tune_ms(self) -> float:
+        """host milliseconds this embedder has spent timing kernel forms at first use"""
+        v = C.c_double(0.0)
+        _check(lib().pb_embed_tune_ms(self._h, C.byref(v)))
+        return float(v.value)
+
+    def get_tuning(self) -> bytes:
+        n = C.c_size_t(0)
+        _check(lib().pb_embed_get_tuning(self._h, None, 0, C.byref(n)))
+        buf = np.zeros(max(int(n.value), 1), dtype=np.uint8)
+        _check(lib().pb_embed_get_tuning(self._h, buf.ctypes.data_as(C.POINTER(C.c_uint8)), buf.size, C.byref(n)))
+        return buf[: int(n.value)].tobytes()
+
+    def set_tuning(self, data: bytes) -> None:
+        buf = np.frombuffer(data, dtype=np.uint8)
+        _check(lib().pb_embed_set_tuning(self._h, buf.ctypes.data_as(C.POINTER(C.c_uint8)), buf.size))
 
     def mlhash(self, rgb: np.ndarray) -> np.ndarray:
         rgb = np.ascontiguousarray(rgb, dtype=np.uint8).reshape(self.h, self.w, 3)

@@ -476,7 +476,7 @@ __global__ __launch_bounds__(512) void k_block_small(const float *__restrict__ x
             constexpr int CNT = decltype(cntc)::value;
             if constexpr (CNT > 0 && P3) {
                 constexpr int KS32 = E / 32;
-                static_assert(E % 32 == 0 && KS32 % 3 == 0, "whole rounds of three weight requests");
+                static_assert(E % 32 == 0, "whole k-steps");
                 const float *brow = s_dwo + li * DP + 8 * kk;  // + 16 pt * DP + 32 s
                 const u32x4 *wl = reinterpret_cast<const u32x4 *>(w.wp3) + (size_t)tile0 * 192 + lane;
                 f32x4 acc[PT][CNT];
@@ -484,7 +484,9 @@ __global__ __launch_bounds__(512) void k_block_small(const float *__restrict__ x
                 for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
                     for (int c = 0; c < CNT; ++c) acc[pt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                u32x4 wa[3][CNT][3];
+                constexpr int RING = CNT * PT > 6 ? 2 : 3;  // weight sets in flight (12 CNT registers each: five tiles x three sets spill)
+                static_assert(KS32 % RING == 0, "whole rounds of weight requests");
+                u32x4 wa[RING][CNT][3];
                 auto load_w = [&](int s0, auto setc) __attribute__((always_inline)) {
                     constexpr int SET = decltype(setc)::value;
                     s0 = s0 < KS32 ? s0 : KS32 - 1;  // past the end: the last step again, never used
@@ -536,13 +538,22 @@ __global__ __launch_bounds__(512) void k_block_small(const float *__restrict__ x
 #pragma unroll
                     for (int pt = 0; pt < PT; ++pt) pb[pt] = p3_split8(rb[pt][0], rb[pt][1]);
                 }
-                for (int s0 = 0; s0 < ((ABL & 8) ? 3 : KS32); s0 += 3) {
-                    load_w(s0 + 2, I2{});
-                    comp(s0, I0{});
-                    load_w(s0 + 3, I0{});
-                    comp(s0 + 1, I1{});
-                    load_w(s0 + 4, I1{});
-                    comp(s0 + 2, I2{});
+                if constexpr (RING == 3) {
+                    for (int s0 = 0; s0 < ((ABL & 8) ? 3 : KS32); s0 += 3) {
+                        load_w(s0 + 2, I2{});
+                        comp(s0, I0{});
+                        load_w(s0 + 3, I0{});
+                        comp(s0 + 1, I1{});
+                        load_w(s0 + 4, I1{});
+                        comp(s0 + 2, I2{});
+                    }
+                } else {
+                    for (int s0 = 0; s0 < ((ABL & 8) ? 2 : KS32); s0 += 2) {
+                        comp(s0, I0{});
+                        load_w(s0 + 2, I0{});
+                        comp(s0 + 1, I1{});
+                        load_w(s0 + 3, I1{});
+                    }
                 }
                 stamp(11);
 #pragma unroll

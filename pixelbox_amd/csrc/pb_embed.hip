@@ -3,6 +3,7 @@
 // fallback.  Weight blob: PBXW0001 (pixelbox_amd/weights.py) -- BN-folded EfficientNet-B0 features +
 // Linear(1280, D) exactly as resources/train.py:30-46,167-174 exports them.
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -100,15 +101,26 @@ struct pb_embedder {
     bool no_band = false, force_band = false;  // PB_NO_BAND / PB_FORCE_BAND: leave out / always take the LDS-ring front kernel where it applies (A/B runs, bit comparisons)
     int tune_pick = 0;    // PB_TUNE_PICK: 0 fastest candidate (default); 1 slowest; 2 a pseudo-random one -- test hook: every form must give the same bits
     uint32_t tune_rng = 12345u;
-    int p3_min_k = 240;   // layers with K >= this (project of blocks 4-15, head, Linear) are P3 layers (pb_gemm_p3.h); PB_P3_MIN_K, PB_NO_P3
+    int p3_min_k = 240;   // p3_layer(): the project layers of blocks 5-15, the head and the Linear are P3 layers (pb_gemm_p3.h); PB_P3_MIN_K, PB_NO_P3
     std::map<std::pair<const void *, long>, std::pair<int, int>> gemm_cfg;  // (layer weights, rows) -> (MR, NR), measured; MR < 0: eight-wave form
     std::map<std::pair<const void *, long>, DwGeom> dw_cfg;
     std::map<std::pair<const void *, long>, int> front_cfg;  // (block, batch) -> 0: expand GEMM + depthwise kernels, else fused kernel config 16 * bands + nc
     size_t part_floats_per_image = 0;      // (layer weights, batch) -> depthwise form, measured
-    // pre-processing scratch (grow-only): source image bytes, vertical-pass f32 rows
-    uint8_t *d_src = nullptr;
+    // the cache keys above are device / host pointers of this embedder; tune_keys names them (block * 8 + kind, 1000 + kind for the
+    // head and the Linear) so that the picks can be saved and restored (pb_embed_get_tuning / pb_embed_set_tuning)
+    std::vector<std::pair<const void *, uint32_t>> tune_keys;
+    double tune_ms = 0.0;  // host time spent in the timing loops (outermost loops only: a front's loop times GEMM loops inside it)
+    int tune_depth = 0;
+    // pre-processing of image batches (prepare_images): two staging slots -- pinned host block, device source block, descriptor
+    // arrays -- so that the host packs and the copy engine moves sub-batch j + 1 while the resize kernels of sub-batch j run;
+    // all grow-only.  d_tmp (vertical-pass f32 rows) is used by one stream only.
+    uint8_t *h_stage_img[2] = {nullptr, nullptr}, *d_src[2] = {nullptr, nullptr};
+    size_t stage_cap[2] = {0, 0};
+    ResizeDesc *h_desc[2] = {nullptr, nullptr}, *d_desc[2] = {nullptr, nullptr};
+    hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_resized[2] = {nullptr, nullptr};
+    bool stage_used[2] = {false, false};
     float *d_tmp = nullptr;
-    size_t d_src_cap = 0, d_tmp_cap = 0;
+    size_t d_tmp_cap = 0;
     std::mutex mu;
 };
 
@@ -150,6 +162,16 @@ bool tune_take(pb_embedder *e, float ms, float best_ms) {
     }
     return ms < best_ms;
 }
+
+// host time of the per-layer timing loops (pb_embed_tune_ms): one of these at the top of every `not measured yet` branch
+struct TuneTimer {
+    pb_embedder *e;
+    std::chrono::steady_clock::time_point t0;
+    explicit TuneTimer(pb_embedder *e_) : e(e_), t0(std::chrono::steady_clock::now()) { ++e->tune_depth; }
+    ~TuneTimer() {
+        if (--e->tune_depth == 0) e->tune_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+};
 
 // torch [N][K] (OI) -> k-major zero-padded [Kpad][Npad] + padded bias
 int make_gemm(pb_embedder *e, Gemm *g, const float *w, const float *b, int N, int K, bool pieces = false, bool fragments_by_step = false) {
@@ -208,6 +230,12 @@ int make_gemm(pb_embedder *e, Gemm *g, const float *w, const float *b, int N, in
     g->p3 = true;
     return PB_OK;
 }
+
+// Which layers are P3 layers (pb_gemm_p3.h) -- a property of the layer's SHAPE only (never of the batch): deep enough that the
+// f32 MFMA chain is what bounds it (K >= 240) and at least five 16-column tiles wide, so that the operand split hides under the
+// tile's own matrix instructions (the 40-column project of block 4 is bound by its 126 MB of activations either way and ran
+// 44 us as a P3 layer against 39 us on the f32 chain).
+bool p3_layer(const pb_embedder *e, int K, int N) { return K >= e->p3_min_k && K % 8 == 0 && (N + 15) / 16 >= 5; }
 
 size_t blob_floats(int D) {
     size_t n = 32 * 27 + 32;
@@ -300,14 +328,26 @@ int load_weights(pb_embedder *e, const uint8_t *blob, size_t len) {
                 if ((rc = upload(e, &bl.se_w2t, w2t)) || (rc = upload(e, &bl.se_b2, b2))) return rc;
                 p += (size_t)E * S + E;
             }
-            if ((rc = make_gemm(e, &bl.project, p, p + (size_t)bl.cout * E, bl.cout, E, E >= e->p3_min_k && E % 8 == 0, true))) return rc;
+            if ((rc = make_gemm(e, &bl.project, p, p + (size_t)bl.cout * E, bl.cout, E, p3_layer(e, E, bl.cout), true))) return rc;
             p += (size_t)bl.cout * E + bl.cout;
             e->blocks.push_back(bl);
         }
-    if ((rc = make_gemm(e, &e->head, p, p + 1280 * 320, 1280, 320, 320 >= e->p3_min_k))) return rc;
+    if ((rc = make_gemm(e, &e->head, p, p + 1280 * 320, 1280, 320, p3_layer(e, 320, 1280)))) return rc;
     p += 1280 * 320 + 1280;
     PB_CHECK(e->D % 4 == 0, PB_ERR_FORMAT, "weight blob: D = %u must be a multiple of 4", e->D);
-    if ((rc = make_gemm(e, &e->fc, p, p + (size_t)e->D * 1280, (int)e->D, 1280, 1280 >= e->p3_min_k))) return rc;
+    if ((rc = make_gemm(e, &e->fc, p, p + (size_t)e->D * 1280, (int)e->D, 1280, p3_layer(e, 1280, (int)e->D)))) return rc;
+    for (size_t b = 0; b < e->blocks.size(); ++b) {
+        const Block &bl = e->blocks[b];
+        const uint32_t base = (uint32_t)b * 8;
+        if (bl.has_expand) e->tune_keys.emplace_back(bl.expand.wt, base + 0);
+        e->tune_keys.emplace_back(bl.project.wt, base + 1);
+        e->tune_keys.emplace_back(bl.dw_w, base + 2);
+        e->tune_keys.emplace_back(&bl, base + 3);
+    }
+    e->tune_keys.emplace_back(e->head.wt, 1000u);
+    if (e->head.wt2) e->tune_keys.emplace_back(e->head.wt2, 1001u);
+    e->tune_keys.emplace_back(e->fc.wt, 1002u);
+    if (e->fc.wt2) e->tune_keys.emplace_back(e->fc.wt2, 1003u);
     return PB_OK;
 }
 
@@ -430,6 +470,7 @@ int launch_p3_tuned(pb_embedder *e, int epi, const P3Args &a, const void *key_pt
     const std::pair<const void *, long> key(key_ptr, tune_bucket(a.M));
     auto it = e->gemm_cfg.find(key);
     if (it == e->gemm_cfg.end()) {
+        TuneTimer tt(e);
         int best = 0;
         float best_ms = 1e30f;
         const bool gate = a.gate != nullptr, kt = (a.K & 31) != 0;
@@ -482,6 +523,7 @@ int launch_gemm(pb_embedder *e, const float *act, long M, const Gemm &g, const f
     auto it = e->gemm_cfg.find(key);
     if (g.p3) return launch_gemm_p3(e, act, M, g, gate, hw, resid, do_silu, out);
     if (it == e->gemm_cfg.end()) {
+        TuneTimer tt(e);
         GemmCfg best{1, 1, 4};
         float best_ms = 1e30f;
         const hipEvent_t e0 = e->tune_e0, e1 = e->tune_e1;  // the embedder's own pair: nothing to release on an early return
@@ -659,6 +701,7 @@ int launch_dw(pb_embedder *e, const Block &bl, const float *in, int B, int H, in
     const std::pair<const void *, long> key(bl.dw_w, tune_bucket(B));
     auto it = e->dw_cfg.find(key);
     if (it == e->dw_cfg.end()) {
+        TuneTimer tt(e);
         DwGeom cands[3] = {dw_geom(bl.e, Ho, Wo, B, e->n_cu), dw_geom_roll(bl.e, bl.k, Ho, Wo, B, e->n_cu),
                            dw_geom_lds(bl.e, bl.k, H, W, Ho, Wo, B, e->n_cu)};
         int best = 0;
@@ -861,6 +904,7 @@ int run_front(pb_embedder *e, const Block &bl, const float *x, int n, int H, int
     auto bands_used = [&](int nb) { const int rpb = (Ho + nb - 1) / nb; return (Ho + rpb - 1) / rpb; };
     auto it = e->front_cfg.find(key);
     if (it == e->front_cfg.end()) {
+        TuneTimer tt(e);
         int tiles = 0;
         int rc = separate(&tiles);  // also warms the GEMM / depthwise selections
         if (rc) return rc;
@@ -1076,6 +1120,7 @@ int forward_device(pb_embedder *e, const uint8_t *d_rgb, int n, uint8_t *d_u8, f
             const std::pair<const void *, long> key(&bl, tune_bucket(n));
             auto it = e->front_cfg.find(key);
             if (it == e->front_cfg.end()) {
+                TuneTimer tt(e);
                 if ((rc = run_unfused())) return rc;  // lets the unfused kernels pick their own forms first
                 float best_ms = 1e30f;
                 int best = 0;
@@ -1124,6 +1169,7 @@ int forward_device(pb_embedder *e, const uint8_t *d_rgb, int n, uint8_t *d_u8, f
             else launch_gemm_t<false, 4, 1>(nr, e->stream, e->buf_x[cur], M, e->head, nullptr, 16, nullptr, 1, e->buf_pool, 1.0f / 16.0f);
         };
         if (it == e->gemm_cfg.end()) {
+            TuneTimer tt(e);
             int best_nr = 1, best_nw = 4;
             float best_ms = 1e30f;
             const int tiles = e->head.Npad / 16;
@@ -1174,7 +1220,14 @@ int forward_device(pb_embedder *e, const uint8_t *d_rgb, int n, uint8_t *d_u8, f
 
 void destroy(pb_embedder *e) {
     for (void *p : e->allocs) (void)hipFree(p);
-    (void)hipFree(e->d_src);
+    for (int i = 0; i < 2; ++i) {
+        (void)hipFree(e->d_src[i]);
+        (void)hipFree(e->d_desc[i]);
+        if (e->h_stage_img[i]) (void)hipHostFree(e->h_stage_img[i]);
+        if (e->h_desc[i]) (void)hipHostFree(e->h_desc[i]);
+        if (e->ev_copied[i]) (void)hipEventDestroy(e->ev_copied[i]);
+        if (e->ev_resized[i]) (void)hipEventDestroy(e->ev_resized[i]);
+    }
     (void)hipFree(e->d_tmp);
     if (e->tune_e0) (void)hipEventDestroy(e->tune_e0);
     for (int i = 0; i < 2; ++i) {
@@ -1193,49 +1246,147 @@ void destroy(pb_embedder *e) {
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
 }
 
-// efficientnet.rs:20 on the device: resize_to_fill(W, H, Triangle) of one host RGB8 image into d_dst[H][W][3]
-// (image 0.25.x semantics; kernels in pb_embed_kernels.h; the tests compare with a CPU restatement bit for bit)
-int resize_to_slot(pb_embedder *e, const uint8_t *rgb, uint32_t w, uint32_t h, uint8_t *d_dst) {
-    PB_CHECK(rgb, PB_ERR_INVALID, "null image");
-    PB_CHECK(w >= 1 && h >= 1 && w <= 65535 && h <= 65535, PB_ERR_INVALID, "image size %ux%u outside 1..65535", w, h);
+// efficientnet.rs:20 on the device for a BATCH of host RGB8 images of individual sizes: resize_to_fill(W, H, Triangle) of image
+// i into d_dst[i][H][W][3] (image 0.25.x semantics; kernels in pb_embed_kernels.h; the tests compare with a CPU restatement bit
+// for bit).  The reference does this per image on a crawler worker (crawler.rs:68-119 -> indexed_image.rs:71 ->
+// efficientnet.rs:19-29); here the batch is cut into sub-batches of <= STAGE_BYTES of source pixels and pipelined over two
+// staging slots: the host packs sub-batch j + 1 into pinned memory (split over four threads) while the copy engine moves
+// sub-batch j and the resize kernels -- TWO launches per sub-batch, over a descriptor array -- run on the embedder's stream.
+// Nothing waits for the GPU except a slot's reuse; the kernels are queued on e->stream, so a forward pass queued after this
+// call is ordered behind them.  On an error the caller drains (drain_streams).
+constexpr size_t STAGE_BYTES = 48u << 20;
+constexpr uint32_t STAGE_MAX_IMAGES = 1024;
+
+void drain_streams(pb_embedder *e) {
+    (void)hipStreamSynchronize(e->h2d_stream);
+    (void)hipStreamSynchronize(e->stream);
+    (void)hipStreamSynchronize(e->d2h_stream);
+}
+
+// copies of many buffers into one block, split over up to four threads by bytes
+void pack_parallel(uint8_t *dst, const uint8_t *const *src, const size_t *bytes, const size_t *off, uint32_t n) {
+    size_t total = 0;
+    for (uint32_t i = 0; i < n; ++i) total += bytes[i];
+    constexpr int NTH = 4;
+    if (total < (4u << 20) || n < 2) {
+        for (uint32_t i = 0; i < n; ++i) memcpy(dst + off[i], src[i], bytes[i]);
+        return;
+    }
+    // thread t takes images [cut[t], cut[t + 1]): contiguous runs of about total / NTH bytes
+    uint32_t cut[NTH + 1];
+    cut[0] = 0;
+    size_t acc = 0;
+    int t = 1;
+    for (uint32_t i = 0; i < n && t < NTH; ++i) {
+        acc += bytes[i];
+        if (acc >= total * t / NTH) cut[t++] = i + 1;
+    }
+    for (; t <= NTH; ++t) cut[t] = n;
+    auto run = [&](uint32_t i0, uint32_t i1) {
+        for (uint32_t i = i0; i < i1; ++i) memcpy(dst + off[i], src[i], bytes[i]);
+    };
+    std::thread th[NTH - 1];
+    int started = 0;
+    try {
+        for (int k = 1; k < NTH; ++k) {
+            if (cut[k] >= cut[k + 1]) continue;
+            th[started] = std::thread(run, cut[k], cut[k + 1]);
+            ++started;
+        }
+    } catch (...) {  // no thread to be had: this thread copies what the missing ones would have
+        for (int k = 0; k < started; ++k) th[k].join();
+        run(0, n);
+        return;
+    }
+    run(cut[0], cut[1]);
+    for (int k = 0; k < started; ++k) th[k].join();
+}
+
+int prepare_images(pb_embedder *e, const uint8_t *const *rgb, const uint32_t *widths, const uint32_t *heights, uint32_t n, uint8_t *d_dst) {
     const uint32_t W = e->W, H = e->H;
-    // src/math/utils.rs resize_dimensions(.., fill = true)
-    const double wratio = (double)W / (double)w, hratio = (double)H / (double)h;
-    const double ratio = wratio > hratio ? wratio : hratio;
-    const double a = std::round((double)w * ratio), b = std::round((double)h * ratio);
-    const uint32_t w2 = a < 1.0 ? 1u : (uint32_t)a, h2 = b < 1.0 ? 1u : (uint32_t)b;
-    PB_CHECK(w2 >= W && h2 >= H, PB_ERR_INVALID, "resize_to_fill: %ux%u does not cover %ux%u", w2, h2, W, H);
-    // src/dynimage.rs resize_to_fill: centre crop along the dimension that overshoots
-    uint32_t cx = 0, cy = 0;
-    if ((uint64_t)W * h2 > (uint64_t)w2 * H) cy = (h2 - H) / 2;
-    else cx = (w2 - W) / 2;
-    const size_t src_bytes = (size_t)w * h * 3;
-    if (src_bytes > e->d_src_cap) {
-        (void)hipFree(e->d_src);
-        e->d_src = nullptr;
-        e->d_src_cap = 0;
-        PB_HIP(hipMalloc(&e->d_src, src_bytes));
-        e->d_src_cap = src_bytes;
+    for (int b = 0; b < 2; ++b) {
+        if (!e->ev_copied[b]) PB_HIP(hipEventCreateWithFlags(&e->ev_copied[b], hipEventDisableTiming));
+        if (!e->ev_resized[b]) PB_HIP(hipEventCreateWithFlags(&e->ev_resized[b], hipEventDisableTiming));
+        if (!e->h_desc[b]) PB_HIP(hipHostMalloc(reinterpret_cast<void **>(&e->h_desc[b]), STAGE_MAX_IMAGES * sizeof(ResizeDesc), hipHostMallocDefault));
+        if (!e->d_desc[b]) PB_HIP(hipMalloc(reinterpret_cast<void **>(&e->d_desc[b]), STAGE_MAX_IMAGES * sizeof(ResizeDesc)));
     }
-    PB_HIP(hipMemcpyAsync(e->d_src, rgb, src_bytes, hipMemcpyHostToDevice, e->stream));
-    const uint32_t n_out = W * H;
-    if (w2 == w && h2 == h) {  // imageops::resize: same dimensions -> copy
-        hipLaunchKernelGGL(k_crop_rgb8, dim3((n_out + 255) / 256), dim3(256), 0, e->stream, e->d_src, w, cx, cy, W, H, d_dst);
+    std::vector<size_t> bytes(STAGE_MAX_IMAGES), off(STAGE_MAX_IMAGES);
+    int slot = 0;
+    for (uint32_t i0 = 0; i0 < n; slot ^= 1) {
+        // ---- the sub-batch [i0, i1): descriptors, offsets, scratch need
+        ResizeDesc *hd = e->h_desc[slot];
+        if (e->stage_used[slot]) PB_HIP(hipEventSynchronize(e->ev_copied[slot]));  // its pinned blocks have been read
+        size_t src_total = 0, tmp_total = 0;
+        uint32_t i1 = i0, max_w = 1;
+        for (; i1 < n && i1 - i0 < STAGE_MAX_IMAGES; ++i1) {
+            const uint32_t w = widths[i1], h = heights[i1];
+            PB_CHECK(rgb[i1], PB_ERR_INVALID, "image %u: null pointer", i1);
+            PB_CHECK(w >= 1 && h >= 1 && w <= 65535 && h <= 65535, PB_ERR_INVALID, "image %u: size %ux%u outside 1..65535", i1, w, h);
+            const size_t sb = (size_t)w * h * 3;
+            if (i1 > i0 && src_total + sb > STAGE_BYTES) break;
+            // src/math/utils.rs resize_dimensions(.., fill = true)
+            const double wratio = (double)W / (double)w, hratio = (double)H / (double)h;
+            const double ratio = wratio > hratio ? wratio : hratio;
+            const double a = std::round((double)w * ratio), b2 = std::round((double)h * ratio);
+            ResizeDesc d;
+            d.w = w; d.h = h;
+            d.w2 = a < 1.0 ? 1u : (uint32_t)a;
+            d.h2 = b2 < 1.0 ? 1u : (uint32_t)b2;
+            PB_CHECK(d.w2 >= W && d.h2 >= H, PB_ERR_INVALID, "resize_to_fill: %ux%u does not cover %ux%u", d.w2, d.h2, W, H);
+            // src/dynimage.rs resize_to_fill: centre crop along the dimension that overshoots
+            d.cx = d.cy = 0;
+            if ((uint64_t)W * d.h2 > (uint64_t)d.w2 * H) d.cy = (d.h2 - H) / 2;
+            else d.cx = (d.w2 - W) / 2;
+            d.resample = (d.w2 == w && d.h2 == h) ? 0u : 1u;  // imageops::resize: same dimensions -> copy
+            d.slot = i1;
+            d.src_off = src_total;
+            d.tmp_off = tmp_total;
+            bytes[i1 - i0] = sb;
+            off[i1 - i0] = src_total;
+            src_total += (sb + 15) & ~(size_t)15;
+            if (d.resample) tmp_total += ((size_t)H * w * 3 + 3) & ~(size_t)3;
+            max_w = std::max(max_w, w);
+            hd[i1 - i0] = d;
+        }
+        const uint32_t m = i1 - i0;
+        // ---- staging blocks (grow-only; a block in use by the GPU is not freed: drain first)
+        if (src_total > e->stage_cap[slot]) {
+            drain_streams(e);
+            if (e->h_stage_img[slot]) (void)hipHostFree(e->h_stage_img[slot]);
+            (void)hipFree(e->d_src[slot]);
+            e->h_stage_img[slot] = nullptr;
+            e->d_src[slot] = nullptr;
+            e->stage_cap[slot] = 0;
+            const size_t cap = std::max(src_total, STAGE_BYTES);
+            PB_HIP(hipHostMalloc(reinterpret_cast<void **>(&e->h_stage_img[slot]), cap, hipHostMallocDefault));
+            PB_HIP(hipMalloc(reinterpret_cast<void **>(&e->d_src[slot]), cap));
+            e->stage_cap[slot] = cap;
+        }
+        if (tmp_total > e->d_tmp_cap) {
+            drain_streams(e);
+            (void)hipFree(e->d_tmp);
+            e->d_tmp = nullptr;
+            e->d_tmp_cap = 0;
+            PB_HIP(hipMalloc(reinterpret_cast<void **>(&e->d_tmp), tmp_total * sizeof(float)));
+            e->d_tmp_cap = tmp_total;
+        }
+        // ---- pack (host), copy (copy engine), resize (embedder's stream)
+        pack_parallel(e->h_stage_img[slot], rgb + i0, bytes.data(), off.data(), m);
+        if (e->stage_used[slot]) PB_HIP(hipStreamWaitEvent(e->h2d_stream, e->ev_resized[slot], 0));  // the kernels that read d_src[slot] last
+        PB_HIP(hipMemcpyAsync(e->d_src[slot], e->h_stage_img[slot], src_total, hipMemcpyHostToDevice, e->h2d_stream));
+        PB_HIP(hipMemcpyAsync(e->d_desc[slot], hd, m * sizeof(ResizeDesc), hipMemcpyHostToDevice, e->h2d_stream));
+        PB_HIP(hipEventRecord(e->ev_copied[slot], e->h2d_stream));
+        e->stage_used[slot] = true;
+        PB_HIP(hipStreamWaitEvent(e->stream, e->ev_copied[slot], 0));
+        if (tmp_total) {
+            hipLaunchKernelGGL(k_resize_v, dim3((max_w + 255) / 256, H, m), dim3(256), 0, e->stream, e->d_src[slot], e->d_desc[slot], e->d_tmp);
+            PB_HIP(hipGetLastError());
+        }
+        hipLaunchKernelGGL(k_resize_h, dim3((W * H + 255) / 256, m), dim3(256), 0, e->stream, e->d_src[slot], e->d_tmp, e->d_desc[slot], W, H, d_dst);
         PB_HIP(hipGetLastError());
-        return PB_OK;
+        PB_HIP(hipEventRecord(e->ev_resized[slot], e->stream));
+        i0 = i1;
     }
-    const size_t tmp_floats = (size_t)H * w * 3;
-    if (tmp_floats > e->d_tmp_cap) {
-        (void)hipFree(e->d_tmp);
-        e->d_tmp = nullptr;
-        e->d_tmp_cap = 0;
-        PB_HIP(hipMalloc(&e->d_tmp, tmp_floats * sizeof(float)));
-        e->d_tmp_cap = tmp_floats;
-    }
-    hipLaunchKernelGGL(k_resize_v, dim3((w + 255) / 256, H), dim3(256), 0, e->stream, e->d_src, w, h, h2, cy, e->d_tmp);
-    PB_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_resize_h, dim3((n_out + 255) / 256), dim3(256), 0, e->stream, e->d_tmp, w, w2, cx, W, H, d_dst);
-    PB_HIP(hipGetLastError());
     return PB_OK;
 }
 
@@ -1404,13 +1555,18 @@ int pb_embed_batch(pb_embedder *e, const uint8_t *rgb, uint32_t n, uint8_t *out_
     // to hide half of its copies was measured and is slower: 148 k against 168 k images/s at 512 -- the half-batches' forwards
     // lose more than the hidden copies save.)
     if (n <= e->max_batch) {  // one chunk: nothing to overlap, one stream, no events
-        PB_HIP(hipMemcpyAsync(e->d_img, rgb, n * img_bytes, hipMemcpyHostToDevice, e->stream));
-        int rc = forward_device(e, e->d_img, (int)n, e->d_out_u8, e->d_out_f32);
-        if (rc) return rc;
-        PB_HIP(hipMemcpyAsync(out_u8, e->d_out_u8, (size_t)n * e->D, hipMemcpyDeviceToHost, e->stream));
-        if (out_f32) PB_HIP(hipMemcpyAsync(out_f32, e->d_out_f32, (size_t)n * e->D * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-        PB_HIP(hipStreamSynchronize(e->stream));
-        return PB_OK;
+        auto body = [&]() -> int {
+            PB_HIP(hipMemcpyAsync(e->d_img, rgb, n * img_bytes, hipMemcpyHostToDevice, e->stream));
+            int rc = forward_device(e, e->d_img, (int)n, e->d_out_u8, e->d_out_f32);
+            if (rc) return rc;
+            PB_HIP(hipMemcpyAsync(out_u8, e->d_out_u8, (size_t)n * e->D, hipMemcpyDeviceToHost, e->stream));
+            if (out_f32) PB_HIP(hipMemcpyAsync(out_f32, e->d_out_f32, (size_t)n * e->D * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+            PB_HIP(hipStreamSynchronize(e->stream));
+            return PB_OK;
+        };
+        const int rc = body();
+        if (rc) (void)hipStreamSynchronize(e->stream);  // a copy may still be reading `rgb` / writing the outputs: not after the call has returned
+        return rc;
     }
     const uint32_t chunk = e->max_batch;
     uint8_t *d_in[2] = {e->d_img, e->d_img_b}, *d_u8[2] = {e->d_out_u8, e->d_out_u8_b};
@@ -1487,24 +1643,41 @@ int pb_embed_batch_images(pb_embedder *e, const uint8_t *const *rgb, const uint3
     PB_CHECK(n == 0 || (rgb && widths && heights && out_u8), PB_ERR_INVALID, "pb_embed_batch_images: null buffer");
     std::lock_guard<std::mutex> lock(e->mu);
     pb::DeviceGuard guard(e->device);
-    const size_t img_bytes = (size_t)e->H * e->W * 3;
-    for (uint32_t i0 = 0; i0 < n; i0 += e->max_batch) {
-        const uint32_t c = std::min(e->max_batch, n - i0);
-        for (uint32_t i = 0; i < c; ++i) {
-            int rc = resize_to_slot(e, rgb[i0 + i], widths[i0 + i], heights[i0 + i], e->d_img + (size_t)i * img_bytes);
-            if (rc) return rc;
-            // the source scratch is reused by the next image: its copy must have been consumed
-            PB_HIP(hipStreamSynchronize(e->stream));
-        }
-        int rc = forward_device(e, e->d_img, (int)c, e->d_out_u8, e->d_out_f32);
+    // chunks of max_batch images through two input slots: the staging + resize of chunk c + 1 is queued while the forward pass
+    // of chunk c runs (the host's packing and the copy engine's transfers hide under it); outputs land in pinned memory on a
+    // third stream and are handed over when their slot comes round again, as in pb_embed_batch
+    uint8_t *d_in[2] = {e->d_img, e->d_img_b}, *d_u8[2] = {e->d_out_u8, e->d_out_u8_b};
+    float *d_f[2] = {e->d_out_f32, e->d_out_f32_b};
+    uint32_t first[2] = {0, 0}, count[2] = {0, 0};
+    auto hand_over = [&](int slot) -> int {
+        if (!count[slot]) return PB_OK;
+        PB_HIP(hipEventSynchronize(e->ev_out[slot]));
+        memcpy(out_u8 + (size_t)first[slot] * e->D, e->h_out_u8[slot], (size_t)count[slot] * e->D);
+        if (out_f32) memcpy(out_f32 + (size_t)first[slot] * e->D, e->h_out_f32[slot], (size_t)count[slot] * e->D * sizeof(float));
+        count[slot] = 0;
+        return PB_OK;
+    };
+    auto run_chunk = [&](int slot, uint32_t i0, uint32_t c) -> int {
+        int rc = hand_over(slot);  // the slot's previous outputs have arrived (so its forward pass, which read d_in[slot], is over)
         if (rc) return rc;
-        PB_HIP(hipMemcpyAsync(out_u8 + (size_t)i0 * e->D, e->d_out_u8, (size_t)c * e->D, hipMemcpyDeviceToHost, e->stream));
+        if ((rc = prepare_images(e, rgb + i0, widths + i0, heights + i0, c, d_in[slot]))) return rc;
+        if ((rc = forward_device(e, d_in[slot], (int)c, d_u8[slot], d_f[slot]))) return rc;
+        PB_HIP(hipEventRecord(e->ev_fwd[slot], e->stream));
+        PB_HIP(hipStreamWaitEvent(e->d2h_stream, e->ev_fwd[slot], 0));
+        PB_HIP(hipMemcpyAsync(e->h_out_u8[slot], d_u8[slot], (size_t)c * e->D, hipMemcpyDeviceToHost, e->d2h_stream));
         if (out_f32)
-            PB_HIP(hipMemcpyAsync(out_f32 + (size_t)i0 * e->D, e->d_out_f32, (size_t)c * e->D * sizeof(float),
-                                  hipMemcpyDeviceToHost, e->stream));
-        PB_HIP(hipStreamSynchronize(e->stream));
-    }
-    return PB_OK;
+            PB_HIP(hipMemcpyAsync(e->h_out_f32[slot], d_f[slot], (size_t)c * e->D * sizeof(float), hipMemcpyDeviceToHost, e->d2h_stream));
+        PB_HIP(hipEventRecord(e->ev_out[slot], e->d2h_stream));
+        first[slot] = i0;
+        count[slot] = c;
+        return PB_OK;
+    };
+    int slot = 0, rc = PB_OK;
+    for (uint32_t i0 = 0; i0 < n && !rc; i0 += e->max_batch, slot ^= 1) rc = run_chunk(slot, i0, std::min(e->max_batch, n - i0));
+    if (!rc) rc = hand_over(slot);
+    if (!rc) rc = hand_over(slot ^ 1);
+    if (rc) drain_streams(e);  // nothing of this call may still be in flight when it returns
+    return rc;
 }
 
 int pb_embed_batch_images_device(pb_embedder *e, const uint8_t *const *rgb, const uint32_t *widths, const uint32_t *heights, uint32_t n,
@@ -1517,17 +1690,17 @@ int pb_embed_batch_images_device(pb_embedder *e, const uint8_t *const *rgb, cons
     if (n == 0) return PB_OK;
     std::lock_guard<std::mutex> lock(e->mu);
     pb::DeviceGuard guard(e->device);
-    const size_t img_bytes = (size_t)e->H * e->W * 3;
-    for (uint32_t i = 0; i < n; ++i) {
-        int rc = resize_to_slot(e, rgb[i], widths[i], heights[i], e->d_img + (size_t)i * img_bytes);
+    auto body = [&]() -> int {
+        int rc = prepare_images(e, rgb, widths, heights, n, e->d_img);
         if (rc) return rc;
-        PB_HIP(hipStreamSynchronize(e->stream));  // the source scratch is reused by the next image
-    }
-    int rc = forward_device(e, e->d_img, (int)n, e->d_out_u8, e->d_out_f32);
-    if (rc) return rc;
-    if (out_u8) PB_HIP(hipMemcpyAsync(out_u8, e->d_out_u8, (size_t)n * e->D, hipMemcpyDeviceToHost, e->stream));
-    PB_HIP(hipStreamSynchronize(e->stream));
-    return PB_OK;
+        if ((rc = forward_device(e, e->d_img, (int)n, e->d_out_u8, e->d_out_f32))) return rc;
+        if (out_u8) PB_HIP(hipMemcpyAsync(out_u8, e->d_out_u8, (size_t)n * e->D, hipMemcpyDeviceToHost, e->stream));
+        PB_HIP(hipStreamSynchronize(e->stream));
+        return PB_OK;
+    };
+    const int rc = body();
+    if (rc) drain_streams(e);
+    return rc;
 }
 
 int pb_mlhash_image(pb_embedder *e, const uint8_t *rgb, uint32_t width, uint32_t height, uint8_t *out, size_t out_len) {
@@ -1541,10 +1714,105 @@ int pb_resize_to_fill(pb_embedder *e, const uint8_t *rgb, uint32_t width, uint32
     PB_CHECK(out_rgb, PB_ERR_INVALID, "pb_resize_to_fill: null output");
     std::lock_guard<std::mutex> lock(e->mu);
     pb::DeviceGuard guard(e->device);
-    int rc = resize_to_slot(e, rgb, width, height, e->d_img);
-    if (rc) return rc;
-    PB_HIP(hipMemcpyAsync(out_rgb, e->d_img, (size_t)e->H * e->W * 3, hipMemcpyDeviceToHost, e->stream));
-    PB_HIP(hipStreamSynchronize(e->stream));
+    auto body = [&]() -> int {
+        int rc = prepare_images(e, &rgb, &width, &height, 1, e->d_img);
+        if (rc) return rc;
+        PB_HIP(hipMemcpyAsync(out_rgb, e->d_img, (size_t)e->H * e->W * 3, hipMemcpyDeviceToHost, e->stream));
+        PB_HIP(hipStreamSynchronize(e->stream));
+        return PB_OK;
+    };
+    const int rc = body();
+    if (rc) drain_streams(e);
+    return rc;
+}
+
+int pb_embed_tune_ms(pb_embedder *e, double *ms) {
+    PB_CHECK(e && ms, PB_ERR_INVALID, "pb_embed_tune_ms: null pointer");
+    std::lock_guard<std::mutex> lock(e->mu);
+    *ms = e->tune_ms;
+    return PB_OK;
+}
+
+namespace {
+// serialised picks: header {magic "PBTN", format, H, W, D, n_entries} then entries {map, key id, bucket, v[6]}.  `format` changes
+// whenever an encoding of gemm_cfg / dw_cfg / front_cfg changes meaning (a new kernel form, a renumbered shape).
+constexpr uint32_t TUNE_MAGIC = 0x4E544250u, TUNE_FORMAT = 4u;
+struct TuneHdr {
+    uint32_t magic, format, H, W, D, n;
+};
+struct TuneEntry {
+    uint32_t map, key;
+    int64_t bucket;
+    int32_t v[6];
+};
+uint32_t tune_key_id(const pb_embedder *e, const void *p) {
+    for (const auto &kv : e->tune_keys)
+        if (kv.first == p) return kv.second;
+    return 0xFFFFFFFFu;
+}
+const void *tune_key_ptr(const pb_embedder *e, uint32_t id) {
+    for (const auto &kv : e->tune_keys)
+        if (kv.second == id) return kv.first;
+    return nullptr;
+}
+}  // namespace
+
+int pb_embed_get_tuning(pb_embedder *e, uint8_t *out, size_t cap, size_t *len) {
+    PB_CHECK(e && len, PB_ERR_INVALID, "pb_embed_get_tuning: null pointer");
+    std::lock_guard<std::mutex> lock(e->mu);
+    std::vector<TuneEntry> ent;
+    for (const auto &kv : e->gemm_cfg) {
+        TuneEntry t{0u, tune_key_id(e, kv.first.first), kv.first.second, {kv.second.first, kv.second.second, 0, 0, 0, 0}};
+        if (t.key != 0xFFFFFFFFu) ent.push_back(t);
+    }
+    for (const auto &kv : e->dw_cfg) {
+        const DwGeom &g = kv.second;
+        TuneEntry t{1u, tune_key_id(e, kv.first.first), kv.first.second, {g.roll, g.zsplit, g.cqpb, g.slots, g.n_tiles, g.strips_per_tile}};
+        if (t.key != 0xFFFFFFFFu) ent.push_back(t);
+    }
+    for (const auto &kv : e->front_cfg) {
+        TuneEntry t{2u, tune_key_id(e, kv.first.first), kv.first.second, {kv.second, 0, 0, 0, 0, 0}};
+        if (t.key != 0xFFFFFFFFu) ent.push_back(t);
+    }
+    // by (map, layer, bucket), not by the maps' pointer order: two embedders with the same picks serialise to the same bytes
+    std::sort(ent.begin(), ent.end(), [](const TuneEntry &a, const TuneEntry &b) {
+        return a.map != b.map ? a.map < b.map : (a.key != b.key ? a.key < b.key : a.bucket < b.bucket);
+    });
+    const size_t need = sizeof(TuneHdr) + ent.size() * sizeof(TuneEntry);
+    *len = need;
+    if (!out) return PB_OK;
+    PB_CHECK(cap >= need, PB_ERR_INVALID, "pb_embed_get_tuning: buffer of %zu bytes, %zu needed", cap, need);
+    const TuneHdr h{TUNE_MAGIC, TUNE_FORMAT, e->H, e->W, e->D, (uint32_t)ent.size()};
+    memcpy(out, &h, sizeof h);
+    if (!ent.empty()) memcpy(out + sizeof h, ent.data(), ent.size() * sizeof(TuneEntry));
+    return PB_OK;
+}
+
+int pb_embed_set_tuning(pb_embedder *e, const uint8_t *data, size_t len) {
+    PB_CHECK(e && data, PB_ERR_INVALID, "pb_embed_set_tuning: null pointer");
+    std::lock_guard<std::mutex> lock(e->mu);
+    TuneHdr h;
+    PB_CHECK(len >= sizeof h, PB_ERR_FORMAT, "tuning data: %zu bytes is shorter than its header", len);
+    memcpy(&h, data, sizeof h);
+    PB_CHECK(h.magic == TUNE_MAGIC && h.format == TUNE_FORMAT, PB_ERR_FORMAT, "tuning data: not a PBTN block of this library build (format %u, want %u)",
+             h.format, TUNE_FORMAT);
+    PB_CHECK(h.H == e->H && h.W == e->W && h.D == e->D, PB_ERR_FORMAT, "tuning data: made for %u x %u -> %u, this embedder is %u x %u -> %u", h.H, h.W,
+             h.D, e->H, e->W, e->D);
+    PB_CHECK(len == sizeof h + (size_t)h.n * sizeof(TuneEntry), PB_ERR_FORMAT, "tuning data: %zu bytes for %u entries", len, h.n);
+    std::vector<TuneEntry> ent(h.n);
+    if (h.n) memcpy(ent.data(), data + sizeof h, (size_t)h.n * sizeof(TuneEntry));
+    for (const TuneEntry &t : ent)  // all or nothing
+        PB_CHECK(t.map <= 2u && tune_key_ptr(e, t.key) && t.bucket >= 1 && (t.bucket & (t.bucket - 1)) == 0, PB_ERR_FORMAT,
+                 "tuning data: entry for layer %u / map %u does not belong to this model", t.key, t.map);
+    for (const TuneEntry &t : ent) {
+        const std::pair<const void *, long> key(tune_key_ptr(e, t.key), (long)t.bucket);
+        if (t.map == 0) e->gemm_cfg[key] = std::make_pair(t.v[0], t.v[1]);
+        else if (t.map == 1) {
+            DwGeom g;
+            g.roll = t.v[0]; g.zsplit = t.v[1]; g.cqpb = t.v[2]; g.slots = t.v[3]; g.n_tiles = t.v[4]; g.strips_per_tile = t.v[5];
+            e->dw_cfg[key] = g;
+        } else e->front_cfg[key] = t.v[0];
+    }
     return PB_OK;
 }
 

@@ -739,9 +739,8 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_t(const float *__restrict__ ac
             // pixels 0..j; lane 0 keeps 0 + v[0]
             f32x4 t = {0.0f + v.x, 0.0f + v.y, 0.0f + v.z, 0.0f + v.w};
 #pragma unroll
-            for (int j = 1; j < 16; ++j) {
-                const float px = dpp_shr1(t.x), py = dpp_shr1(t.y), pz = dpp_shr1(t.z), pw = dpp_shr1(t.w);
-                if (li >= j) { t.x = px + v.x; t.y = py + v.y; t.z = pz + v.z; t.w = pw + v.w; }
+            for (int j = 1; j < 16; ++j) {  // unconditional: a lane that already holds its prefix sum recomputes the same value (see k_gemm_p3)
+                t.x = dpp_shr1(t.x) + v.x; t.y = dpp_shr1(t.y) + v.y; t.z = dpp_shr1(t.z) + v.z; t.w = dpp_shr1(t.w) + v.w;
             }
             if (mval && li == 15 && n < N) {
                 const f32x4 r = {t.x * scale, t.y * scale, t.z * scale, t.w * scale};
@@ -1929,42 +1928,66 @@ __device__ __forceinline__ void resize_window(uint32_t o, uint32_t in_size, uint
     right = (int)r;
     input = in0 - 0.5f;
 }
-// vertical pass: src u8 [h][w][3] -> tmp f32 [rows][w][3] for output rows oy0 .. oy0 + rows - 1 of the h2-row image
-__global__ __launch_bounds__(256) void k_resize_v(const uint8_t *__restrict__ src, uint32_t w, uint32_t h, uint32_t h2,
-                                                  uint32_t oy0, float *__restrict__ tmp) {
+// One image of a batch: where its bytes sit in the staged source block, its geometry (src/math/utils.rs resize_dimensions with
+// fill = true, src/dynimage.rs resize_to_fill's centre crop: computed on the host), where its vertical-pass rows go, and which
+// slot of the network's input batch receives the result.
+struct ResizeDesc {
+    unsigned long long src_off;  // bytes into the source block: u8 [h][w][3]
+    unsigned long long tmp_off;  // floats into the scratch block: f32 [H][w][3] (unused when resample = 0)
+    uint32_t w, h, w2, h2;       // source size, size after scaling to cover W x H
+    uint32_t cx, cy;             // crop origin in the scaled image
+    uint32_t resample;           // 0: the source already has the scaled size (imageops::resize copies): crop only
+    uint32_t slot;               // image index in the destination batch
+};
+// vertical pass of a whole batch: src u8 [h][w][3] -> tmp f32 [H][w][3], output rows cy .. cy + H - 1 of the h2-row image.
+// grid = (ceil(max w / 256), H, images); same arithmetic, in the same order, for an image whatever batch it is part of.
+__global__ __launch_bounds__(256) void k_resize_v(const uint8_t *__restrict__ src_base, const ResizeDesc *__restrict__ desc,
+                                                  float *__restrict__ tmp_base) {
+    const ResizeDesc d = desc[blockIdx.z];
     const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t row = blockIdx.y;
-    if (x >= w) return;
+    if (!d.resample || x >= d.w) return;
+    const uint8_t *src = src_base + d.src_off;
     int left, right;
     float input, sratio;
-    resize_window(oy0 + row, h, h2, left, right, input, sratio);
+    resize_window(d.cy + row, d.h, d.h2, left, right, input, sratio);
     float sum = 0.0f;
     for (int i = left; i < right; ++i) sum = sum + triangle_kernel(((float)i - input) / sratio);
     float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;
     for (int i = left; i < right; ++i) {
         const float wgt = triangle_kernel(((float)i - input) / sratio) / sum;
-        const uint8_t *p = src + ((size_t)i * w + x) * 3;
+        const uint8_t *p = src + ((size_t)i * d.w + x) * 3;
         const float m0 = (float)p[0] * wgt, m1 = (float)p[1] * wgt, m2 = (float)p[2] * wgt;
         t0 = t0 + m0; t1 = t1 + m1; t2 = t2 + m2;
     }
-    float *o = tmp + ((size_t)row * w + x) * 3;
+    float *o = tmp_base + d.tmp_off + ((size_t)row * d.w + x) * 3;
     o[0] = t0; o[1] = t1; o[2] = t2;
 }
-// horizontal pass + crop: tmp f32 [H][w][3] -> dst u8 [H][W][3], output columns ox0 .. ox0 + W - 1 of the w2-column image
-__global__ __launch_bounds__(256) void k_resize_h(const float *__restrict__ tmp, uint32_t w, uint32_t w2, uint32_t ox0,
-                                                  uint32_t W, uint32_t H, uint8_t *__restrict__ dst) {
+// horizontal pass + crop of a whole batch: tmp f32 [H][w][3] -> dst u8 [slot][H][W][3], output columns cx .. cx + W - 1 of the
+// w2-column image; an image that needs no resampling is cropped straight from its source.  grid = (ceil(W H / 256), images).
+__global__ __launch_bounds__(256) void k_resize_h(const uint8_t *__restrict__ src_base, const float *__restrict__ tmp_base,
+                                                  const ResizeDesc *__restrict__ desc, uint32_t W, uint32_t H,
+                                                  uint8_t *__restrict__ dst_base) {
+    const ResizeDesc d = desc[blockIdx.y];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= W * H) return;
     const uint32_t y = i / W, xo = i % W;
+    uint8_t *o = dst_base + ((size_t)d.slot * W * H + i) * 3;
+    if (!d.resample) {  // same-size source: crop only
+        const uint8_t *p = src_base + d.src_off + ((size_t)(d.cy + y) * d.w + d.cx + xo) * 3;
+        o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
+        return;
+    }
+    const float *tmp = tmp_base + d.tmp_off;
     int left, right;
     float input, sratio;
-    resize_window(ox0 + xo, w, w2, left, right, input, sratio);
+    resize_window(d.cx + xo, d.w, d.w2, left, right, input, sratio);
     float sum = 0.0f;
     for (int k = left; k < right; ++k) sum = sum + triangle_kernel(((float)k - input) / sratio);
     float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;
     for (int k = left; k < right; ++k) {
         const float wgt = triangle_kernel(((float)k - input) / sratio) / sum;
-        const float *p = tmp + ((size_t)y * w + k) * 3;
+        const float *p = tmp + ((size_t)y * d.w + k) * 3;
         const float m0 = p[0] * wgt, m1 = p[1] * wgt, m2 = p[2] * wgt;
         t0 = t0 + m0; t1 = t1 + m1; t2 = t2 + m2;
     }
@@ -1972,18 +1995,7 @@ __global__ __launch_bounds__(256) void k_resize_h(const float *__restrict__ tmp,
         t = t < 0.0f ? 0.0f : (t > 255.0f ? 255.0f : t);
         return (uint8_t)roundf(t);  // f32::round: half away from zero
     };
-    uint8_t *o = dst + (size_t)i * 3;
     o[0] = to_u8(t0); o[1] = to_u8(t1); o[2] = to_u8(t2);
-}
-// same-size source (imageops::resize copies instead of resampling): crop only
-__global__ __launch_bounds__(256) void k_crop_rgb8(const uint8_t *__restrict__ src, uint32_t w, uint32_t cx, uint32_t cy,
-                                                   uint32_t W, uint32_t H, uint8_t *__restrict__ dst) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= W * H) return;
-    const uint32_t y = i / W, x = i % W;
-    const uint8_t *p = src + ((size_t)(cy + y) * w + cx + x) * 3;
-    uint8_t *o = dst + (size_t)i * 3;
-    o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
 }
 
 // tanh + u8 quantiser (efficientnet.rs:39) on the Linear(1280, D) outputs (computed by k_gemm1x1, bias included)

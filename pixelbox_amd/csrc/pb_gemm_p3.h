@@ -282,11 +282,14 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_p3(const float *__restrict__ a
                 const f32x4 b = *reinterpret_cast<const f32x4 *>(bias + nc);
                 f32x4 v = acc[r][c];
                 v.x = silu_f(v.x + b.x); v.y = silu_f(v.y + b.y); v.z = silu_f(v.z + b.z); v.w = silu_f(v.w + b.w);
-                f32x4 s = {0.0f + v.x, 0.0f + v.y, 0.0f + v.z, 0.0f + v.w};  // k_avgpool's order: t = 0; t = t + v[p]
+                // k_avgpool's order (t = 0; t = t + v[p] over the 16 pixels) as 15 unconditional steps t = t[lane - 1] + v: lane j
+                // holds its final prefix sum after step j and every later step recomputes the same value from the (final) lane
+                // below it, lane 0 keeps 0 + v[0] -- so no lane needs a predicate and a step is one v_add_f32 with a DPP source
+                // per value (the predicated form: a move, an add and a select)
+                f32x4 s = {0.0f + v.x, 0.0f + v.y, 0.0f + v.z, 0.0f + v.w};
 #pragma unroll
                 for (int j = 1; j < 16; ++j) {
-                    const float px = dpp_shr1(s.x), py = dpp_shr1(s.y), pz = dpp_shr1(s.z), pw = dpp_shr1(s.w);
-                    if (li >= j) { s.x = px + v.x; s.y = py + v.y; s.z = pz + v.z; s.w = pw + v.w; }
+                    s.x = dpp_shr1(s.x) + v.x; s.y = dpp_shr1(s.y) + v.y; s.z = dpp_shr1(s.z) + v.z; s.w = dpp_shr1(s.w) + v.w;
                 }
                 if (mval[r] && li == 15 && n < N) {
                     const f32x4 o = {s.x * scale, s.y * scale, s.z * scale, s.w * scale};

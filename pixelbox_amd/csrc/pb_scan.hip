@@ -106,8 +106,9 @@ struct pb_index {
     uint32_t *h_done = nullptr;     // pinned: completion stamp of a one-query call, written last by k_select_rescore and polled by the host
     uint32_t done_seq = 0;
     bool poll_pending = false;      // the select launch of this call carries a stamp
-    bool env_no_poll = false;       // PB_NO_POLL: wait for the stream instead (comparison); also set after a stamp time-out
-    uint64_t stamp_timeouts = 0;
+    bool env_no_poll = false;       // PB_NO_POLL: wait for the stream instead of the completion stamp (comparison)
+    uint32_t stamp_timeouts_row = 0;  // consecutive stamp time-outs
+    uint32_t no_poll_calls = 0;       // one-query calls left on the stream wait after three time-outs in a row
     bool tail_dirty = false;        // a ticketed (DYN) filter launch was queued without the k_select_rescore that clears d_tail
     bool env_loop_static = false;   // PB_LOOP_STATIC: the looped filter launch with fixed tile strides per wave (comparison)
 
@@ -819,13 +820,20 @@ int search_chunk(pb_index *ix, uint32_t cq, uint32_t k, double max_dist, const f
             const uint32_t want = ix->done_seq;
             const auto t0 = std::chrono::steady_clock::now();
             for (uint32_t spins = 0;; ++spins) {
-                if (__atomic_load_n(&ix->h_done[0], __ATOMIC_ACQUIRE) == want) return PB_OK;
+                if (__atomic_load_n(&ix->h_done[0], __ATOMIC_ACQUIRE) == want) {
+                    ix->stamp_timeouts_row = 0;
+                    return PB_OK;
+                }
                 __builtin_ia32_pause();
                 if ((spins & 4095u) == 4095u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
             }
-            // the stamp did not arrive in time (it has never been seen to happen): do not spin 20 ms on every later call
-            ++ix->stamp_timeouts;
-            ix->env_no_poll = true;
+            // the stamp did not arrive in time (a GPU shared with ingest or another process): counted (pb_index_get_stats);
+            // three in a row put the next 256 one-query calls on the stream wait, then the stamp gets another chance
+            ++ix->stats.stamp_timeouts;
+            if (++ix->stamp_timeouts_row >= 3) {
+                ix->stamp_timeouts_row = 0;
+                ix->no_poll_calls = 256;
+            }
         }
         PB_HIP(hipStreamSynchronize(ix->stream));
         return PB_OK;
@@ -845,7 +853,8 @@ int search_chunk(pb_index *ix, uint32_t cq, uint32_t k, double max_dist, const f
         ix->argq.p = hp[0];
         memcpy(ix->argq.q, hq, 256);
         ix->argq_pending = true;
-        if (host_out && !ix->env_no_poll) {  // results go straight to pinned host memory: completion by stamp
+        if (ix->no_poll_calls) --ix->no_poll_calls;
+        if (host_out && !ix->env_no_poll && !ix->no_poll_calls) {  // results go straight to pinned host memory: completion by stamp
             ix->poll_pending = true;
             if (++ix->done_seq == 0) ix->done_seq = 1;
         }

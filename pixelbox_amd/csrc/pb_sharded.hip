@@ -521,6 +521,7 @@ int pb_sharded_get_stats(pb_sharded *s, pb_scan_stats *out, int reset) {
         tot.fast_path += st.fast_path;
         tot.fallback += st.fallback;
         tot.second_chance += st.second_chance;
+        tot.stamp_timeouts += st.stamp_timeouts;
         tot.profiled_launches += st.profiled_launches;
         tot.profiled_ms += st.profiled_ms;
         tot.profiled_bytes += st.profiled_bytes;

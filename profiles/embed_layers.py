@@ -7,7 +7,7 @@ dense f32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md).
     python3 profiles/embed_layers.py <kt_kernel_trace.csv> [batch = 512] [mfma_busy.json]
 
 Kernels are attributed to MBConv blocks by walking the network (pixelbox_amd.weights.blocks()) alongside the trace: a block
-ends at its project GEMM (a gated k_gemm1x1 / k_gemm_t / k_gemm_b3) or at its k_block_small."""
+ends at its project GEMM (a gated k_gemm1x1 / k_gemm_t / k_gemm_p3) or at its k_block_small."""
 import csv
 import os
 import sys
@@ -59,6 +59,8 @@ def main(path, batch):
             f_se = 2 * 2 * b.expanded * b.squeeze
             f_proj = 2 * ho * wo * b.expanded * b.cout
             gated = "true" in short
+            if fam == "k_gemm_p3":  # <NR, MR, GATE, NW, EPI, DIRECT, KT>: the project layers are the gated ones
+                gated = short.split("<")[1].split(",")[2].strip() == "true"
             if fam == "k_block_small":
                 fl = f_exp + f_dw + f_se + f_proj
                 bi += 1
@@ -68,14 +70,14 @@ def main(path, batch):
                 fl = f_dw
             elif fam == "k_se":
                 fl = f_se
-            elif fam == "k_gemm_stream" or (fam in ("k_gemm1x1", "k_gemm_t", "k_gemm_b3", "k_gemm_thin") and gated):
+            elif fam == "k_gemm_stream" or (fam in ("k_gemm1x1", "k_gemm_t", "k_gemm_p3", "k_gemm_thin") and gated):
                 fl = f_proj
                 bi += 1
-            elif fam in ("k_gemm1x1", "k_gemm_t", "k_gemm_b3", "k_gemm_thin"):
+            elif fam in ("k_gemm1x1", "k_gemm_t", "k_gemm_p3", "k_gemm_thin"):
                 fl = f_exp  # the expand GEMM of an unfused front
         else:
             label = "tail"
-            if fam in ("k_gemm1x1", "k_gemm_t", "k_gemm_b3"):
+            if fam in ("k_gemm1x1", "k_gemm_t", "k_gemm_p3"):
                 fl = 2 * 16 * 320 * 1280 if tail_gemms == 0 else 2 * 1280 * 256  # head conv (+ pool), then the Linear
                 tail_gemms += 1
         fl *= batch
@@ -88,6 +90,8 @@ def main(path, batch):
         tot_gap += gap
         print(f"{short[:38]:38s} {label:>5s} {dur:8.1f} {fl / 1e9:8.2f} {tf:8.1f} {tf / PEAK_TF:7.3f} {gap:7.1f}")
         if "k_tanh_quant" in n or ("k_gemm_t" in n and short.rstrip(">").endswith(", 2")):
+            break
+        if fam == "k_gemm_p3" and short.split("<")[1].split(",")[4].strip() == "2":  # the Linear + tanh + quantiser epilogue
             break
     tf = tot_fl / tot_us / 1e6
     print(f"{'total':38s} {'':>5s} {tot_us:8.1f} {tot_fl / 1e9:8.2f} {tf:8.1f} {tf / PEAK_TF:7.3f}   (sum of kernel durations; gaps between them {tot_gap:.1f} us; batch {batch})")

@@ -320,3 +320,32 @@ def test_round3_kernel_forms_give_the_same_bits(monkeypatch, switch):
         u8, f = other.embed(imgs[:n])
         assert np.array_equal(f.view(np.uint32), f_ref[:n].view(np.uint32)), (switch, n)
         assert np.array_equal(u8, u8_ref[:n])
+
+
+def test_tuning_picks_can_be_saved_and_restored():
+    # pb_embed_get_tuning / pb_embed_set_tuning: the kernel-form picks an embedder measured at first use, restored into a fresh
+    # embedder (another max_batch), spare it the timing loops -- a lazily created model's first mlhash runs on whatever thread
+    # asks for it (efficientnet.rs:10-14, engine.rs:352-361) -- and change no bit.
+    blob = W.synthetic_blob(synth.SEED_WEIGHTS, 128, 128, 256)
+    imgs = synth.synthetic_images(synth.SEED_IMAGES, 1200, 12, 128, 128)
+    a = capi.Embedder(blob, max_batch=16)
+    assert a.tune_ms() == 0.0
+    u8_a, f_a = a.embed(imgs)
+    _ = a.embed(imgs[:1])
+    assert a.tune_ms() > 1.0  # the loops ran (tens of milliseconds)
+    saved = a.get_tuning()
+    assert saved[:4] == b"PBTN" and len(saved) > 24
+    b = capi.Embedder(blob, max_batch=32)
+    b.set_tuning(saved)
+    u8_b, f_b = b.embed(imgs)
+    u8_1, f_1 = b.embed(imgs[:1])
+    assert b.tune_ms() == 0.0  # every (layer, batch bucket) it met was covered
+    assert np.array_equal(f_b.view(np.uint32), f_a.view(np.uint32)) and np.array_equal(u8_b, u8_a)
+    assert np.array_equal(f_1.view(np.uint32), f_a[:1].view(np.uint32))
+    assert b.get_tuning() == saved
+    # a block of another model shape, a truncated block and garbage are refused whole
+    other = capi.Embedder(W.synthetic_blob(synth.SEED_WEIGHTS, 96, 96, 64), max_batch=4)
+    for bad in (saved, saved[:-8], b"PBTN" + bytes(40)):
+        with pytest.raises(capi.PixelboxError) as ei:
+            (other if bad is saved else b).set_tuning(bad)
+        assert ei.value.code == -5  # PB_ERR_FORMAT
