@@ -285,6 +285,11 @@ int pb_embed_batch_images(pb_embedder *e, const uint8_t *const *rgb, const uint3
 /* the pre-processed W x H RGB8 image itself (what the network sees before /255): out_rgb[H*W*3] */
 int pb_resize_to_fill(pb_embedder *e, const uint8_t *rgb, uint32_t width, uint32_t height, uint8_t *out_rgb);
 
+/* Page-locked host memory (hipHostMalloc) for a caller's image batches: pb_embed_batch transfers a batch that sits in such a
+ * buffer without staging it first (what the decode workers of crawler.rs:68-119 would fill).  Free with pb_pinned_free. */
+int pb_pinned_alloc(void **out, size_t bytes);
+int pb_pinned_free(void *p);
+
 #define PB_OPT_EMBED_STREAM 3 /* value = hipStream_t the forward pass is launched on (0 = the embedder's own stream) */
 #define PB_OPT_EMBED_ASYNC 4  /* 1: pb_embed_batch_device returns with the forward pass queued (see its stream contract); default 0 */
 int pb_embed_set_option(pb_embedder *e, int option, int64_t value);

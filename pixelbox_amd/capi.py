@@ -41,7 +41,7 @@ SYMBOLS = [
     "pb_index_set_option", "pb_index_get_stats",
     "pb_embed_create", "pb_embed_destroy", "pb_embed_info", "pb_embed_batch", "pb_embed_batch_device", "pb_mlhash",
     "pb_mlhash_image", "pb_embed_batch_images", "pb_embed_batch_images_device", "pb_resize_to_fill",
-    "pb_embed_set_option", "pb_embed_tune_ms", "pb_embed_get_tuning", "pb_embed_set_tuning", "pb_fill_synthetic", "pb_fill_synthetic_images", "pb_fill_synthetic_scenes",
+    "pb_embed_set_option", "pb_pinned_alloc", "pb_pinned_free", "pb_embed_tune_ms", "pb_embed_get_tuning", "pb_embed_set_tuning", "pb_fill_synthetic", "pb_fill_synthetic_images", "pb_fill_synthetic_scenes",
     "pb_phash_create", "pb_phash_destroy", "pb_phash_image", "pb_phash_small_image",
 ]
 
@@ -121,8 +121,11 @@ def lib():
         L.pb_mlhash.argtypes = [vp, u8p, u8p, C.c_size_t]
         L.pb_mlhash_image.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, u8p, C.c_size_t]
         L.pb_embed_batch_images.argtypes = [vp, C.POINTER(u8p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint32, u8p, C.POINTER(C.c_float)]
+        L.pb_embed_batch_images_device.argtypes = [vp, C.POINTER(u8p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint32, u8p, C.POINTER(vp)]
         L.pb_resize_to_fill.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, u8p]
         L.pb_embed_set_option.argtypes = [vp, C.c_int, C.c_int64]
+        L.pb_pinned_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
+        L.pb_pinned_free.argtypes = [vp]
         L.pb_embed_tune_ms.argtypes = [vp, C.POINTER(C.c_double)]
         L.pb_embed_get_tuning.argtypes = [vp, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
         L.pb_embed_set_tuning.argtypes = [vp, u8p, C.c_size_t]
@@ -459,6 +462,24 @@ class Embedder:
         _check(lib().pb_embed_batch_images(self._h, ptrs, ws, hs, n, _p(u8, C.c_uint8), _p(f, C.c_float) if want_f32 else None))
         return u8, f
 
+    @staticmethod
+    def image_batch_args(images):
+        """The (pointers, widths, heights, n, keep-alive list) a pb_embed_batch_images* call takes, built once for a list of RGB8 arrays."""
+        imgs = [np.ascontiguousarray(im, dtype=np.uint8) for im in images]
+        n = len(imgs)
+        ptrs = (C.POINTER(C.c_uint8) * n)(*[_p(im, C.c_uint8) for im in imgs])
+        ws = (C.c_uint32 * n)(*[im.shape[1] for im in imgs])
+        hs = (C.c_uint32 * n)(*[im.shape[0] for im in imgs])
+        return ptrs, ws, hs, n, imgs
+
+    def embed_images_device(self, batch_args, host_copy: np.ndarray = None) -> int:
+        """pb_embed_batch_images_device: resize + forward of n <= max_batch images of individual sizes; returns the DEVICE pointer of
+        the uint8[n][D] hashes (the embedder's own buffer, valid until its next call); host_copy (uint8 [n, D]) receives a copy."""
+        ptrs, ws, hs, n, _keep = batch_args
+        d = C.c_void_p(0)
+        _check(lib().pb_embed_batch_images_device(self._h, ptrs, ws, hs, n, _p(host_copy, C.c_uint8) if host_copy is not None else None, C.byref(d)))
+        return int(d.value or 0)
+
     def resize_to_fill(self, rgb: np.ndarray) -> np.ndarray:
         rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
         h, w = rgb.shape[:2]
@@ -511,6 +532,27 @@ def fill_synthetic_device(device: int, seed: int, byte_offset: int, nbytes: int,
 
 def fill_synthetic_scenes_device(device: int, seed: int, start: int, n: int, h: int, w: int, d_ptr: int, grid: int = 4):
     _check(lib().pb_fill_synthetic_scenes(device, seed, start, n, h, w, grid, C.c_void_p(d_ptr)))
+
+
+class PinnedBuffer:
+    """pb_pinned_alloc'ed host memory as a numpy uint8 array (`.array`): what a decoder would write its pixels into."""
+
+    def __init__(self, nbytes: int):
+        self._p = C.c_void_p()
+        _check(lib().pb_pinned_alloc(C.byref(self._p), nbytes))
+        self.array = np.ctypeslib.as_array(C.cast(self._p, C.POINTER(C.c_uint8)), shape=(nbytes,))
+
+    def close(self):
+        if self._p:
+            self.array = None
+            lib().pb_pinned_free(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def fill_synthetic_images_device(device: int, seed: int, start: int, n: int, h: int, w: int, d_ptr: int):

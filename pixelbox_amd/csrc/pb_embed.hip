@@ -1263,13 +1263,33 @@ void drain_streams(pb_embedder *e) {
     (void)hipStreamSynchronize(e->d2h_stream);
 }
 
+// copy into a staging block with streaming (non-temporal) stores: the block is read next by the copy engine, not by this
+// core, and a cached store would first fetch every destination line (one more pass over host memory, which is what bounds
+// the packing: profiles/ingest_probe.py).  dst is 16-byte aligned (staging offsets are multiples of 16).
+void stream_copy(uint8_t *dst, const uint8_t *src, size_t n) {
+    typedef long long v2di __attribute__((vector_size(16)));
+    size_t i = 0;
+    if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+        for (; i + 64 <= n; i += 64) {
+            v2di a, b, c, d;
+            memcpy(&a, src + i, 16); memcpy(&b, src + i + 16, 16); memcpy(&c, src + i + 32, 16); memcpy(&d, src + i + 48, 16);
+            __builtin_nontemporal_store(a, reinterpret_cast<v2di *>(dst + i));
+            __builtin_nontemporal_store(b, reinterpret_cast<v2di *>(dst + i + 16));
+            __builtin_nontemporal_store(c, reinterpret_cast<v2di *>(dst + i + 32));
+            __builtin_nontemporal_store(d, reinterpret_cast<v2di *>(dst + i + 48));
+        }
+        __builtin_ia32_sfence();
+    }
+    if (i < n) memcpy(dst + i, src + i, n - i);
+}
+
 // copies of many buffers into one block, split over up to four threads by bytes
 void pack_parallel(uint8_t *dst, const uint8_t *const *src, const size_t *bytes, const size_t *off, uint32_t n) {
     size_t total = 0;
     for (uint32_t i = 0; i < n; ++i) total += bytes[i];
     constexpr int NTH = 4;
     if (total < (4u << 20) || n < 2) {
-        for (uint32_t i = 0; i < n; ++i) memcpy(dst + off[i], src[i], bytes[i]);
+        for (uint32_t i = 0; i < n; ++i) stream_copy(dst + off[i], src[i], bytes[i]);
         return;
     }
     // thread t takes images [cut[t], cut[t + 1]): contiguous runs of about total / NTH bytes
@@ -1283,7 +1303,7 @@ void pack_parallel(uint8_t *dst, const uint8_t *const *src, const size_t *bytes,
     }
     for (; t <= NTH; ++t) cut[t] = n;
     auto run = [&](uint32_t i0, uint32_t i1) {
-        for (uint32_t i = i0; i < i1; ++i) memcpy(dst + off[i], src[i], bytes[i]);
+        for (uint32_t i = i0; i < i1; ++i) stream_copy(dst + off[i], src[i], bytes[i]);
     };
     std::thread th[NTH - 1];
     int started = 0;
@@ -1370,8 +1390,16 @@ int prepare_images(pb_embedder *e, const uint8_t *const *rgb, const uint32_t *wi
             PB_HIP(hipMalloc(reinterpret_cast<void **>(&e->d_tmp), tmp_total * sizeof(float)));
             e->d_tmp_cap = tmp_total;
         }
-        // ---- pack (host), copy (copy engine), resize (embedder's stream)
-        pack_parallel(e->h_stage_img[slot], rgb + i0, bytes.data(), off.data(), m);
+        // ---- pack (host), copy (copy engine), resize (embedder's stream).  (Transferring images that already sit in pinned
+        // memory one by one instead was measured and is slower -- 112 k against 182 k images/s at 256 x 256, 45 k against 49 k at
+        // 640 x 480: a copy command per image costs more than the packing pass saves.)
+        {
+            const auto tp0 = std::chrono::steady_clock::now();
+            pack_parallel(e->h_stage_img[slot], rgb + i0, bytes.data(), off.data(), m);
+            if (e->trace_tune >= 3)
+                fprintf(stderr, "prepare_images: sub-batch of %u images, %.1f MB packed in %.3f ms\n", m, src_total / 1e6,
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count());
+        }
         if (e->stage_used[slot]) PB_HIP(hipStreamWaitEvent(e->h2d_stream, e->ev_resized[slot], 0));  // the kernels that read d_src[slot] last
         PB_HIP(hipMemcpyAsync(e->d_src[slot], e->h_stage_img[slot], src_total, hipMemcpyHostToDevice, e->h2d_stream));
         PB_HIP(hipMemcpyAsync(e->d_desc[slot], hd, m * sizeof(ResizeDesc), hipMemcpyHostToDevice, e->h2d_stream));
@@ -1411,7 +1439,7 @@ int pb_embed_create(pb_embedder **out, int device, const void *weights_blob, siz
     if (const char *pk = getenv("PB_P3_MIN_K")) e->p3_min_k = atoi(pk);  // A/B runs; the default is part of the arithmetic's definition
     if (getenv("PB_NO_P3")) e->p3_min_k = 1 << 30;
     if (const char *tp = getenv("PB_TUNE_PICK")) e->tune_pick = atoi(tp);
-    if (const char *tt = getenv("PB_TRACE_TUNE")) e->trace_tune = tt[0] == '2' ? 2 : 1;
+    if (const char *tt = getenv("PB_TRACE_TUNE")) e->trace_tune = tt[0] == '3' ? 3 : (tt[0] == '2' ? 2 : 1);  // 3: + host-side staging times
     e->no_stem_fusion = getenv("PB_NO_STEM_FUSION") != nullptr;
     e->fold_se = getenv("PB_FOLD_SE") != nullptr;
     e->no_gemm_t = getenv("PB_NO_GEMM_T") != nullptr;
@@ -1724,6 +1752,20 @@ int pb_resize_to_fill(pb_embedder *e, const uint8_t *rgb, uint32_t width, uint32
     const int rc = body();
     if (rc) drain_streams(e);
     return rc;
+}
+
+int pb_pinned_alloc(void **out, size_t bytes) {
+    PB_CHECK(out, PB_ERR_INVALID, "pb_pinned_alloc: null out pointer");
+    *out = nullptr;
+    void *p = nullptr;
+    PB_HIP(hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault));
+    *out = p;
+    return PB_OK;
+}
+
+int pb_pinned_free(void *p) {
+    if (p) PB_HIP(hipHostFree(p));
+    return PB_OK;
 }
 
 int pb_embed_tune_ms(pb_embedder *e, double *ms) {

@@ -135,3 +135,49 @@ def test_mlhash_of_any_size_image_is_mlhash_of_the_preprocessed_image():
     assert np.array_equal(emb.mlhash_image(imgs[1]), emb.mlhash(imgs[1]))  # already 128x128: untouched
     with pytest.raises(capi.PixelboxError):
         emb.mlhash_image(np.zeros((0, 5, 3), dtype=np.uint8))
+
+
+@pytest.mark.gpu
+def test_image_batches_span_staging_sub_batches_and_chunks_without_changing_a_bit():
+    # pb_embed_batch_images[_device] prepare a batch in sub-batches of <= 48 MB of source pixels over two pinned staging slots
+    # (pack on the host, one transfer, two resize launches over a descriptor array) and, beyond max_batch images, in chunks
+    # whose staging overlaps the previous chunk's forward pass.  80 images of mixed sizes (camera frames, thumbnails, network-size
+    # frames that are only cropped, a wide strip, a 1 x 1 image): 80 MB of sources -> several sub-batches, three
+    # chunks of 32 -- every hash equals the hash of the image pre-processed on its own by the CPU restatement, and the device
+    # form leaves the same bytes in the embedder's output buffer.
+    import torch
+
+    from pixelbox_amd import capi, synth
+    from pixelbox_amd import weights as W
+
+    rng = np.random.default_rng(11)
+    sizes = [(480, 640), (128, 128), (256, 256), (1080, 1920), (100, 1000), (131, 257), (1, 1), (128, 300)]
+    imgs = []
+    for i in range(80):
+        h, w = sizes[i % len(sizes)]
+        base = rng.integers(0, 256, size=(h // 16 + 1, w // 16 + 1, 3), dtype=np.uint8)
+        imgs.append(np.kron(base, np.ones((16, 16, 1), dtype=np.uint8))[:h, :w].copy())
+    assert sum(im.size for im in imgs) > 48 << 20
+    blob = W.synthetic_blob(synth.SEED_WEIGHTS, 128, 128, 256)
+    pre = np.stack([oracle.resize_to_fill(im, 128, 128) for im in imgs])
+    big = capi.Embedder(blob, max_batch=128)
+    want_u8, want_f = big.embed(pre)
+    emb = capi.Embedder(blob, max_batch=32)
+    for _ in range(2):  # the staging slots and events are reused across calls
+        got_u8, got_f = emb.embed_images(imgs)
+        assert np.array_equal(got_u8, want_u8) and np.array_equal(got_f.view(np.uint32), want_f.view(np.uint32))
+    host = np.zeros((80, 256), dtype=np.uint8)
+    d_ptr = big.embed_images_device(capi.Embedder.image_batch_args(imgs), host_copy=host)
+    assert np.array_equal(host, want_u8)
+    idx = capi.Index(256, 128)
+    idx.append_device(np.arange(1, 81, dtype=np.int64), d_ptr)  # the device copy is what the index stores
+    _, rows = idx.read(0, 80)
+    assert np.array_equal(rows, want_u8)
+    torch.cuda.synchronize()
+    # an invalid image in the middle of a batch fails the call as a whole and leaves the embedder usable
+    bad = list(imgs[:10])
+    bad[5] = np.zeros((0, 7, 3), dtype=np.uint8)
+    with pytest.raises(capi.PixelboxError):
+        emb.embed_images(bad)
+    got_u8, _ = emb.embed_images(imgs[:10])
+    assert np.array_equal(got_u8, want_u8[:10])
