@@ -49,11 +49,12 @@ class Crawler {
     using BatchSink = std::function<void(size_t model_index, std::vector<IndexedImage> &batch, const uint8_t *d_hashes)>;
 
     Crawler(const Embedder &model, const PHasher *hasher, Decoder decode = decode_pnm, uint32_t max_batch = 512)
-        : models_{&model}, hasher_(hasher), decode_(std::move(decode)), max_batch_(max_batch) {}
+        : models_{&model}, hasher_(hasher), decode_(std::move(decode)), max_batch_(std::min(max_batch, model.max_batch())) {}
     // one embed thread per model (one model per GPU); `hasher` (optional) must be usable from all of them
     Crawler(std::vector<const Embedder *> models, const PHasher *hasher, Decoder decode = decode_pnm, uint32_t max_batch = 512,
             BatchSink sink = nullptr)
         : models_(std::move(models)), hasher_(hasher), decode_(std::move(decode)), max_batch_(max_batch), sink_(std::move(sink)) {
+        for (const Embedder *m : models_) max_batch_ = std::min(max_batch_, m->max_batch());  // a batch must fit every embedder's workspace
         if (models_.empty()) throw Error(PB_ERR_INVALID, "Crawler: no embedder");
     }
     ~Crawler() {
@@ -227,7 +228,10 @@ class Crawler {
             std::vector<RgbImage> imgs;
             imgs.reserve(batch.size());
             for (Decoded &d : batch) imgs.push_back(std::move(d.img));
-            // resize_to_fill + network, one batch; the hashes stay on the GPU as well (for the sink)
+            // resize_to_fill + network, one batch; the hashes stay on the GPU as well (for the sink).  The embedder is this
+            // thread's from here to the end of the sink's device-to-device insert: d_hashes is the embedder's own output buffer,
+            // and a query hashed on the same embedder meanwhile (ShardedEngine::query_by_image_hash_from_file) would overwrite it
+            std::unique_lock<std::recursive_mutex> own(model.exclusive());
             const uint8_t *d_hashes = nullptr;
             const std::vector<std::vector<uint8_t>> hashes = image_hashes::mlhash_batch(model, imgs, sink_ ? &d_hashes : nullptr);
             std::vector<IndexedImage> recs(batch.size());
@@ -240,6 +244,7 @@ class Crawler {
                 r.visual_hash = hashes[i];
             }
             if (sink_) sink_(m, recs, d_hashes);
+            own.unlock();
             for (IndexedImage &r : recs) {
                 std::unique_lock<std::mutex> lk(mu_);
                 cv_space_.wait(lk, [&] { return out_.size() < MAX_PENDING_TX || cancelled_; });  // bounded(128): a slow consumer stalls the stage

@@ -215,11 +215,18 @@ int pb_sharded_append(pb_sharded *s, const int64_t *image_ids, const uint8_t *ro
 /* The multi-GPU form of the crawler -> embed -> insert pipeline (engine.rs:177-205,228-259; crawler.rs:68-119): rows that are
  * already in the DEVICE memory of shard `shard`'s GPU -- the hashes a pb_embedder on that device has just written -- are
  * stored on that shard with no host round trip (pb_index_append_device).  image_ids: HOST array of fresh ids (strictly
- * ascending, greater than every id of that shard, stored on no other shard: last_insert_rowid() values).  Calls for
- * DIFFERENT shards may run concurrently from different host threads (one embed thread per device); pb_sharded_shard_device
- * tells which device a shard lives on, so that an embedder can be created beside it. */
+ * ascending, greater than every id of that shard, stored on no other shard: last_insert_rowid() values) -- an id that is
+ * stored already, or that a concurrent call is storing, REJECTS the call (PB_ERR_INVALID, nothing stored): INSERT OR IGNORE
+ * and out-of-order ids are pb_sharded_append's.  PB_ERR_CAPACITY when the shard (ceil(capacity / n) rows) or the table is
+ * full -- rows that other shards still have room for can go through pb_sharded_append, which spills.  Calls for DIFFERENT
+ * shards may run concurrently from different host threads (one embed thread per device): what a call is about to store is
+ * reserved under the table's lock first, so concurrent calls cannot overrun the capacity or store one id twice.
+ * pb_sharded_shard_device tells which device a shard lives on, so that an embedder can be created beside it. */
 int pb_sharded_append_device(pb_sharded *s, int shard, const int64_t *image_ids, const uint8_t *d_rows, uint64_t n);
 int pb_sharded_shard_device(const pb_sharded *s, int shard, int *device);
+/* *found = 1 iff a row with this image_id is stored on some shard (pb_index_contains over the shards; rows a concurrent
+ * pb_sharded_append_device is still copying do not count yet) */
+int pb_sharded_contains(pb_sharded *s, int64_t image_id, int *found);
 /* Engine::query_by_image_hash_from_image (engine.rs:363-396) over all shards; arguments as pb_index_search */
 int pb_sharded_search(pb_sharded *s, const uint8_t *queries, uint32_t nq, uint32_t k, double max_dist, int64_t *out_ids,
                       float *out_dist, uint32_t *out_count);

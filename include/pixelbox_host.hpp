@@ -23,6 +23,7 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -59,7 +60,14 @@ class Embedder {
     uint32_t width() const { return width_; }
     uint32_t height() const { return height_; }
     uint32_t dim() const { return dim_; }
+    uint32_t max_batch() const { return max_batch_; }
     pb_embedder *raw() const { return h_.get(); }
+    // Whoever needs the embedder's DEVICE output to stay put beyond one call holds this lock across the call and its use of the
+    // pointer (pb_embed_batch_images_device: "valid until the next call on this embedder") -- the crawler's embed thread from
+    // the forward pass to the end of the device-to-device insert.  Every hashing helper below takes it for its own call, so a
+    // query hashed on the same embedder while indexing runs (the reference allows it: engine.rs:352-361 beside :177-205) waits
+    // for the insert instead of overwriting the batch it reads.  Recursive: the holder calls those helpers.
+    std::recursive_mutex &exclusive() const { return use_mu_; }
 
   private:
     struct Del {
@@ -67,6 +75,7 @@ class Embedder {
     };
     std::unique_ptr<pb_embedder, Del> h_;
     uint32_t width_ = 0, height_ = 0, dim_ = 0, max_batch_ = 0;
+    mutable std::recursive_mutex use_mu_;
 };
 
 class PHasher {
@@ -103,6 +112,7 @@ inline std::vector<uint8_t> mlhash(const Embedder &model, const RgbImage &img) {
     if (img.width == 0 || img.height == 0 || img.pixels.size() != (size_t)img.width * img.height * 3)
         throw Error(PB_ERR_INVALID, "mlhash: empty image or pixel buffer of the wrong size");
     std::vector<uint8_t> out(model.dim());
+    std::lock_guard<std::recursive_mutex> use(model.exclusive());
     check(pb_mlhash_image(model.raw(), img.pixels.data(), img.width, img.height, out.data(), out.size()));
     return out;
 }
@@ -120,6 +130,7 @@ inline std::vector<std::vector<uint8_t>> mlhash_batch(const Embedder &model, con
         ws[i] = imgs[i].width;
         hs[i] = imgs[i].height;
     }
+    std::lock_guard<std::recursive_mutex> use(model.exclusive());
     if (d_hashes) check(pb_embed_batch_images_device(model.raw(), ptrs.data(), ws.data(), hs.data(), (uint32_t)imgs.size(), out.data(), d_hashes));
     else check(pb_embed_batch_images(model.raw(), ptrs.data(), ws.data(), hs.data(), (uint32_t)imgs.size(), out.data(), nullptr));
     std::vector<std::vector<uint8_t>> res(imgs.size());

@@ -109,7 +109,8 @@ class ShardedEngine {
         }
         cached_search_results_ = std::move(out);
     }
-    // engine.rs:352-361 (the query image is hashed on shard 0's GPU)
+    // engine.rs:352-361 (the query image is hashed on shard 0's GPU; while indexing runs it waits, inside the hashing helper, for
+    // that GPU's embed thread to finish the batch it is storing: Embedder::exclusive)
     bool query_by_image_hash_from_file(const std::string &path, const PHasher *hasher = nullptr, const Decoder &decode = decode_pnm) {
         cached_search_results_.reset();
         std::optional<IndexedImage> img = indexed_image_from_file_path(path, model(0), hasher, decode);
@@ -136,7 +137,12 @@ class ShardedEngine {
         return (size_t)n;
     }
     // a finished batch of GPU g: ids under the lock (ascending per shard because a GPU's batches are numbered in the order it
-    // finishes them), then the device-to-device insert outside it
+    // finishes them), then the device-to-device insert outside it.  Two things can refuse that insert without anything being
+    // wrong: the shard is full while others have room (shards hold ceil(capacity / n) rows each and the GPUs take batches from
+    // one queue, so a fast GPU fills its shard first), or an id smaller than the batch's reached this shard first
+    // (insert_image_from_memory during indexing places its row on the least-full shard).  Those rows then go through
+    // pb_sharded_append with the host copies of their hashes -- any order, spilling to the least-full shard.  If the rows cannot
+    // be stored at all, the records are taken back out of the maps: a later start_indexing must not skip their paths.
     void store_batch(size_t g, std::vector<IndexedImage> &batch, const uint8_t *d_hashes) {
         std::vector<int64_t> ids;
         std::vector<uint32_t> rows;  // positions of the batch's NEW images (UNIQUE(path): a known path is ignored, engine.rs:40,231)
@@ -156,17 +162,36 @@ class ShardedEngine {
             }
         }
         if (ids.empty()) return;
-        if (ids.size() == batch.size()) {  // the common case: the whole batch is new -- one device-to-device copy
-            check(pb_sharded_append_device(idx_.get(), (int)g, ids.data(), d_hashes, ids.size()));
-            return;
-        }
-        // some paths were known: the new rows are runs of the device buffer
-        size_t a = 0;
-        while (a < rows.size()) {
-            size_t b = a + 1;
-            while (b < rows.size() && rows[b] == rows[b - 1] + 1) ++b;
-            check(pb_sharded_append_device(idx_.get(), (int)g, ids.data() + a, d_hashes + (size_t)rows[a] * dim_, b - a));
-            a = b;
+        try {
+            // the new rows are runs of the device buffer (one run when the whole batch is new: the common case)
+            size_t a = 0;
+            while (a < rows.size()) {
+                size_t b = a + 1;
+                while (b < rows.size() && rows[b] == rows[b - 1] + 1) ++b;
+                const int rc = pb_sharded_append_device(idx_.get(), (int)g, ids.data() + a, d_hashes + (size_t)rows[a] * dim_, b - a);
+                if (rc == PB_ERR_CAPACITY || rc == PB_ERR_INVALID) {  // this shard cannot take the run: the host path places it
+                    std::vector<uint8_t> host((b - a) * (size_t)dim_);
+                    for (size_t i = a; i < b; ++i) {
+                        const std::vector<uint8_t> &vh = *batch[rows[i]].visual_hash;
+                        if (vh.size() != dim_) throw Error(PB_ERR_INVALID, "visual_hash length != index dim");
+                        std::copy(vh.begin(), vh.end(), host.begin() + (i - a) * (size_t)dim_);
+                    }
+                    uint64_t stored = 0;
+                    check(pb_sharded_append(idx_.get(), ids.data() + a, host.data(), b - a, &stored));
+                } else {
+                    check(rc);
+                }
+                a = b;
+            }
+        } catch (...) {
+            std::lock_guard<std::mutex> lk(mu_);
+            for (size_t i = 0; i < rows.size(); ++i) {  // rows that did reach a shard keep their records
+                int found = 0;
+                if (pb_sharded_contains(idx_.get(), ids[i], &found) == PB_OK && found) continue;
+                images_.erase(ids[i]);
+                by_path_.erase(batch[rows[i]].path);
+            }
+            throw;
         }
     }
 

@@ -36,7 +36,7 @@ SYMBOLS = [
     "pb_last_error", "pb_version", "pb_device_count",
     "pb_index_create", "pb_index_create_metric", "pb_index_destroy", "pb_index_size", "pb_index_dim", "pb_index_contains",
     "pb_sharded_create", "pb_sharded_destroy", "pb_sharded_info", "pb_sharded_size", "pb_sharded_load", "pb_sharded_append",
-    "pb_sharded_search", "pb_sharded_append_device", "pb_sharded_shard_device", "pb_sharded_fill_synthetic", "pb_sharded_set_option", "pb_sharded_get_stats", "pb_topk_merge_packed_device", "pb_index_append", "pb_index_append_device", "pb_index_load",
+    "pb_sharded_search", "pb_sharded_append_device", "pb_sharded_shard_device", "pb_sharded_contains", "pb_sharded_fill_synthetic", "pb_sharded_set_option", "pb_sharded_get_stats", "pb_topk_merge_packed_device", "pb_index_append", "pb_index_append_device", "pb_index_load",
     "pb_index_search", "pb_index_search_device", "pb_index_search_packed", "pb_topk_merge_packed", "pb_topk_merge", "pb_index_read", "pb_index_fill_synthetic",
     "pb_index_set_option", "pb_index_get_stats",
     "pb_embed_create", "pb_embed_destroy", "pb_embed_info", "pb_embed_batch", "pb_embed_batch_device", "pb_mlhash",
@@ -105,6 +105,7 @@ def lib():
         L.pb_sharded_search.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, C.c_double, i64p, f32p, u32p]
         L.pb_sharded_append_device.argtypes = [vp, C.c_int, i64p, vp, C.c_uint64]
         L.pb_sharded_shard_device.argtypes = [vp, C.c_int, C.POINTER(C.c_int)]
+        L.pb_sharded_contains.argtypes = [vp, C.c_int64, C.POINTER(C.c_int)]
         L.pb_sharded_fill_synthetic.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int64]
         L.pb_sharded_set_option.argtypes = [vp, C.c_int, C.c_int64]
         L.pb_sharded_get_stats.argtypes = [vp, C.POINTER(ScanStats), C.c_int]
@@ -345,6 +346,11 @@ class ShardedIndexC:
         """rows already in the memory of the shard's GPU (an embedder's output): no host round trip"""
         ids = np.ascontiguousarray(image_ids, dtype=np.int64)
         _check(lib().pb_sharded_append_device(self._h, shard, _p(ids, C.c_int64), C.c_void_p(d_rows_ptr), ids.shape[0]))
+
+    def contains(self, image_id: int) -> bool:
+        f = C.c_int(0)
+        _check(lib().pb_sharded_contains(self._h, int(image_id), C.byref(f)))
+        return bool(f.value)
 
     def shard_device(self, shard: int) -> int:
         d = C.c_int(-1)

@@ -161,6 +161,11 @@ struct pb_sharded {
     std::vector<ncclComm_t> comms;
     std::vector<Worker *> workers;
     uint64_t n_exchanges = 0;               // all-gathers (or copy exchanges) issued
+    // device-side appends (pb_sharded_append_device) copy outside `mu`, so that the embed threads of different GPUs insert
+    // concurrently: what they are about to store is RESERVED under `mu` first -- rows per shard (the capacity checks count them)
+    // and the ids themselves (the uniqueness checks of concurrent calls see them) -- and released when the copy has returned
+    std::vector<uint64_t> pending;
+    std::unordered_set<int64_t> inflight;
     std::mutex mu;
 };
 
@@ -408,13 +413,14 @@ int pb_sharded_append(pb_sharded *s, const int64_t *image_ids, const uint8_t *ro
             int rc = pb_index_contains(s->shards[g], image_ids[i], &found);
             if (rc) return rc;
         }
-        if (found || !seen.insert(image_ids[i]).second) continue;
+        if (found || s->inflight.count(image_ids[i]) || !seen.insert(image_ids[i]).second) continue;  // (an id a device-side append is storing right now is taken)
         ids.push_back(image_ids[i]);
         data.insert(data.end(), rows + i * d, rows + (i + 1) * d);
     }
     uint64_t stored = 0, pos = 0;
     uint64_t room = s->capacity;  // the TOTAL is the contract (per-shard capacities round up: their sum may exceed it)
-    for (int g = 0; g < s->n; ++g) room -= std::min<uint64_t>(room, shard_size(s, g));
+    if (s->pending.size() != (size_t)s->n) s->pending.assign(s->n, 0);
+    for (int g = 0; g < s->n; ++g) room -= std::min<uint64_t>(room, shard_size(s, g) + s->pending[g]);
     while (pos < ids.size()) {
         if (room == 0) {
             if (n_inserted) *n_inserted = stored;
@@ -424,7 +430,7 @@ int pb_sharded_append(pb_sharded *s, const int64_t *image_ids, const uint8_t *ro
         int best = -1;
         uint64_t best_free = 0, best_size = 0;
         for (int g = 0; g < s->n; ++g) {
-            const uint64_t sz = shard_size(s, g), fr = s->shard_cap[g] - sz;
+            const uint64_t sz = shard_size(s, g) + s->pending[g], fr = s->shard_cap[g] > sz ? s->shard_cap[g] - sz : 0;
             if (fr && (best < 0 || sz < best_size)) {
                 best = g;
                 best_free = fr;
@@ -458,6 +464,17 @@ int pb_sharded_shard_device(const pb_sharded *s, int shard, int *device) {
     return PB_OK;
 }
 
+int pb_sharded_contains(pb_sharded *s, int64_t image_id, int *found) {
+    PB_CHECK(s && found, PB_ERR_INVALID, "pb_sharded_contains: null argument");
+    *found = 0;
+    std::lock_guard<std::mutex> lock(s->mu);
+    for (int g = 0; g < s->n && !*found; ++g) {
+        int rc = pb_index_contains(s->shards[g], image_id, found);
+        if (rc) return rc;
+    }
+    return PB_OK;
+}
+
 int pb_sharded_append_device(pb_sharded *s, int shard, const int64_t *image_ids, const uint8_t *d_rows, uint64_t n) {
     PB_CHECK(s, PB_ERR_INVALID, "pb_sharded_append_device: null handle");
     PB_CHECK(shard >= 0 && shard < s->n, PB_ERR_INVALID, "pb_sharded_append_device: shard %d of %d", shard, s->n);
@@ -466,15 +483,20 @@ int pb_sharded_append_device(pb_sharded *s, int shard, const int64_t *image_ids,
     {
         // bookkeeping under the table's lock (the device copy below runs under the SHARD's lock only, so the embed threads
         // of different devices insert concurrently): capacity, and the ids must be new to EVERY shard -- fresh
-        // last_insert_rowid() values (engine.rs:233,249); an update or a re-insert goes through pb_sharded_append
+        // last_insert_rowid() values (engine.rs:233,249); an update or a re-insert goes through pb_sharded_append.  Rows and ids
+        // of appends still in flight count as stored.
         std::lock_guard<std::mutex> lock(s->mu);
+        if (s->pending.size() != (size_t)s->n) s->pending.assign(s->n, 0);
         uint64_t total = 0;
-        for (int g = 0; g < s->n; ++g) total += shard_size(s, g);
+        for (int g = 0; g < s->n; ++g) total += shard_size(s, g) + s->pending[g];
         PB_CHECK(total + n <= s->capacity, PB_ERR_CAPACITY, "pb_sharded_append_device: %llu rows + %llu > capacity %llu",
                  (unsigned long long)total, (unsigned long long)n, (unsigned long long)s->capacity);
-        PB_CHECK(shard_size(s, shard) + n <= s->shard_cap[shard], PB_ERR_CAPACITY, "pb_sharded_append_device: shard %d is full (%llu of %llu rows)",
-                 shard, (unsigned long long)shard_size(s, shard), (unsigned long long)s->shard_cap[shard]);
-        for (uint64_t i = 0; i < n; ++i)
+        PB_CHECK(shard_size(s, shard) + s->pending[shard] + n <= s->shard_cap[shard], PB_ERR_CAPACITY,
+                 "pb_sharded_append_device: shard %d is full (%llu of %llu rows)", shard, (unsigned long long)(shard_size(s, shard) + s->pending[shard]),
+                 (unsigned long long)s->shard_cap[shard]);
+        for (uint64_t i = 0; i < n; ++i) {
+            PB_CHECK(!s->inflight.count(image_ids[i]), PB_ERR_INVALID, "pb_sharded_append_device: image_id %lld is being stored by a concurrent call",
+                     (long long)image_ids[i]);
             for (int g = 0; g < s->n; ++g) {
                 if (g == shard) continue;  // the shard itself checks its own ids (ascending, beyond everything stored)
                 int found = 0;
@@ -482,8 +504,20 @@ int pb_sharded_append_device(pb_sharded *s, int shard, const int64_t *image_ids,
                 if (rc) return rc;
                 PB_CHECK(!found, PB_ERR_INVALID, "pb_sharded_append_device: image_id %lld is already stored on shard %d", (long long)image_ids[i], g);
             }
+        }
+        for (uint64_t i = 1; i < n; ++i)  // (checked again by the shard; here so that nothing is reserved for a call that will fail)
+            PB_CHECK(image_ids[i] > image_ids[i - 1], PB_ERR_INVALID, "pb_sharded_append_device: image_ids must be strictly ascending (row %llu)",
+                     (unsigned long long)i);
+        s->inflight.insert(image_ids, image_ids + n);
+        s->pending[shard] += n;
     }
-    return pb_index_append_device(s->shards[shard], image_ids, d_rows, n);
+    const int rc = pb_index_append_device(s->shards[shard], image_ids, d_rows, n);
+    {
+        std::lock_guard<std::mutex> lock(s->mu);
+        for (uint64_t i = 0; i < n; ++i) s->inflight.erase(image_ids[i]);
+        s->pending[shard] -= n;
+    }
+    return rc;
 }
 
 int pb_sharded_fill_synthetic(pb_sharded *s, uint64_t seed, uint64_t n, int64_t first_id) {

@@ -1096,6 +1096,41 @@ def test_sharded_index_through_the_c_abi(n_shards):
     assert st.queries > 0
 
 
+def test_configs3_at_full_size_through_eight_shards_on_one_device():
+    # BASELINE configs[3] -- 10M x 256 rows over EIGHT shards -- through the product's sharded code at full size, the eight
+    # shards sharing this GPU (an 8-GPU node runs the same code with RCCL's all-gather in place of the copy exchange):
+    # pb_sharded_fill_synthetic splits the synthetic stream by contiguous ranges (1.25M rows per shard), 64 queries go through
+    # per-shard top-k + exchange + device merge; ids and distance bits must equal the single 10M-row index for all 64, and
+    # the CPU oracle over the whole table for one.  Reference: engine.rs:363-396.
+    n, d, k = 10_000_000, 256, 100
+    sh = capi.ShardedIndexC(d, n, [0] * 8)
+    sh.fill_synthetic(synth.SEED_INDEX, n, 1)
+    tot, per = sh.sizes()
+    assert tot == n and list(per) == [n // 8] * 8 and sh.info()["n_shards"] == 8
+    one = capi.Index(d, n)
+    one.fill_synthetic(synth.SEED_INDEX, 0, n, 1)
+    q = np.stack([synth.fill_synthetic(synth.SEED_QUERY + i, 0, d) for i in range(64)])
+    # a stored row (distance ~ 0 at the top), the last row of a shard and the first of the next one as queries as well
+    for j, r in ((1, 123_456), (2, n // 8 - 1), (3, n // 8)):
+        q[j] = synth.fill_synthetic(synth.SEED_INDEX, r * d, d)
+    s_ids, s_d, s_c = sh.search(q, k, 1e3)
+    o_ids, o_d, o_c = one.search(q, k, 1e3)
+    assert np.array_equal(s_c, o_c) and int(s_c.min()) == k
+    assert np.array_equal(s_ids, o_ids) and np.array_equal(s_d.view(np.uint32), o_d.view(np.uint32))
+    assert [int(s_ids[j, 0]) for j in (1, 2, 3)] == [123_457, n // 8, n // 8 + 1]  # ids = row + 1
+    # one query against the oracle over the whole table (2.56 GB of rows generated in 1M-row pieces)
+    best_ids, best_d = np.empty(0, np.int64), np.empty(0, np.float32)
+    step = 1_000_000
+    for r0 in range(0, n, step):
+        rows = synth.fill_synthetic(synth.SEED_INDEX, r0 * d, step * d).reshape(step, d)
+        wi, wd = oracle.scan_topk(q[0], rows, np.arange(r0 + 1, r0 + step + 1, dtype=np.int64), k, 1e3)
+        allv = sorted(zip(np.concatenate([best_d, wd]).tolist(), np.concatenate([best_ids, wi]).tolist()))[:k]
+        best_d = np.array([v[0] for v in allv], dtype=np.float32)
+        best_ids = np.array([v[1] for v in allv], dtype=np.int64)
+    assert np.array_equal(s_ids[0], best_ids) and np.array_equal(s_d[0].view(np.uint32), best_d.view(np.uint32))
+    assert sh.info()["n_exchanges"] >= 1
+
+
 def test_sharded_index_single_shard_through_rccl(monkeypatch):
     # PB_SHARDED_FORCE_RCCL=1: a one-device communicator (ncclCommInitAll with n = 1) runs the real all-gather path
     monkeypatch.setenv("PB_SHARDED_FORCE_RCCL", "1")
