@@ -1041,6 +1041,24 @@ int launch_block(pb_embedder *e, const Block &bl, int shape, const float *x, int
     return PB_ERR_INTERNAL;
 }
 
+// squeeze-excite gates of n images from the pooled sums in buf_part -> buf_gate (k_se)
+int launch_se(pb_embedder *e, const Block &bl, int n_tiles, int n, int hw, int se_qp) {
+#define PB_SE1(SPV, IMGV)                                                                                                  \
+    hipLaunchKernelGGL((k_se<SPV, IMGV>), dim3((n + (IMGV) - 1) / (IMGV)), dim3(se_qp * ((SPV) < 16 ? 1 : (SPV) / 16)), 0, e->stream, \
+                       e->buf_part, n_tiles, bl.e, 1.0f / (float)hw, bl.se_w1, bl.se_b1, bl.se_w2t, bl.se_b2, e->buf_gate, se_qp, n)
+    // the widest layers (2 x 48 x 1152 weights = 442 KB per block) run two images per block from 64 images
+    // on: measured 24 -> 19 us per launch at batch 512; the narrower ones lose more parallelism than they
+    // save traffic (9 -> 13 us) and keep one image per block
+    if (bl.sp == 8) PB_SE1(8, 1);
+    else if (bl.sp == 16) PB_SE1(16, 1);
+    else if (bl.sp == 32) PB_SE1(32, 1);
+    else if (n >= 64) PB_SE1(48, 2);
+    else PB_SE1(48, 1);
+#undef PB_SE1
+    PB_HIP(hipGetLastError());
+    return PB_OK;
+}
+
 int forward_device(pb_embedder *e, const uint8_t *d_rgb, int n, uint8_t *d_u8, float *d_f32) {
     int H = (int)e->H / 2, W = (int)e->W / 2;
     // arrival counters of the squeeze-excite tails: every tail leaves them zero; cleared anyway (a failed launch must not poison the next forward)
@@ -1091,22 +1109,8 @@ int forward_device(pb_embedder *e, const uint8_t *d_rgb, int n, uint8_t *d_u8, f
             struct { int n_tiles; } g{part_tiles};
             // block = (channel quads rounded up to a wave multiple) x (groups of 16 squeeze units)
             const int se_qp = ((bl.e / 4 + 63) / 64) * 64;
-#define PB_SE1(SPV, IMGV)                                                                                                  \
-        hipLaunchKernelGGL((k_se<SPV, IMGV>), dim3((n + (IMGV) - 1) / (IMGV)), dim3(se_qp * ((SPV) < 16 ? 1 : (SPV) / 16)), 0, e->stream, \
-                           e->buf_part, g.n_tiles, bl.e, 1.0f / (float)(Ho * Wo), bl.se_w1, bl.se_b1, bl.se_w2t, bl.se_b2,     \
-                           e->buf_gate, se_qp, n)
-            // the widest layers (2 x 48 x 1152 weights = 442 KB per block) run two images per block from 64 images
-            // on: measured 24 -> 19 us per launch at batch 512; the narrower ones lose more parallelism than they
-            // save traffic (9 -> 13 us) and keep one image per block
-            if (folded) {
-            } else if (bl.sp == 8) PB_SE1(8, 1);
-            else if (bl.sp == 16) PB_SE1(16, 1);
-            else if (bl.sp == 32) PB_SE1(32, 1);
-            else if (n >= 64) PB_SE1(48, 2);
-            else PB_SE1(48, 1);
-#undef PB_SE1
-            PB_HIP(hipGetLastError());
             const long Mo = (long)n * Ho * Wo;
+            if (!folded && (rc = launch_se(e, bl, g.n_tiles, n, Ho * Wo, se_qp))) return rc;
             if ((rc = launch_gemm(e, e->buf_dw, Mo, bl.project, e->buf_gate, Ho * Wo, bl.residual ? x : nullptr, 0,
                                   e->buf_x[cur ^ 1])))
                 return rc;

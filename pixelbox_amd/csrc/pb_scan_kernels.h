@@ -285,13 +285,42 @@ __global__ void k_row_norms(const uint8_t *__restrict__ rows, uint64_t first, ui
         const uint8_t *row = rows + r * (uint64_t)d;
         float acc = 0.0f;
         int32_t sb = 0, sb2 = 0;
-        for (int i = 0; i < d; ++i) {
-            const int v = row[i];
-            const float x = s_lut[v];
-            const float p = x * x;
-            acc = acc + p;
-            sb += v;
-            sb2 += v * v;
+        auto take = [&](uint32_t w) __attribute__((always_inline)) {  // four bytes, in order: the fold stays sequential (engine.rs:580)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int v = (int)((w >> (8 * b)) & 0xFF);
+                const float x = s_lut[v];
+                const float p = x * x;
+                acc = acc + p;
+                sb += v;
+                sb2 += v * v;
+            }
+        };
+        if (d == 256) {
+            // a lane owns a row (the fold is sequential), but it asks for the row's sixteen 16-byte pieces back to back: the
+            // eight requests that fall into one 128-byte line merge on their way to memory.  Byte loads at a 256-byte stride
+            // fetched the table 5.8 times over (profiles/r03_scan_pmc.json: 14.96 GB for 2.56 GB of rows)
+            uint4 q[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) q[j] = *reinterpret_cast<const uint4 *>(row + 16 * j);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                take(q[j].x); take(q[j].y); take(q[j].z); take(q[j].w);
+            }
+        } else if ((d & 15) == 0) {
+            for (int i = 0; i < d; i += 16) {
+                const uint4 q = *reinterpret_cast<const uint4 *>(row + i);
+                take(q.x); take(q.y); take(q.z); take(q.w);
+            }
+        } else {
+            for (int i = 0; i < d; ++i) {
+                const int v = row[i];
+                const float x = s_lut[v];
+                const float p = x * x;
+                acc = acc + p;
+                sb += v;
+                sb2 += v * v;
+            }
         }
         norms[r] = sqrtf(acc);  // correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt default)
         sum_b[r] = sb;                                   // exact integers for the multi-query pass
