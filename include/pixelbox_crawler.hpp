@@ -234,13 +234,15 @@ class Crawler {
             std::unique_lock<std::recursive_mutex> own(model.exclusive());
             const uint8_t *d_hashes = nullptr;
             const std::vector<std::vector<uint8_t>> hashes = image_hashes::mlhash_batch(model, imgs, sink_ ? &d_hashes : nullptr);
+            std::vector<std::vector<uint8_t>> phashes;
+            if (hasher_) phashes = image_hashes::phash_batch(*hasher_, imgs);  // the batch's phashes in one call too
             std::vector<IndexedImage> recs(batch.size());
             for (size_t i = 0; i < batch.size(); ++i) {
                 IndexedImage &r = recs[i];
                 r.filename = batch[i].filename;
                 r.path = batch[i].path;
                 r.resolution = {imgs[i].width, imgs[i].height};
-                if (hasher_) r.phash = image_hashes::phash(*hasher_, imgs[i]);
+                if (hasher_) r.phash = std::move(phashes[i]);
                 r.visual_hash = hashes[i];
             }
             if (sink_) sink_(m, recs, d_hashes);

@@ -327,6 +327,11 @@ int pb_phash_destroy(pb_phasher *p);
  * the reference.  The resampling (image 0.25.x semantics, restated: oracle/pb_oracle_phash.c) runs on the GPU; its filter
  * weights are computed on the host with libm's expf. */
 int pb_phash_image(pb_phasher *p, const uint8_t *rgb, uint32_t width, uint32_t height, uint8_t *out, size_t out_len, uint32_t *n_bytes);
+/* The same for n images of individual sizes in ONE call (the crawler's batch, crawler.rs:68-119 -> indexed_image.rs:70): two
+ * launches and one wait per <= 64 MB of source pixels instead of a transfer, three launches and two waits per image.
+ * out: HOST uint8[n][32] (image i's hash in out[32 i ..], unused bytes zero), n_bytes: HOST uint32[n]. */
+int pb_phash_batch_images(pb_phasher *p, const uint8_t *const *rgb, const uint32_t *widths, const uint32_t *heights, uint32_t n, uint8_t *out,
+                          uint32_t *n_bytes);
 /* the resized image itself (what `small` holds in phash.rs:7): out_rgb[<= 16*16*3], its size in *out_w x *out_h */
 int pb_phash_small_image(pb_phasher *p, const uint8_t *rgb, uint32_t width, uint32_t height, uint8_t *out_rgb, uint32_t *out_w, uint32_t *out_h);
 

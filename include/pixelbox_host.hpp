@@ -105,6 +105,23 @@ inline std::vector<uint8_t> phash(const PHasher &hasher, const RgbImage &img) {
     out.resize(n);
     return out;
 }
+// the same for a batch of images in one call (pb_phash_batch_images: two launches per <= 64 MB of source pixels)
+inline std::vector<std::vector<uint8_t>> phash_batch(const PHasher &hasher, const std::vector<RgbImage> &imgs) {
+    std::vector<const uint8_t *> ptrs(imgs.size());
+    std::vector<uint32_t> ws(imgs.size()), hs(imgs.size()), nb(imgs.size());
+    for (size_t i = 0; i < imgs.size(); ++i) {
+        if (imgs[i].width == 0 || imgs[i].height == 0 || imgs[i].pixels.size() != (size_t)imgs[i].width * imgs[i].height * 3)
+            throw Error(PB_ERR_INVALID, "phash_batch: empty image or pixel buffer of the wrong size");
+        ptrs[i] = imgs[i].pixels.data();
+        ws[i] = imgs[i].width;
+        hs[i] = imgs[i].height;
+    }
+    std::vector<uint8_t> out(imgs.size() * 32);
+    check(pb_phash_batch_images(hasher.raw(), ptrs.data(), ws.data(), hs.data(), (uint32_t)imgs.size(), out.data(), nb.data()));
+    std::vector<std::vector<uint8_t>> res(imgs.size());
+    for (size_t i = 0; i < imgs.size(); ++i) res[i].assign(out.begin() + i * 32, out.begin() + i * 32 + nb[i]);
+    return res;
+}
 // pub fn mlhash(img:&DynamicImage) -> Vec<u8>   (the model is an explicit handle instead of a lazy static)
 // Any image size: `resize_to_fill(W, H, Triangle)` of efficientnet.rs:20 runs on the GPU (pb_mlhash_image); an
 // image that already has the model's input size goes straight in, as in the image crate.

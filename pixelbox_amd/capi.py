@@ -42,7 +42,7 @@ SYMBOLS = [
     "pb_embed_create", "pb_embed_destroy", "pb_embed_info", "pb_embed_batch", "pb_embed_batch_device", "pb_mlhash",
     "pb_mlhash_image", "pb_embed_batch_images", "pb_embed_batch_images_device", "pb_resize_to_fill",
     "pb_embed_set_option", "pb_pinned_alloc", "pb_pinned_free", "pb_embed_tune_ms", "pb_embed_get_tuning", "pb_embed_set_tuning", "pb_fill_synthetic", "pb_fill_synthetic_images", "pb_fill_synthetic_scenes",
-    "pb_phash_create", "pb_phash_destroy", "pb_phash_image", "pb_phash_small_image",
+    "pb_phash_create", "pb_phash_destroy", "pb_phash_image", "pb_phash_batch_images", "pb_phash_small_image",
 ]
 
 
@@ -133,6 +133,7 @@ def lib():
         L.pb_phash_create.argtypes = [C.POINTER(vp), C.c_int]
         L.pb_phash_destroy.argtypes = [vp]
         L.pb_phash_image.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, u8p, C.c_size_t, u32p]
+        L.pb_phash_batch_images.argtypes = [vp, C.POINTER(u8p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint32, u8p, u32p]
         L.pb_phash_small_image.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, u8p, u32p, u32p]
         L.pb_fill_synthetic.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, vp]
         L.pb_fill_synthetic_images.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, vp]
@@ -522,6 +523,18 @@ class PHasher:
         n = C.c_uint32(0)
         _check(lib().pb_phash_image(self._h, _p(rgb, C.c_uint8), w, h, _p(out, C.c_uint8), 32, C.byref(n)))
         return out[: n.value].copy()
+
+    def phash_batch(self, images):
+        """pb_phash_batch_images: list of RGB8 arrays of individual sizes -> list of hashes (32 bytes for a square image)."""
+        imgs = [np.ascontiguousarray(im, dtype=np.uint8) for im in images]
+        n = len(imgs)
+        ptrs = (C.POINTER(C.c_uint8) * n)(*[_p(im, C.c_uint8) for im in imgs])
+        ws = (C.c_uint32 * n)(*[im.shape[1] for im in imgs])
+        hs = (C.c_uint32 * n)(*[im.shape[0] for im in imgs])
+        out = np.zeros((n, 32), dtype=np.uint8)
+        nb = np.zeros(n, dtype=np.uint32)
+        _check(lib().pb_phash_batch_images(self._h, ptrs, ws, hs, n, _p(out, C.c_uint8), _p(nb, C.c_uint32)))
+        return [out[i, : nb[i]].copy() for i in range(n)]
 
     def small_image(self, rgb: np.ndarray) -> np.ndarray:
         rgb = np.ascontiguousarray(rgb, dtype=np.uint8)

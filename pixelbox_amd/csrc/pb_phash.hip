@@ -23,6 +23,13 @@ struct pb_phasher {
     uint8_t *d_out = nullptr;   // 32 hash bytes + 768 bytes of the resized image
     uint32_t *d_nb = nullptr;
     size_t src_cap = 0, tmp_cap = 0, wts_cap = 0;
+    // batch form (pb_phash_batch_images): pinned staging of a sub-batch's sources, weights, windows and descriptors; results
+    uint8_t *h_bsrc = nullptr, *d_bsrc = nullptr;
+    float *h_bwts = nullptr, *d_bwts = nullptr, *d_btmp = nullptr;
+    uint32_t *h_bmeta = nullptr, *d_bmeta = nullptr, *h_bnb = nullptr, *d_bnb = nullptr;
+    pbp::PhashDesc *h_bdesc = nullptr, *d_bdesc = nullptr;
+    uint8_t *h_bout = nullptr, *d_bout = nullptr;
+    size_t bsrc_cap = 0, bwts_cap = 0, btmp_cap = 0, bimg_cap = 0;
     std::mutex mu;
 };
 
@@ -134,6 +141,99 @@ int phash_one(pb_phasher *p, const uint8_t *rgb, uint32_t w, uint32_t h, uint8_t
     return PB_OK;
 }
 
+// ---- batch form: n images of individual sizes -> out[n][32] (+ n_bytes[n]) with two launches per sub-batch of <= 64 MB of
+// source pixels: sources packed into one pinned block (one transfer), the Gaussian weights and windows of every image computed
+// on the host (libm expf, as for one image) into one block, a descriptor per image; ONE wait per sub-batch.
+constexpr size_t PH_STAGE_BYTES = 64u << 20;
+constexpr uint32_t PH_STAGE_IMAGES = 1024;
+
+template <typename T>
+int grow_pair(T **h, T **d, size_t *cap, size_t want) {
+    if (want <= *cap) return PB_OK;
+    if (*h) (void)hipHostFree(*h);
+    (void)hipFree(*d);
+    *h = nullptr; *d = nullptr; *cap = 0;
+    PB_HIP(hipHostMalloc(reinterpret_cast<void **>(h), want * sizeof(T), hipHostMallocDefault));
+    PB_HIP(hipMalloc(reinterpret_cast<void **>(d), want * sizeof(T)));
+    *cap = want;
+    return PB_OK;
+}
+
+int phash_batch(pb_phasher *p, const uint8_t *const *rgb, const uint32_t *widths, const uint32_t *heights, uint32_t n, uint8_t *out,
+                uint32_t *n_bytes) {
+    if (p->bimg_cap < PH_STAGE_IMAGES) {
+        size_t c1 = p->bimg_cap, c2 = p->bimg_cap, c3 = p->bimg_cap, c4 = p->bimg_cap;
+        int rc = grow_pair(&p->h_bdesc, &p->d_bdesc, &c1, (size_t)PH_STAGE_IMAGES);
+        if (!rc) rc = grow_pair(&p->h_bmeta, &p->d_bmeta, &c2, (size_t)PH_STAGE_IMAGES * 64);
+        if (!rc) rc = grow_pair(&p->h_bout, &p->d_bout, &c3, (size_t)PH_STAGE_IMAGES * 32);
+        if (!rc) rc = grow_pair(&p->h_bnb, &p->d_bnb, &c4, (size_t)PH_STAGE_IMAGES);
+        if (rc) return rc;
+        p->bimg_cap = PH_STAGE_IMAGES;
+    }
+    std::vector<float> wts;
+    std::vector<std::vector<float>> wv, wh;
+    for (uint32_t i0 = 0; i0 < n;) {
+        size_t src_total = 0, tmp_total = 0;
+        uint32_t i1 = i0, max_w = 1;
+        wts.clear();
+        for (; i1 < n && i1 - i0 < PH_STAGE_IMAGES; ++i1) {
+            const uint32_t w = widths[i1], h = heights[i1];
+            PB_CHECK(rgb[i1], PB_ERR_INVALID, "pb_phash_batch_images: image %u: null pointer", i1);
+            PB_CHECK(w >= 1 && h >= 1 && w <= 65535 && h <= 65535, PB_ERR_INVALID, "pb_phash_batch_images: image %u: size %ux%u outside 1..65535", i1, w, h);
+            const size_t sb = (size_t)w * h * 3;
+            if (i1 > i0 && src_total + sb > PH_STAGE_BYTES) break;
+            pbp::PhashDesc d{};
+            d.w = w; d.h = h;
+            fit16(w, h, &d.w2, &d.h2);
+            d.resample = (d.w2 == w && d.h2 == h) ? 0u : 1u;
+            d.src_off = src_total;
+            d.tmp_off = tmp_total;
+            uint32_t *meta = p->h_bmeta + (size_t)(i1 - i0) * 64;
+            memset(meta, 0, 64 * sizeof(uint32_t));
+            if (d.resample) {
+                d.sv = make_weights(h, d.h2, wv, meta, meta + 16);
+                d.sh = make_weights(w, d.w2, wh, meta + 32, meta + 48);
+                d.wv_off = (uint32_t)wts.size();
+                wts.resize(wts.size() + (size_t)16 * d.sv, 0.0f);
+                for (uint32_t o = 0; o < d.h2; ++o) std::copy(wv[o].begin(), wv[o].end(), wts.begin() + d.wv_off + (size_t)o * d.sv);
+                d.wh_off = (uint32_t)wts.size();
+                wts.resize(wts.size() + (size_t)16 * d.sh, 0.0f);
+                for (uint32_t o = 0; o < d.w2; ++o) std::copy(wh[o].begin(), wh[o].end(), wts.begin() + d.wh_off + (size_t)o * d.sh);
+                tmp_total += ((size_t)d.h2 * w * 3 + 3) & ~(size_t)3;
+            }
+            src_total += (sb + 15) & ~(size_t)15;
+            max_w = std::max(max_w, w);
+            p->h_bdesc[i1 - i0] = d;
+        }
+        const uint32_t m = i1 - i0;
+        int rc = grow_pair(&p->h_bsrc, &p->d_bsrc, &p->bsrc_cap, std::max(src_total, PH_STAGE_BYTES));
+        if (!rc) rc = grow_pair(&p->h_bwts, &p->d_bwts, &p->bwts_cap, std::max<size_t>(wts.size(), 1u << 16));
+        if (!rc) rc = grow(&p->d_btmp, &p->btmp_cap, std::max<size_t>(tmp_total, 1));
+        if (rc) return rc;
+        for (uint32_t i = 0; i < m; ++i) memcpy(p->h_bsrc + p->h_bdesc[i].src_off, rgb[i0 + i], (size_t)p->h_bdesc[i].w * p->h_bdesc[i].h * 3);
+        if (!wts.empty()) memcpy(p->h_bwts, wts.data(), wts.size() * sizeof(float));
+        PB_HIP(hipMemcpyAsync(p->d_bsrc, p->h_bsrc, src_total, hipMemcpyHostToDevice, p->stream));
+        if (!wts.empty()) PB_HIP(hipMemcpyAsync(p->d_bwts, p->h_bwts, wts.size() * sizeof(float), hipMemcpyHostToDevice, p->stream));
+        PB_HIP(hipMemcpyAsync(p->d_bmeta, p->h_bmeta, (size_t)m * 64 * sizeof(uint32_t), hipMemcpyHostToDevice, p->stream));
+        PB_HIP(hipMemcpyAsync(p->d_bdesc, p->h_bdesc, (size_t)m * sizeof(pbp::PhashDesc), hipMemcpyHostToDevice, p->stream));
+        if (tmp_total) {
+            hipLaunchKernelGGL(pbp::k_phash_v_batch, dim3((max_w * 3 + 255) / 256, 16, m), dim3(256), 0, p->stream, p->d_bsrc, p->d_bdesc, p->d_bwts,
+                               p->d_bmeta, p->d_btmp);
+            PB_HIP(hipGetLastError());
+        }
+        hipLaunchKernelGGL(pbp::k_phash_h_batch, dim3(m), dim3(256), 0, p->stream, p->d_btmp, p->d_bsrc, p->d_bdesc, p->d_bwts, p->d_bmeta, p->d_bout,
+                           p->d_bnb);
+        PB_HIP(hipGetLastError());
+        PB_HIP(hipMemcpyAsync(p->h_bout, p->d_bout, (size_t)m * 32, hipMemcpyDeviceToHost, p->stream));
+        PB_HIP(hipMemcpyAsync(p->h_bnb, p->d_bnb, (size_t)m * sizeof(uint32_t), hipMemcpyDeviceToHost, p->stream));
+        PB_HIP(hipStreamSynchronize(p->stream));  // the pinned blocks are reused by the next sub-batch
+        memcpy(out + (size_t)i0 * 32, p->h_bout, (size_t)m * 32);
+        memcpy(n_bytes + i0, p->h_bnb, (size_t)m * sizeof(uint32_t));
+        i0 = i1;
+    }
+    return PB_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -176,6 +276,14 @@ int pb_phash_destroy(pb_phasher *p) {
         (void)hipFree(p->d_meta);
         (void)hipFree(p->d_out);
         (void)hipFree(p->d_nb);
+        (void)hipFree(p->d_bsrc); (void)hipFree(p->d_bwts); (void)hipFree(p->d_btmp); (void)hipFree(p->d_bmeta); (void)hipFree(p->d_bnb);
+        (void)hipFree(p->d_bdesc); (void)hipFree(p->d_bout);
+        if (p->h_bsrc) (void)hipHostFree(p->h_bsrc);
+        if (p->h_bwts) (void)hipHostFree(p->h_bwts);
+        if (p->h_bmeta) (void)hipHostFree(p->h_bmeta);
+        if (p->h_bnb) (void)hipHostFree(p->h_bnb);
+        if (p->h_bdesc) (void)hipHostFree(p->h_bdesc);
+        if (p->h_bout) (void)hipHostFree(p->h_bout);
         if (p->stream) (void)hipStreamDestroy(p->stream);
     }
     delete p;
@@ -188,6 +296,18 @@ int pb_phash_image(pb_phasher *p, const uint8_t *rgb, uint32_t width, uint32_t h
     std::lock_guard<std::mutex> lock(p->mu);
     pb::DeviceGuard guard(p->device);
     return phash_one(p, rgb, width, height, out, n_bytes, nullptr);
+}
+
+int pb_phash_batch_images(pb_phasher *p, const uint8_t *const *rgb, const uint32_t *widths, const uint32_t *heights, uint32_t n, uint8_t *out,
+                          uint32_t *n_bytes) {
+    PB_CHECK(p, PB_ERR_INVALID, "pb_phash_batch_images: null handle");
+    PB_CHECK(n == 0 || (rgb && widths && heights && out && n_bytes), PB_ERR_INVALID, "pb_phash_batch_images: null buffer");
+    if (n == 0) return PB_OK;
+    std::lock_guard<std::mutex> lock(p->mu);
+    pb::DeviceGuard guard(p->device);
+    const int rc = phash_batch(p, rgb, widths, heights, n, out, n_bytes);
+    if (rc) (void)hipStreamSynchronize(p->stream);  // nothing of this call may still be reading its staging blocks
+    return rc;
 }
 
 int pb_phash_small_image(pb_phasher *p, const uint8_t *rgb, uint32_t width, uint32_t height, uint8_t *out_rgb, uint32_t *out_w, uint32_t *out_h) {

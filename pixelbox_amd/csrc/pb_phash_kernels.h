@@ -91,4 +91,85 @@ __global__ __launch_bounds__(256) void k_phash_h(const float *__restrict__ tmp, 
     if (i == 0) *out_nbytes = nb;
 }
 
+// ---- a whole batch of images in two launches (pb_phash_batch_images): the same arithmetic per image, driven by a descriptor
+struct PhashDesc {
+    unsigned long long src_off;  // bytes into the staged source block: u8 [h][w][3]
+    unsigned long long tmp_off;  // floats into the scratch block: f32 [h2][w][3]
+    uint32_t w, h, w2, h2;
+    uint32_t wv_off, wh_off;     // floats into the weights block: [h2][sv] and [w2][sh]
+    uint32_t sv, sh;             // longest window of either pass (row pitch of its weights)
+    uint32_t resample;           // 0: the source already has the fitted size (imageops::resize copies)
+    uint32_t pad;
+};
+// per image 64 words of meta: left_v[16] cnt_v[16] left_h[16] cnt_h[16].  grid (ceil(max w * 3 / 256), 16, images)
+__global__ __launch_bounds__(256) void k_phash_v_batch(const uint8_t *__restrict__ src_base, const PhashDesc *__restrict__ desc,
+                                                       const float *__restrict__ wts_base, const uint32_t *__restrict__ meta_base,
+                                                       float *__restrict__ tmp_base) {
+    const PhashDesc d = desc[blockIdx.z];
+    const uint32_t xc = blockIdx.x * blockDim.x + threadIdx.x;  // column * 3 + channel
+    const uint32_t oy = blockIdx.y;
+    if (!d.resample || oy >= d.h2 || xc >= d.w * 3) return;
+    const uint32_t *meta = meta_base + (size_t)blockIdx.z * 64;
+    const uint8_t *src = src_base + d.src_off;
+    const uint32_t l = meta[oy], n = meta[16 + oy];
+    const float *ws = wts_base + d.wv_off + (size_t)oy * d.sv;
+    float t = 0.0f;
+    for (uint32_t i = 0; i < n; ++i) {
+        const float m = (float)src[(size_t)(l + i) * d.w * 3 + xc] * ws[i];
+        t = t + m;
+    }
+    tmp_base[d.tmp_off + (size_t)oy * d.w * 3 + xc] = t;
+}
+// one workgroup per image; out_hash [images][32] (unused bytes zero), out_nbytes [images]
+__global__ __launch_bounds__(256) void k_phash_h_batch(const float *__restrict__ tmp_base, const uint8_t *__restrict__ src_base,
+                                                       const PhashDesc *__restrict__ desc, const float *__restrict__ wts_base,
+                                                       const uint32_t *__restrict__ meta_base, uint8_t *__restrict__ out_hash,
+                                                       uint32_t *__restrict__ out_nbytes) {
+    __shared__ uint32_t s_sum;
+    __shared__ uint8_t s_grey[256];
+    const PhashDesc d = desc[blockIdx.x];
+    const uint32_t *meta = meta_base + (size_t)blockIdx.x * 64;
+    const uint32_t i = threadIdx.x;
+    const uint32_t n = d.w2 * d.h2;
+    if (i == 0) s_sum = 0;
+    __syncthreads();
+    if (i < n) {
+        const uint32_t y = i / d.w2, ox = i % d.w2;
+        uint8_t px[3];
+        if (d.resample) {
+            const float *tmp = tmp_base + d.tmp_off;
+            const uint32_t l = meta[32 + ox], c = meta[48 + ox];
+            const float *ws = wts_base + d.wh_off + (size_t)ox * d.sh;
+            float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;
+            for (uint32_t k = 0; k < c; ++k) {
+                const float *pp = tmp + ((size_t)y * d.w + l + k) * 3;
+                const float wgt = ws[k];
+                const float m0 = pp[0] * wgt, m1 = pp[1] * wgt, m2 = pp[2] * wgt;
+                t0 = t0 + m0; t1 = t1 + m1; t2 = t2 + m2;
+            }
+            auto to_u8 = [](float t) -> uint8_t {
+                t = t < 0.0f ? 0.0f : (t > 255.0f ? 255.0f : t);
+                return (uint8_t)roundf(t);  // f32::round: half away from zero
+            };
+            px[0] = to_u8(t0); px[1] = to_u8(t1); px[2] = to_u8(t2);
+        } else {
+            const uint8_t *pp = src_base + d.src_off + (size_t)i * 3;
+            px[0] = pp[0]; px[1] = pp[1]; px[2] = pp[2];
+        }
+        const uint32_t grey = (2126u * px[0] + 7152u * px[1] + 722u * px[2]) / 10000u;  // color.rs rgb_to_luma (u32, truncating)
+        s_grey[i] = (uint8_t)grey;
+        atomicAdd(&s_sum, grey);
+    }
+    __syncthreads();
+    const uint32_t mean = (s_sum / 256u) & 0xFFu;  // phash.rs:10: sum / (16 * 16) as u8
+    const uint32_t nb = n / 8;
+    if (i < 32) {
+        uint32_t acc = 0;
+        if (i < nb)
+            for (int b = 0; b < 8; ++b) acc |= (s_grey[8 * i + b] > mean) ? (1u << b) : 0u;
+        out_hash[(size_t)blockIdx.x * 32 + i] = (uint8_t)acc;
+    }
+    if (i == 0) out_nbytes[blockIdx.x] = nb;
+}
+
 }  // namespace pbp

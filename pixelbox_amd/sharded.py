@@ -28,21 +28,23 @@ def shard_range(n_total: int, rank: int, world: int) -> tuple[int, int]:
 
 
 class ShardedIndex:
-    def __init__(self, dim: int, capacity_total: int, rank: int = 0, world: int = 1, device: int = 0, group=None,
-                 local_index=None):
-        """`local_index`: object with .search(queries, k, max_dist) -> (ids, dist, count) standing in for the
-        HIP shard (CPU tests of the collective path inject the oracle here); default: capi.Index on `device`."""
+    def __init__(self, dim: int, capacity_total: int, rank: int = 0, world: int = 1, device: int = 0, group=None):
         self.dim, self.rank, self.world, self.group = dim, rank, world, group
         self.capacity_total = capacity_total
         lo, hi = shard_range(capacity_total, rank, world)
         self.row_lo, self.row_hi = lo, hi
         self.device = device
-        self.index = local_index if local_index is not None else capi.Index(dim, max(hi - lo, 1), device)
+        self.index = self._make_shard(dim, max(hi - lo, 1), device)
         self._torch = None
         if world > 1 or group is not None:
             import torch
 
             self._torch = torch
+
+    def _make_shard(self, dim: int, rows: int, device: int):
+        """This rank's shard: the HIP index.  (The CPU tests of the collective + merge plumbing subclass this class in the
+        TEST and return a stand-in with the same .load / .search; nothing in this package can produce anything else.)"""
+        return capi.Index(dim, rows, device)
 
     # -- store ---------------------------------------------------------------------------------------------
     def fill_synthetic(self, seed: int, first_id: int = 1):

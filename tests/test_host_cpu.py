@@ -117,7 +117,10 @@ d, n = 64, 3001
 rows = synth.fill_synthetic(synth.SEED_INDEX, 0, n * d).reshape(n, d).copy()
 rows[1500] = rows[10]; rows[2999] = rows[10]            # ties across shards -> image_id order
 ids = np.arange(n, dtype=np.int64) * 3 + 1
-sh = sharded.ShardedIndex(d, n, rank=rank, world=world, group=dist.group.WORLD, local_index=OracleShard(d))
+class OracleSharded(sharded.ShardedIndex):  # the launcher-side class with the HIP shard swapped for the stand-in (no GPU here)
+    def _make_shard(self, dim, rows, device): return OracleShard(dim)
+
+sh = OracleSharded(d, n, rank=rank, world=world, group=dist.group.WORLD)
 sh.load(ids, rows)
 queries = np.stack([rows[10], synth.fill_synthetic(synth.SEED_QUERY, 0, d), 255 - rows[10]])
 for k, md in ((100, 1e3), (5, 1e3), (100, 2e6), (100, 1e-3)):

@@ -126,6 +126,30 @@ def test_gpu_phash_matches_the_restatement_bit_for_bit():
 
 
 @pytest.mark.gpu
+def test_gpu_phash_of_a_batch_is_the_phash_of_each_image():
+    # pb_phash_batch_images: the crawler's batch in one call (two launches per sub-batch over a descriptor array) -- every
+    # hash, and its length (non-square images give fewer than 32 bytes, as in the reference), equals the restatement's;
+    # 75 MB of sources: two staging sub-batches
+    from pixelbox_amd import capi
+
+    rng = np.random.default_rng(21)
+    imgs = list(_images())
+    for (h, w) in [(1080, 1920), (16, 16), (1, 1), (480, 640), (2000, 100), (17, 16)] * 10:
+        base = rng.integers(0, 256, size=(h // 8 + 1, w // 8 + 1, 3), dtype=np.uint8)
+        imgs.append(np.kron(base, np.ones((8, 8, 1), dtype=np.uint8))[:h, :w].copy())
+    assert sum(im.size for im in imgs) > 64 << 20
+    ph = capi.PHasher()
+    got = ph.phash_batch(imgs)
+    for im, g in zip(imgs, got):
+        want = oracle.phash(im)
+        assert np.array_equal(g, want), im.shape
+    assert [len(x) for x in ph.phash_batch(imgs[:3])] == [len(oracle.phash(im)) for im in imgs[:3]]  # the blocks are reused
+    with pytest.raises(capi.PixelboxError):
+        ph.phash_batch([imgs[0], np.zeros((0, 5, 3), np.uint8)])
+    assert np.array_equal(ph.phash(imgs[0]), oracle.phash(imgs[0]))  # the handle survives a failed batch
+
+
+@pytest.mark.gpu
 def test_gpu_phash_feeds_the_hamming_scan():
     # the `phashes` table (engine.rs:106-109) scanned with hamming_distance (engine.rs:594-604): a resized copy of an
     # image lands next to the original (phash.rs:52-55 asserts hamming < 0.0001 for a resized copy)
