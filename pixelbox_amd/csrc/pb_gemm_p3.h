@@ -93,7 +93,10 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_p3(const float *__restrict__ a
                                                     const float *__restrict__ gate, int hw, const float *__restrict__ resid,
                                                     int do_silu, float *__restrict__ out, float scale, uint8_t *__restrict__ out_u8) {
     constexpr int NTHR = 64 * NW;
-    constexpr int PD = DIRECT ? 4 : (NR * MR >= 4 ? 4 : 6);  // k-steps of activations in flight (even: a step's parity is its ring slot's)
+    // k-steps in flight (even: a step's parity is its ring slot's).  The one-wave form is a chain of K / 32 dependent steps fed
+    // straight from memory, once per forward at batch 1: with 4 steps in flight a K = 1152 layer took 36 / 4 round trips = 11 us;
+    // a lone wave has the whole register file, so the single-tile shape keeps 8 (28 registers per step)
+    constexpr int PD = DIRECT ? (NR == 1 ? 8 : 4) : (NR * MR >= 4 ? 4 : 6);
     static_assert(PD % 2 == 0, "parity of a step = parity of its slot");
     constexpr int FR = NR * 192;                                               // 16-byte pieces per k-step of this block's tiles
     constexpr int WREGS = DIRECT ? 1 : (FR + NTHR - 1) / NTHR;
@@ -247,7 +250,9 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_p3(const float *__restrict__ a
         else if (q == 2) request(2, std::integral_constant<int, 2 % PD>{});
         else if (q == 3) request(3, std::integral_constant<int, 3 % PD>{});
         else if (q == 4) request(4, std::integral_constant<int, 4 % PD>{});
-        else request(5, std::integral_constant<int, 5 % PD>{});
+        else if (q == 5) request(5, std::integral_constant<int, 5 % PD>{});
+        else if (q == 6) request(6, std::integral_constant<int, 6 % PD>{});
+        else request(7, std::integral_constant<int, 7 % PD>{});
     }
     load_w(0, I0{});
     store_w(0, I0{});
@@ -261,6 +266,8 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_p3(const float *__restrict__ a
         if constexpr (PD > 3) k_step(t + 3, (t + 3) & 1, std::integral_constant<int, 3 % PD>{});
         if constexpr (PD > 4) k_step(t + 4, (t + 4) & 1, std::integral_constant<int, 4 % PD>{});
         if constexpr (PD > 5) k_step(t + 5, (t + 5) & 1, std::integral_constant<int, 5 % PD>{});
+        if constexpr (PD > 6) k_step(t + 6, (t + 6) & 1, std::integral_constant<int, 6 % PD>{});
+        if constexpr (PD > 7) k_step(t + 7, (t + 7) & 1, std::integral_constant<int, 7 % PD>{});
     }
     {   // the steps left over (fewer than PD, once per kernel), each on the slot it was requested into
         const int rem = n_steps - t;
@@ -269,6 +276,8 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_p3(const float *__restrict__ a
         if constexpr (PD > 3) { if (rem > 2) k_step(t + 2, (t + 2) & 1, std::integral_constant<int, 2 % PD>{}); }
         if constexpr (PD > 4) { if (rem > 3) k_step(t + 3, (t + 3) & 1, std::integral_constant<int, 3 % PD>{}); }
         if constexpr (PD > 5) { if (rem > 4) k_step(t + 4, (t + 4) & 1, std::integral_constant<int, 4 % PD>{}); }
+        if constexpr (PD > 6) { if (rem > 5) k_step(t + 5, (t + 5) & 1, std::integral_constant<int, 5 % PD>{}); }
+        if constexpr (PD > 7) { if (rem > 6) k_step(t + 6, (t + 6) & 1, std::integral_constant<int, 6 % PD>{}); }
     }
     // ---- epilogues (k_gemm_t's, per row tile)
 #pragma unroll
