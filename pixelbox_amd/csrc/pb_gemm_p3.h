@@ -24,6 +24,10 @@
 // MFMA is 16 contiguous bytes, a wave's 1 KB; zero beyond K and N.
 #pragma once
 
+#ifndef PB_P3_ABL
+#define PB_P3_ABL 0  // timing experiments only (results invalid): 1 no operand split, 2 no gate, 4 weights never restaged (no staging loads /
+#endif               // stores / barrier after the first step), 8 activations never re-requested
+
 namespace pbe {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_p3(const float *__restrict__ a
         for (int r = 0; r < MR; ++r) {
             ar[SLOT][r][0] = *reinterpret_cast<const f32x4 *>(ap[r] + kb);
             ar[SLOT][r][1] = *reinterpret_cast<const f32x4 *>(ap[r] + kb + 4);
-            if constexpr (GATE) {
+            if constexpr (GATE && (PB_P3_ABL & 2) == 0) {
                 gr[SLOT][r][0] = *reinterpret_cast<const f32x4 *>(gp[r] + kb);
                 gr[SLOT][r][1] = *reinterpret_cast<const f32x4 *>(gp[r] + kb + 4);
             }
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_p3(const float *__restrict__ a
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 a[r][h] = ar[SLOT][r][h];
-                if constexpr (GATE) {
+                if constexpr (GATE && (PB_P3_ABL & 2) == 0) {
                     const f32x4 g = gr[SLOT][r][h];
                     a[r][h].x = a[r][h].x * g.x; a[r][h].y = a[r][h].y * g.y; a[r][h].z = a[r][h].z * g.z; a[r][h].w = a[r][h].w * g.w;
                 }
@@ -218,12 +222,18 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_p3(const float *__restrict__ a
         // (3) the weight fetch of step t + 2, then the activation request of step t + PD into the slot just read.  The weight
         //     fetch comes FIRST: loads return in order, and the staging store at the end of step t + 1 must not have to wait for
         //     the (younger) ring loads
-        load_w(t + 2, std::integral_constant<int, SLOT & 1>{});
-        request(t + PD, slotc);
+        if constexpr ((PB_P3_ABL & (4 | 32)) == 0) load_w(t + 2, std::integral_constant<int, SLOT & 1>{});
+        if constexpr ((PB_P3_ABL & 8) == 0) request(t + PD, slotc);
         __builtin_amdgcn_sched_barrier(0);
         P3Act pa[MR];
 #pragma unroll
-        for (int r = 0; r < MR; ++r) pa[r] = p3_split8(a[r][0], a[r][1]);
+        for (int r = 0; r < MR; ++r) {
+            if constexpr ((PB_P3_ABL & 1) != 0) {
+                pa[r].h = pa[r].m = pa[r].l = (u32x4){__float_as_uint(a[r][0].x), __float_as_uint(a[r][0].z), __float_as_uint(a[r][1].x), __float_as_uint(a[r][1].z)};
+            } else {
+                pa[r] = p3_split8(a[r][0], a[r][1]);
+            }
+        }
         // the six passes, pass outermost: consecutive MFMAs write different accumulators; every accumulator receives its six
         // products in the order of p3_step
 #define PB_P3_PASS(WP, AP)                                                                       \
@@ -236,9 +246,9 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_p3(const float *__restrict__ a
         PB_P3_PASS(0, m)
         PB_P3_PASS(0, h)
 #undef PB_P3_PASS
-        if constexpr (!DIRECT) {
-            store_w(buf ^ 1, std::integral_constant<int, (SLOT & 1) ^ 1>{});
-            __syncthreads();
+        if constexpr (!DIRECT && (PB_P3_ABL & 4) == 0) {
+            if constexpr ((PB_P3_ABL & 32) == 0) store_w(buf ^ 1, std::integral_constant<int, (SLOT & 1) ^ 1>{});
+            if constexpr ((PB_P3_ABL & 16) == 0) __syncthreads();
         }
         __builtin_amdgcn_sched_barrier(0);
     };
