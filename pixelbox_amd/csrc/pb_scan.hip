@@ -447,7 +447,12 @@ int run_fast(pb_index *ix, uint32_t nq) {
         // the ticketed tail pays from ~4M rows on (10M: -5..8 us per call); on a small table its 4-tile tickets are coarse
         // against the ~2 tail tiles a wave would take (1M rows: 60.3 us ticketed, 55.8 us with static shares)
         if (ix->env_static_tail || (ix->n_rows < (4ull << 20) && !ix->env_force_tickets)) {
+            if (getenv("PB_SMALL_STATIC"))
             hipLaunchKernelGGL((k_scan_filter<16, 8, true, F_WAVES, 0, false, true>), dim3(n_wg, 1), dim3(F_WAVES * 64), 0,
+                               ix->stream, ix->d_rows, ix->n_rows, ix->d_queries, ix->d_qp, ix->d_lists, ix->d_hdrs, 0, 1,
+                               ix->d_queries, ix->d_qp, ix->argq, nullptr);
+            else
+            hipLaunchKernelGGL((k_scan_filter<16, 8, true, F_WAVES, 0, false, true, false, true>), dim3(n_wg, 1), dim3(F_WAVES * 64), 0,
                                ix->stream, ix->d_rows, ix->n_rows, ix->d_queries, ix->d_qp, ix->d_lists, ix->d_hdrs, 0, 1,
                                ix->d_queries, ix->d_qp, ix->argq, nullptr);
         } else {
@@ -1740,6 +1745,22 @@ int pb_debug_mq_stamps(unsigned long long *out, int reset) {
     if (reset) {
         unsigned long long z[8] = {0};
         PB_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_mq_stamp), z, sizeof(z)));
+    }
+    return PB_OK;
+}
+#endif
+
+#ifdef PB_SCAN_STAMP
+// instrumented build only (profiles/scan_stamps.py): out_filter [F_MAX_WG * 16 * 8], out_sel [16], host_now: this clock now
+int pb_debug_scan_stamps(unsigned long long *out_filter, unsigned long long *out_sel, int reset) {
+    PB_HIP(hipDeviceSynchronize());
+    PB_HIP(hipMemcpyFromSymbol(out_filter, HIP_SYMBOL(pbk::g_scan_stamp), sizeof(unsigned long long) * F_MAX_WG * 16 * 8));
+    PB_HIP(hipMemcpyFromSymbol(out_sel, HIP_SYMBOL(pbk::g_sel_stamp), sizeof(unsigned long long) * 16));
+    if (reset) {
+        void *p = nullptr;
+        PB_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(pbk::g_scan_stamp)));
+        PB_HIP(hipMemset(p, 0, sizeof(unsigned long long) * F_MAX_WG * 16 * 8));
+        PB_HIP(hipDeviceSynchronize());
     }
     return PB_OK;
 }

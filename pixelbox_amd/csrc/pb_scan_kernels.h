@@ -201,6 +201,80 @@ __device__ __forceinline__ uint64_t wave_keep_smallest(uint64_t *buf, int cnt, i
     return ((uint64_t)pre_hi << 32) | pre_lo;
 }
 
+// ---- bitonic networks over ONE u64 key per lane (the ends of the filter passes: a wave's <= 64 buffered keys are sorted in
+// 21 compare-exchange steps, two sorted 32-key lists are merged in 6).  A ballot radix-select of the same keys costs 32+
+// dependent bit-steps (2.3 us per wave, 7.5 us for the workgroup's 256 keys -- stamps: profiles/r04_scan_stamps.txt); the
+// networks run at DPP speed for partner distances 1, 2 and 8 and pay an LDS-crossbar permute for 4, 16 and 32.
+template <int D>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v) {
+    if constexpr (D == 1) return (uint32_t)dpp_mov<0xB1>((int)v);        // quad_perm [1,0,3,2]
+    else if constexpr (D == 2) return (uint32_t)dpp_mov<0x4E>((int)v);   // quad_perm [2,3,0,1]
+    else if constexpr (D == 8) return (uint32_t)dpp_mov<0x128>((int)v);  // row_ror:8 = lane ^ 8 within a row of 16
+    else return (uint32_t)__shfl_xor((int)v, D);
+}
+// compare-exchange with lane ^ D: this lane keeps the smaller key of the pair iff keep_min
+template <int D>
+__device__ __forceinline__ uint64_t lane_cmpx(uint64_t key, bool keep_min) {
+    const uint32_t ph = lane_xor<D>((uint32_t)(key >> 32)), pl = lane_xor<D>((uint32_t)key);
+    const uint64_t p = ((uint64_t)ph << 32) | pl;
+    return ((p < key) == keep_min) ? p : key;
+}
+// lanes hold a bitonic sequence (ascending then descending) -> ascending over the 64 lanes
+__device__ __forceinline__ uint64_t wave_merge64(uint64_t key) {
+    const int lane = lane_id();
+    key = lane_cmpx<32>(key, (lane & 32) == 0);
+    key = lane_cmpx<16>(key, (lane & 16) == 0);
+    key = lane_cmpx<8>(key, (lane & 8) == 0);
+    key = lane_cmpx<4>(key, (lane & 4) == 0);
+    key = lane_cmpx<2>(key, (lane & 2) == 0);
+    key = lane_cmpx<1>(key, (lane & 1) == 0);
+    return key;
+}
+// any 64 keys -> ascending over the 64 lanes
+__device__ __forceinline__ uint64_t wave_sort64(uint64_t key) {
+    const int lane = lane_id();
+#define PB_CX(D, K) key = lane_cmpx<D>(key, ((lane & (D)) == 0) == (((lane >> (K)) & 1) == 0))
+    PB_CX(1, 1);
+    PB_CX(2, 2); PB_CX(1, 2);
+    PB_CX(4, 3); PB_CX(2, 3); PB_CX(1, 3);
+    PB_CX(8, 4); PB_CX(4, 4); PB_CX(2, 4); PB_CX(1, 4);
+    PB_CX(16, 5); PB_CX(8, 5); PB_CX(4, 5); PB_CX(2, 5); PB_CX(1, 5);
+#undef PB_CX
+    return wave_merge64(key);
+}
+// A wave's buffered keys (cnt <= 64, distinct) -> its F_KW smallest, ascending, in buf[0..F_KW) (unused slots ~0).
+// Returns the smallest key it discarded (~0: none); cnt becomes min(cnt, F_KW).
+__device__ __forceinline__ uint64_t wave_finish_list(uint64_t *buf, int &cnt) {
+    const int lane = lane_id();
+    uint64_t key = lane < cnt ? buf[lane] : ~0ull;
+    key = wave_sort64(key);
+    const uint64_t first_out = __shfl((unsigned long long)key, F_KW);
+    if (lane < F_KW) buf[lane] = key;
+    cnt = cnt < F_KW ? cnt : F_KW;
+    return first_out;
+}
+// Wave 0 merges the NW sorted wave lists (bufs[w * pitch .. + F_KW), ~0-padded) into the workgroup's F_KWG best, ascending
+// over lanes 0..31 of the result; *n_out their number, *first_out the smallest key discarded here (~0: none).
+template <int NW>
+__device__ __forceinline__ uint64_t wave_merge_lists(const uint64_t *bufs, int pitch, int *n_out, uint64_t *first_out) {
+    static_assert(F_KW == 32 && F_KWG == 32, "two 32-key lists fill one wave");
+    const int lane = lane_id();
+    uint64_t oth[NW];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) oth[w] = bufs[(size_t)w * pitch + (63 - lane < F_KW ? 63 - lane : 0)];  // lanes >= 32: list w reversed
+    uint64_t key = lane < F_KW ? bufs[lane] : ~0ull;
+    uint64_t out_min = ~0ull;
+#pragma unroll
+    for (int w = 1; w < NW; ++w) {
+        key = wave_merge64(lane < F_KW ? key : oth[w]);
+        const uint64_t o = __shfl((unsigned long long)key, F_KW);
+        out_min = o < out_min ? o : out_min;
+    }
+    *n_out = __popcll(__ballot(lane < F_KWG && key != ~0ull));
+    *first_out = out_min;
+    return key;
+}
+
 // ------------------------------------------------------------------------------------------------
 // exact reference arithmetic for one row (engine.rs:575-587); row_norm = sqrt(fold(x^2)) of the row,
 // precomputed at append time by k_row_norms with the same arithmetic.  s_lut/s_qf live in LDS.
@@ -346,6 +420,23 @@ __global__ void k_row_norms(const uint8_t *__restrict__ rows, uint64_t first, ui
 // through the kernarg segment) instead of being staged in device memory by a copy or a staging kernel first -- the filter
 // launch is then the first command of the call; workgroup 0 parks them in slot 0 of the staged arrays for the kernels
 // that follow (k_select_rescore, the fallbacks).
+#ifdef PB_SCAN_STAMP
+// instrumented build (profiles/scan_stamps.py): wall-clock stamps (s_memrealtime, 100 MHz) of the one-query filter launch,
+// [wave of the grid][8], and of k_select_rescore, [16]
+__device__ unsigned long long g_scan_stamp[F_MAX_WG * 16 * 8];
+__device__ unsigned long long g_sel_stamp[16];
+#define PB_STAMP(slot)                                                                                          \
+    do {                                                                                                        \
+        if (ARGQ && lane == 0) g_scan_stamp[((size_t)blockIdx.x * NW + wave) * 8 + (slot)] = wall_clock64();     \
+    } while (0)
+#define PB_SEL_STAMP(slot)                                             \
+    do {                                                               \
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_sel_stamp[slot] = wall_clock64(); \
+    } while (0)
+#else
+#define PB_STAMP(slot) do { } while (0)
+#define PB_SEL_STAMP(slot) do { } while (0)
+#endif
 struct QArg256 {
     QParams p;
     uint8_t q[256];
@@ -375,7 +466,7 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
                                                          uint32_t *tail_ctr = nullptr) {
     static_assert(!ARGQ || (LPR == 16 && !LOOPQ), "ARGQ: one 256-byte query per launch");
     static_assert(!DYN || (ARGQ && MAPB == 0), "DYN: the one-query launch only");
-    static_assert(!WGT || (LOOPQ && MAPB == 0), "WGT: the looped launch only");
+    static_assert(!WGT || ((LOOPQ || ARGQ) && MAPB == 0 && !DYN), "WGT: the looped launch, or the one-query launch with static shares");
     constexpr int D = LPR * 16;
     constexpr int RPT = WAVE / LPR;                // rows per wave-instruction
     // U = loads in flight per lane (U KiB per wave); NT = non-temporal loads (the table is streamed once per query)
@@ -383,16 +474,14 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
     constexpr int ROUNDS = (U + LPR - 1) / LPR;    // evaluation rounds (one row per lane each)
     constexpr int NPAR = WGT ? 2 : 1;
     __shared__ uint64_t s_buf[NPAR][NW][F_CAPW];
-    __shared__ int s_cnt[NPAR][NW];
     __shared__ float s_drop[NPAR][NW];
     __shared__ uint32_t s_ticket[2];
 
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: loop bounds and LDS bases stay in SGPRs
+    PB_STAMP(0);
     const int sub = lane % LPR;
     const int g = lane / LPR;
-    constexpr int ME = NW * F_KW / WAVE;  // entries per lane (workgroup merge)
-    __shared__ uint64_t s_merge[NW * F_KW];
     if constexpr (WGT) {
         if (threadIdx.x < 2) s_ticket[threadIdx.x] = 0u;
         __syncthreads();
@@ -482,6 +571,10 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
         if (lane == 0) wg_pend = atomicAdd(&s_ticket[par], 1u);
         s = (uint64_t)__builtin_amdgcn_readfirstlane(wg_pend) * gridDim.x + blockIdx.x;
     }
+    PB_STAMP(1);
+#ifdef PB_SCAN_STAMP
+    bool first_tile = true;
+#endif
     for (; DYN ? (s != ~0ull) : (s < n_super);) {
         if constexpr (WGT) {
             if (lane == 0) wg_pend = atomicAdd(&s_ticket[par], 1u);  // the next ticket, requested ahead of this tile's loads
@@ -536,6 +629,12 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
                 }
             }
         }
+#ifdef PB_SCAN_STAMP
+        if (first_tile) {
+            PB_STAMP(2);
+            first_tile = false;
+        }
+#endif
         if constexpr (DYN) {
             if (!dyn_on) {
                 s += stride;
@@ -556,46 +655,33 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
             s += stride;
         }
     }
-    if (cnt > F_KW) {
-        const uint64_t kth = wave_keep_smallest<F_CAPW / WAVE>(buf, cnt, F_KW);
-        cnt = F_KW;
-        dropped = filter_key_cos(kth);
+    PB_STAMP(3);
+    {   // the wave's list: its F_KW best, sorted (cnt <= 64 here: the loop prunes above that)
+        const uint64_t first_out = wave_finish_list(buf, cnt);
+        if (first_out != ~0ull) dropped = filter_key_cos(first_out);  // >= thr: everything buffered had passed it
     }
-    if (lane == 0) {
-        s_cnt[par][wave] = cnt;
-        s_drop[par][wave] = dropped;
-    }
+    if (lane == 0) s_drop[par][wave] = dropped;
+    PB_STAMP(4);
     __syncthreads();
+    PB_STAMP(5);
     if (wave == 0) {
-        // workgroup list: the F_KWG best of the <= 16*32 entries, sorted, by wave 0
-        int total = 0;
-        float drop = 0.0f;
-        for (int w = 0; w < NW; ++w) {
-            const int c = s_cnt[par][w];
-            if (lane < c) s_merge[total + lane] = s_buf[par][w][lane];
-            total += c;
-            drop = fmaxf(drop, s_drop[par][w]);
-        }
-        if (total > F_KWG) {
-            const uint64_t kth = wave_keep_smallest<ME>(s_merge, total, F_KWG);
-            total = F_KWG;
-            drop = fmaxf(drop, filter_key_cos(kth));
-        }
-        // rank sort (<= 32 distinct keys)
-        const uint64_t mykey = lane < total ? s_merge[lane] : ~0ull;
-        int rank = 0;
-        for (int j = 0; j < total; ++j) {
-            const uint64_t o = __shfl((unsigned long long)mykey, j);
-            rank += o < mykey ? 1 : 0;
-        }
+        // workgroup list: the F_KWG best of the NW sorted wave lists, by wave 0 (NW - 1 bitonic merges of 32 + 32 keys)
+        int total;
+        uint64_t first_out;
+        const uint64_t mykey = wave_merge_lists<NW>(&s_buf[par][0][0], F_CAPW, &total, &first_out);
+        float drop = lane < NW ? s_drop[par][lane] : 0.0f;
+        for (int off = 8; off >= 1; off >>= 1) drop = fmaxf(drop, __shfl_xor(drop, off));
+        drop = __shfl(drop, 0);
+        if (first_out != ~0ull) drop = fmaxf(drop, filter_key_cos(first_out));
         uint64_t *out = lists + ((size_t)q * gridDim.x + blockIdx.x) * F_KWG;
-        if (lane < total) out[rank] = mykey;
+        if (lane < total) out[lane] = mykey;
         if (lane == 0) {
             ListHdr h;
             h.count = (uint32_t)total;
             h.dropped = drop;
             hdrs[(size_t)q * gridDim.x + blockIdx.x] = h;
         }
+        PB_STAMP(6);
     }
     if constexpr (LOOPQ && !WGT) __syncthreads();  // the wave buffers are reused by the next query (WGT: the other parity's are)
   }
@@ -619,15 +705,12 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_dist(const uint8_t *__restri
     constexpr int ROWS_IT = U * RPT;
     constexpr int ROUNDS = (U + LPR - 1) / LPR;
     __shared__ uint64_t s_buf[NW][F_CAPW];
-    __shared__ int s_cnt[NW];
     __shared__ uint64_t s_drop[NW];
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: loop bounds and LDS bases stay in SGPRs
     const int sub = lane % LPR;
     const int g = lane / LPR;
     uint64_t *buf = s_buf[wave];
-    constexpr int ME = NW * F_KW / WAVE;
-    __shared__ uint64_t s_merge[NW * F_KW];
   // nq_loop queries one after the other in this launch (one table pass each), as k_scan_filter's LOOPQ form
   for (int qi = 0; qi < nq_loop; ++qi) {
     const int q = q_base + qi;
@@ -690,38 +773,20 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_dist(const uint8_t *__restri
             }
         }
     }
-    if (cnt > F_KW) {
-        const uint64_t kth = wave_keep_smallest<F_CAPW / WAVE>(buf, cnt, F_KW);
-        cnt = F_KW;
-        dropped = kth + 1 < dropped ? kth + 1 : dropped;
+    {   // the wave's list: its F_KW best, sorted (cnt <= 64 here)
+        const uint64_t first_out = wave_finish_list(buf, cnt);
+        dropped = first_out < dropped ? first_out : dropped;
     }
-    if (lane == 0) {
-        s_cnt[wave] = cnt;
-        s_drop[wave] = dropped;
-    }
+    if (lane == 0) s_drop[wave] = dropped;
     __syncthreads();
     if (wave == 0) {
-    int total = 0;
-    uint64_t drop = ~0ull;
-    for (int w = 0; w < NW; ++w) {
-        const int c = s_cnt[w];
-        if (lane < c) s_merge[total + lane] = s_buf[w][lane];
-        total += c;
-        drop = s_drop[w] < drop ? s_drop[w] : drop;
-    }
-    if (total > F_KWG) {
-        const uint64_t kth = wave_keep_smallest<ME>(s_merge, total, F_KWG);
-        total = F_KWG;
-        drop = kth + 1 < drop ? kth + 1 : drop;
-    }
-    const uint64_t mykey = lane < total ? s_merge[lane] : ~0ull;
-    int rank = 0;
-    for (int j = 0; j < total; ++j) {
-        const uint64_t o = __shfl((unsigned long long)mykey, j);
-        rank += o < mykey ? 1 : 0;
-    }
+    int total;
+    uint64_t first_out;
+    const uint64_t mykey = wave_merge_lists<NW>(&s_buf[0][0], F_CAPW, &total, &first_out);
+    uint64_t drop = first_out;
+    for (int w = 0; w < NW; ++w) drop = s_drop[w] < drop ? s_drop[w] : drop;
     uint64_t *out = lists + ((size_t)q * gridDim.x + blockIdx.x) * F_KWG;
-    if (lane < total) out[rank] = mykey;
+    if (lane < total) out[lane] = mykey;
     if (lane == 0) {
         ListHdr h;
         h.count = (uint32_t)total;
@@ -782,6 +847,7 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
     __shared__ uint32_t s_u[8];
     const int q = blockIdx.x;
     const int tid = threadIdx.x;
+    PB_SEL_STAMP(0);
     const QParams P = qp[q];
     const uint64_t *ql = lists + (size_t)q * n_lists * F_KWG;
     const ListHdr *qh = hdrs + (size_t)q * n_lists;
@@ -802,6 +868,7 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
     for (int i = tid; i < SEL_BINS; i += SEL_BLOCK) s_hist[i] = 0;
     if (tid < 8) s_u[tid] = 0;
     __syncthreads();
+    PB_SEL_STAMP(1);
     if (tid < d) s_qf[tid] = s_lut[qbyte];
 
     // ---- lower bound LB on the k-th largest filter cosine: histogram over the first j entries of
@@ -865,6 +932,7 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
         lb = fmaxf(lb, P.thr0);
     }
     const float cut = lb - 2.0f * P.m;
+    PB_SEL_STAMP(2);
 
     // ---- candidates: every listed entry with cos_filter >= cut (from the registers loaded above)
 #pragma unroll
@@ -880,6 +948,7 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
     const uint32_t n_cand_raw = s_u[2];
     const int n_cand = n_cand_raw < SEL_MAX_CAND ? (int)n_cand_raw : SEL_MAX_CAND;
     const bool overflow = n_cand_raw > SEL_MAX_CAND;
+    PB_SEL_STAMP(3);
 
     // ---- exact re-scoring, one candidate per thread (reference arithmetic, engine.rs:575-587); the row, its norm and
     //      its image_id are requested together
@@ -900,6 +969,7 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
         else filtered = true;
     }
     __syncthreads();
+    PB_SEL_STAMP(4);
     // largest exact cosine among candidates rejected by `dist < max_dist` (monotone: everything at or
     // below it is rejected too)
     float cfilt = filtered ? my_cs : -2.0f;
@@ -943,12 +1013,14 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
     }
     // ---- certificate (DESIGN.md "certificate"): exact cosine of the k-th result vs. the best any
     //      unexamined row could reach
+    PB_SEL_STAMP(5);
     for (int off = 32; off >= 1; off >>= 1) ck = fminf(ck, __shfl_xor(ck, off));
     if ((tid & 63) == 0) s_ck[tid >> 6] = ck;
     // done_flag (one-query calls): the host polls a word in pinned memory instead of waiting for the stream, so the
     // result stores above must be visible there before the flag is: system-scope fence on every storing thread
     if (done_flag) __threadfence_system();
     __syncthreads();
+    PB_SEL_STAMP(6);
     if (tid == 0) {
         ck = 3.0f;
         for (int w = 0; w < SEL_BLOCK / WAVE; ++w) ck = fminf(ck, s_ck[w]);
@@ -971,6 +1043,7 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
             __threadfence_system();
             __hip_atomic_store(&done_flag[q], done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
+        PB_SEL_STAMP(7);
     }
 }
 
