@@ -329,6 +329,32 @@ __device__ __forceinline__ float ref_fold_dot256(const uint8_t *__restrict__ row
     }
     return dot;
 }
+// The same fold for a 256-byte row by EIGHT consecutive lanes (lane `part` = threadIdx & 7 owns bytes 32 part .. 32 part + 31,
+// already loaded: v0, v1): the 256 de-quantisations (an LDS look-up each) and products are the long part of a re-scoring and
+// do not depend on each other, so each lane makes 32 of them; the sum itself stays the reference's one chain -- the group walks
+// its eight parts in order, every lane adding its own products to what it holds, and after each part the sums move one lane
+// up (row_shr:1), so that lane p starts part p from the sum through part p - 1.  Same operations in the same order on the
+// value that counts: bit-identical.  All eight lanes must be active; the result is lane 7's.
+__device__ __forceinline__ float ref_fold_dot256_by8(const uint4 v0, const uint4 v1, const float *s_qf, const float *s_lut, int part) {
+    float p[32];
+    const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float4 qf = *reinterpret_cast<const float4 *>(s_qf + 32 * part + 4 * c);
+        p[4 * c + 0] = qf.x * s_lut[w[c] & 0xFF];
+        p[4 * c + 1] = qf.y * s_lut[(w[c] >> 8) & 0xFF];
+        p[4 * c + 2] = qf.z * s_lut[(w[c] >> 16) & 0xFF];
+        p[4 * c + 3] = qf.w * s_lut[w[c] >> 24];
+    }
+    float a = 0.0f;
+#pragma unroll
+    for (int ph = 0; ph < 8; ++ph) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) a = a + p[i];
+        if (ph < 7) a = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x111, 0xF, 0xF, true));  // row_shr:1
+    }
+    return a;
+}
 __device__ __forceinline__ float ref_fold_dot_any(const uint8_t *__restrict__ row, const float *s_qf, const float *s_lut, int d) {
     return d == 256 ? ref_fold_dot256(row, s_qf, s_lut) : ref_fold_dot(row, s_qf, s_lut, d);
 }
@@ -429,9 +455,11 @@ __device__ unsigned long long g_sel_stamp[16];
     do {                                                                                                        \
         if (ARGQ && lane == 0) g_scan_stamp[((size_t)blockIdx.x * NW + wave) * 8 + (slot)] = wall_clock64();     \
     } while (0)
+// (slots 0 and 7: thread 0; the others: the last thread, whose wave re-scores nothing -- a stamp is a global store, and the
+// stamping wave's next wait for its loads also waits for that store)
 #define PB_SEL_STAMP(slot)                                             \
     do {                                                               \
-        if (blockIdx.x == 0 && threadIdx.x == 0) g_sel_stamp[slot] = wall_clock64(); \
+        if (blockIdx.x == 0 && threadIdx.x == (((slot) == 0 || (slot) == 7) ? 0 : SEL_BLOCK - 1)) g_sel_stamp[slot] = wall_clock64(); \
     } while (0)
 #else
 #define PB_STAMP(slot) do { } while (0)
@@ -674,7 +702,7 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
         drop = __shfl(drop, 0);
         if (first_out != ~0ull) drop = fmaxf(drop, filter_key_cos(first_out));
         uint64_t *out = lists + ((size_t)q * gridDim.x + blockIdx.x) * F_KWG;
-        if (lane < total) out[lane] = mykey;
+        if (lane < F_KWG) out[lane] = mykey;  // every slot: the unused ones hold ~0, which is how k_select_rescore tells them
         if (lane == 0) {
             ListHdr h;
             h.count = (uint32_t)total;
@@ -839,11 +867,10 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
     if (tail_ctr && blockIdx.x == 0 && threadIdx.x < DYN_REGIONS) tail_ctr[threadIdx.x * DYN_CTR_STRIDE] = 0u;
     __shared__ float s_lut[256];
     __shared__ float s_qf[1024];
-    __shared__ uint32_t s_hist[SEL_BINS];
-    __shared__ uint64_t s_key[SEL_MAX_CAND];   // candidates (filter keys), then exact keys
+    __shared__ __attribute__((aligned(16))) float s_top[SEL_BINS];  // the first j_top filter cosines of every list (-1: unused slot)
+    __shared__ __attribute__((aligned(16))) uint64_t s_key[SEL_MAX_CAND];   // candidates (filter keys), then exact keys
     __shared__ float s_red[SEL_BLOCK / WAVE];
     __shared__ float s_ck[SEL_BLOCK / WAVE];
-    __shared__ uint32_t s_wsum[SEL_BINS / WAVE];
     __shared__ uint32_t s_u[8];
     const int q = blockIdx.x;
     const int tid = threadIdx.x;
@@ -852,44 +879,38 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
     const uint64_t *ql = lists + (size_t)q * n_lists * F_KWG;
     const ListHdr *qh = hdrs + (size_t)q * n_lists;
 
-    // ---- one round trip: this thread's list slots (slot i = list i / 32, entry i % 32) and their headers
+    // ---- one round trip: this thread's list slots (slot i = list i / 32, entry i % 32; an unused slot holds ~0) and, on the
+    //      first n_lists threads, a list's `dropped` bound
     const int total_slots = n_lists * F_KWG;
     uint64_t my_key[SEL_SLOTS];
-    ListHdr my_hdr[SEL_SLOTS];
 #pragma unroll
     for (int j = 0; j < SEL_SLOTS; ++j) {
         const int i = tid + j * SEL_BLOCK;
-        const int ic = i < total_slots ? i : total_slots - 1;
-        my_key[j] = ql[ic];
-        my_hdr[j] = qh[ic / F_KWG];
+        my_key[j] = i < total_slots ? ql[i] : ~0ull;
     }
+    float dmax = tid < n_lists ? qh[tid].dropped : 0.0f;
     const uint8_t qbyte = tid < d ? queries[(size_t)q * d + tid] : (uint8_t)0;
     s_lut[tid & 255] = lut[tid & 255];
-    for (int i = tid; i < SEL_BINS; i += SEL_BLOCK) s_hist[i] = 0;
     if (tid < 8) s_u[tid] = 0;
     __syncthreads();
     PB_SEL_STAMP(1);
     if (tid < d) s_qf[tid] = s_lut[qbyte];
 
-    // ---- lower bound LB on the k-th largest filter cosine: histogram over the first j entries of
-    //      every (sorted) list, j = ceil(k / n_lists)
-    const int j_top = (int)((P.k + n_lists - 1) / n_lists);
-    const float span = 1.0002f - P.thr0;
-    const float scale = (float)SEL_BINS / span;
-    float dmax = 0.0f;
+    // ---- lower bound LB on the k-th largest filter cosine: the k-th largest among the first j entries of every (sorted)
+    //      list, j = ceil(k / n_lists) -- the k-th largest of a subset is <= the k-th largest of all.  Found by counting:
+    //      the T = n_lists * j values (< k + n_lists <= 768) go to LDS, thread t counts the values above and equal to its own.
+    const int j_need = (int)((P.k + n_lists - 1) / n_lists);
+    const int j_top = j_need < F_KWG ? j_need : F_KWG;  // (fewer than k listed entries in all: LB = thr0 below)
+    const int n_topset = n_lists * j_top;
     uint32_t n_top = 0;
 #pragma unroll
     for (int j = 0; j < SEL_SLOTS; ++j) {
         const int i = tid + j * SEL_BLOCK;
         const int e = i % F_KWG;
-        const bool live = i < total_slots && e < (int)my_hdr[j].count;
-        if (i < total_slots) dmax = fmaxf(dmax, my_hdr[j].dropped);
-        if (live && e < j_top) {
-            const float cs = filter_key_cos(my_key[j]);
-            int bin = (int)((cs - P.thr0) * scale);
-            bin = bin < 0 ? 0 : (bin >= SEL_BINS ? SEL_BINS - 1 : bin);
-            atomicAdd(&s_hist[bin], 1u);
-            ++n_top;
+        if (i < total_slots && e < j_top) {
+            const bool live = my_key[j] != ~0ull;
+            s_top[(i / F_KWG) * j_top + e] = live ? filter_key_cos(my_key[j]) : -1.0f;
+            n_top += live ? 1u : 0u;
         }
     }
     for (int off = 32; off >= 1; off >>= 1) {
@@ -900,36 +921,30 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
         s_red[tid >> 6] = dmax;
         if (n_top) atomicAdd(&s_u[0], n_top);
     }
+    for (int i = n_topset + tid; i < ((n_topset + 15) & ~15); i += SEL_BLOCK) s_top[i] = -1.0f;  // pad to whole batches of reads
     __syncthreads();
     dmax = 0.0f;
     for (int w = 0; w < SEL_BLOCK / WAVE; ++w) dmax = fmaxf(dmax, s_red[w]);
     const uint32_t top_total = s_u[0];
     float lb = P.thr0;
-    if (top_total >= P.k) {
-        // suffix scan from the top bin: every wave sums its 64-bin chunk, wave 0 finds the chunk in which the running
-        // count reaches k and scans inside it
-        const int chunk = tid >> 6;                       // 16 chunks of 64 bins, chunk 15 = highest
-        const int bin = chunk * WAVE + (WAVE - 1 - (tid & 63));  // lane 0 = highest bin of the chunk
-        const uint32_t v = s_hist[bin];
-        uint32_t incl = v;
-        for (int off = 1; off < WAVE; off <<= 1) {
-            const uint32_t o = __shfl_up(incl, off);
-            if ((tid & 63) >= off) incl += o;
-        }
-        if ((tid & 63) == WAVE - 1) s_wsum[chunk] = incl;
-        __syncthreads();
-        uint32_t above = 0;  // count in the chunks above this one
-        for (int c = SEL_BINS / WAVE - 1; c > chunk; --c) above += s_wsum[c];
-        const uint64_t hit = __ballot(above + incl >= P.k);
-        // the chunk that crosses k: above < k <= above + chunk total
-        if (above < P.k && above + s_wsum[chunk] >= P.k && (tid & 63) == 0) {
-            const int first = __ffsll((unsigned long long)hit) - 1;
-            s_u[1] = (uint32_t)(chunk * WAVE + (WAVE - 1 - first));
+    if (top_total >= P.k) {  // uniform
+        if (tid < n_topset) {
+            const float v = s_top[tid];
+            uint32_t above = 0, same = 0;
+            for (int u = 0; u < n_topset; u += 16) {  // four 16-byte LDS reads in flight (one per trip is a chain of LDS latencies)
+                float4 o[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) o[c] = *reinterpret_cast<const float4 *>(s_top + u + 4 * c);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    above += (o[c].x > v ? 1u : 0u) + (o[c].y > v ? 1u : 0u) + (o[c].z > v ? 1u : 0u) + (o[c].w > v ? 1u : 0u);
+                    same += (o[c].x == v ? 1u : 0u) + (o[c].y == v ? 1u : 0u) + (o[c].z == v ? 1u : 0u) + (o[c].w == v ? 1u : 0u);
+                }
+            }
+            if (above < P.k && P.k <= above + same) s_u[1] = __float_as_uint(v);  // ties write the same word
         }
         __syncthreads();
-        const int found = (int)s_u[1];
-        lb = P.thr0 + (float)found / scale - 2e-6f;
-        lb = fmaxf(lb, P.thr0);
+        lb = fmaxf(__uint_as_float(s_u[1]), P.thr0);
     }
     const float cut = lb - 2.0f * P.m;
     PB_SEL_STAMP(2);
@@ -938,8 +953,7 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
 #pragma unroll
     for (int j = 0; j < SEL_SLOTS; ++j) {
         const int i = tid + j * SEL_BLOCK;
-        const bool live = i < total_slots && (i % F_KWG) < (int)my_hdr[j].count;
-        if (live && filter_key_cos(my_key[j]) >= cut) {
+        if (my_key[j] != ~0ull && filter_key_cos(my_key[j]) >= cut) {
             const uint32_t pos = atomicAdd(&s_u[2], 1u);
             if (pos < SEL_MAX_CAND) s_key[pos] = my_key[j];
         }
@@ -949,6 +963,13 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
     const int n_cand = n_cand_raw < SEL_MAX_CAND ? (int)n_cand_raw : SEL_MAX_CAND;
     const bool overflow = n_cand_raw > SEL_MAX_CAND;
     PB_SEL_STAMP(3);
+#ifdef PB_SCAN_STAMP
+    if (blockIdx.x == 0 && threadIdx.x == SEL_BLOCK - 1) {
+        g_sel_stamp[8] = n_cand_raw;
+        g_sel_stamp[9] = __float_as_uint(lb);
+        g_sel_stamp[10] = __float_as_uint(cut);
+    }
+#endif
 
     // ---- exact re-scoring, one candidate per thread (reference arithmetic, engine.rs:575-587); the row, its norm and
     //      its image_id are requested together
@@ -956,11 +977,38 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
     float my_cs = -2.0f, my_dist = 0.0f;
     int64_t my_id = 0;
     bool filtered = false;
+    float nrm_c = 0.0f;
+    if (tid < n_cand) {  // requested before the rows, consumed after them
+        const uint32_t r = (uint32_t)s_key[tid];
+        nrm_c = norms[r];
+        my_id = ids[r];
+    }
+    if (d == 256) {
+        // eight lanes per candidate (ref_fold_dot256_by8), 128 candidates per pass; the rows of the first two passes are
+        // requested together (one round trip for up to 256 candidates); the sums go to thread `candidate` through LDS
+        constexpr int PER = SEL_BLOCK / 8;
+        const int part = tid & 7;
+        for (int c0 = tid >> 3; c0 < n_cand; c0 += 2 * PER) {
+            const int c1 = c0 + PER;
+            const bool two = c1 < n_cand;  // uniform over the eight lanes
+            const uint8_t *r0 = rows + (uint64_t)(uint32_t)s_key[c0] * 256 + 32 * part;
+            const uint8_t *r1 = rows + (uint64_t)(uint32_t)s_key[two ? c1 : c0] * 256 + 32 * part;
+            const uint4 a0 = *reinterpret_cast<const uint4 *>(r0), a1 = *reinterpret_cast<const uint4 *>(r0 + 16);
+            const uint4 b0 = *reinterpret_cast<const uint4 *>(r1), b1 = *reinterpret_cast<const uint4 *>(r1 + 16);
+            const float d0 = ref_fold_dot256_by8(a0, a1, s_qf, s_lut, part);
+            if (part == 7) s_top[c0] = d0;
+            __builtin_amdgcn_sched_barrier(0);  // (the two folds interleaved need twice the product registers: scratch)
+            if (two) {
+                const float d1 = ref_fold_dot256_by8(b0, b1, s_qf, s_lut, part);
+                if (part == 7) s_top[c1] = d1;
+            }
+        }
+        __syncthreads();
+    }
     if (tid < n_cand) {
         const uint32_t r = (uint32_t)s_key[tid];
-        const float nrm = norms[r];
-        my_id = ids[r];
-        const float dot = ref_fold_dot_any(rows + (uint64_t)r * d, s_qf, s_lut, d);
+        const float nrm = nrm_c;
+        const float dot = d == 256 ? s_top[tid] : ref_fold_dot(rows + (uint64_t)r * d, s_qf, s_lut, d);
         float cs;
         const float dist = ref_distance(dot, P.sqrt_sa, nrm, &cs);
         my_cs = cs;
@@ -990,7 +1038,13 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
         // order by counting: keys are distinct (row in the low word), rank = number of exact keys below mine
         if (tid < n_cand && xkey != ~0ull) {
             uint32_t rank = 0;
-            for (int j = 0; j < n_cand; ++j) rank += s_key[j] < xkey ? 1u : 0u;
+            for (int j = 0; j < n_cand; j += 16) {  // eight 16-byte LDS reads in flight (slots up to nsort >= 64 hold ~0)
+                ulonglong2 o[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) o[c] = *reinterpret_cast<const ulonglong2 *>(s_key + j + 2 * c);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) rank += (o[c].x < xkey ? 1u : 0u) + (o[c].y < xkey ? 1u : 0u);
+            }
             if (rank < n_out) {
                 out_ids[(size_t)q * out_stride + rank] = my_id;
                 out_dist[(size_t)q * out_stride + rank] = my_dist;

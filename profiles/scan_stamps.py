@@ -43,6 +43,7 @@ for i in range(32):
         v = v[v > 0]
         row += [(v.min() - base) / 100.0, (np.median(v) - base) / 100.0, (v.max() - base) / 100.0]
     sel = (bs[:8].astype(np.float64) - base) / 100.0
+    n_cand = int(bs[8])
     acc.append(row + sel.tolist() + [float(live.sum())])
     if i == 31 and os.environ.get("PB_STAMP_DETAIL"):
         full = bf.reshape(-1, 8, 8).astype(np.float64)  # [workgroup][wave][slot]
@@ -58,3 +59,4 @@ for s in range(7):
 sn = ["k_select_rescore starts", "lists + headers loaded", "lower bound found", "candidates chosen", "candidates re-scored", "ordered + results stored", "fence + barrier", "header + stamp stored"]
 for s in range(8):
     print(f"  {sn[s]:24s} {a[21 + s]:7.2f}")
+print(f"  candidates of the last call: {n_cand}; lower bound {np.array([bs[9]], dtype=np.uint64).astype(np.uint32).view(np.float32)[0]:.6f}, cut {np.array([bs[10]], dtype=np.uint64).astype(np.uint32).view(np.float32)[0]:.6f}")
