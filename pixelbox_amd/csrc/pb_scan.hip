@@ -103,7 +103,7 @@ struct pb_index {
     int64_t *h_res_ids = nullptr;
     float *h_res_dist = nullptr;
     ResultHdr *h_res_hdr = nullptr;
-    uint32_t *h_done = nullptr;     // pinned: completion stamp of a one-query call, written last by k_select_rescore and polled by the host
+    uint32_t *h_done = nullptr;     // pinned: the result granules of a one-query call ({payload[3], tag} x (2 + PB_MAX_K), sel_put_granule), polled by the host
     uint32_t done_seq = 0;
     bool poll_pending = false;      // the select launch of this call carries a stamp
     bool env_no_poll = false;       // PB_NO_POLL: wait for the stream instead of the completion stamp (comparison)
@@ -175,8 +175,8 @@ int alloc_workspace(pb_index *ix) {
     PB_HIP(hipHostMalloc(&ix->h_res_ids, (size_t)PIPE_Q * PB_MAX_K * sizeof(int64_t), hipHostMallocCoherent));
     PB_HIP(hipHostMalloc(&ix->h_res_dist, (size_t)PIPE_Q * PB_MAX_K * sizeof(float), hipHostMallocCoherent));
     PB_HIP(hipHostMalloc(&ix->h_res_hdr, PIPE_Q * sizeof(ResultHdr), hipHostMallocCoherent));
-    PB_HIP(hipHostMalloc(&ix->h_done, 64, hipHostMallocCoherent));
-    memset(ix->h_done, 0, 64);
+    PB_HIP(hipHostMalloc(&ix->h_done, (size_t)(PB_MAX_K + 2) * 16, hipHostMallocCoherent));
+    memset(ix->h_done, 0, (size_t)(PB_MAX_K + 2) * 16);
     return PB_OK;
 }
 
@@ -818,27 +818,66 @@ int search_chunk(pb_index *ix, uint32_t cq, uint32_t k, double max_dist, const f
     auto wait_headers = [&]() -> int {
         if (!host_out) PB_HIP(hipMemcpyAsync(ix->h_res_hdr, ix->d_res_hdr, cq * sizeof(ResultHdr), hipMemcpyDeviceToHost, ix->stream));
         if (ix->poll_pending) {
-            // one-query call: k_select_rescore stamps h_done after its results have reached host memory; seeing the stamp
-            // spares the end-of-kernel and stream-wait latency (the stream drains behind the caller's back; everything
-            // queued later is ordered after it).  A stamp that does not come within 20 ms falls back to the stream wait.
+            // one-query call: k_select_rescore publishes its results as tagged 16-byte granules in pinned memory
+            // (sel_put_granule); a granule counts once its tag is this call's sequence number.  Seeing them spares the
+            // end-of-kernel and stream-wait latency (the stream drains behind the caller's back; everything queued later
+            // is ordered after it).  Granules that do not come within 20 ms fall back to the stream wait.
             ix->poll_pending = false;
             const uint32_t want = ix->done_seq;
+            const uint32_t *g = ix->h_done;
             const auto t0 = std::chrono::steady_clock::now();
-            for (uint32_t spins = 0;; ++spins) {
-                if (__atomic_load_n(&ix->h_done[0], __ATOMIC_ACQUIRE) == want) {
-                    ix->stamp_timeouts_row = 0;
-                    return PB_OK;
+            uint32_t spins = 0;
+            bool late = false;
+            auto wait_tag = [&](uint32_t slot) -> bool {  // tag first, payload after it (loads stay in order)
+                while (__atomic_load_n(&g[4 * slot + 3], __ATOMIC_ACQUIRE) != want) {
+                    if (late) return false;
+                    __builtin_ia32_pause();
+                    if ((++spins & 4095u) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) {
+                        late = true;
+                        return false;
+                    }
                 }
-                __builtin_ia32_pause();
-                if ((spins & 4095u) == 4095u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+                return true;
+            };
+            auto unpack = [&]() {
+                ResultHdr &h = ix->h_res_hdr[0];
+                h.count = g[0];
+                h.status = g[1];
+                h.n_cand = g[2];
+                memcpy(&h.o_max, &g[4], 4);
+                memcpy(&h.ck, &g[5], 4);
+            };
+            bool ok = wait_tag(0) && wait_tag(1);
+            if (ok) {
+                unpack();
+                const uint32_t n = std::min<uint32_t>(ix->h_res_hdr[0].count, PB_MAX_K);
+                for (uint32_t i = 0; i < n && ok; ++i) {
+                    ok = wait_tag(2 + i);
+                    if (!ok) break;
+                    ix->h_res_ids[i] = (int64_t)(((uint64_t)g[4 * (2 + i) + 1] << 32) | g[4 * (2 + i)]);
+                    memcpy(&ix->h_res_dist[i], &g[4 * (2 + i) + 2], 4);
+                }
             }
-            // the stamp did not arrive in time (a GPU shared with ingest or another process): counted (pb_index_get_stats);
-            // three in a row put the next 256 one-query calls on the stream wait, then the stamp gets another chance
+            if (ok) {
+                ix->stamp_timeouts_row = 0;
+                return PB_OK;
+            }
+            // the granules did not arrive in time (a GPU shared with ingest or another process): counted
+            // (pb_index_get_stats); three in a row put the next 256 one-query calls on the stream wait, then polling gets
+            // another chance.  After the stream wait every granule is there.
             ++ix->stats.stamp_timeouts;
             if (++ix->stamp_timeouts_row >= 3) {
                 ix->stamp_timeouts_row = 0;
                 ix->no_poll_calls = 256;
             }
+            PB_HIP(hipStreamSynchronize(ix->stream));
+            unpack();
+            const uint32_t n = std::min<uint32_t>(ix->h_res_hdr[0].count, PB_MAX_K);
+            for (uint32_t i = 0; i < n; ++i) {
+                ix->h_res_ids[i] = (int64_t)(((uint64_t)g[4 * (2 + i) + 1] << 32) | g[4 * (2 + i)]);
+                memcpy(&ix->h_res_dist[i], &g[4 * (2 + i) + 2], 4);
+            }
+            return PB_OK;
         }
         PB_HIP(hipStreamSynchronize(ix->stream));
         return PB_OK;

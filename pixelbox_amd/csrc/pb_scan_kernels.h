@@ -855,6 +855,17 @@ __device__ __forceinline__ void block_bitonic_sort(uint64_t *s, int n) {
 // together) and serves both the lower-bound histogram and the candidate selection from registers; a candidate's row, norm
 // and image_id are requested together; and up to SEL_RANK_MAX candidates are ordered by counting (each candidate counts the
 // keys below its own from LDS: one barrier) instead of a 36-barrier bitonic network -- 29 -> ~17 us per query.
+// One-query calls answered into pinned host memory (done_flag != nullptr) publish their results as 16-byte GRANULES
+// {payload[3], tag}: one store instruction of one lane each, so a granule arrives whole, and the host accepts a granule once
+// its tag equals the call's sequence number -- no fence between the result stores and a separate completion flag (which cost
+// the store round trip over PCIe, ~2 us at the end of every query), no flag.  Granule 0: {count, status, n_cand}, 1: {o_max,
+// ck, 0}, 2 + i: {id low, id high, distance} of result i.  The host reads the tag first (search_chunk in pb_scan.hip).
+__device__ __forceinline__ void sel_put_granule(uint32_t *base, uint32_t slot, uint32_t a, uint32_t b, uint32_t c, uint32_t tag) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 g;
+    g.x = a; g.y = b; g.z = c; g.w = tag;
+    *reinterpret_cast<u32x4 *>(base + 4 * (size_t)slot) = g;
+}
 constexpr int SEL_SLOTS = F_MAX_WG * F_KWG / SEL_BLOCK;  // list slots per thread (16)
 constexpr int SEL_RANK_MAX = 256;
 __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
@@ -1046,8 +1057,12 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
                 for (int c = 0; c < 8; ++c) rank += (o[c].x < xkey ? 1u : 0u) + (o[c].y < xkey ? 1u : 0u);
             }
             if (rank < n_out) {
-                out_ids[(size_t)q * out_stride + rank] = my_id;
-                out_dist[(size_t)q * out_stride + rank] = my_dist;
+                if (done_flag) {
+                    sel_put_granule(done_flag, 2 + rank, (uint32_t)my_id, (uint32_t)((uint64_t)my_id >> 32), __float_as_uint(my_dist), done_seq);
+                } else {
+                    out_ids[(size_t)q * out_stride + rank] = my_id;
+                    out_dist[(size_t)q * out_stride + rank] = my_dist;
+                }
                 ck = my_cs;
             }
         }
@@ -1056,8 +1071,13 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
         if (tid < (int)n_out) {
             const uint64_t key = s_key[tid];
             const uint32_t r = (uint32_t)key;
-            out_ids[(size_t)q * out_stride + tid] = ids[r];
-            out_dist[(size_t)q * out_stride + tid] = unsortable_f32((uint32_t)(key >> 32));
+            const int64_t id = ids[r];
+            if (done_flag) {
+                sel_put_granule(done_flag, 2 + tid, (uint32_t)id, (uint32_t)((uint64_t)id >> 32), (uint32_t)__float_as_uint(unsortable_f32((uint32_t)(key >> 32))), done_seq);
+            } else {
+                out_ids[(size_t)q * out_stride + tid] = id;
+                out_dist[(size_t)q * out_stride + tid] = unsortable_f32((uint32_t)(key >> 32));
+            }
         }
         if (n_out > 0) {
             const uint64_t kth_key = s_key[n_out - 1];
@@ -1070,9 +1090,6 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
     PB_SEL_STAMP(5);
     for (int off = 32; off >= 1; off >>= 1) ck = fminf(ck, __shfl_xor(ck, off));
     if ((tid & 63) == 0) s_ck[tid >> 6] = ck;
-    // done_flag (one-query calls): the host polls a word in pinned memory instead of waiting for the stream, so the
-    // result stores above must be visible there before the flag is: system-scope fence on every storing thread
-    if (done_flag) __threadfence_system();
     __syncthreads();
     PB_SEL_STAMP(6);
     if (tid == 0) {
@@ -1092,10 +1109,11 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
         h.n_cand = n_cand_raw;
         h.o_max = o_max;
         h.ck = n_out == P.k ? ck : -1.0f;
-        out_hdr[q] = h;
         if (done_flag) {
-            __threadfence_system();
-            __hip_atomic_store(&done_flag[q], done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            sel_put_granule(done_flag, 0, h.count, h.status, h.n_cand, done_seq);
+            sel_put_granule(done_flag, 1, __float_as_uint(h.o_max), __float_as_uint(h.ck), 0u, done_seq);
+        } else {
+            out_hdr[q] = h;
         }
         PB_SEL_STAMP(7);
     }
