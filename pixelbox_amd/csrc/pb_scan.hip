@@ -114,6 +114,7 @@ struct pb_index {
 
     bool env_static_tail = false;      // PB_STATIC_TAIL: the one-query filter launch without the ticketed tail (comparison)
     bool env_force_tickets = false;    // PB_FORCE_TAIL_TICKETS: the ticketed tail also under 4M rows (tests)
+    bool env_small_static = false;     // PB_SMALL_STATIC: under 4M rows, fixed strides per wave instead of workgroup tickets (comparison)
     bool env_exact_lane_rows = false;  // PB_EXACT_LANE_ROWS: the lane-per-row exhaustive kernel also for 256-byte cosine rows (comparison)
     int opt_second_chance = 0;         // PB_OPT_SECOND_CHANCE: 0 = cost model, 1 = always, 2 = never
     float sc_success = 1.0f;           // running success rate of the second chance on this index (optimistic start)
@@ -351,14 +352,15 @@ void finish_qparams(const pb_index *ix, float acc, int64_t sum_a, int64_t sum_a2
 // bandwidth would no longer be an HBM number).  The tuning knobs (options 4-7) exist for profiles/scan_sweep.py.
 template <int LPR, int U, bool NT, int NW, int MAPB>
 void launch_filter_t(pb_index *ix, int n_wg, uint32_t q_base, uint32_t nq) {
-    hipLaunchKernelGGL((k_scan_filter<LPR, U, NT, NW, MAPB>), dim3(n_wg, nq), dim3(NW * 64), 0, ix->stream, ix->d_rows,
+    constexpr int HS = (LPR == 16 && U == 8) ? 4 : 0;  // k_scan_filter: load placement
+    hipLaunchKernelGGL((k_scan_filter<LPR, U, NT, NW, MAPB, false, false, false, false, HS>), dim3(n_wg, nq), dim3(NW * 64), 0, ix->stream, ix->d_rows,
                        ix->n_rows, ix->d_queries, ix->d_qp, ix->d_lists, ix->d_hdrs, (int)q_base, 1, (uint8_t *)nullptr,
                        (QParams *)nullptr, QArg256{});
 }
 // one launch, every workgroup answers the nq queries one after the other (k_scan_filter LOOPQ)
 template <int NW, int U = 8, int MAPB = 0, bool WGT = false>
 void launch_filter_loop(pb_index *ix, int n_wg, uint32_t q_base, uint32_t nq) {
-    hipLaunchKernelGGL((k_scan_filter<16, U, true, NW, MAPB, true, false, false, WGT>), dim3(n_wg, 1), dim3(NW * 64), 0, ix->stream,
+    hipLaunchKernelGGL((k_scan_filter<16, U, true, NW, MAPB, true, false, false, WGT, (U == 8 ? 4 : 0)>), dim3(n_wg, 1), dim3(NW * 64), 0, ix->stream,
                        ix->d_rows, ix->n_rows, ix->d_queries, ix->d_qp, ix->d_lists, ix->d_hdrs, (int)q_base, (int)nq,
                        (uint8_t *)nullptr, (QParams *)nullptr, QArg256{});
 }
@@ -447,21 +449,23 @@ int run_fast(pb_index *ix, uint32_t nq) {
         // the ticketed tail pays from ~4M rows on (10M: -5..8 us per call); on a small table its 4-tile tickets are coarse
         // against the ~2 tail tiles a wave would take (1M rows: 60.3 us ticketed, 55.8 us with static shares)
         if (ix->env_static_tail || (ix->n_rows < (4ull << 20) && !ix->env_force_tickets)) {
-            if (getenv("PB_SMALL_STATIC"))
-            hipLaunchKernelGGL((k_scan_filter<16, 8, true, F_WAVES, 0, false, true>), dim3(n_wg, 1), dim3(F_WAVES * 64), 0,
-                               ix->stream, ix->d_rows, ix->n_rows, ix->d_queries, ix->d_qp, ix->d_lists, ix->d_hdrs, 0, 1,
-                               ix->d_queries, ix->d_qp, ix->argq, nullptr);
+            // static shares per workgroup, handed to its waves by tickets from an LDS counter (round 4: a wave of a 1M-row
+            // pass has 15 or 16 tiles of 2.4 us, fixed strides end with seven waves waiting for the eighth; 49.4 -> 47.5 us)
+            if (ix->env_small_static)
+                hipLaunchKernelGGL((k_scan_filter<16, 8, true, F_WAVES, 0, false, true>), dim3(n_wg, 1), dim3(F_WAVES * 64), 0,
+                                   ix->stream, ix->d_rows, ix->n_rows, ix->d_queries, ix->d_qp, ix->d_lists, ix->d_hdrs, 0, 1,
+                                   ix->d_queries, ix->d_qp, ix->argq, nullptr);
             else
-            hipLaunchKernelGGL((k_scan_filter<16, 8, true, F_WAVES, 0, false, true, false, true>), dim3(n_wg, 1), dim3(F_WAVES * 64), 0,
-                               ix->stream, ix->d_rows, ix->n_rows, ix->d_queries, ix->d_qp, ix->d_lists, ix->d_hdrs, 0, 1,
-                               ix->d_queries, ix->d_qp, ix->argq, nullptr);
+                hipLaunchKernelGGL((k_scan_filter<16, 8, true, F_WAVES, 0, false, true, false, true>), dim3(n_wg, 1), dim3(F_WAVES * 64),
+                                   0, ix->stream, ix->d_rows, ix->n_rows, ix->d_queries, ix->d_qp, ix->d_lists, ix->d_hdrs, 0, 1,
+                                   ix->d_queries, ix->d_qp, ix->argq, nullptr);
         } else {
             if (ix->tail_dirty) {  // an earlier call failed between its ticketed launch and the launch that resets the tickets
                 PB_HIP(hipMemsetAsync(ix->d_tail, 0, (size_t)DYN_REGIONS * DYN_CTR_STRIDE * sizeof(uint32_t), ix->stream));
                 ix->tail_dirty = false;
             }
             ix->tail_dirty = true;
-            hipLaunchKernelGGL((k_scan_filter<16, 8, true, F_WAVES, 0, false, true, true>), dim3(n_wg, 1), dim3(F_WAVES * 64),
+            hipLaunchKernelGGL((k_scan_filter<16, 8, true, F_WAVES, 0, false, true, true, false, 4>), dim3(n_wg, 1), dim3(F_WAVES * 64),
                                0, ix->stream, ix->d_rows, ix->n_rows, ix->d_queries, ix->d_qp, ix->d_lists, ix->d_hdrs, 0, 1,
                                ix->d_queries, ix->d_qp, ix->argq, ix->d_tail);
             dyn = true;
@@ -1338,6 +1342,7 @@ int pb_index_create(pb_index **out, int device, uint32_t dim, uint64_t capacity_
     ix->env_exact_lane_rows = getenv("PB_EXACT_LANE_ROWS") != nullptr;
     ix->env_static_tail = getenv("PB_STATIC_TAIL") != nullptr;
     ix->env_force_tickets = getenv("PB_FORCE_TAIL_TICKETS") != nullptr;
+    ix->env_small_static = getenv("PB_SMALL_STATIC") != nullptr;
     ix->env_no_poll = getenv("PB_NO_POLL") != nullptr;
     ix->env_loop_static = getenv("PB_LOOP_STATIC") != nullptr;
     make_lut(ix->lut);

@@ -221,7 +221,9 @@ __device__ __forceinline__ uint64_t lane_cmpx(uint64_t key, bool keep_min) {
 }
 // lanes hold a bitonic sequence (ascending then descending) -> ascending over the 64 lanes
 __device__ __forceinline__ uint64_t wave_merge64(uint64_t key) {
-    const int lane = lane_id();
+    int lane = lane_id();
+    asm volatile("" : "+v"(lane));  // the lane predicates below are made HERE: hoisted out of a filter kernel's query loop they
+                                    // stay live as ~20 SGPR pairs across its streaming loop, which then spills (-2 % at 10M rows)
     key = lane_cmpx<32>(key, (lane & 32) == 0);
     key = lane_cmpx<16>(key, (lane & 16) == 0);
     key = lane_cmpx<8>(key, (lane & 8) == 0);
@@ -232,7 +234,8 @@ __device__ __forceinline__ uint64_t wave_merge64(uint64_t key) {
 }
 // any 64 keys -> ascending over the 64 lanes
 __device__ __forceinline__ uint64_t wave_sort64(uint64_t key) {
-    const int lane = lane_id();
+    int lane = lane_id();
+    asm volatile("" : "+v"(lane));  // as in wave_merge64
 #define PB_CX(D, K) key = lane_cmpx<D>(key, ((lane & (D)) == 0) == (((lane >> (K)) & 1) == 0))
     PB_CX(1, 1);
     PB_CX(2, 2); PB_CX(1, 2);
@@ -485,7 +488,7 @@ constexpr int DYN_CTR_STRIDE = 64;  // uint32 between counters (256 B: different
 // takes fewer tickets of that query -- so the merge (and the second barrier that protected the buffers) leaves the
 // critical path: it is ~1 % of a pass over 10M rows but ~5 % of one over a 1.25M-row shard (8-GPU strong scaling).
 template <int LPR, int U = 8, bool NT = true, int NW = F_WAVES, int MAPB = 0, bool LOOPQ = false, bool ARGQ = false, bool DYN = false,
-          bool WGT = false>
+          bool WGT = false, int HS = 0>
 __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__restrict__ rows, uint64_t n_rows,
                                                          const uint8_t *queries, const QParams *qp,
                                                          uint64_t *__restrict__ lists,
@@ -609,8 +612,7 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
         }
         const uint64_t row0 = s * ROWS_IT;
         uint4 b[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
+        auto load_row = [&](int u) {
             uint64_t r = row0 + (uint64_t)(u * RPT + g);
             r = r < n_rows ? r : n_rows - 1;
             typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -619,7 +621,17 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
             if constexpr (NT) t = __builtin_nontemporal_load(src);
             else t = *src;
             b[u] = make_uint4(t.x, t.y, t.z, t.w);
-        }
+        };
+        // HS > 0: HS loads leave first, each of the others behind the evaluation of the load HS places before it (pinned with
+        // scheduling barriers); 0: all U requested in source order and hipcc places them.  Over a table that streams from HBM
+        // four-then-one-by-one is the fastest (64 passes over 10M rows, one box, TB/s: 2: 5.74, 3: 6.64, 4: 7.17, 5: 7.13, 6: 7.09,
+        // all 8 at once: 7.04; hipcc's own placement was 4 + 4 in round 3 and became 6 + 2 when the code after the loop changed:
+        // 7.17 -> 7.09); over a table that sits in the Infinity Cache more in flight is better (1M rows: 49.7 us with 4, 47.5 left
+        // to hipcc) -- so the instances for large tables pin 4 and the one-query launch for small tables does not
+        constexpr int H = (HS > 0 && HS < U) ? HS : U;
+#pragma unroll
+        for (int u = 0; u < H; ++u) load_row(u);
+        if constexpr (H < U) __builtin_amdgcn_sched_barrier(0);
         int sp[ROUNDS], ss[ROUNDS], sq[ROUNDS];
 #pragma unroll
         for (int rd = 0; rd < ROUNDS; ++rd) sp[rd] = ss[rd] = sq[rd] = 0;
@@ -634,6 +646,10 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
             sp[u / LPR] = mine ? tp : sp[u / LPR];
             ss[u / LPR] = mine ? ts : ss[u / LPR];
             sq[u / LPR] = mine ? tq : sq[u / LPR];
+            if constexpr (H < U) {
+                if (u + H < U) load_row(u + H);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 #pragma unroll
         for (int rd = 0; rd < ROUNDS; ++rd) {
