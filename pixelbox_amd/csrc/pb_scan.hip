@@ -18,6 +18,17 @@
 #pragma clang fp contract(off)
 
 using namespace pbk;
+#ifdef PB_CALL_TRACE
+// instrumented build: host-side time points of a one-query call (ns since the call's entry), averaged and printed at destroy
+static double g_ct_sum[8];
+static uint64_t g_ct_n;
+static std::chrono::steady_clock::time_point g_ct0;
+#define PB_CT_BEGIN() (g_ct0 = std::chrono::steady_clock::now())
+#define PB_CT(i) (g_ct_sum[i] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - g_ct0).count())
+#else
+#define PB_CT_BEGIN() ((void)0)
+#define PB_CT(i) ((void)0)
+#endif
 
 namespace {
 
@@ -492,6 +503,7 @@ int run_fast(pb_index *ix, uint32_t nq) {
         int rc = launch_filter(ix, n_wg, 0, nq);
         if (rc) return rc;
     }
+    PB_CT(2);
     if (ix->opt_profile) PB_HIP(hipEventRecord(ix->ev1, ix->stream));
     hipLaunchKernelGGL(k_select_rescore, dim3(nq), dim3(SEL_BLOCK), 0, ix->stream, ix->d_rows, ix->d_ids, ix->d_norms,
                        (int)ix->dim, ix->d_queries, ix->d_qp, ix->d_lut, ix->d_lists, ix->d_hdrs, n_wg, ix->r_ids,
@@ -894,6 +906,7 @@ int search_chunk(pb_index *ix, uint32_t cq, uint32_t k, double max_dist, const f
     const bool use_fast = use_dist || (ix->metric == 0 && (ix->opt_path == 0 || ix->opt_path == 2 || ix->opt_path == 3) && fast_dim(d));
     { int rcm = refresh_min_den(ix); if (rcm) return rcm; }
     make_qparams_batch(ix, hq, cq, k, max_dist, hp);
+    PB_CT(1);
     const bool default_shape = ix->opt_variant == 0 && ix->opt_waves == F_WAVES && ix->opt_wg_per_cu == 1 && ix->opt_grid == 0;
     if (cq == 1 && d == 256 && ix->metric == 0 && default_shape && (ix->opt_path == 0 || ix->opt_path == 2) && !multi_eligible(ix, cq)) {
         // the reference's call shape (one query per call, engine.rs:363-396) on the filter path: the query bytes and
@@ -929,7 +942,9 @@ int search_chunk(pb_index *ix, uint32_t cq, uint32_t k, double max_dist, const f
             ix->poll_pending = ix->argq_pending = false;  // nothing was launched that would stamp / consume them
             return rc;
         }
+        PB_CT(3);
         { int rcw = wait_headers(); if (rcw) return rcw; }
+        PB_CT(4);
         if (ix->opt_profile) {
             int rc2 = use_multi ? account_profile(ix, 1, 1) : account_profile(ix, cq, (ix->opt_mode == 1 || loop_mode(ix, cq) || (use_dist && ix->opt_mode == 2)) ? 1 : cq);
             if (rc2) return rc2;
@@ -1551,9 +1566,20 @@ int pb_index_search(pb_index *ix, const uint8_t *queries, uint32_t nq, uint32_t 
     PB_CHECK(k >= 1 && k <= PB_MAX_K, PB_ERR_INVALID, "pb_index_search: k = %u outside 1..%u", k, PB_MAX_K);
     PB_CHECK(nq == 0 || (queries && out_ids && out_dist && out_count), PB_ERR_INVALID, "pb_index_search: null buffer");
     if (nq == 0) return PB_OK;
+    PB_CT_BEGIN();
     std::lock_guard<std::mutex> lock(ix->mu);
     pb::DeviceGuard guard(ix->device);
-    return search_locked(ix, queries, nq, k, max_dist, out_ids, out_dist, out_count);
+    PB_CT(0);
+    const int rc_s = search_locked(ix, queries, nq, k, max_dist, out_ids, out_dist, out_count);
+    PB_CT(6);
+#ifdef PB_CALL_TRACE
+    if (++g_ct_n % 64 == 0) {
+        fprintf(stderr, "call trace (us, mean of 64): device guard %.2f | qparams %.2f | filter launched %.2f | select launched %.2f | results seen %.2f | return %.2f\n",
+                g_ct_sum[0] / 64, g_ct_sum[1] / 64, g_ct_sum[2] / 64, g_ct_sum[3] / 64, g_ct_sum[4] / 64, g_ct_sum[6] / 64);
+        for (double &x : g_ct_sum) x = 0;
+    }
+#endif
+    return rc_s;
 }
 
 int pb_index_search_device(pb_index *ix, const uint8_t *queries, uint32_t nq, uint32_t k, double max_dist,
