@@ -125,7 +125,8 @@ struct pb_index {
 
     bool env_static_tail = false;      // PB_STATIC_TAIL: the one-query filter launch without the ticketed tail (comparison)
     bool env_force_tickets = false;    // PB_FORCE_TAIL_TICKETS: the ticketed tail also under 4M rows (tests)
-    bool env_small_static = false;     // PB_SMALL_STATIC: under 4M rows, fixed strides per wave instead of workgroup tickets (comparison)
+    uint32_t env_steal_lead = 0;       // PB_STEAL_LEAD: chunks a request runs ahead of its chunk (experiments)
+    bool env_force_steal = false;      // PB_FORCE_STEAL: the chunked tail also under 2M rows (tests)
     bool env_exact_lane_rows = false;  // PB_EXACT_LANE_ROWS: the lane-per-row exhaustive kernel also for 256-byte cosine rows (comparison)
     int opt_second_chance = 0;         // PB_OPT_SECOND_CHANCE: 0 = cost model, 1 = always, 2 = never
     float sc_success = 1.0f;           // running success rate of the second chance on this index (optimistic start)
@@ -454,31 +455,58 @@ int run_fast(pb_index *ix, uint32_t nq) {
     if (ix->argq_pending) {
         // one 256-byte query, default launch shape: the query rides in the kernel arguments (k_scan_filter ARGQ)
         ix->argq_pending = false;
-        // (a one-query launch over a cache-sized table does NOT gain from the looped launch's shape for such tables, with
-        // or without tickets: 55.4 us either way at 1M rows, of which ~19 us do not depend on the table size;
-        // profiles/small_table_probe.py)
-        // the ticketed tail pays from ~4M rows on (10M: -5..8 us per call); on a small table its 4-tile tickets are coarse
-        // against the ~2 tail tiles a wave would take (1M rows: 60.3 us ticketed, 55.8 us with static shares)
-        if (ix->env_static_tail || (ix->n_rows < (4ull << 20) && !ix->env_force_tickets)) {
-            // static shares per workgroup, handed to its waves by tickets from an LDS counter (round 4: a wave of a 1M-row
-            // pass has 15 or 16 tiles of 2.4 us, fixed strides end with seven waves waiting for the eighth; 49.4 -> 47.5 us)
-            if (ix->env_small_static)
-                hipLaunchKernelGGL((k_scan_filter<16, 8, true, F_WAVES, 0, false, true>), dim3(n_wg, 1), dim3(F_WAVES * 64), 0,
-                                   ix->stream, ix->d_rows, ix->n_rows, ix->d_queries, ix->d_qp, ix->d_lists, ix->d_hdrs, 0, 1,
-                                   ix->d_queries, ix->d_qp, ix->argq, nullptr);
-            else
-                hipLaunchKernelGGL((k_scan_filter<16, 8, true, F_WAVES, 0, false, true, false, true>), dim3(n_wg, 1), dim3(F_WAVES * 64),
-                                   0, ix->stream, ix->d_rows, ix->n_rows, ix->d_queries, ix->d_qp, ix->d_lists, ix->d_hdrs, 0, 1,
-                                   ix->d_queries, ix->d_qp, ix->argq, nullptr);
-        } else {
-            if (ix->tail_dirty) {  // an earlier call failed between its ticketed launch and the launch that resets the tickets
-                PB_HIP(hipMemsetAsync(ix->d_tail, 0, (size_t)DYN_REGIONS * DYN_CTR_STRIDE * sizeof(uint32_t), ix->stream));
-                ix->tail_dirty = false;
-            }
+        // Three forms of the one-query launch (k_scan_filter ARGQ):
+        //   STEAL (from 2M rows): a workgroup's own 7/8 share by LDS tickets, the rest of the table in chunks from per-region
+        //     device counters, one request per workgroup and chunk (pb_scan_kernels.h).  One box, us per call, this form /
+        //     the next: 10M rows 380 / 389 (round 2's tickets), 4M 172 / 175, 2M 101 / 102, 1M 73.8 / 72.8, 500k 57.2 / 55.4 --
+        //     a small table does not earn the requests back (PB_FORCE_STEAL: this form at any size, for tests);
+        //   static (under 2M rows, or PB_STATIC_TAIL): equal shares per workgroup, LDS tickets inside it, nothing crosses
+        //     workgroups;
+        //   PB_FORCE_TAIL_TICKETS: round 2's form -- fixed strides per wave, the last eighth by one device ticket per wave and
+        //     4 tiles (what tables from 4M rows up used until round 4).
+        const uint64_t n_super = (ix->n_rows + 31) / 32;
+        StealGeo sg{};
+        sg.S = (uint32_t)((n_super - n_super / 8) / (uint64_t)n_wg);
+        const uint64_t pool = n_super - (uint64_t)sg.S * n_wg;
+        sg.n_reg = std::min<uint32_t>((uint32_t)(n_wg + 7) / 8, (uint32_t)DYN_REGIONS);
+        const uint64_t per = (pool + sg.n_reg - 1) / sg.n_reg;
+        sg.shift = 3;  // 8 tiles = one per wave
+        while (((per + (1ull << sg.shift) - 1) >> sg.shift) > (uint64_t)ST_MAXC - 6) ++sg.shift;
+        sg.per_reg = ((per + (1ull << sg.shift) - 1) >> sg.shift) << sg.shift;
+        // a request leads its chunk by one chunk of tile time; an 8-tile chunk is ONE tile time (~2.4 us), about what the atomic's
+        // round trip takes under load, so the smallest chunks are asked for two ahead
+        sg.lead = sg.shift == 3 ? (ix->env_steal_lead ? ix->env_steal_lead : 2u) : 1u;
+        const bool can_steal = sg.S >= sg.lead * (1u << sg.shift) && n_wg >= 8 && (ix->n_rows >= (2ull << 20) || ix->env_force_steal);
+        const bool old_tickets = ix->env_force_tickets;
+        if (ix->tail_dirty) {  // an earlier call failed between a ticketed launch and the launch that resets the counters
+            PB_HIP(hipMemsetAsync(ix->d_tail, 0, (size_t)DYN_REGIONS * DYN_CTR_STRIDE * sizeof(uint32_t), ix->stream));
+            ix->tail_dirty = false;
+        }
+        if (old_tickets) {
             ix->tail_dirty = true;
             hipLaunchKernelGGL((k_scan_filter<16, 8, true, F_WAVES, 0, false, true, true, false, 4>), dim3(n_wg, 1), dim3(F_WAVES * 64),
                                0, ix->stream, ix->d_rows, ix->n_rows, ix->d_queries, ix->d_qp, ix->d_lists, ix->d_hdrs, 0, 1,
-                               ix->d_queries, ix->d_qp, ix->argq, ix->d_tail);
+                               ix->d_queries, ix->d_qp, ix->argq, ix->d_tail, StealGeo{});
+            dyn = true;
+        } else if (ix->env_static_tail || !can_steal) {
+            if (ix->n_rows < (4ull << 20))  // load placement left to hipcc under 4M rows, pinned above (k_scan_filter HS)
+                hipLaunchKernelGGL((k_scan_filter<16, 8, true, F_WAVES, 0, false, true, false, true>), dim3(n_wg, 1), dim3(F_WAVES * 64),
+                                   0, ix->stream, ix->d_rows, ix->n_rows, ix->d_queries, ix->d_qp, ix->d_lists, ix->d_hdrs, 0, 1,
+                                   ix->d_queries, ix->d_qp, ix->argq, nullptr, StealGeo{});
+            else
+                hipLaunchKernelGGL((k_scan_filter<16, 8, true, F_WAVES, 0, false, true, false, true, 4>), dim3(n_wg, 1), dim3(F_WAVES * 64),
+                                   0, ix->stream, ix->d_rows, ix->n_rows, ix->d_queries, ix->d_qp, ix->d_lists, ix->d_hdrs, 0, 1,
+                                   ix->d_queries, ix->d_qp, ix->argq, nullptr, StealGeo{});
+        } else {
+            ix->tail_dirty = true;
+            if (ix->n_rows < (4ull << 20))
+                hipLaunchKernelGGL((k_scan_filter<16, 8, true, F_WAVES, 0, false, true, false, true, 0, true>), dim3(n_wg, 1),
+                                   dim3(F_WAVES * 64), 0, ix->stream, ix->d_rows, ix->n_rows, ix->d_queries, ix->d_qp, ix->d_lists,
+                                   ix->d_hdrs, 0, 1, ix->d_queries, ix->d_qp, ix->argq, ix->d_tail, sg);
+            else
+                hipLaunchKernelGGL((k_scan_filter<16, 8, true, F_WAVES, 0, false, true, false, true, 4, true>), dim3(n_wg, 1),
+                                   dim3(F_WAVES * 64), 0, ix->stream, ix->d_rows, ix->n_rows, ix->d_queries, ix->d_qp, ix->d_lists,
+                                   ix->d_hdrs, 0, 1, ix->d_queries, ix->d_qp, ix->argq, ix->d_tail, sg);
             dyn = true;
         }
         PB_HIP(hipGetLastError());
@@ -1357,7 +1385,8 @@ int pb_index_create(pb_index **out, int device, uint32_t dim, uint64_t capacity_
     ix->env_exact_lane_rows = getenv("PB_EXACT_LANE_ROWS") != nullptr;
     ix->env_static_tail = getenv("PB_STATIC_TAIL") != nullptr;
     ix->env_force_tickets = getenv("PB_FORCE_TAIL_TICKETS") != nullptr;
-    ix->env_small_static = getenv("PB_SMALL_STATIC") != nullptr;
+    ix->env_steal_lead = getenv("PB_STEAL_LEAD") ? (uint32_t)atoi(getenv("PB_STEAL_LEAD")) : 0u;
+    ix->env_force_steal = getenv("PB_FORCE_STEAL") != nullptr;
     ix->env_no_poll = getenv("PB_NO_POLL") != nullptr;
     ix->env_loop_static = getenv("PB_LOOP_STATIC") != nullptr;
     make_lut(ix->lut);

@@ -482,20 +482,37 @@ constexpr int DYN_DEN = PB_DYN_DEN;  // k_scan_filter DYN: 1/DYN_DEN of the tabl
 constexpr int DYN_CH = PB_DYN_CH;    // super-tiles per ticket
 constexpr int DYN_REGIONS = 32;     // ticket counters
 constexpr int DYN_CTR_STRIDE = 64;  // uint32 between counters (256 B: different L2 channels)
+// STEAL (one-query launch, with WGT): a workgroup's own share (tickets below sg.S) is 7/8 of an equal split; the rest of the
+// table is a pool, cut into DYN_REGIONS regions (one per group of 8 consecutive workgroups = one workgroup of every XCD each)
+// and handed out in CHUNKS of 2^sg.shift tiles through one device-scope counter per region.  A chunk is requested by ONE
+// wave for the whole workgroup, a chunk ahead of its use (the wave that draws the first ticket of chunk c - 1 asks for chunk c:
+// one atomic per 8+ tiles instead of one per wave and tile, issued before that wave's own loads, so its round trip hides
+// behind them), and published to the other waves through an LDS table indexed by the workgroup's chunk number -- a wave whose
+// ticket falls into a chunk that is not there yet spins on LDS, never on memory.  Fast workgroups (XCDs 1 and 3 finish a
+// 1M-row pass ~8 % before 0 and 6, profiles/r04_scan_stamps.txt) take more chunks.  k_select_rescore zeroes the counters.
+struct StealGeo {
+    uint32_t S;        // tickets of a workgroup's own share (tile = ticket * grid + workgroup)
+    uint32_t shift;    // log2(tiles per chunk)
+    uint32_t n_reg;    // regions of the pool
+    uint32_t lead;     // a chunk is requested `lead` chunks ahead of its first ticket (1 or 2)
+    unsigned long long per_reg;  // tiles per region (a multiple of the chunk)
+};
+constexpr int ST_MAXC = 256;  // chunks a workgroup can take (the host picks the chunk size so that a region has fewer)
 // WGT (with LOOPQ): the waves of a workgroup take the workgroup's super-tiles by tickets from an LDS counter instead of
 // fixed strides, and the per-wave buffers are double-buffered by query parity.  The workgroup list of query i is merged
 // by wave 0 AFTER the barrier that ends query i while the other waves are already streaming query i + 1 -- wave 0 simply
 // takes fewer tickets of that query -- so the merge (and the second barrier that protected the buffers) leaves the
 // critical path: it is ~1 % of a pass over 10M rows but ~5 % of one over a 1.25M-row shard (8-GPU strong scaling).
 template <int LPR, int U = 8, bool NT = true, int NW = F_WAVES, int MAPB = 0, bool LOOPQ = false, bool ARGQ = false, bool DYN = false,
-          bool WGT = false, int HS = 0>
+          bool WGT = false, int HS = 0, bool STEAL = false>
 __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__restrict__ rows, uint64_t n_rows,
                                                          const uint8_t *queries, const QParams *qp,
                                                          uint64_t *__restrict__ lists,
                                                          ListHdr *__restrict__ hdrs, int q_base, int nq_loop,
                                                          uint8_t *stage_q, QParams *stage_p, const QArg256 qarg,
-                                                         uint32_t *tail_ctr = nullptr) {
+                                                         uint32_t *tail_ctr = nullptr, const StealGeo sg = StealGeo{}) {
     static_assert(!ARGQ || (LPR == 16 && !LOOPQ), "ARGQ: one 256-byte query per launch");
+    static_assert(!STEAL || (WGT && ARGQ), "STEAL: the one-query launch with workgroup tickets");
     static_assert(!DYN || (ARGQ && MAPB == 0), "DYN: the one-query launch only");
     static_assert(!WGT || ((LOOPQ || ARGQ) && MAPB == 0 && !DYN), "WGT: the looped launch, or the one-query launch with static shares");
     constexpr int D = LPR * 16;
@@ -507,6 +524,7 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
     __shared__ uint64_t s_buf[NPAR][NW][F_CAPW];
     __shared__ float s_drop[NPAR][NW];
     __shared__ uint32_t s_ticket[2];
+    __shared__ uint32_t s_chunk[STEAL ? ST_MAXC : 1];  // STEAL: 1 + the region counter's answer for the workgroup's c-th chunk (0: not there yet)
 
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: loop bounds and LDS bases stay in SGPRs
@@ -515,6 +533,8 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
     const int g = lane / LPR;
     if constexpr (WGT) {
         if (threadIdx.x < 2) s_ticket[threadIdx.x] = 0u;
+        if constexpr (STEAL)
+            for (int i = threadIdx.x; i < ST_MAXC; i += NW * WAVE) s_chunk[i] = 0u;
         __syncthreads();
     }
   for (int qi = 0; qi < (LOOPQ ? nq_loop : 1); ++qi) {
@@ -598,15 +618,52 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
         }
     }
     uint32_t wg_pend = 0;
+    // STEAL state: the region of this workgroup, and the chunk request this wave has in flight (st_rq, for chunk st_rc)
+    uint64_t st_lo = 0, st_hi = 0;
+    uint32_t *st_ctr = nullptr;
+    uint32_t st_rq = 0, st_rc = 0;
+    bool st_req = false;
+    // ticket -> tile; asks for a chunk on the way if this ticket is the one that does (see above)
+    auto st_resolve = [&](uint32_t t) -> uint64_t {
+        const uint32_t cht = 1u << sg.shift, from = sg.S - sg.lead * cht;
+        st_req = t >= from && ((t - from) & (cht - 1u)) == 0u && ((t - from) >> sg.shift) < (uint32_t)ST_MAXC;
+        if (st_req) {
+            st_rc = (t - from) >> sg.shift;
+            if (lane == 0) st_rq = atomicAdd(st_ctr, 1u);
+        }
+        if (t < sg.S) return (uint64_t)t * gridDim.x + blockIdx.x;
+        const uint32_t j = t - sg.S, c = j >> sg.shift;
+        if (c >= (uint32_t)ST_MAXC) return ~0ull;  // past any region's last chunk (host geometry)
+        uint32_t e;
+        while ((e = __hip_atomic_load(&s_chunk[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0u) __builtin_amdgcn_s_sleep(1);
+        const uint64_t tile = st_lo + ((uint64_t)(e - 1u) << sg.shift) + (j & (cht - 1u));
+        return tile < st_hi ? tile : ~0ull;
+    };
+    auto st_publish = [&]() {
+        if (st_req) {
+            const uint32_t v = __builtin_amdgcn_readfirstlane(st_rq);
+            if (lane == 0) __hip_atomic_store(&s_chunk[st_rc], v + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            st_req = false;
+        }
+    };
     if constexpr (WGT) {
         if (lane == 0) wg_pend = atomicAdd(&s_ticket[par], 1u);
-        s = (uint64_t)__builtin_amdgcn_readfirstlane(wg_pend) * gridDim.x + blockIdx.x;
+        if constexpr (STEAL) {
+            const uint32_t reg = (blockIdx.x >> 3) % sg.n_reg;
+            st_lo = (uint64_t)sg.S * gridDim.x + (uint64_t)reg * sg.per_reg;
+            st_hi = st_lo + sg.per_reg < n_super ? st_lo + sg.per_reg : n_super;
+            st_ctr = tail_ctr + reg * DYN_CTR_STRIDE;
+            s = st_resolve((uint32_t)__builtin_amdgcn_readfirstlane(wg_pend));
+            if (s == ~0ull) st_publish();
+        } else {
+            s = (uint64_t)__builtin_amdgcn_readfirstlane(wg_pend) * gridDim.x + blockIdx.x;
+        }
     }
     PB_STAMP(1);
 #ifdef PB_SCAN_STAMP
     bool first_tile = true;
 #endif
-    for (; DYN ? (s != ~0ull) : (s < n_super);) {
+    for (; (DYN || STEAL) ? (s != ~0ull) : (s < n_super);) {
         if constexpr (WGT) {
             if (lane == 0) wg_pend = atomicAdd(&s_ticket[par], 1u);  // the next ticket, requested ahead of this tile's loads
         }
@@ -631,6 +688,10 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
         constexpr int H = (HS > 0 && HS < U) ? HS : U;
 #pragma unroll
         for (int u = 0; u < H; ++u) load_row(u);
+        if constexpr (STEAL) {  // the chunk this wave asked for (before these loads) goes to the workgroup's table
+            __builtin_amdgcn_sched_barrier(0);
+            st_publish();
+        }
         if constexpr (H < U) __builtin_amdgcn_sched_barrier(0);
         int sp[ROUNDS], ss[ROUNDS], sq[ROUNDS];
 #pragma unroll
@@ -693,6 +754,9 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
             } else {
                 s = next_dyn();
             }
+        } else if constexpr (STEAL) {
+            s = st_resolve((uint32_t)__builtin_amdgcn_readfirstlane(wg_pend));
+            if (s == ~0ull) st_publish();  // leaving: the chunk it asked for on the way out is still owed to the others
         } else if constexpr (WGT) {
             s = (uint64_t)__builtin_amdgcn_readfirstlane(wg_pend) * gridDim.x + blockIdx.x;
         } else {
@@ -979,7 +1043,6 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
     // ---- candidates: every listed entry with cos_filter >= cut (from the registers loaded above)
 #pragma unroll
     for (int j = 0; j < SEL_SLOTS; ++j) {
-        const int i = tid + j * SEL_BLOCK;
         if (my_key[j] != ~0ull && filter_key_cos(my_key[j]) >= cut) {
             const uint32_t pos = atomicAdd(&s_u[2], 1u);
             if (pos < SEL_MAX_CAND) s_key[pos] = my_key[j];

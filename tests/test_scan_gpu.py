@@ -105,9 +105,11 @@ def test_uniform_sizes(n, path):
 
 @pytest.mark.parametrize("n", [31, 32 * 2048 + 5, 300007, 2100001])
 def test_one_query_calls_hand_out_the_table_tail_by_tickets(n, monkeypatch):
-    # a one-query call's filter launch gives the last eighth of the table out in ticketed chunks (k_scan_filter DYN):
-    # neighbours planted at both ends of the static share, across the ticket regions and in the last rows must all be
-    # found, twice in a row (the counters are cleared between launches), and PB_STATIC_TAIL=1 gives the same answer
+    # a one-query call's filter launch gives the last eighth of the table out dynamically -- in chunks a workgroup requests
+    # from per-region counters and shares among its waves through LDS (k_scan_filter STEAL, PB_FORCE_STEAL: tables under 2M
+    # rows take static shares by default), or, in round 2's form, by one ticket per wave (DYN, PB_FORCE_TAIL_TICKETS):
+    # neighbours planted at both ends of the static share, across the regions and in the last rows must all be found, three
+    # times in a row (the counters are cleared between launches), and the static form gives the same answer
     rng = np.random.default_rng(4242 + n)
     rows = rng.integers(0, 256, size=(n, 256), dtype=np.uint8)
     ids = np.arange(n, dtype=np.int64) * 3 + 1
@@ -117,11 +119,12 @@ def test_one_query_calls_hand_out_the_table_tail_by_tickets(n, monkeypatch):
     for j, r in enumerate(spots):
         rows[r] = q
         rows[r, j % 256] ^= np.uint8(1 + j % 7)
-    monkeypatch.setenv("PB_FORCE_TAIL_TICKETS", "1")  # tables under 4M rows take static shares by default
-    ix = make_index(rows, ids)
-    for _ in range(3):
-        check_against_oracle(ix, rows, ids, q[None, :])
-    monkeypatch.delenv("PB_FORCE_TAIL_TICKETS")
+    for force in ("PB_FORCE_STEAL", "PB_FORCE_TAIL_TICKETS"):
+        monkeypatch.setenv(force, "1")
+        ix = make_index(rows, ids)
+        for _ in range(3):
+            check_against_oracle(ix, rows, ids, q[None, :])
+        monkeypatch.delenv(force)
     check_against_oracle(make_index(rows, ids), rows, ids, q[None, :])  # the default for this size
     monkeypatch.setenv("PB_STATIC_TAIL", "1")
     check_against_oracle(make_index(rows, ids), rows, ids, q[None, :])
