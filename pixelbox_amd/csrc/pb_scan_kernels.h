@@ -524,6 +524,7 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
     __shared__ uint64_t s_buf[NPAR][NW][F_CAPW];
     __shared__ float s_drop[NPAR][NW];
     __shared__ uint32_t s_ticket[2];
+    __shared__ uint32_t s_node[8];  // one-query launch: arrival counters of the list-merging tree (4 pairs, 2 quads, 1 root)
     __shared__ uint32_t s_chunk[STEAL ? ST_MAXC : 1];  // STEAL: 1 + the region counter's answer for the workgroup's c-th chunk (0: not there yet)
 
     const int lane = lane_id();
@@ -533,6 +534,7 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
     const int g = lane / LPR;
     if constexpr (WGT) {
         if (threadIdx.x < 2) s_ticket[threadIdx.x] = 0u;
+        if (threadIdx.x < 8) s_node[threadIdx.x] = 0u;
         if constexpr (STEAL)
             for (int i = threadIdx.x; i < ST_MAXC; i += NW * WAVE) s_chunk[i] = 0u;
         __syncthreads();
@@ -768,6 +770,47 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
         const uint64_t first_out = wave_finish_list(buf, cnt);
         if (first_out != ~0ull) dropped = filter_key_cos(first_out);  // >= thr: everything buffered had passed it
     }
+    if constexpr (ARGQ && WGT && NW == 8) {
+        // One query per launch: no barrier and no single merging wave -- an arrival tree.  A wave leaves its sorted list and
+        // its bound in LDS and takes a number at its pair's node; the SECOND to arrive merges the two lists (one bitonic
+        // merge, 0.25 us) and carries the result to the next node.  Behind the workgroup's last wave there are its own
+        // sort and three merges instead of a barrier and seven (stamps: 2.1 -> ~1.2 us).
+        int slot = wave;          // where the list this wave carries sits in s_buf
+        float carried = dropped;  // the bound that goes with it
+        uint64_t key = ~0ull;
+        bool last = true;
+#pragma unroll
+        for (int lv = 0; lv < 3; ++lv) {
+            if (lane == 0) s_drop[par][slot] = carried;
+            uint32_t pos = 0;
+            if (lane == 0) pos = atomicAdd(&s_node[(lv == 0 ? 0 : (lv == 1 ? 4 : 6)) + (wave >> (lv + 1))], 1u);
+            pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
+            if (pos == 0u) {  // the partner is still streaming: it will find this list here
+                last = false;
+                break;
+            }
+            const int lo = (wave >> (lv + 1)) << (lv + 1), hi = lo + (1 << lv);
+            key = wave_merge64(lane < F_KW ? s_buf[par][lo][lane] : s_buf[par][hi][63 - lane]);
+            const uint64_t first_out = __shfl((unsigned long long)key, F_KW);
+            carried = fmaxf(s_drop[par][lo], s_drop[par][hi]);
+            if (first_out != ~0ull) carried = fmaxf(carried, filter_key_cos(first_out));
+            if (lv < 2 && lane < F_KW) s_buf[par][lo][lane] = key;
+            slot = lo;
+        }
+        PB_STAMP(4);
+        if (last) {
+            const int total = __popcll(__ballot(lane < F_KWG && key != ~0ull));
+            uint64_t *out = lists + ((size_t)q * gridDim.x + blockIdx.x) * F_KWG;
+            if (lane < F_KWG) out[lane] = key;  // every slot: the unused ones hold ~0, which is how k_select_rescore tells them
+            if (lane == 0) {
+                ListHdr h;
+                h.count = (uint32_t)total;
+                h.dropped = carried;
+                hdrs[(size_t)q * gridDim.x + blockIdx.x] = h;
+            }
+            PB_STAMP(6);
+        }
+    } else {
     if (lane == 0) s_drop[par][wave] = dropped;
     PB_STAMP(4);
     __syncthreads();
@@ -790,6 +833,7 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
             hdrs[(size_t)q * gridDim.x + blockIdx.x] = h;
         }
         PB_STAMP(6);
+    }
     }
     if constexpr (LOOPQ && !WGT) __syncthreads();  // the wave buffers are reused by the next query (WGT: the other parity's are)
   }
