@@ -130,6 +130,39 @@ def test_one_query_calls_hand_out_the_table_tail_by_tickets(n, monkeypatch):
     check_against_oracle(make_index(rows, ids), rows, ids, q[None, :])
 
 
+def test_one_query_calls_repeat_exactly_in_every_form(monkeypatch):
+    # The dynamic forms of the one-query launch depend on timing (which workgroup gets which chunk, in which order requests
+    # are answered), so one passing call proves little: a first version of the chunked form let requests overtake each other
+    # and 2-3 % of calls over this table silently missed a row of the pool -- certified, wrong.  150 calls per form, four
+    # queries (one with ~150 planted near-duplicates), every answer compared with the oracle's.
+    n = 2100001
+    rng = np.random.default_rng(4242 + n)
+    rows = rng.integers(0, 256, size=(n, 256), dtype=np.uint8)
+    ids = np.arange(n, dtype=np.int64) * 3 + 1
+    q = rng.integers(0, 256, size=256, dtype=np.uint8)
+    spots = np.unique(np.concatenate([np.arange(8), n - 1 - np.arange(40), (n * 7 // 8 + np.arange(-20, 20) * 32) % n,
+                                      rng.integers(0, n, size=60)]))
+    for j, r in enumerate(spots):
+        rows[r] = q
+        rows[r, j % 256] ^= np.uint8(1 + j % 7)
+    qs = np.concatenate([q[None, :], rng.integers(0, 256, size=(3, 256), dtype=np.uint8)])
+    want = [oracle.scan_topk(x, rows, ids, 100, 1e3) for x in qs]
+    for form in (None, "PB_FORCE_TAIL_TICKETS", "PB_STATIC_TAIL"):  # None: the default for this size, the chunked form
+        if form:
+            monkeypatch.setenv(form, "1")
+        ix = make_index(rows, ids)
+        for rep in range(150):
+            qi = rep % len(qs)
+            gi, gd, gc = ix.search(qs[qi:qi + 1], 100, 1e3)
+            c = int(gc[0])
+            assert c == len(want[qi][0]), (form, rep, qi)
+            assert np.array_equal(gi[0, :c], want[qi][0]), (form, rep, qi)
+            assert np.array_equal(gd[0, :c].view(np.uint32), want[qi][1].view(np.uint32)), (form, rep, qi)
+        assert ix.stats().stamp_timeouts == 0
+        if form:
+            monkeypatch.delenv(form)
+
+
 @pytest.mark.parametrize("k", [1, 7, 100, 256])
 def test_k_values(k):
     rng = np.random.default_rng(5)
