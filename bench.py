@@ -617,7 +617,8 @@ def bench_sweep(args, torch, device):
         res[name] = {"kernel_ms": round(kms, 4), "kernel_GB/s": round(1_000_000 * d / (kms * 1e-3) / 1e9, 1),
                      "call_ms_median": round(sorted(wall)[len(wall) // 2], 4)}
     # the same table, 64 batch-1 queries per call (one looped launch, a pass per query): what a pass costs without a
-    # launch of its own (a lone launch's ~19 us of launch, ramp-up and drain do not depend on the table size)
+    # launch of its own (a lone launch's ~11 us of launch, ramp-up, spread between workgroups and list ends do not depend on the
+    # table size: profiles/r04_scan_stamps.txt)
     ix.set_option(capi.PB_OPT_SCAN_LAUNCH, 2)
     gbs_l, ms_l, st_l = timed(ix, q[3], 4)
     res["sixty_four_queries_per_call"] = {"kernel_ms_per_pass": round(ms_l / B, 4), "kernel_GB/s": round(gbs_l, 1),

@@ -120,11 +120,11 @@ struct pb_index {
     bool env_no_poll = false;       // PB_NO_POLL: wait for the stream instead of the completion stamp (comparison)
     uint32_t stamp_timeouts_row = 0;  // consecutive stamp time-outs
     uint32_t no_poll_calls = 0;       // one-query calls left on the stream wait after three time-outs in a row
-    bool tail_dirty = false;        // a ticketed (DYN) filter launch was queued without the k_select_rescore that clears d_tail
+    bool tail_dirty = false;        // a filter launch that uses the counters in d_tail (STEAL / DYN) was queued without the k_select_rescore that clears them
     bool env_loop_static = false;   // PB_LOOP_STATIC: the looped filter launch with fixed tile strides per wave (comparison)
 
-    bool env_static_tail = false;      // PB_STATIC_TAIL: the one-query filter launch without the ticketed tail (comparison)
-    bool env_force_tickets = false;    // PB_FORCE_TAIL_TICKETS: the ticketed tail also under 4M rows (tests)
+    bool env_static_tail = false;      // PB_STATIC_TAIL: the one-query filter launch with static shares per workgroup at any size (comparison)
+    bool env_force_tickets = false;    // PB_FORCE_TAIL_TICKETS: round 2's form of the dynamic tail (one device ticket per wave), at any size (comparison, tests)
     uint32_t env_steal_lead = 0;       // PB_STEAL_LEAD: chunks a request runs ahead of its chunk (experiments)
     bool env_force_steal = false;      // PB_FORCE_STEAL: the chunked tail also under 2M rows (tests)
     bool env_exact_lane_rows = false;  // PB_EXACT_LANE_ROWS: the lane-per-row exhaustive kernel also for 256-byte cosine rows (comparison)
