@@ -118,6 +118,7 @@ struct pb_index {
     uint32_t done_seq = 0;
     bool poll_pending = false;      // the select launch of this call carries a stamp
     bool env_no_poll = false;       // PB_NO_POLL: wait for the stream instead of the completion stamp (comparison)
+    int64_t poll_timeout_us = 20000;  // PB_POLL_TIMEOUT_US: how long a one-query call polls for its result granules before it waits for the stream (tests: 0)
     uint32_t stamp_timeouts_row = 0;  // consecutive stamp time-outs
     uint32_t no_poll_calls = 0;       // one-query calls left on the stream wait after three time-outs in a row
     bool tail_dirty = false;        // a filter launch that uses the counters in d_tail (STEAL / DYN) was queued without the k_select_rescore that clears them
@@ -876,7 +877,8 @@ int search_chunk(pb_index *ix, uint32_t cq, uint32_t k, double max_dist, const f
                 while (__atomic_load_n(&g[4 * slot + 3], __ATOMIC_ACQUIRE) != want) {
                     if (late) return false;
                     __builtin_ia32_pause();
-                    if ((++spins & 4095u) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) {
+                    if (((++spins & 4095u) == 0u || ix->poll_timeout_us < 100) &&
+                        std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(ix->poll_timeout_us)) {
                         late = true;
                         return false;
                     }
@@ -1388,6 +1390,7 @@ int pb_index_create(pb_index **out, int device, uint32_t dim, uint64_t capacity_
     ix->env_steal_lead = getenv("PB_STEAL_LEAD") ? (uint32_t)atoi(getenv("PB_STEAL_LEAD")) : 0u;
     ix->env_force_steal = getenv("PB_FORCE_STEAL") != nullptr;
     ix->env_no_poll = getenv("PB_NO_POLL") != nullptr;
+    if (getenv("PB_POLL_TIMEOUT_US")) ix->poll_timeout_us = std::max<int64_t>(0, atoll(getenv("PB_POLL_TIMEOUT_US")));
     ix->env_loop_static = getenv("PB_LOOP_STATIC") != nullptr;
     make_lut(ix->lut);
     auto body = [&]() -> int {

@@ -163,6 +163,25 @@ def test_one_query_calls_repeat_exactly_in_every_form(monkeypatch):
             monkeypatch.delenv(form)
 
 
+def test_one_query_calls_that_give_up_polling_still_answer(monkeypatch):
+    # a one-query call polls pinned memory for its result granules; on a busy GPU they may be late: after the time-out the
+    # call waits for the stream and reads the same granules, three time-outs in a row rest the polling for 256 calls
+    # (ordinary result arrays), then it is tried again.  PB_POLL_TIMEOUT_US=0 makes every polled call time out.
+    monkeypatch.setenv("PB_POLL_TIMEOUT_US", "0")
+    rng = np.random.default_rng(77)
+    rows = rng.integers(0, 256, size=(70001, 256), dtype=np.uint8)
+    ids = np.arange(70001, dtype=np.int64) * 2 + 5
+    qs = rng.integers(0, 256, size=(4, 256), dtype=np.uint8)
+    ix = make_index(rows, ids)
+    for rep in range(270):
+        if rep < 12 or rep % 40 == 0 or rep > 258:
+            check_against_oracle(ix, rows, ids, qs[rep % 4][None, :])
+        else:
+            ix.search(qs[rep % 4][None, :], 100, 1e3)
+    st = ix.stats()
+    assert 3 <= st.stamp_timeouts <= 12, st.stamp_timeouts  # 3, a rest of 256 calls, then again
+
+
 @pytest.mark.parametrize("k", [1, 7, 100, 256])
 def test_k_values(k):
     rng = np.random.default_rng(5)
