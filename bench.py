@@ -601,21 +601,37 @@ def bench_sweep(args, torch, device):
     ix.search(q1[:1], k, args.max_dist)
     res = {}
     for name, do_evict in (("warm", False), ("cold", True)):
+        # kernel time: PB_OPT_PROFILE attaches the timing events to the filter dispatch itself (a profiled launch goes through
+        # hipExtLaunchKernelGGL, which costs the HOST more), so the call's wall time is taken in a second loop without it
         ix.stats(reset=True)
         ix.set_option(capi.PB_OPT_PROFILE, 1)
-        wall = []
         for i in range(16):
+            if do_evict:
+                evict.fill_(i)
+                torch.cuda.synchronize()
+            ix.search(q1[i:i + 1], k, args.max_dist)
+        ix.set_option(capi.PB_OPT_PROFILE, 0)
+        st = ix.stats()
+        kms = st.profiled_ms / max(1, st.profiled_launches)
+        wall, wall_py = [], []
+        for i in range(16):
+            call, _, _, _ = ix.prepared_search(q1[16 + i:17 + i], k, args.max_dist)  # the C call on pre-converted arguments
             if do_evict:
                 evict.fill_(i)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            ix.search(q1[i:i + 1], k, args.max_dist)
+            call()
             wall.append((time.perf_counter() - t0) * 1e3)
-        ix.set_option(capi.PB_OPT_PROFILE, 0)
-        st = ix.stats()
-        kms = st.profiled_ms / max(1, st.profiled_launches)
+            if do_evict:
+                evict.fill_(i)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ix.search(q1[32 + i:33 + i], k, args.max_dist)
+            wall_py.append((time.perf_counter() - t0) * 1e3)
         res[name] = {"kernel_ms": round(kms, 4), "kernel_GB/s": round(1_000_000 * d / (kms * 1e-3) / 1e9, 1),
-                     "call_ms_median": round(sorted(wall)[len(wall) // 2], 4)}
+                     "frac_of_hbm_peak": round(1_000_000 * d / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "call_ms_median": round(sorted(wall)[len(wall) // 2], 4),
+                     "call_ms_median_python": round(sorted(wall_py)[len(wall_py) // 2], 4)}
     # the same table, 64 batch-1 queries per call (one looped launch, a pass per query): what a pass costs without a
     # launch of its own (a lone launch's ~11 us of launch, ramp-up, spread between workgroups and list ends do not depend on the
     # table size: profiles/r04_scan_stamps.txt)
@@ -625,7 +641,8 @@ def bench_sweep(args, torch, device):
                                           "frac_of_hbm_peak": round(gbs_l / HBM_PEAK_GBS, 4)}
     res["note"] = ("BASELINE configs[1]: 1M x 256 u8, batch-1 query, one launch per query; the 256 MB table fits the 256 MiB "
                    "Infinity Cache, so 'warm' (passes back to back) is a cache number and only 'cold' (512 MiB written between "
-                   "queries) is an HBM number")
+                   "queries) is an HBM number; kernel_ms: events attached to the filter dispatch (what a kernel trace reports); "
+                   "call_ms_median: the C call on pre-converted arguments, as roofline_single_call.ms_per_call")
     out["scan_1m"] = res
     return out
 

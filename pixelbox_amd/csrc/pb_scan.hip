@@ -12,6 +12,8 @@
 #include <unordered_set>
 #include <vector>
 
+#include <hip/hip_ext.h>
+
 #include "pb_common.h"
 #include "pb_scan_kernels.h"
 
@@ -72,6 +74,7 @@ struct pb_index {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed_by_launch = false;   // this call's filter launch carries ev0 / ev1 itself (PB_LAUNCH_TIMED)
     int n_cu = 256;
 
     // search workspace (device)
@@ -363,6 +366,20 @@ void finish_qparams(const pb_index *ix, float acc, int64_t sum_a, int64_t sum_a2
 // Filter pass launch.  Default (mode 0): ONE launch per query, one workgroup per CU -- each query is its own pass
 // over HBM (queries that run concurrently would share row reads through L2 / Infinity Cache and the measured
 // bandwidth would no longer be an HBM number).  The tuning knobs (options 4-7) exist for profiles/scan_sweep.py.
+// A filter launch that is the ONLY one of its call (one-query calls, the looped launch): with PB_OPT_PROFILE the timing events
+// are attached to the dispatch itself (hipExtLaunchKernelGGL: start / stop from the packet's own timestamps, what a kernel
+// trace reports) instead of being recorded as packets of their own before and after it -- those brackets add the command
+// processor's hand-over between packets, ~2 us, which is nothing beside 22 ms of 64 passes but 5 % of a 1M-row pass (1M rows,
+// same run: 47.4 us by brackets, 45.2 us in the kernel trace, profiles/r04_full_kernel_stats.csv).
+#define PB_LAUNCH_TIMED(KERN, GRID, BLOCK, ...)                                                                    \
+    do {                                                                                                           \
+        if (ix->opt_profile) {                                                                                     \
+            hipExtLaunchKernelGGL(KERN, GRID, BLOCK, 0, ix->stream, ix->ev0, ix->ev1, 0, __VA_ARGS__);             \
+            ix->timed_by_launch = true;                                                                            \
+        } else {                                                                                                   \
+            hipLaunchKernelGGL(KERN, GRID, BLOCK, 0, ix->stream, __VA_ARGS__);                                     \
+        }                                                                                                          \
+    } while (0)
 template <int LPR, int U, bool NT, int NW, int MAPB>
 void launch_filter_t(pb_index *ix, int n_wg, uint32_t q_base, uint32_t nq) {
     constexpr int HS = (LPR == 16 && U == 8) ? 4 : 0;  // k_scan_filter: load placement
@@ -373,9 +390,9 @@ void launch_filter_t(pb_index *ix, int n_wg, uint32_t q_base, uint32_t nq) {
 // one launch, every workgroup answers the nq queries one after the other (k_scan_filter LOOPQ)
 template <int NW, int U = 8, int MAPB = 0, bool WGT = false>
 void launch_filter_loop(pb_index *ix, int n_wg, uint32_t q_base, uint32_t nq) {
-    hipLaunchKernelGGL((k_scan_filter<16, U, true, NW, MAPB, true, false, false, WGT, (U == 8 ? 4 : 0)>), dim3(n_wg, 1), dim3(NW * 64), 0, ix->stream,
-                       ix->d_rows, ix->n_rows, ix->d_queries, ix->d_qp, ix->d_lists, ix->d_hdrs, (int)q_base, (int)nq,
-                       (uint8_t *)nullptr, (QParams *)nullptr, QArg256{});
+    PB_LAUNCH_TIMED((k_scan_filter<16, U, true, NW, MAPB, true, false, false, WGT, (U == 8 ? 4 : 0)>), dim3(n_wg, 1), dim3(NW * 64),
+                    (const uint8_t *)ix->d_rows, (uint64_t)ix->n_rows, (const uint8_t *)ix->d_queries, (const QParams *)ix->d_qp, ix->d_lists,
+                    ix->d_hdrs, (int)q_base, (int)nq, (uint8_t *)nullptr, (QParams *)nullptr, QArg256{}, (uint32_t *)nullptr, StealGeo{});
 }
 
 int filter_u(const pb_index *ix) {
@@ -452,7 +469,9 @@ int run_fast(pb_index *ix, uint32_t nq) {
         const uint64_t n_super = (ix->n_rows + 63) / 64, want = (n_super + F_WAVES - 1) / F_WAVES;
         n_wg = (int)std::max<uint64_t>(1, std::min<uint64_t>(want, std::min<uint64_t>(F_MAX_WG, 2ull * ix->n_cu)));
     }
-    if (ix->opt_profile) PB_HIP(hipEventRecord(ix->ev0, ix->stream));
+    ix->timed_by_launch = false;
+    const bool one_launch = ix->argq_pending || cache_sized || loop_mode(ix, nq);  // PB_LAUNCH_TIMED carries the events
+    if (ix->opt_profile && !one_launch) PB_HIP(hipEventRecord(ix->ev0, ix->stream));
     if (ix->argq_pending) {
         // one 256-byte query, default launch shape: the query rides in the kernel arguments (k_scan_filter ARGQ)
         ix->argq_pending = false;
@@ -483,33 +502,26 @@ int run_fast(pb_index *ix, uint32_t nq) {
             PB_HIP(hipMemsetAsync(ix->d_tail, 0, (size_t)DYN_REGIONS * DYN_CTR_STRIDE * sizeof(uint32_t), ix->stream));
             ix->tail_dirty = false;
         }
+        // (the arguments of every form; the query and its constants ride in ix->argq)
+#define PB_ARGQ_ARGS(TAIL, GEO)                                                                                                    \
+    (const uint8_t *)ix->d_rows, (uint64_t)ix->n_rows, (const uint8_t *)ix->d_queries, (const QParams *)ix->d_qp, ix->d_lists, ix->d_hdrs, \
+        0, 1, ix->d_queries, ix->d_qp, ix->argq, TAIL, GEO
+        const dim3 grid(n_wg, 1), block(F_WAVES * 64);
+        const bool pin4 = ix->n_rows >= (4ull << 20);  // load placement (k_scan_filter HS): left to hipcc under 4M rows, pinned above
         if (old_tickets) {
             ix->tail_dirty = true;
-            hipLaunchKernelGGL((k_scan_filter<16, 8, true, F_WAVES, 0, false, true, true, false, 4>), dim3(n_wg, 1), dim3(F_WAVES * 64),
-                               0, ix->stream, ix->d_rows, ix->n_rows, ix->d_queries, ix->d_qp, ix->d_lists, ix->d_hdrs, 0, 1,
-                               ix->d_queries, ix->d_qp, ix->argq, ix->d_tail, StealGeo{});
+            PB_LAUNCH_TIMED((k_scan_filter<16, 8, true, F_WAVES, 0, false, true, true, false, 4>), grid, block, PB_ARGQ_ARGS(ix->d_tail, StealGeo{}));
             dyn = true;
         } else if (ix->env_static_tail || !can_steal) {
-            if (ix->n_rows < (4ull << 20))  // load placement left to hipcc under 4M rows, pinned above (k_scan_filter HS)
-                hipLaunchKernelGGL((k_scan_filter<16, 8, true, F_WAVES, 0, false, true, false, true>), dim3(n_wg, 1), dim3(F_WAVES * 64),
-                                   0, ix->stream, ix->d_rows, ix->n_rows, ix->d_queries, ix->d_qp, ix->d_lists, ix->d_hdrs, 0, 1,
-                                   ix->d_queries, ix->d_qp, ix->argq, nullptr, StealGeo{});
-            else
-                hipLaunchKernelGGL((k_scan_filter<16, 8, true, F_WAVES, 0, false, true, false, true, 4>), dim3(n_wg, 1), dim3(F_WAVES * 64),
-                                   0, ix->stream, ix->d_rows, ix->n_rows, ix->d_queries, ix->d_qp, ix->d_lists, ix->d_hdrs, 0, 1,
-                                   ix->d_queries, ix->d_qp, ix->argq, nullptr, StealGeo{});
+            if (!pin4) PB_LAUNCH_TIMED((k_scan_filter<16, 8, true, F_WAVES, 0, false, true, false, true>), grid, block, PB_ARGQ_ARGS((uint32_t *)nullptr, StealGeo{}));
+            else PB_LAUNCH_TIMED((k_scan_filter<16, 8, true, F_WAVES, 0, false, true, false, true, 4>), grid, block, PB_ARGQ_ARGS((uint32_t *)nullptr, StealGeo{}));
         } else {
             ix->tail_dirty = true;
-            if (ix->n_rows < (4ull << 20))
-                hipLaunchKernelGGL((k_scan_filter<16, 8, true, F_WAVES, 0, false, true, false, true, 0, true>), dim3(n_wg, 1),
-                                   dim3(F_WAVES * 64), 0, ix->stream, ix->d_rows, ix->n_rows, ix->d_queries, ix->d_qp, ix->d_lists,
-                                   ix->d_hdrs, 0, 1, ix->d_queries, ix->d_qp, ix->argq, ix->d_tail, sg);
-            else
-                hipLaunchKernelGGL((k_scan_filter<16, 8, true, F_WAVES, 0, false, true, false, true, 4, true>), dim3(n_wg, 1),
-                                   dim3(F_WAVES * 64), 0, ix->stream, ix->d_rows, ix->n_rows, ix->d_queries, ix->d_qp, ix->d_lists,
-                                   ix->d_hdrs, 0, 1, ix->d_queries, ix->d_qp, ix->argq, ix->d_tail, sg);
+            if (!pin4) PB_LAUNCH_TIMED((k_scan_filter<16, 8, true, F_WAVES, 0, false, true, false, true, 0, true>), grid, block, PB_ARGQ_ARGS(ix->d_tail, sg));
+            else PB_LAUNCH_TIMED((k_scan_filter<16, 8, true, F_WAVES, 0, false, true, false, true, 4, true>), grid, block, PB_ARGQ_ARGS(ix->d_tail, sg));
             dyn = true;
         }
+#undef PB_ARGQ_ARGS
         PB_HIP(hipGetLastError());
     } else if (cache_sized) {
         launch_filter_loop<8, 16, 0, true>(ix, n_wg, 0, nq);
@@ -533,7 +545,7 @@ int run_fast(pb_index *ix, uint32_t nq) {
         if (rc) return rc;
     }
     PB_CT(2);
-    if (ix->opt_profile) PB_HIP(hipEventRecord(ix->ev1, ix->stream));
+    if (ix->opt_profile && !ix->timed_by_launch) PB_HIP(hipEventRecord(ix->ev1, ix->stream));
     hipLaunchKernelGGL(k_select_rescore, dim3(nq), dim3(SEL_BLOCK), 0, ix->stream, ix->d_rows, ix->d_ids, ix->d_norms,
                        (int)ix->dim, ix->d_queries, ix->d_qp, ix->d_lut, ix->d_lists, ix->d_hdrs, n_wg, ix->r_ids,
                        ix->r_dist, ix->r_hdr, (uint32_t)PB_MAX_K, dyn ? ix->d_tail : nullptr,
