@@ -177,14 +177,16 @@ typedef struct pb_scan_stats {
     uint64_t queries;         /* queries answered */
     uint64_t fast_path;       /* answered by the int-dot filter pass with a passing certificate */
     uint64_t fallback;        /* re-run through the exhaustive exact scan */
-    uint64_t profiled_launches; /* scan-kernel launches bracketed by events (PB_OPT_PROFILE) */
+    uint64_t profiled_launches; /* scan-kernel launches timed by events (PB_OPT_PROFILE): attached to the dispatch where a call
+                                   has one filter launch, recorded before and after the launches otherwise */
     double profiled_ms;       /* their summed duration */
     uint64_t profiled_bytes;  /* algorithmic bytes those launches streamed (rows * dim per query) */
     uint64_t second_chance;   /* no certificate at first, answered exactly by the second-chance pass: every row within
                                  the error margin of the first attempt's k-th cosine listed and re-scored */
-    uint64_t stamp_timeouts;  /* one-query calls whose completion stamp did not arrive within 20 ms and that fell back to the
-                                 stream wait (a GPU shared with ingest or another process); after 3 in a row the index waits
-                                 on the stream for its next 256 one-query calls, then tries the stamp again */
+    uint64_t stamp_timeouts;  /* one-query calls whose results (tagged granules in pinned memory, polled by the host) did not
+                                 arrive within 20 ms and that fell back to the stream wait (a GPU shared with ingest or another
+                                 process); after 3 in a row the index waits on the stream for its next 256 one-query calls,
+                                 then polls again */
 } pb_scan_stats;                /* queries = fast_path + second_chance + fallback */
 int pb_index_get_stats(pb_index *idx, pb_scan_stats *out, int reset);
 
