@@ -992,10 +992,12 @@ __device__ __forceinline__ void block_bitonic_sort(uint64_t *s, int n) {
 
 // (1b) candidate selection from the workgroup lists, exact re-scoring, certificate.  One block per query.
 // This kernel is the latency tail of every query (one workgroup, a chain of dependent phases), so it is written to make
-// as few round trips as it can: every thread fetches its share of the list slots and headers ONCE (all loads in flight
-// together) and serves both the lower-bound histogram and the candidate selection from registers; a candidate's row, norm
-// and image_id are requested together; and up to SEL_RANK_MAX candidates are ordered by counting (each candidate counts the
-// keys below its own from LDS: one barrier) instead of a 36-barrier bitonic network -- 29 -> ~17 us per query.
+// as few round trips as it can: every thread fetches its share of the list slots ONCE (all loads in flight together; an
+// unused slot holds ~0) and serves both the lower bound (the k-th largest list head, by counting) and the candidate selection
+// from registers; a candidate's row, norm and image_id are requested together, its 256 look-ups and products are made by eight
+// lanes (ref_fold_dot256_by8); and up to SEL_RANK_MAX candidates are ordered by counting (each candidate counts the keys
+// below its own from LDS: one barrier) instead of a 36-barrier bitonic network -- 29 us in round 1, 13 us now
+// (profiles/r04_scan_stamps.txt).
 // One-query calls answered into pinned host memory (done_flag != nullptr) publish their results as 16-byte GRANULES
 // {payload[3], tag}: one store instruction of one lane each, so a granule arrives whole, and the host accepts a granule once
 // its tag equals the call's sequence number -- no fence between the result stores and a separate completion flag (which cost
