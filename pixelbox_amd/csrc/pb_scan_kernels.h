@@ -1043,6 +1043,8 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
         my_key[j] = i < total_slots ? ql[i] : ~0ull;
     }
     float dmax = tid < n_lists ? qh[tid].dropped : 0.0f;
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_key);  // lower-bound counts per list head (s_key holds candidates only later)
+    s_cnt[tid] = 0u;
     const uint8_t qbyte = tid < d ? queries[(size_t)q * d + tid] : (uint8_t)0;
     s_lut[tid & 255] = lut[tid & 255];
     if (tid < 8) s_u[tid] = 0;
@@ -1082,10 +1084,17 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
     const uint32_t top_total = s_u[0];
     float lb = P.thr0;
     if (top_total >= P.k) {  // uniform
-        if (tid < n_topset) {
-            const float v = s_top[tid];
+        // all 1 024 threads count: the values' indices are padded to a power of two tp, thread t counts for value t % tp over
+        // part t / tp of the set (256 list heads: four parts of 64) and adds {above, equal} as two 16-bit halves into s_cnt
+        int lg_tp = 6;
+        while ((1 << lg_tp) < n_topset) ++lg_tp;
+        const int vi = tid & ((1 << lg_tp) - 1), part = tid >> lg_tp, n_part = SEL_BLOCK >> lg_tp;
+        const int len = (((n_topset + n_part - 1) / n_part) + 15) & ~15;  // values per part, whole batches of four 16-byte reads
+        if (vi < n_topset) {
+            const float v = s_top[vi];
             uint32_t above = 0, same = 0;
-            for (int u = 0; u < n_topset; u += 16) {  // four 16-byte LDS reads in flight (one per trip is a chain of LDS latencies)
+            const int u_end = (part + 1) * len < n_topset ? (part + 1) * len : n_topset;  // (s_top is padded with -1 to a multiple of 16)
+            for (int u = part * len; u < u_end; u += 16) {  // four 16-byte LDS reads in flight (one per trip is a chain of LDS latencies)
                 float4 o[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) o[c] = *reinterpret_cast<const float4 *>(s_top + u + 4 * c);
@@ -1095,7 +1104,12 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
                     same += (o[c].x == v ? 1u : 0u) + (o[c].y == v ? 1u : 0u) + (o[c].z == v ? 1u : 0u) + (o[c].w == v ? 1u : 0u);
                 }
             }
-            if (above < P.k && P.k <= above + same) s_u[1] = __float_as_uint(v);  // ties write the same word
+            if (above | same) atomicAdd(&s_cnt[vi], above | (same << 16));
+        }
+        __syncthreads();
+        if (tid < n_topset) {
+            const uint32_t c = s_cnt[tid], above = c & 0xFFFFu, same = c >> 16;
+            if (above < P.k && P.k <= above + same) s_u[1] = __float_as_uint(s_top[tid]);  // ties write the same word
         }
         __syncthreads();
         lb = fmaxf(__uint_as_float(s_u[1]), P.thr0);
