@@ -21,7 +21,7 @@
 
 using namespace pbk;
 #ifdef PB_CALL_TRACE
-// instrumented build: host-side time points of a one-query call (ns since the call's entry), averaged and printed at destroy
+// instrumented build: host-side time points of a pb_index_search call (us since its entry), mean of every 64 calls printed to stderr
 static double g_ct_sum[8];
 static uint64_t g_ct_n;
 static std::chrono::steady_clock::time_point g_ct0;
