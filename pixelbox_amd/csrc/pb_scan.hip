@@ -549,7 +549,7 @@ int run_fast(pb_index *ix, uint32_t nq) {
     hipLaunchKernelGGL(k_select_rescore, dim3(nq), dim3(SEL_BLOCK), 0, ix->stream, ix->d_rows, ix->d_ids, ix->d_norms,
                        (int)ix->dim, ix->d_queries, ix->d_qp, ix->d_lut, ix->d_lists, ix->d_hdrs, n_wg, ix->r_ids,
                        ix->r_dist, ix->r_hdr, (uint32_t)PB_MAX_K, dyn ? ix->d_tail : nullptr,
-                       ix->poll_pending ? ix->h_done : nullptr, ix->done_seq);
+                       ix->poll_pending ? ix->h_done : nullptr, ix->done_seq, (uint32_t)ix->n_rows);
     PB_HIP(hipGetLastError());
     if (dyn) ix->tail_dirty = false;  // k_select_rescore is queued: it leaves the ticket counters zero
     return PB_OK;

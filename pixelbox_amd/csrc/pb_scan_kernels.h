@@ -70,6 +70,9 @@ struct QArg {
 struct ListHdr {
     uint32_t count;
     float dropped;  // every row this workgroup saw and did not list has cos_filter <= dropped (0: none)
+    uint32_t rows_seen;  // rows this workgroup evaluated for the query (k_scan_filter): the certificate of k_select_rescore also
+                         // requires that the workgroups' counts add up to the table -- the partition of the table over
+                         // workgroups is dynamic in some launch forms, and a tile nobody read must cost time, not an answer
 };
 
 struct ResultHdr {
@@ -523,6 +526,7 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
     constexpr int NPAR = WGT ? 2 : 1;
     __shared__ uint64_t s_buf[NPAR][NW][F_CAPW];
     __shared__ float s_drop[NPAR][NW];
+    __shared__ uint32_t s_seen[NPAR][NW];
     __shared__ uint32_t s_ticket[2];
     __shared__ uint32_t s_node[8];  // one-query launch: arrival counters of the list-merging tree (4 pairs, 2 quads, 1 root)
     __shared__ uint32_t s_turn;     // STEAL: the chunk number whose request may go out next
@@ -564,6 +568,7 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
     float thr = P.thr0;
     float dropped = 0.0f;
     int cnt = 0;
+    uint32_t rows_seen = 0;  // scalar: rows of the tiles this wave evaluated
     const int k_num = 65025 * D - 510 * P.sum_a;  // num = 4P - 510*S + k_num
     const int k_den = 65025 * D;
 
@@ -682,6 +687,10 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
             if (lane == 0) wg_pend = atomicAdd(&s_ticket[par], 1u);  // the next ticket, requested ahead of this tile's loads
         }
         const uint64_t row0 = s * ROWS_IT;
+#ifdef PB_FAULT_SKIP_TILE  // fault injection (profiles/r04_scan_stamps.txt): one tile is counted as nobody's
+        if (s != (uint64_t)PB_FAULT_SKIP_TILE)
+#endif
+        rows_seen += row0 < n_rows ? (uint32_t)(n_rows - row0 < (uint64_t)ROWS_IT ? n_rows - row0 : (uint64_t)ROWS_IT) : 0u;
         uint4 b[U];
         auto load_row = [&](int u) {
             uint64_t r = row0 + (uint64_t)(u * RPT + g);
@@ -789,11 +798,15 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
         // sort and three merges instead of a barrier and seven (stamps: 2.1 -> ~1.2 us).
         int slot = wave;          // where the list this wave carries sits in s_buf
         float carried = dropped;  // the bound that goes with it
+        uint32_t seen = rows_seen;  // and the rows behind it
         uint64_t key = ~0ull;
         bool last = true;
 #pragma unroll
         for (int lv = 0; lv < 3; ++lv) {
-            if (lane == 0) s_drop[par][slot] = carried;
+            if (lane == 0) {
+                s_drop[par][slot] = carried;
+                s_seen[par][slot] = seen;
+            }
             uint32_t pos = 0;
             // release: this wave's list and bound are in LDS before its number is taken; acquire: the partner's are read after
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -810,6 +823,7 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
             key = wave_merge64(lane < F_KW ? s_buf[par][lo][lane] : s_buf[par][hi][63 - lane]);
             const uint64_t first_out = __shfl((unsigned long long)key, F_KW);
             carried = fmaxf(s_drop[par][lo], s_drop[par][hi]);
+            seen = s_seen[par][lo] + s_seen[par][hi];
             if (first_out != ~0ull) carried = fmaxf(carried, filter_key_cos(first_out));
             if (lv < 2 && lane < F_KW) s_buf[par][lo][lane] = key;
             slot = lo;
@@ -823,12 +837,16 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
                 ListHdr h;
                 h.count = (uint32_t)total;
                 h.dropped = carried;
+                h.rows_seen = seen;
                 hdrs[(size_t)q * gridDim.x + blockIdx.x] = h;
             }
             PB_STAMP(6);
         }
     } else {
-    if (lane == 0) s_drop[par][wave] = dropped;
+    if (lane == 0) {
+        s_drop[par][wave] = dropped;
+        s_seen[par][wave] = rows_seen;
+    }
     PB_STAMP(4);
     __syncthreads();
     PB_STAMP(5);
@@ -847,6 +865,9 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
             ListHdr h;
             h.count = (uint32_t)total;
             h.dropped = drop;
+            uint32_t seen = 0;
+            for (int w = 0; w < NW; ++w) seen += s_seen[par][w];
+            h.rows_seen = seen;
             hdrs[(size_t)q * gridDim.x + blockIdx.x] = h;
         }
         PB_STAMP(6);
@@ -960,6 +981,7 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_dist(const uint8_t *__restri
         ListHdr h;
         h.count = (uint32_t)total;
         h.dropped = 0.0f;
+        h.rows_seen = 0u;
         hdrs[(size_t)q * gridDim.x + blockIdx.x] = h;
         drop_keys[(size_t)q * gridDim.x + blockIdx.x] = drop;  // every key this workgroup saw and did not list is >= drop
     }
@@ -1016,7 +1038,7 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
     int d, const uint8_t *__restrict__ queries, const QParams *__restrict__ qp,
     const float *__restrict__ lut, const uint64_t *__restrict__ lists, const ListHdr *__restrict__ hdrs,
     int n_lists, int64_t *__restrict__ out_ids, float *__restrict__ out_dist, ResultHdr *__restrict__ out_hdr,
-    uint32_t out_stride, uint32_t *tail_ctr = nullptr, uint32_t *done_flag = nullptr, uint32_t done_seq = 0) {
+    uint32_t out_stride, uint32_t *tail_ctr = nullptr, uint32_t *done_flag = nullptr, uint32_t done_seq = 0, uint32_t n_rows = 0) {
     // the filter launch before this one handed out its tail through these counters (k_scan_filter DYN): clear them
     if (tail_ctr && blockIdx.x == 0 && threadIdx.x < DYN_REGIONS) tail_ctr[threadIdx.x * DYN_CTR_STRIDE] = 0u;
     __shared__ float s_lut[256];
@@ -1043,6 +1065,7 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
         my_key[j] = i < total_slots ? ql[i] : ~0ull;
     }
     float dmax = tid < n_lists ? qh[tid].dropped : 0.0f;
+    uint32_t seen = tid < n_lists ? qh[tid].rows_seen : 0u;  // summed below: must come to the whole table
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_key);  // lower-bound counts per list head (s_key holds candidates only later)
     s_cnt[tid] = 0u;
     const uint8_t qbyte = tid < d ? queries[(size_t)q * d + tid] : (uint8_t)0;
@@ -1072,10 +1095,12 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
     for (int off = 32; off >= 1; off >>= 1) {
         dmax = fmaxf(dmax, __shfl_xor(dmax, off));
         n_top += (uint32_t)__shfl_xor((int)n_top, off);
+        seen += (uint32_t)__shfl_xor((int)seen, off);
     }
     if ((tid & 63) == 0) {
         s_red[tid >> 6] = dmax;
         if (n_top) atomicAdd(&s_u[0], n_top);
+        if (seen) atomicAdd(&s_u[4], seen);
     }
     for (int i = n_topset + tid; i < ((n_topset + 15) & ~15); i += SEL_BLOCK) s_top[i] = -1.0f;  // pad to whole batches of reads
     __syncthreads();
@@ -1252,7 +1277,7 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
         ck = 3.0f;
         for (int w = 0; w < SEL_BLOCK / WAVE; ++w) ck = fminf(ck, s_ck[w]);
         const float o_max = fmaxf(fmaxf(cut, dmax), P.thr0) + P.m;  // no unexamined row's exact cos reaches this
-        bool ok = !overflow;
+        bool ok = !overflow && s_u[4] == n_rows;  // every row of the table was evaluated by exactly one workgroup of the filter pass
         if (n_out == P.k) {
             ok = ok && (o_max <= ck * (1.0f - 1e-6f));
         } else {
