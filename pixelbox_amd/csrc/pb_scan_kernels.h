@@ -5,9 +5,10 @@
 // paths built here:
 //   (1) k_scan_filter  -- the HBM-bound pass: per-row EXACT INTEGER dot / norms with v_dot4_u32_u8,
 //       an f32 cosine that is within M_GLOB of the reference's f32 cosine for every possible row,
-//       per-wave candidate buffers in LDS pruned by a ballot radix-select, one sorted list per
-//       workgroup;  k_select_rescore then re-scores the few candidates with the reference's exact
-//       sequential f32 arithmetic and certifies that no other row can belong to the top-k.
+//       per-wave candidate buffers in LDS pruned by a ballot radix-select while streaming and closed by bitonic
+//       networks, one sorted list per workgroup plus the count of rows it evaluated;  k_select_rescore then re-scores
+//       the few candidates with the reference's exact sequential f32 arithmetic and certifies that no other row can
+//       belong to the top-k -- and that every row of the table was evaluated exactly once.
 //   (2) k_scan_exact / k_merge_lists -- exhaustive exact scan (every row re-scored); used when the
 //       certificate of (1) fails, for dims (1) does not cover, or when forced (PB_OPT_SEARCH_PATH).
 // All keys are u64 "smaller is better": (order-preserving score bits << 32) | row position; rows are
