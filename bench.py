@@ -52,7 +52,9 @@ def parse(argv=None):
     ap.add_argument("--embed-batch", type=int, default=512)
     ap.add_argument("--embed-steps", type=int, default=10)
     ap.add_argument("--no-embed", action="store_true")
-    ap.add_argument("--ingest-images", type=int, default=4096, help="host images per size of the crawler-shaped ingest leg (0: skip)")
+    ap.add_argument("--ingest-images", type=int, default=8192,
+                    help="host images of the crawler-shaped ingest leg: this many at 640x480, twice as many at 256x256 (0: skip); with 4096 "
+                         "the eight threads get one batch of 512 each at 640x480 and the leg measures the pipeline's fill, not its rate")
     ap.add_argument("--e2e-images", type=int, default=1_000_000,
                     help="end-to-end leg (BASELINE configs[4]): embed + insert this many synthetic images, then serve "
                          "1000 concurrent queries (0: skip; the configuration itself is 1000000, the default)")
@@ -769,7 +771,7 @@ def bench_embed(args, torch, device, distributed):
 def bench_ingest_images(args, torch, device, forward_ips):
     """The crawler's hot loop as the reference shapes it (crawler.rs:68-119 -> indexed_image.rs:71 -> efficientnet.rs:19-29 ->
     engine.rs:251-256): decoded RGB8 images of camera / thumbnail sizes in HOST memory -> resize_to_fill(128, 128, Triangle) ->
-    forward -> hash stored in the device index, per size: 4096 images through pb_embed_batch_images_device ->
+    forward -> hash stored in the device index, per size: 8192 (640x480) / 16384 (256x256) images through pb_embed_batch_images_device ->
     pb_index_append_device in batches of 512 from EIGHT host threads with an embedder each (the reference runs PARALLEL_FILE_PROCESSORS = 4 of them,
     engine.rs:22; this host has cores to spare: one thread's packing and staging copies run under the others' forward passes; the index serialises the appends).  Reported against min(PCIe bound, forward rate): the PCIe bound
     is this box's pinned host-to-device rate, measured here, over the image's bytes."""
@@ -794,7 +796,7 @@ def bench_ingest_images(args, torch, device, forward_ips):
     embs = [capi.Embedder(blob, max_batch=nb, device=device) for _ in range(NT)]
     res = {"host_to_device_GB_per_s_pinned": round(h2d / 1e9, 2), "threads": NT, "batch": nb}
     for (h, w) in ((256, 256), (480, 640)):
-        n = 2 * args.ingest_images if h * w <= 256 * 256 else args.ingest_images  # 4096 camera-size images are 3.8 GB of host memory
+        n = 2 * args.ingest_images if h * w <= 256 * 256 else args.ingest_images  # 8192 camera-size images are 7.5 GB of host memory
         per = h * w * 3
         # distinct pixels per image (a splitmix64 stream), pageable memory like a decoder's output
         pool = synth.fill_synthetic(synth.SEED_IMAGES + 7, 0, 64 * per).reshape(64, h, w, 3)
