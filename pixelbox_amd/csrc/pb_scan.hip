@@ -1443,7 +1443,8 @@ int pb_index_create(pb_index **out, int device, uint32_t dim, uint64_t capacity_
             float cand_ms[4] = {0.f, 0.f, 0.f, 0.f};
             int n_cand = 0, best = 0;
             int rc_alloc = PB_OK;
-            constexpr int NQP = 64;  // passes per probe launch
+            // passes per probe launch: 64 up to 10M rows (~23 ms), fewer over larger tables (never under 8)
+            const int NQP = (int)std::max<uint64_t>(8, std::min<uint64_t>(64, 640000000ull / std::max<uint64_t>(1, capacity_rows)));
             if (tries > 1) {
                 std::vector<QParams> pq(NQP);
                 memset(pq.data(), 0, NQP * sizeof(QParams));
