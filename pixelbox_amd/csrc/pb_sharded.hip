@@ -165,6 +165,11 @@ struct pb_sharded {
     // concurrently: what they are about to store is RESERVED under `mu` first -- rows per shard (the capacity checks count them)
     // and the ids themselves (the uniqueness checks of concurrent calls see them) -- and released when the copy has returned
     std::vector<uint64_t> pending;
+    std::vector<uint64_t> base;     // rows of a shard counted as stored while it has appends in flight (pending > 0): its size when the
+                                    // first of them was admitted + what has been committed since.  The shard's LIVE size cannot be used
+                                    // then: between a device-side append's completion and the release of its reservation its rows are
+                                    // in the live size AND in `pending`, and a concurrent call saw a full table that was not (one flaky
+                                    // "index full: capacity 80" in ~20 runs of the tight-capacity ingest test)
     std::unordered_set<int64_t> inflight;
     std::mutex mu;
 };
@@ -238,6 +243,12 @@ uint64_t shard_size(pb_sharded *s, int g) {
     uint64_t n = 0;
     (void)pb_index_size(s->shards[g], &n);
     return n;
+}
+// rows of shard g that count against the capacities (caller holds s->mu)
+uint64_t shard_used(pb_sharded *s, int g) {
+    if (s->pending.size() != (size_t)s->n) s->pending.assign(s->n, 0);
+    if (s->base.size() != (size_t)s->n) s->base.assign(s->n, 0);
+    return s->pending[g] ? s->base[g] + s->pending[g] : shard_size(s, g);
 }
 
 // exchange of the per-shard messages: after it d_gathered[0] holds message g at [g * count, (g+1) * count)
@@ -419,8 +430,7 @@ int pb_sharded_append(pb_sharded *s, const int64_t *image_ids, const uint8_t *ro
     }
     uint64_t stored = 0, pos = 0;
     uint64_t room = s->capacity;  // the TOTAL is the contract (per-shard capacities round up: their sum may exceed it)
-    if (s->pending.size() != (size_t)s->n) s->pending.assign(s->n, 0);
-    for (int g = 0; g < s->n; ++g) room -= std::min<uint64_t>(room, shard_size(s, g) + s->pending[g]);
+    for (int g = 0; g < s->n; ++g) room -= std::min<uint64_t>(room, shard_used(s, g));
     while (pos < ids.size()) {
         if (room == 0) {
             if (n_inserted) *n_inserted = stored;
@@ -430,7 +440,7 @@ int pb_sharded_append(pb_sharded *s, const int64_t *image_ids, const uint8_t *ro
         int best = -1;
         uint64_t best_free = 0, best_size = 0;
         for (int g = 0; g < s->n; ++g) {
-            const uint64_t sz = shard_size(s, g) + s->pending[g], fr = s->shard_cap[g] > sz ? s->shard_cap[g] - sz : 0;
+            const uint64_t sz = shard_used(s, g), fr = s->shard_cap[g] > sz ? s->shard_cap[g] - sz : 0;
             if (fr && (best < 0 || sz < best_size)) {
                 best = g;
                 best_free = fr;
@@ -444,6 +454,7 @@ int pb_sharded_append(pb_sharded *s, const int64_t *image_ids, const uint8_t *ro
         const uint64_t take = std::min<uint64_t>(std::min<uint64_t>(best_free, room), ids.size() - pos);
         uint64_t got = 0;
         int rc = pb_index_append(s->shards[best], ids.data() + pos, data.data() + pos * d, take, &got);
+        if (s->pending[best]) s->base[best] += got;  // a shard with device-side appends in flight is counted by its base
         stored += got;
         room -= std::min<uint64_t>(room, got);
         if (rc) {
@@ -486,13 +497,12 @@ int pb_sharded_append_device(pb_sharded *s, int shard, const int64_t *image_ids,
         // last_insert_rowid() values (engine.rs:233,249); an update or a re-insert goes through pb_sharded_append.  Rows and ids
         // of appends still in flight count as stored.
         std::lock_guard<std::mutex> lock(s->mu);
-        if (s->pending.size() != (size_t)s->n) s->pending.assign(s->n, 0);
         uint64_t total = 0;
-        for (int g = 0; g < s->n; ++g) total += shard_size(s, g) + s->pending[g];
+        for (int g = 0; g < s->n; ++g) total += shard_used(s, g);
         PB_CHECK(total + n <= s->capacity, PB_ERR_CAPACITY, "pb_sharded_append_device: %llu rows + %llu > capacity %llu",
                  (unsigned long long)total, (unsigned long long)n, (unsigned long long)s->capacity);
-        PB_CHECK(shard_size(s, shard) + s->pending[shard] + n <= s->shard_cap[shard], PB_ERR_CAPACITY,
-                 "pb_sharded_append_device: shard %d is full (%llu of %llu rows)", shard, (unsigned long long)(shard_size(s, shard) + s->pending[shard]),
+        PB_CHECK(shard_used(s, shard) + n <= s->shard_cap[shard], PB_ERR_CAPACITY,
+                 "pb_sharded_append_device: shard %d is full (%llu of %llu rows)", shard, (unsigned long long)shard_used(s, shard),
                  (unsigned long long)s->shard_cap[shard]);
         for (uint64_t i = 0; i < n; ++i) {
             PB_CHECK(!s->inflight.count(image_ids[i]), PB_ERR_INVALID, "pb_sharded_append_device: image_id %lld is being stored by a concurrent call",
@@ -509,6 +519,7 @@ int pb_sharded_append_device(pb_sharded *s, int shard, const int64_t *image_ids,
             PB_CHECK(image_ids[i] > image_ids[i - 1], PB_ERR_INVALID, "pb_sharded_append_device: image_ids must be strictly ascending (row %llu)",
                      (unsigned long long)i);
         s->inflight.insert(image_ids, image_ids + n);
+        if (s->pending[shard] == 0) s->base[shard] = shard_size(s, shard);  // nothing in flight on this shard: its live size is exact
         s->pending[shard] += n;
     }
     const int rc = pb_index_append_device(s->shards[shard], image_ids, d_rows, n);
@@ -516,6 +527,7 @@ int pb_sharded_append_device(pb_sharded *s, int shard, const int64_t *image_ids,
         std::lock_guard<std::mutex> lock(s->mu);
         for (uint64_t i = 0; i < n; ++i) s->inflight.erase(image_ids[i]);
         s->pending[shard] -= n;
+        if (rc == PB_OK) s->base[shard] += n;  // committed (pb_index_append_device stores all n rows or none)
     }
     return rc;
 }
