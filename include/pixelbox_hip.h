@@ -56,9 +56,8 @@ typedef struct pb_index pb_index;
  * does not enforce blob length (engine.rs:585 zip-truncates) -- documented deviation: other lengths
  * are rejected.  `device` is the HIP device ordinal.
  * Placement: where the driver puts a multi-GB buffer decides how fast it streams (3-4 % between two allocations of one
- * process, for as long as they live), so a 256-byte-row table of 256 MB or more is allocated up to three times (while three
- * fit in half the free memory), the filter pass is timed over each and the fastest kept: ~50 ms per candidate at 10M rows,
- * once per index.  PB_INDEX_PLACEMENT_TRIES=1 in the environment takes the first allocation. */
+ * process, for as long as they live).  PB_INDEX_PLACEMENT_TRIES=n in the environment (an experiment, off by default) makes
+ * the call allocate a large 256-byte-row table n times, time the filter pass over each and keep the fastest. */
 int pb_index_create(pb_index **out, int device, uint32_t dim, uint64_t capacity_rows);
 /* Same table for the reference's other two blob distances: the `phashes` table has
  * the semantic_hashes schema (engine.rs:106-109) and the UDFs byte_distance / hamming_distance are registered

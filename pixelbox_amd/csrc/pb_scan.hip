@@ -1427,14 +1427,15 @@ int pb_index_create(pb_index **out, int device, uint32_t dim, uint64_t capacity_
         { int rcw = alloc_workspace(ix); if (rcw) return rcw; }
         {   // The table.  Where the driver puts a multi-GB buffer decides how fast the filter pass streams it: a process that
             // creates six 2.56 GB tables measures 22.7 ms per 64 passes over some and 23.4-23.6 over others, and a table keeps its
-            // rate on every stream for as long as it lives (profiles/r04_scan_stamps.txt).  So a 256-byte-row table of 256 MB or
-            // more is allocated up to PB_INDEX_PLACEMENT_TRIES times (default 3, while that many fit in half the free memory);
-            // each candidate is filled with pseudo-random bytes (a table of constant bytes is scanned at half rate whatever its
-            // placement) and THE FILTER PASS ITSELF -- the looped launch, 64 queries nothing can pass -- runs over it twice, the
-            // second time timed (the first also brings an idling GPU up to its clocks).  The fastest is kept: ~50 ms per candidate
-            // at 10M rows.
+            // rate on every stream for as long as it lives (profiles/r04_scan_stamps.txt).  PB_INDEX_PLACEMENT_TRIES=n (2..4; an
+            // EXPERIMENT, off by default) allocates a 256-byte-row table of 256 MB or more n times (while that many fit in half the
+            // free memory), fills each candidate with pseudo-random bytes (a table of constant bytes is scanned at half rate
+            // whatever its placement), runs THE FILTER PASS ITSELF over it twice -- the looped launch, 64 queries nothing can pass;
+            // the first run also brings an idling GPU up to its clocks -- and keeps the fastest.  Measured: it removes the bad draws
+            // (23.3-23.6 ms) but not the good ones' margin -- with three candidates every table ends at 23.0, the first allocation
+            // alone is a coin between 22.7 and 23.3 -- so the default stays one allocation.
             const size_t bytes = (capacity_rows + 64) * (size_t)dim;
-            int tries = getenv("PB_INDEX_PLACEMENT_TRIES") ? atoi(getenv("PB_INDEX_PLACEMENT_TRIES")) : 3;
+            int tries = getenv("PB_INDEX_PLACEMENT_TRIES") ? atoi(getenv("PB_INDEX_PLACEMENT_TRIES")) : 1;
             size_t free_b = 0, total_b = 0;
             PB_HIP(hipMemGetInfo(&free_b, &total_b));
             if (dim != 256 || bytes < (256ull << 20) || (double)bytes * tries > 0.5 * (double)free_b) tries = 1;
