@@ -17,7 +17,7 @@ _lib = None
 
 
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(_HERE, f) for f in ("pb_oracle.c", "pb_oracle_effnet.c", "pb_oracle_resize.c", "pb_oracle_phash.c", "pb_oracle_sqlite.c", "pb_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("pb_oracle.c", "pb_oracle_effnet.c", "pb_oracle_effnet_f64.c", "pb_oracle_effnet_body.h", "pb_oracle_resize.c", "pb_oracle_phash.c", "pb_oracle_sqlite.c", "pb_oracle.h")]
     stale = not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-B", "libpb_oracle.so"], stdout=subprocess.DEVNULL)
@@ -50,6 +50,8 @@ def lib():
         L.pbo_effnet_forward.restype = C.c_int
         L.pbo_mlhash_batch.argtypes = [u8p, C.c_size_t, u8p, C.c_size_t, C.c_int, u8p, f32p]
         L.pbo_mlhash_batch.restype = C.c_int
+        L.pbo_effnet_batch_f64.argtypes = [u8p, C.c_size_t, u8p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
+        L.pbo_effnet_batch_f64.restype = C.c_int
         L.pbo_resize_to_fill_rgb8.argtypes = [u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u8p]
         L.pbo_resize_to_fill_rgb8.restype = C.c_int
         L.pbo_resize_dimensions_fill.argtypes = [C.c_uint32] * 4 + [C.POINTER(C.c_uint32)] * 2
@@ -176,6 +178,18 @@ def mlhash_batch(blob: bytes, imgs: np.ndarray, d: int, nthreads: int = 4, want_
     if rc:
         raise RuntimeError(f"pbo_mlhash_batch rc={rc}")
     return out, f
+
+
+def effnet_batch_f64(blob: bytes, imgs: np.ndarray, d: int, nthreads: int = 4) -> np.ndarray:
+    """The embed network in f64 (pb_oracle_effnet_f64.c): [n, d] tanh outputs -- the third point under the 1e-5 bar."""
+    b = np.frombuffer(blob, dtype=np.uint8)
+    imgs = np.ascontiguousarray(imgs, dtype=np.uint8)
+    n = imgs.shape[0]
+    out = np.empty((n, d), dtype=np.float64)
+    rc = lib().pbo_effnet_batch_f64(_u8(b), b.size, _u8(imgs), n, nthreads, out.ctypes.data_as(C.POINTER(C.c_double)))
+    if rc:
+        raise RuntimeError(f"pbo_effnet_batch_f64 rc={rc}")
+    return out
 
 
 def resize_to_fill(img: np.ndarray, nw: int, nh: int) -> np.ndarray:

@@ -79,6 +79,10 @@ int pbo_effnet_forward(const uint8_t *blob, size_t blob_len, const uint8_t *img,
 /* mlhash (efficientnet.rs:31-42) over n images, batch-1 per call on nthreads threads. */
 int pbo_mlhash_batch(const uint8_t *blob, size_t blob_len, const uint8_t *imgs, size_t n,
                      int nthreads, uint8_t *out_u8, float *out_f32);
+/* The same network evaluated in f64 (pb_oracle_effnet_f64.c): the third point under the embed bar -- both f32 evaluations
+ * (the oracle's, the HIP path's) are measured against it.  out[D] / out_f64[n][D] = tanh outputs before the quantiser. */
+int pbo_effnet_forward_f64(const uint8_t *blob, size_t blob_len, const uint8_t *img, double *out);
+int pbo_effnet_batch_f64(const uint8_t *blob, size_t blob_len, const uint8_t *imgs, size_t n, int nthreads, double *out_f64);
 
 /* ---- pre-processing (pb_oracle_resize.c): efficientnet.rs:20 `resize_to_fill(W, H, Triangle).to_rgb8()` --------
  * image 0.25.x's published algorithm restated for an RGB8 source.  PARITY UNPINNED (third-party crate, absent). */

@@ -19,7 +19,9 @@
  *
  * Accumulation order chosen here (documented, arbitrary): acc = bias; then taps in
  * (ky, kx, ci) order for dense convs, (ky, kx) for depthwise, ci ascending for 1x1 / FC;
- * separate f32 multiply and add (no FMA).
+ * separate f32 multiply and add (no FMA).  The network itself is written once, over the scalar
+ * type, in pb_oracle_effnet_body.h; this file instantiates it in f32 (the oracle) and
+ * pb_oracle_effnet_f64.c in f64 (the third point under the embed bar).
  *
  * Activations are NHWC f32.  Weight blob layout: see pixelbox_amd/weights.py (PBXW0001).
  */
@@ -29,201 +31,19 @@
 #include <stdlib.h>
 #include <string.h>
 
-typedef struct {
-    int expand, k, stride, cin, cout, repeats;
-} stage_t;
-
-/* torchvision efficientnet_b0 inverted-residual setting */
-static const stage_t STAGES[7] = {
-    {1, 3, 1, 32, 16, 1},  {6, 3, 2, 16, 24, 2},   {6, 5, 2, 24, 40, 2},  {6, 3, 2, 40, 80, 3},
-    {6, 5, 1, 80, 112, 3}, {6, 5, 2, 112, 192, 4}, {6, 3, 1, 192, 320, 1},
-};
-
-static inline float silu(float x) { return x / (1.0f + expf(-x)); }
-static inline float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
-
-/* out[p][co] = act(b[co] + sum_ci in[p][ci] * w[co][ci]);  w is OI (torch layout) */
-static void conv1x1(const float *in, int npix, int cin, const float *w, const float *b, int cout,
-                    float *out, int act /*0 none, 1 silu*/) {
-    float *wt = (float *)malloc(sizeof(float) * (size_t)cin * cout);
-    for (int co = 0; co < cout; ++co)
-        for (int ci = 0; ci < cin; ++ci) wt[(size_t)ci * cout + co] = w[(size_t)co * cin + ci];
-    for (int p = 0; p < npix; ++p) {
-        float *o = out + (size_t)p * cout;
-        const float *x = in + (size_t)p * cin;
-        for (int co = 0; co < cout; ++co) o[co] = b[co];
-        for (int ci = 0; ci < cin; ++ci) {
-            const float a = x[ci];
-            const float *wr = wt + (size_t)ci * cout;
-            for (int co = 0; co < cout; ++co) {
-                float prod = a * wr[co];
-                o[co] = o[co] + prod;
-            }
-        }
-        if (act)
-            for (int co = 0; co < cout; ++co) o[co] = silu(o[co]);
-    }
-    free(wt);
-}
-
-/* depthwise kxk, stride s, pad (k-1)/2, + bias + SiLU. w is [C][k][k]. */
-static void dwconv(const float *in, int h, int wd, int c, const float *w, const float *b, int k,
-                   int s, float *out, int ho, int wo) {
-    const int pad = (k - 1) / 2;
-    for (int y = 0; y < ho; ++y)
-        for (int x = 0; x < wo; ++x) {
-            float *o = out + ((size_t)y * wo + x) * c;
-            for (int ch = 0; ch < c; ++ch) o[ch] = b[ch];
-            for (int ky = 0; ky < k; ++ky) {
-                int iy = y * s + ky - pad;
-                if (iy < 0 || iy >= h) continue;
-                for (int kx = 0; kx < k; ++kx) {
-                    int ix = x * s + kx - pad;
-                    if (ix < 0 || ix >= wd) continue;
-                    const float *ip = in + ((size_t)iy * wd + ix) * c;
-                    const float *wp = w + ky * k + kx;
-                    for (int ch = 0; ch < c; ++ch) {
-                        float prod = ip[ch] * wp[(size_t)ch * k * k];
-                        o[ch] = o[ch] + prod;
-                    }
-                }
-            }
-            for (int ch = 0; ch < c; ++ch) o[ch] = silu(o[ch]);
-        }
-}
-
-/* stem: 3x3 s2 p1, 3 -> 32, + bias + SiLU; input u8 HWC; w is [32][3][3][3] (OIHW) */
-static void stem(const uint8_t *img, int h, int wd, const float *w, const float *b, float *out,
-                 int ho, int wo) {
-    for (int y = 0; y < ho; ++y)
-        for (int x = 0; x < wo; ++x) {
-            float *o = out + ((size_t)y * wo + x) * 32;
-            for (int co = 0; co < 32; ++co) o[co] = b[co];
-            for (int ky = 0; ky < 3; ++ky) {
-                int iy = y * 2 + ky - 1;
-                if (iy < 0 || iy >= h) continue;
-                for (int kx = 0; kx < 3; ++kx) {
-                    int ix = x * 2 + kx - 1;
-                    if (ix < 0 || ix >= wd) continue;
-                    for (int ci = 0; ci < 3; ++ci) {
-                        /* efficientnet.rs:27  img[(x,y)][c] as f32 / 255.0 */
-                        float a = (float)img[((size_t)iy * wd + ix) * 3 + ci] / 255.0f;
-                        for (int co = 0; co < 32; ++co) {
-                            float prod = a * w[((co * 3 + ci) * 3 + ky) * 3 + kx];
-                            o[co] = o[co] + prod;
-                        }
-                    }
-                }
-            }
-            for (int co = 0; co < 32; ++co) o[co] = silu(o[co]);
-        }
-}
-
-static size_t blob_floats(int D) {
-    size_t n = 32 * 27 + 32;
-    for (int s = 0; s < 7; ++s) {
-        const stage_t *st = &STAGES[s];
-        for (int r = 0; r < st->repeats; ++r) {
-            int cin = r == 0 ? st->cin : st->cout;
-            int e = cin * st->expand;
-            int sq = cin / 4 > 1 ? cin / 4 : 1;
-            if (st->expand != 1) n += (size_t)e * cin + e;
-            n += (size_t)e * st->k * st->k + e;
-            n += (size_t)sq * e + sq;
-            n += (size_t)e * sq + e;
-            n += (size_t)st->cout * e + st->cout;
-        }
-    }
-    n += 1280 * 320 + 1280;
-    n += (size_t)D * 1280 + D;
-    return n;
-}
-
-#define PBXW_HEADER_BYTES 32
-
-/* Returns 0 on success. out_f32[D] = tanh output; img is H*W*3 u8 (RGB, HWC). */
-int pbo_effnet_forward(const uint8_t *blob, size_t blob_len, const uint8_t *img, float *out_f32) {
-    if (blob_len < PBXW_HEADER_BYTES || memcmp(blob, "PBXW0001", 8) != 0) return -1;
-    uint32_t hdr[4];
-    uint64_t nfl;
-    memcpy(hdr, blob + 8, 16);
-    memcpy(&nfl, blob + 24, 8);
-    const int H = (int)hdr[0], W = (int)hdr[1], D = (int)hdr[2];
-    if (nfl != blob_floats(D) || blob_len != PBXW_HEADER_BYTES + nfl * 4) return -2;
-    if (H % 32 || W % 32) return -3;
-    const float *p = (const float *)(blob + PBXW_HEADER_BYTES);
-
-    int h = H / 2, w = W / 2, c = 32;
-    size_t maxact = (size_t)h * w * 96 * 2; /* >= largest expanded activation (stage 2: 96 ch @ H/2) */
-    float *x = (float *)malloc(sizeof(float) * maxact);
-    float *t1 = (float *)malloc(sizeof(float) * maxact);
-    float *t2 = (float *)malloc(sizeof(float) * maxact);
-    float sebuf[1152 * 2 + 64];
-
-    stem(img, H, W, p, p + 32 * 27, x, h, w);
-    p += 32 * 27 + 32;
-
-    for (int s = 0; s < 7; ++s) {
-        const stage_t *st = &STAGES[s];
-        for (int r = 0; r < st->repeats; ++r) {
-            const int cin = r == 0 ? st->cin : st->cout;
-            const int stride = r == 0 ? st->stride : 1;
-            const int e = cin * st->expand;
-            const int sq = cin / 4 > 1 ? cin / 4 : 1;
-            const int k = st->k;
-            const int ho = (h + stride - 1) / stride, wo = (w + stride - 1) / stride;
-            const float *ein = x;
-            if (st->expand != 1) {
-                conv1x1(x, h * w, cin, p, p + (size_t)e * cin, e, t1, 1);
-                p += (size_t)e * cin + e;
-                ein = t1;
-            }
-            dwconv(ein, h, w, e, p, p + (size_t)e * k * k, k, stride, t2, ho, wo);
-            p += (size_t)e * k * k + e;
-            /* squeeze-excite: mean over pixels (row-major order), FC+SiLU, FC+sigmoid, scale */
-            float *mean = sebuf, *sv = sebuf + 1152, *gate = sebuf + 1152 + 64;
-            for (int ch = 0; ch < e; ++ch) mean[ch] = 0.0f;
-            for (int px = 0; px < ho * wo; ++px)
-                for (int ch = 0; ch < e; ++ch) mean[ch] = mean[ch] + t2[(size_t)px * e + ch];
-            const float inv = 1.0f / (float)(ho * wo);
-            for (int ch = 0; ch < e; ++ch) mean[ch] = mean[ch] * inv;
-            conv1x1(mean, 1, e, p, p + (size_t)sq * e, sq, sv, 1);
-            p += (size_t)sq * e + sq;
-            conv1x1(sv, 1, sq, p, p + (size_t)e * sq, e, gate, 0);
-            p += (size_t)e * sq + e;
-            for (int ch = 0; ch < e; ++ch) gate[ch] = sigmoidf(gate[ch]);
-            for (int px = 0; px < ho * wo; ++px)
-                for (int ch = 0; ch < e; ++ch) t2[(size_t)px * e + ch] = t2[(size_t)px * e + ch] * gate[ch];
-            /* project (no activation) + residual */
-            conv1x1(t2, ho * wo, e, p, p + (size_t)st->cout * e, st->cout, t1, 0);
-            p += (size_t)st->cout * e + st->cout;
-            if (stride == 1 && cin == st->cout) {
-                for (size_t i = 0; i < (size_t)ho * wo * st->cout; ++i) t1[i] = x[i] + t1[i];
-            }
-            float *tmp = x;
-            x = t1;
-            t1 = tmp;
-            h = ho;
-            w = wo;
-            c = st->cout;
-        }
-    }
-    /* head conv 1x1 320 -> 1280 + SiLU, global average pool, Linear + tanh */
-    conv1x1(x, h * w, c, p, p + 1280 * 320, 1280, t1, 1);
-    p += 1280 * 320 + 1280;
-    float *pool = t2;
-    for (int ch = 0; ch < 1280; ++ch) pool[ch] = 0.0f;
-    for (int px = 0; px < h * w; ++px)
-        for (int ch = 0; ch < 1280; ++ch) pool[ch] = pool[ch] + t1[(size_t)px * 1280 + ch];
-    const float invp = 1.0f / (float)(h * w);
-    for (int ch = 0; ch < 1280; ++ch) pool[ch] = pool[ch] * invp;
-    conv1x1(pool, 1, 1280, p, p + (size_t)D * 1280, D, out_f32, 0);
-    for (int i = 0; i < D; ++i) out_f32[i] = tanhf(out_f32[i]);
-    free(x);
-    free(t1);
-    free(t2);
-    return 0;
-}
+#define REAL float
+#define R(x) x##f
+#define REXP expf
+#define RTANH tanhf
+#define FN(name) name##_f32
+#define PBO_FORWARD pbo_effnet_forward
+#include "pb_oracle_effnet_body.h"
+#undef REAL
+#undef R
+#undef REXP
+#undef RTANH
+#undef FN
+#undef PBO_FORWARD
 
 /* mlhash over a batch (efficientnet.rs:31-42), batch-1 per call on `nthreads` threads
  * (PARALLEL_FILE_PROCESSORS = 4, engine.rs:22). out_u8[n][D]; out_f32 may be NULL. */

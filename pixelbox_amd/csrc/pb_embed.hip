@@ -66,7 +66,8 @@ struct pb_embedder {
     uint32_t H = 0, W = 0, D = 0, max_batch = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     std::vector<void *> allocs;
-    float *stem_w = nullptr, *stem_b = nullptr;  // [27][32], [32]
+    uint16_t *stem_w3 = nullptr;  // the stem as bf16 pieces of w / 255 in MFMA fragment order (stem_tile, pb_embed_kernels.h): [2 channel tiles][3 planes][64 lanes][8]
+    float *stem_b = nullptr;     // [32]
     std::vector<Block> blocks;
     Gemm head;
     Gemm fc;  // Linear(1280, D) as a GEMM over the pooled features
@@ -267,13 +268,30 @@ int load_weights(pb_embedder *e, const uint8_t *blob, size_t len) {
     PB_CHECK(nfl == blob_floats((int)e->D) && len == 32 + nfl * 4, PB_ERR_FORMAT, "weight blob: size mismatch");
     const float *p = reinterpret_cast<const float *>(blob + 32);
     int rc;
-    {  // stem [32][3][3][3] (OIHW) -> [ky][kx][ci][32]
-        std::vector<float> w(27 * 32), b(p + 27 * 32, p + 27 * 32 + 32);
-        for (int co = 0; co < 32; ++co)
-            for (int ci = 0; ci < 3; ++ci)
-                for (int ky = 0; ky < 3; ++ky)
-                    for (int kx = 0; kx < 3; ++kx) w[((ky * 3 + kx) * 3 + ci) * 32 + co] = p[((co * 3 + ci) * 3 + ky) * 3 + kx];
-        if ((rc = upload(e, &e->stem_w, w)) || (rc = upload(e, &e->stem_b, b))) return rc;
+    {  // stem [32][3][3][3] (OIHW) -> w' = fl(w / 255.0f) (the reference's px / 255, efficientnet.rs:27, folded into the weight: the
+       // pixel bytes themselves are exact bf16 operands), split exactly into three bf16 pieces, in the fragment order of stem_tile:
+       // lane (li, kq), slot j -> kq < 3: tap (ky = kq, kx = j / 3, ci = j % 3); kq = 3: j < 3: tap (ky = j, kx = 2, ci = 2), else 0
+        std::vector<float> b(p + 27 * 32, p + 27 * 32 + 32);
+        std::vector<uint16_t> w3((size_t)2 * 3 * 64 * 8, 0);
+        auto bits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+        auto flt = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
+        for (int c = 0; c < 2; ++c)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int li = lane & 15, kq = lane >> 4, co = 16 * c + li;
+                    int ky, kx, ci;
+                    if (kq < 3) { ky = kq; kx = j / 3; ci = j % 3; }
+                    else if (j < 3) { ky = j; kx = 2; ci = 2; }
+                    else continue;
+                    const float x = p[((co * 3 + ci) * 3 + ky) * 3 + kx] / 255.0f;
+                    const float r1 = x - flt(bits(x) & 0xFFFF0000u);
+                    const float r2 = r1 - flt(bits(r1) & 0xFFFF0000u);
+                    const uint16_t piece[3] = {(uint16_t)(bits(x) >> 16), (uint16_t)(bits(r1) >> 16), (uint16_t)(bits(r2) >> 16)};
+                    for (int pl = 0; pl < 3; ++pl) w3[(((size_t)c * 3 + pl) * 64 + lane) * 8 + j] = piece[pl];
+                }
+        if ((rc = dalloc(e, &e->stem_w3, w3.size()))) return rc;
+        PB_HIP(hipMemcpy(e->stem_w3, w3.data(), w3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        if ((rc = upload(e, &e->stem_b, b))) return rc;
         p += 27 * 32 + 32;
     }
     for (const Stage &st : STAGES)
@@ -1077,14 +1095,14 @@ int forward_device(pb_embedder *e, const uint8_t *d_rgb, int n, uint8_t *d_u8, f
         stem_bands = (H + rpb - 1) / rpb;
         if (fused_lds > 48 * 1024)
             PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stem_dw), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds));
-        hipLaunchKernelGGL(k_stem_dw, dim3(stem_bands, n), dim3(256), fused_lds, e->stream, d_rgb, n, (int)e->H, (int)e->W, e->stem_w,
-                           e->stem_b, b0.dw_w, b0.dw_b, e->buf_dw, e->buf_part, stem_bands, rpb, se_tail(e, b0, H, W));
+        hipLaunchKernelGGL(k_stem_dw, dim3(stem_bands, n), dim3(256), fused_lds, e->stream, d_rgb, n, (int)e->H, (int)e->W,
+                           reinterpret_cast<const u32x4s *>(e->stem_w3), e->stem_b, b0.dw_w, b0.dw_b, e->buf_dw, e->buf_part, stem_bands, rpb, se_tail(e, b0, H, W));
         PB_HIP(hipGetLastError());
     } else {
         // one block per output row, taps from LDS-staged input rows (W is a multiple of 32 and <= 1024: 37 KB at most)
         const int grid = (int)std::min<long>((long)n * H, (long)e->n_cu * 16);
-        hipLaunchKernelGGL(k_stem, dim3(grid), dim3(256), (size_t)3 * (e->W + 1) * 3 * sizeof(float), e->stream, d_rgb, n,
-                           (int)e->H, (int)e->W, e->stem_w, e->stem_b, e->buf_x[0]);
+        hipLaunchKernelGGL(k_stem, dim3(grid), dim3(256), (size_t)3 * (e->W * 3 + 4), e->stream, d_rgb, n,
+                           (int)e->H, (int)e->W, reinterpret_cast<const u32x4s *>(e->stem_w3), e->stem_b, e->buf_x[0]);
         PB_HIP(hipGetLastError());
     }
     int cur = 0;

@@ -27,24 +27,26 @@ __device__ __forceinline__ float dpp_shr1(float v) {
 // associative, so the pooled mean -- and with it the whole embedding -- is bit-identical whatever the batch size,
 // tiling or kernel form that produced the partial sums.  (f32 partial sums made an image's hash depend, in the
 // last bit, on how many images shared its batch.)
+// The conversion is ONE instruction per value: q = v_cvt_rpi_i32_f32(o * 2^24) = floor(o * 2^24 + 0.5) as an i32
+// (round 5; rounds 1-4: rint() through v_rndne + v_cvt + a magnitude test per quad with an i64 conversion behind it --
+// 7.5 vector instructions per element where the depthwise phases are issue-bound, now 4).  The 2^-24 grid is this
+// library's own definition (the oracle sums f32), so which way a tie rounds is immaterial; what matters is that every
+// form goes through this one function.  Domain: |o| < 128 (2^31 / 2^24).  A depthwise output beyond that -- none in any
+// model seen: these are post-SiLU activations of a batch-normalised network, O(1-10) -- enters the pooled sum as whatever
+// the instruction returns for an out-of-range input, the same in every form and batch size (deterministic, no trap).
 struct ll4 {
     long long x, y, z, w;
 };
+__device__ __forceinline__ int se_fix(float o) {
+    int q;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(q) : "v"(o * 16777216.0f));
+    return q;
+}
 __device__ __forceinline__ void se_acc(ll4 &s, const f32x4 &o) {
-    const float a = o.x * 16777216.0f, b = o.y * 16777216.0f, c = o.z * 16777216.0f, d = o.w * 16777216.0f;
-    // |o| < 128 (every activation seen in practice): the scaled value fits an i32, and rndne + cvt_i32 is a fifth
-    // of the instructions of the generic f32 -> i64 conversion; both give rint() exactly
-    if (fmaxf(fmaxf(fabsf(a), fabsf(b)), fmaxf(fabsf(c), fabsf(d))) < 2147483648.0f) {
-        s.x += (long long)__float2int_rn(a);
-        s.y += (long long)__float2int_rn(b);
-        s.z += (long long)__float2int_rn(c);
-        s.w += (long long)__float2int_rn(d);
-    } else {
-        s.x += __float2ll_rn(a);
-        s.y += __float2ll_rn(b);
-        s.z += __float2ll_rn(c);
-        s.w += __float2ll_rn(d);
-    }
+    s.x += (long long)se_fix(o.x);
+    s.y += (long long)se_fix(o.y);
+    s.z += (long long)se_fix(o.z);
+    s.w += (long long)se_fix(o.w);
 }
 __device__ __forceinline__ void se_add(ll4 &s, const ll4 &o) {
     s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;

@@ -12,6 +12,8 @@
 
 namespace pbe {
 
+typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
+
 // ------------------------------------------------------------------------------------------------
 // The squeeze-excite gate computed in the TAIL of the kernel that produced the pooled sums, by the workgroup that finishes an
 // image last -- for the blocks whose excite weights are small (squeeze width <= 16: the stem-fused first block and the five
@@ -137,77 +139,119 @@ __device__ __forceinline__ void se_gate_image_sp(const long long *part, int n_ti
 }
 
 // ------------------------------------------------------------------------------------------------
-// stem: u8 NHWC [B,H,W,3] -> f32 NHWC [B,H/2,W/2,32]; 3x3 stride 2 pad 1, + bias, SiLU, as an im2col GEMM on the
-// f32 matrix cores: K = 27 taps (padded to 32), N = 32 channels, M = output pixels.  A block owns one output row
-// (b, y): its three input rows are loaded as dwords (coalesced), converted through the v/255 table (the px/255 of
-// efficientnet.rs:27, correctly rounded, tabulated once per block) and laid out as floats behind one zero pixel
-// (the left border; rows above the image are zeros).  A wave takes 16 consecutive output pixels per trip: lane
-// (li, kq) reads the 8 taps k = 16s + 4kq + e of pixel li from LDS (one ds_read_b32 each), the weights
-// [32 channels][32 taps] sit in 16 registers per lane for the whole kernel, 16 MFMAs produce 16 pixels x 32
-// channels, and each lane ends up with 4 consecutive channels of its pixel (float4 store, 128 contiguous bytes
-// per pixel).  Input sizes are multiples of 32 (checked at load), so rows are whole dwords and whole MFMA tiles.
-// w: [27][32] (tap-major: ky, kx, ci).
+// stem: u8 NHWC [B,H,W,3] -> f32 NHWC [B,H/2,W/2,32]; 3x3 stride 2 pad 1, + bias, SiLU (efficientnet.rs:19-29 feeds it
+// px / 255).  Round 5: the stem on the bf16 matrix cores, from the BYTES.
+//
+// THE ARITHMETIC OF THE STEM (one definition: stem_tile below; k_stem and k_stem_dw both call it, so both give the same bits):
+//   out[p][co] = silu( S + bias[co] ),   S = the value of an f32 accumulator that starts at 0 and receives THREE
+//   v_mfma_f32_16x16x32_bf16 in this order:  (w'_lo, px)  (w'_mid, px)  (w'_hi, px)
+//   where px is the pixel byte itself (0..255: eight significant bits, EXACT as a bf16), w' = fl(w / 255.0f) on the host,
+//   split exactly into three bf16 pieces (hi + mid + lo, truncation split as in pb_gemm_p3.h), all 27 taps in the ONE k-step
+//   of 32 (five zero slots), every piece product exact in f32 (8 x 8 significant bits), the matrix pipe accumulating in f32.
+// Against the reference's fl(px / 255) * w summed in f32 (the oracle) this differs by rounding only, and less: the reference
+// rounds px / 255 AND every product, here nothing is rounded before the accumulator (one rounding on w / 255).  Rounds 1-4
+// gathered fl(px / 255) through a 256-entry LDS table into an f32 MFMA chain of 8 steps: 39 % of the kernel's LDS cycles were
+// bank conflicts on that table (profiles/r04_embed_layers.txt), 16 f32 MFMAs (512 clocks) per 16-pixel tile where this is 6
+// bf16 ones (~110).
+//
+// Operand maps (v_mfma_f32_16x16x32_bf16: lane (li, kq) holds k = 8 kq + j, j = 0..7, of A row li / B column li):
+//   A = weights (row = output channel 16 c + li), B = pixels (column = output pixel x = 16 tx + li), so a lane ends with 4
+//   consecutive channels 16 c + 4 kq .. + 3 of its pixel (float4 epilogue, as before).
+//   k slot -> tap:  kq = 0, 1, 2: input row ky = kq, bytes j = 0..7 of the pixel's 9-byte window (kx = j / 3, ci = j % 3);
+//                   kq = 3: j = 0, 1, 2 -> byte 8 (kx = 2, ci = 2) of rows ky = 0, 1, 2; j = 3..7 empty.
+// Input rows are staged in LDS as bytes: per row 4 pad bytes (bytes 1..3 = pixel -1 = 0) then the W * 3 row bytes, RSB =
+// W * 3 + 4 per row; the window of output pixel x starts at staged byte 6 x + 1 (never dword-aligned): a lane reads the three
+// aligned dwords around its 8 bytes and shifts them out (v_alignbyte); the kq = 3 lanes read one dword of each of the three
+// rows and pick one byte of each (two v_perm with a per-lane selector).  18 vector instructions + 3 LDS reads per fragment.
+struct StemFrag {
+    u32x4s w[2][3];    // [channel tile][plane hi / mid / lo] weight fragments (stem_w3, 16 B per lane each)
+    f32x4 bv[2];       // bias of the lane's 4 channels per channel tile
+    int a0, a1, a2;    // byte offsets of the lane's three dwords from (staged row 0 of the window rows) + 96 tx
+    uint32_t sh;       // byte shift of the window inside its first dword: (6 li + 1) & 3
+    uint32_t sel_a, sel_b, mask_hi;
+};
+__device__ __forceinline__ void stem_frag_init(StemFrag &f, const u32x4s *__restrict__ w3, const float *__restrict__ bias, int lane, int RSB) {
+    const int li = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) f.w[c][p] = w3[(c * 3 + p) * 64 + lane];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) f.bv[c] = *reinterpret_cast<const f32x4 *>(bias + 16 * c + 4 * kq);
+    const int ws = 6 * li + 1, wb = ws & ~3;
+    f.sh = (uint32_t)(ws & 3);
+    if (kq < 3) {
+        f.a0 = kq * RSB + wb; f.a1 = f.a0 + 4; f.a2 = f.a0 + 8;
+        f.sel_a = 0x03020100u; f.sel_b = 0x03020100u; f.mask_hi = 0xFFFFFFFFu;
+    } else {
+        f.a0 = wb + 8; f.a1 = RSB + wb + 8; f.a2 = 2 * RSB + wb + 8;
+        f.sel_a = 0x0C0C0400u;  // [lo.b0, hi.b0, 0, 0]
+        f.sel_b = 0x0C040100u;  // [.b0, .b1, t2.b0, 0]
+        f.mask_hi = 0u;
+    }
+}
+// rows: staged byte 0 of the tile's first window row (input row 2 y - 1), advanced by 96 tx (16 pixels x 6 bytes); 4-byte aligned
+__device__ __forceinline__ void stem_tile(const StemFrag &f, const uint8_t *rows, f32x4 out[2]) {
+    const uint32_t d0 = *reinterpret_cast<const uint32_t *>(rows + f.a0);
+    const uint32_t d1 = *reinterpret_cast<const uint32_t *>(rows + f.a1);
+    const uint32_t d2 = *reinterpret_cast<const uint32_t *>(rows + f.a2);
+    uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, f.sh);
+    uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, f.sh);
+    const uint32_t t2 = d2 >> (8u * f.sh);
+    lo = __builtin_amdgcn_perm(t2, __builtin_amdgcn_perm(hi, lo, f.sel_a), f.sel_b);
+    hi &= f.mask_hi;
+    float b[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        b[j] = (float)((lo >> (8 * j)) & 0xFFu);      // v_cvt_f32_ubyteN
+        b[4 + j] = (float)((hi >> (8 * j)) & 0xFFu);
+    }
+    u32x4s px;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) px[j] = __builtin_amdgcn_perm(__float_as_uint(b[2 * j + 1]), __float_as_uint(b[2 * j]), 0x07060302u);  // top halves: exact bf16
+    typedef __bf16 bf16x8s __attribute__((ext_vector_type(8)));
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8s, f.w[c][2]), __builtin_bit_cast(bf16x8s, px), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8s, f.w[c][1]), __builtin_bit_cast(bf16x8s, px), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8s, f.w[c][0]), __builtin_bit_cast(bf16x8s, px), acc, 0, 0, 0);
+        out[c] = (f32x4){silu_f(acc.x + f.bv[c].x), silu_f(acc.y + f.bv[c].y), silu_f(acc.z + f.bv[c].z), silu_f(acc.w + f.bv[c].w)};
+    }
+}
+
+// k_stem: the stem alone (inputs wider than the fused kernel's LDS ring allows, or PB_NO_STEM_FUSION).  A block owns one
+// output row (b, y): its three input rows are staged as bytes (coalesced dwords), a wave takes 16 consecutive output pixels
+// per trip (stem_tile).  Input sizes are multiples of 32 (checked at load): rows are whole dwords and whole MFMA tiles.
+// dynamic LDS = 3 * (W * 3 + 4) bytes.
 __global__ __launch_bounds__(256) void k_stem(const uint8_t *__restrict__ img, int B, int H, int W,
-                                                   const float *__restrict__ w, const float *__restrict__ bias,
-                                                   float *__restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) float s_rows[];  // [3][(W + 1) * 3] floats, pixel -1 first
-    __shared__ float s_px[256];
-    s_px[threadIdx.x & 255] = (float)(threadIdx.x & 255) / 255.0f;
+                                              const u32x4s *__restrict__ w3, const float *__restrict__ bias,
+                                              float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_rows[];  // [3][RSB]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 15, kq = lane >> 4;
     const int Ho = H / 2, Wo = W / 2;
-    const int RS = (W + 1) * 3;  // floats per staged row
-    int toff[8];
-    bool t_on[8];
-    float wreg[2][8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int k = 16 * (j >> 2) + 4 * kq + (j & 3);
-        const int ky = k / 9, kx = (k % 9) / 3, ci = k % 3;
-        t_on[j] = k < 27;
-        toff[j] = t_on[j] ? ky * RS + kx * 3 + ci : 0;  // relative to staged pixel (2x - 1) of row 0
-#pragma unroll
-        for (int c = 0; c < 2; ++c) wreg[c][j] = t_on[j] ? w[k * 32 + 16 * c + li] : 0.0f;
-    }
-    f32x4 bv[2];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) bv[c] = *reinterpret_cast<const f32x4 *>(bias + 16 * c + 4 * kq);
-    __syncthreads();
+    const int RSB = W * 3 + 4;
+    StemFrag f;
+    stem_frag_init(f, w3, bias, lane, RSB);
     const int row_dwords = W * 3 / 4;
     for (int ry = blockIdx.x; ry < B * Ho; ry += gridDim.x) {
         const int b = ry / Ho, y = ry - b * Ho;
-        // stage input rows 2y - 1, 2y, 2y + 1
-        for (int i = threadIdx.x; i < 3 * row_dwords; i += 256) {
-            const int r = i / row_dwords, dq = i - r * row_dwords;
+        // stage input rows 2y - 1, 2y, 2y + 1 (rows above the image: zero bytes)
+        for (int i = threadIdx.x; i < 3 * (row_dwords + 1); i += 256) {
+            const int r = i / (row_dwords + 1), dq = i - r * (row_dwords + 1);  // dq = 0: the pad dword
             const int iy = 2 * y - 1 + r;
-            float *dst = s_rows + r * RS + 3 + 4 * dq;
-            if (iy >= 0) {
-                const uint32_t u = *reinterpret_cast<const uint32_t *>(img + ((size_t)b * H + iy) * W * 3 + 4 * dq);
-                dst[0] = s_px[u & 0xFF]; dst[1] = s_px[(u >> 8) & 0xFF]; dst[2] = s_px[(u >> 16) & 0xFF]; dst[3] = s_px[u >> 24];
-            } else {
-                dst[0] = 0.f; dst[1] = 0.f; dst[2] = 0.f; dst[3] = 0.f;
-            }
+            uint32_t u = 0;
+            if (dq > 0 && iy >= 0) u = *reinterpret_cast<const uint32_t *>(img + ((size_t)b * H + iy) * W * 3 + 4 * (dq - 1));
+            *reinterpret_cast<uint32_t *>(s_rows + (size_t)r * RSB + 4 * dq) = u;
         }
-        if (threadIdx.x < 9) s_rows[(threadIdx.x / 3) * RS + threadIdx.x % 3] = 0.0f;  // pixel -1 of each row
         __syncthreads();
         for (int tx = wave; tx < Wo / 16; tx += 4) {
-            const int x = tx * 16 + li;
-            const float *base = s_rows + 2 * x * 3;  // staged pixel index 2x <-> image column 2x - 1
-            float v[8];
+            f32x4 r[2];
+            stem_tile(f, s_rows + 96 * tx, r);
+            float *o = out + ((size_t)ry * Wo + tx * 16 + li) * 32;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = t_on[j] ? base[toff[j]] : 0.0f;
-            f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-#pragma unroll
-                for (int c = 0; c < 2; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[c][j], v[j], acc[c], 0, 0, 0);
-            float *o = out + ((size_t)ry * Wo + x) * 32;
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                f32x4 r = acc[c];
-                r.x = silu_f(r.x + bv[c].x); r.y = silu_f(r.y + bv[c].y); r.z = silu_f(r.z + bv[c].z); r.w = silu_f(r.w + bv[c].w);
-                *reinterpret_cast<f32x4 *>(o + 16 * c + 4 * kq) = r;
-            }
+            for (int c = 0; c < 2; ++c) *reinterpret_cast<f32x4 *>(o + 16 * c + 4 * kq) = r[c];
         }
         __syncthreads();
     }
@@ -218,23 +262,20 @@ __global__ __launch_bounds__(256) void k_stem(const uint8_t *__restrict__ img, i
 // 268 MB per 512-image batch, written once and read once by nothing but that depthwise conv -- the first block has
 // no expansion and no residual) never leaves the CU.  A block owns a band of output rows.  It first loads ALL the
 // input rows the band needs (2 rows per stem row + 1, as raw bytes, coalesced dwords, one memory round trip for the
-// whole band) into LDS; then, per stem row, the MFMA stem of k_stem with its taps gathered from those bytes through
-// the v/255 table, the activated row written into a 3-row LDS ring ([pixel + 1][36 floats]: 4 floats of padding
-// per pixel keep the MFMA-layout float4 writes conflict-free; one zero pixel on each side and zero rows outside the
-// image are the depthwise zero padding), and once three rows are in the ring the depthwise filter of the middle
-// row from LDS (a thread = one pixel x channel quad, bias-first (ky, kx) accumulation with separately rounded
-// products, as k_dwconv), + SiLU, store, SE partial sums.  Stem rows at band edges are recomputed by the
+// whole band) into LDS; then, per stem row, stem_tile on those bytes, the activated row written into a 3-row LDS ring
+// ([pixel + 1][36 floats]: 4 floats of padding per pixel keep the MFMA-layout float4 writes conflict-free; one zero pixel
+// on each side and zero rows outside the image are the depthwise zero padding), and once three rows are in the ring the
+// depthwise filter of the middle row from LDS (a thread = one pixel x channel quad -- the quad is the thread's for the
+// whole kernel, so its 9 taps and bias live in registers; bias-first (ky, kx) accumulation, one fused multiply-add per
+// tap as in every depthwise form), + SiLU, store, SE partial sums.  Stem rows at band edges are recomputed by the
 // neighbouring band.  Identical arithmetic to k_stem + k_dwconv: same bits.
 // grid = (n_bands, B); dynamic LDS = (2 rows_per_band + 5) * RSB bytes + 3 * (W / 2 + 2) * 36 floats.
 __global__ __launch_bounds__(256) void k_stem_dw(const uint8_t *__restrict__ img, int B, int H, int W,
-                                                 const float *__restrict__ w, const float *__restrict__ bias,
+                                                 const u32x4s *__restrict__ w3, const float *__restrict__ bias,
                                                  const float *__restrict__ dw_w, const float *__restrict__ dw_b,
                                                  float *__restrict__ out, long long *__restrict__ part, int n_bands,
                                                  int rows_per_band, SeTail se) {
     extern __shared__ __attribute__((aligned(16))) float s_sd[];
-    __shared__ float s_px[256];
-    __shared__ f32x4 s_dww[9 * 8];
-    __shared__ f32x4 s_dwb[8];
     __shared__ ll4 s_red[256];
     const int Ho = H / 2, Wo = W / 2;
     const int RSB = W * 3 + 4;     // bytes per staged input row: 4 pad bytes (bytes 1..3 = pixel -1 = 0), then the row
@@ -242,17 +283,14 @@ __global__ __launch_bounds__(256) void k_stem_dw(const uint8_t *__restrict__ img
     float *s_ring = s_sd;
     uint8_t *s_in = reinterpret_cast<uint8_t *>(s_sd + 3 * RP);
     const int tid = threadIdx.x;
-    s_px[tid & 255] = (float)(tid & 255) / 255.0f;
-    if (tid < 72) s_dww[tid] = *reinterpret_cast<const f32x4 *>(dw_w + (tid >> 3) * 32 + (tid & 7) * 4);
-    if (tid < 8) s_dwb[tid] = *reinterpret_cast<const f32x4 *>(dw_b + tid * 4);
     for (int i = tid; i < 3 * 2 * 36; i += 256) {  // the ring's border pixels (columns -1 and Wo) stay zero
-        const int r = i / 72, side = (i % 72) / 36, f = i % 36;
-        s_ring[r * RP + (side ? (Wo + 1) * 36 : 0) + f] = 0.0f;
+        const int r = i / 72, side = (i % 72) / 36, fl = i % 36;
+        s_ring[r * RP + (side ? (Wo + 1) * 36 : 0) + fl] = 0.0f;
     }
     const int b = blockIdx.y, band = blockIdx.x;
     const int y0 = band * rows_per_band;
     const int y1 = (y0 + rows_per_band) < Ho ? (y0 + rows_per_band) : Ho;
-    // input rows 2 (y0 - 1) - 1 .. 2 y1 + 1 -> staged rows 0 .. ; rows outside the image are zero bytes (v/255 = 0)
+    // input rows 2 (y0 - 1) - 1 .. 2 y1 + 1 -> staged rows 0 .. ; rows outside the image are zero bytes
     const int iy0 = 2 * (y0 - 1) - 1;
     const int n_in = 2 * (y1 - y0 + 2) + 1;
     const int row_dwords = W * 3 / 4;
@@ -265,45 +303,25 @@ __global__ __launch_bounds__(256) void k_stem_dw(const uint8_t *__restrict__ img
     }
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: what it indexes stays in SGPRs
     const int li = lane & 15, kq = lane >> 4;
-    int toff[8];
-    bool t_on[8];
-    float wreg[2][8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int k = 16 * (j >> 2) + 4 * kq + (j & 3);
-        const int ky = k / 9, kx = (k % 9) / 3, ci = k % 3;
-        t_on[j] = k < 27;
-        toff[j] = t_on[j] ? ky * RSB + kx * 3 + ci : 0;  // bytes, relative to staged pixel (2x - 1) of the stem row's first input row
-#pragma unroll
-        for (int c = 0; c < 2; ++c) wreg[c][j] = t_on[j] ? w[k * 32 + 16 * c + li] : 0.0f;
-    }
-    f32x4 bv[2];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) bv[c] = *reinterpret_cast<const f32x4 *>(bias + 16 * c + 4 * kq);
+    StemFrag f;
+    stem_frag_init(f, w3, bias, lane, RSB);
     const int quad = tid & 7;
+    f32x4 tw[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) tw[t] = *reinterpret_cast<const f32x4 *>(dw_w + t * 32 + quad * 4);
+    const f32x4 tb = *reinterpret_cast<const f32x4 *>(dw_b + quad * 4);
     ll4 psum = {0, 0, 0, 0};
     __syncthreads();
     for (int sy = y0 - 1; sy <= y1; ++sy) {
         float *ring = s_ring + ((sy + 3) % 3) * RP;
         if (sy >= 0 && sy < Ho) {
-            const uint8_t *rows0 = s_in + (size_t)(2 * (sy - y0 + 1)) * RSB + 1;  // staged pixel 0 (= column -1) of input row 2 sy - 1
+            const uint8_t *rows0 = s_in + (size_t)(2 * (sy - y0 + 1)) * RSB;  // staged byte 0 of input row 2 sy - 1
             for (int tx = wave; tx < Wo / 16; tx += 4) {
-                const int x = tx * 16 + li;
-                const uint8_t *base = rows0 + 6 * x;
-                float v[8];
+                f32x4 r[2];
+                stem_tile(f, rows0 + 96 * tx, r);
+                float *rp = ring + (tx * 16 + li + 1) * 36 + 4 * kq;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = t_on[j] ? s_px[base[toff[j]]] : 0.0f;
-                f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[c][j], v[j], acc[c], 0, 0, 0);
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    f32x4 r = acc[c];
-                    r.x = silu_f(r.x + bv[c].x); r.y = silu_f(r.y + bv[c].y); r.z = silu_f(r.z + bv[c].z); r.w = silu_f(r.w + bv[c].w);
-                    *reinterpret_cast<f32x4 *>(ring + (x + 1) * 36 + 16 * c + 4 * kq) = r;
-                }
+                for (int c = 0; c < 2; ++c) *reinterpret_cast<f32x4 *>(rp + 16 * c) = r[c];
             }
         } else {
             for (int i = tid; i < Wo * 8; i += 256)
@@ -314,15 +332,14 @@ __global__ __launch_bounds__(256) void k_stem_dw(const uint8_t *__restrict__ img
         if (oy >= y0 && oy < y1) {
             const float *r0 = s_ring + ((oy - 1 + 3) % 3) * RP, *r1 = s_ring + ((oy + 3) % 3) * RP, *r2 = s_ring + ((oy + 1 + 3) % 3) * RP;
             for (int px = tid >> 3; px < Wo; px += 32) {
-                f32x4 acc = s_dwb[quad];
+                f32x4 acc = tb;
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
                     const float *rr = ky == 0 ? r0 : (ky == 1 ? r1 : r2);
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
                         const f32x4 v = *reinterpret_cast<const f32x4 *>(rr + (px + kx) * 36 + 4 * quad);
-                        const f32x4 wv = s_dww[(ky * 3 + kx) * 8 + quad];
-                        dw_tap(acc, v, wv);
+                        dw_tap(acc, v, tw[ky * 3 + kx]);
                     }
                 }
                 const f32x4 r = {silu_f(acc.x), silu_f(acc.y), silu_f(acc.z), silu_f(acc.w)};
