@@ -757,6 +757,21 @@ def bench_embed(args, torch, device, distributed):
     if int(os.environ.get("RANK", "0")) == 0 and not args.no_cpu_baseline:
         from oracle import capi as oracle
 
+        # parity of THIS batch, outside every timed region (the oracle is the checker): the HIP floats of the bench's own 512
+        # images against the f32 oracle and against the same network evaluated in f64 (the third point: VERDICT r4 item 2)
+        nthr = min(64, os.cpu_count() or 8)
+        _, f_hip = emb.embed(host_imgs)
+        _, f_orc = oracle.mlhash_batch(blob, host_imgs, 256, nthreads=nthr)
+        f_64 = oracle.effnet_batch_f64(blob, host_imgs, 256, nthreads=nthr)
+        e_hip = np.abs(f_hip.astype(np.float64) - f_64).max(axis=1)
+        e_orc = np.abs(f_orc.astype(np.float64) - f_64).max(axis=1)
+        res["parity"] = {"images": int(nb), "max_err_vs_oracle_all_images": float(np.abs(f_hip - f_orc).max()),
+                         "max_err_vs_f64": float(e_hip.max()), "oracle_max_err_vs_f64": float(e_orc.max()),
+                         "median_err_vs_f64": float(np.median(e_hip)), "oracle_median_err_vs_f64": float(np.median(e_orc)),
+                         "n_saturated": int((np.abs(f_64).max(axis=1) >= 0.999).sum()),
+                         "note": "max over the 256 outputs of |difference| per image, then max / median over the batch's images; f64 = "
+                                 "oracle/pb_oracle_effnet_f64.c (same weights and pixels, double arithmetic); the saturating parity set "
+                                 "(synth.synthetic_images) is held to the same comparison in tests/test_embed_gpu.py"}
         n = 2048
         sample = synth.fill_synthetic(synth.SEED_IMAGES, 0, n * 128 * 128 * 3).reshape(n, 128, 128, 3)
         t0 = time.perf_counter()

@@ -91,6 +91,7 @@ struct pb_embedder {
     int opt_async = 0;    // PB_OPT_EMBED_ASYNC
     int trace_tune = 0;   // PB_TRACE_TUNE (1: chosen forms, 2: every candidate), PB_NO_STEM_FUSION: read once at create
     bool no_stem_fusion = false;
+    int stem_rpp = 0;  // PB_STEM_RPP: stem rows per phase of k_stem_dw (0: the default)
     unsigned *d_se_cnt = nullptr;  // [max_batch] arrival counters of the squeeze-excite tails (zero between launches)
     bool fold_se = false;          // PB_FOLD_SE=1: the gates of the first six blocks come from the producing kernels' tails instead of k_se
                                    // launches (measured: +0.04 ms per batch-512 forward and per batch-1 forward -- see SeTail; off by default)
@@ -1087,16 +1088,25 @@ int forward_device(pb_embedder *e, const uint8_t *d_rgb, int n, uint8_t *d_u8, f
     // bands of 16 output rows (2 stem rows of halo each), fewer rows per band for small batches (<= 32 partial tiles)
     int rpb = 16;
     while (rpb > 4 && (long)n * ((H + rpb - 1) / rpb) < 2L * e->n_cu && (H + rpb / 2 - 1) / (rpb / 2) <= 32) rpb /= 2;
-    const size_t fused_lds = (size_t)3 * (W + 2) * 36 * sizeof(float) + (size_t)(2 * rpb + 5) * (e->W * 3 + 4);
+    // stem rows per phase (pb_embed_kernels.h, k_stem_dw): 2 where the 4-slot ring still leaves three workgroups per CU
+    auto stem_lds = [&](int r) { return (size_t)(r + 2) * (W + 2) * 36 * sizeof(float) + (size_t)(2 * rpb + 5) * (e->W * 3 + 4); };
+    const int rpp = e->stem_rpp ? e->stem_rpp : (3 * stem_lds(2) <= 160 * 1024 ? 2 : 1);
+    const size_t fused_lds = stem_lds(rpp);
     const bool fuse_stem = !b0.has_expand && b0.k == 3 && b0.stride == 1 && b0.e == 32 && fused_lds <= 60 * 1024 &&
                            (H + rpb - 1) / rpb <= 32 && !e->no_stem_fusion;
     int stem_bands = 0;
     if (fuse_stem) {
         stem_bands = (H + rpb - 1) / rpb;
-        if (fused_lds > 48 * 1024)
-            PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stem_dw), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds));
-        hipLaunchKernelGGL(k_stem_dw, dim3(stem_bands, n), dim3(256), fused_lds, e->stream, d_rgb, n, (int)e->H, (int)e->W,
-                           reinterpret_cast<const u32x4s *>(e->stem_w3), e->stem_b, b0.dw_w, b0.dw_b, e->buf_dw, e->buf_part, stem_bands, rpb, se_tail(e, b0, H, W));
+        auto go = [&](auto kern) -> int {
+            if (fused_lds > 48 * 1024)
+                PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds));
+            hipLaunchKernelGGL(kern, dim3(stem_bands, n), dim3(256), fused_lds, e->stream, d_rgb, n, (int)e->H, (int)e->W,
+                               reinterpret_cast<const u32x4s *>(e->stem_w3), e->stem_b, b0.dw_w, b0.dw_b, e->buf_dw, e->buf_part, stem_bands, rpb,
+                               se_tail(e, b0, H, W));
+            return PB_OK;
+        };
+        const int rc_s = rpp == 1 ? go(k_stem_dw<1>) : go(k_stem_dw<2>);
+        if (rc_s) return rc_s;
         PB_HIP(hipGetLastError());
     } else {
         // one block per output row, taps from LDS-staged input rows (W is a multiple of 32 and <= 1024: 37 KB at most)
@@ -1463,6 +1473,7 @@ int pb_embed_create(pb_embedder **out, int device, const void *weights_blob, siz
     if (const char *tp = getenv("PB_TUNE_PICK")) e->tune_pick = atoi(tp);
     if (const char *tt = getenv("PB_TRACE_TUNE")) e->trace_tune = tt[0] == '3' ? 3 : (tt[0] == '2' ? 2 : 1);  // 3: + host-side staging times
     e->no_stem_fusion = getenv("PB_NO_STEM_FUSION") != nullptr;
+    if (const char *v = getenv("PB_STEM_RPP")) e->stem_rpp = atoi(v) == 1 ? 1 : 2;
     e->fold_se = getenv("PB_FOLD_SE") != nullptr;
     e->no_gemm_t = getenv("PB_NO_GEMM_T") != nullptr;
     e->no_tail_fusion = getenv("PB_NO_TAIL_FUSION") != nullptr;

@@ -270,20 +270,26 @@ __global__ __launch_bounds__(256) void k_stem(const uint8_t *__restrict__ img, i
 // tap as in every depthwise form), + SiLU, store, SE partial sums.  Stem rows at band edges are recomputed by the
 // neighbouring band.  Identical arithmetic to k_stem + k_dwconv: same bits.
 // grid = (n_bands, B); dynamic LDS = (2 rows_per_band + 5) * RSB bytes + 3 * (W / 2 + 2) * 36 floats.
+// RPP: stem rows per phase (1 or 2).  A phase = the tiles of RPP stem rows (Wo / 16 tiles each, dealt over the 4 waves), a barrier,
+// the depthwise filter of the RPP output rows whose three stem rows are now in the ring (RPP + 2 slots), a barrier.  With one row
+// per phase a wave had ONE tile (3 LDS reads -> 18 vector instructions -> 2 x 3 dependent MFMAs -> 8 SiLU) and two filter items
+// between two barriers and three waves per SIMD to hide it under: RPP = 2 halves the barriers and gives every wave two independent
+// tiles / four items per phase (measured: profiles/r05_stem.txt).
+template <int RPP>
 __global__ __launch_bounds__(256) void k_stem_dw(const uint8_t *__restrict__ img, int B, int H, int W,
                                                  const u32x4s *__restrict__ w3, const float *__restrict__ bias,
                                                  const float *__restrict__ dw_w, const float *__restrict__ dw_b,
                                                  float *__restrict__ out, long long *__restrict__ part, int n_bands,
                                                  int rows_per_band, SeTail se) {
+    constexpr int RING = RPP + 2;
     extern __shared__ __attribute__((aligned(16))) float s_sd[];
-    __shared__ ll4 s_red[256];
     const int Ho = H / 2, Wo = W / 2;
     const int RSB = W * 3 + 4;     // bytes per staged input row: 4 pad bytes (bytes 1..3 = pixel -1 = 0), then the row
     const int RP = (Wo + 2) * 36;  // floats per ring row
     float *s_ring = s_sd;
-    uint8_t *s_in = reinterpret_cast<uint8_t *>(s_sd + 3 * RP);
+    uint8_t *s_in = reinterpret_cast<uint8_t *>(s_sd + RING * RP);
     const int tid = threadIdx.x;
-    for (int i = tid; i < 3 * 2 * 36; i += 256) {  // the ring's border pixels (columns -1 and Wo) stay zero
+    for (int i = tid; i < RING * 2 * 36; i += 256) {  // the ring's border pixels (columns -1 and Wo) stay zero
         const int r = i / 72, side = (i % 72) / 36, fl = i % 36;
         s_ring[r * RP + (side ? (Wo + 1) * 36 : 0) + fl] = 0.0f;
     }
@@ -311,44 +317,49 @@ __global__ __launch_bounds__(256) void k_stem_dw(const uint8_t *__restrict__ img
     for (int t = 0; t < 9; ++t) tw[t] = *reinterpret_cast<const f32x4 *>(dw_w + t * 32 + quad * 4);
     const f32x4 tb = *reinterpret_cast<const f32x4 *>(dw_b + quad * 4);
     ll4 psum = {0, 0, 0, 0};
+    const int tiles = Wo / 16;
     __syncthreads();
-    for (int sy = y0 - 1; sy <= y1; ++sy) {
-        float *ring = s_ring + ((sy + 3) % 3) * RP;
-        if (sy >= 0 && sy < Ho) {
-            const uint8_t *rows0 = s_in + (size_t)(2 * (sy - y0 + 1)) * RSB;  // staged byte 0 of input row 2 sy - 1
-            for (int tx = wave; tx < Wo / 16; tx += 4) {
-                f32x4 r[2];
-                stem_tile(f, rows0 + 96 * tx, r);
+    for (int sy = y0 - 1; sy <= y1; sy += RPP) {
+        // ---- stem rows sy .. sy + RPP - 1 (rows beyond y1: not needed by this band; rows outside the image: zeros)
+#pragma unroll
+        for (int rr = 0; rr < RPP; ++rr) {
+            const int row = sy + rr;
+            if (row > y1) continue;  // uniform
+            const bool in_img = row >= 0 && row < Ho;
+            const uint8_t *rows0 = s_in + (size_t)(2 * (row - y0 + 1)) * RSB;  // staged byte 0 of input row 2 row - 1
+            float *ring = s_ring + ((row + RING) % RING) * RP;
+            for (int tx = wave; tx < tiles; tx += 4) {
+                f32x4 r[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+                if (in_img) stem_tile(f, rows0 + 96 * tx, r);
                 float *rp = ring + (tx * 16 + li + 1) * 36 + 4 * kq;
 #pragma unroll
                 for (int c = 0; c < 2; ++c) *reinterpret_cast<f32x4 *>(rp + 16 * c) = r[c];
             }
-        } else {
-            for (int i = tid; i < Wo * 8; i += 256)
-                *reinterpret_cast<f32x4 *>(ring + ((i >> 3) + 1) * 36 + 4 * (i & 7)) = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
         __syncthreads();
-        const int oy = sy - 1;
-        if (oy >= y0 && oy < y1) {
-            const float *r0 = s_ring + ((oy - 1 + 3) % 3) * RP, *r1 = s_ring + ((oy + 3) % 3) * RP, *r2 = s_ring + ((oy + 1 + 3) % 3) * RP;
+        // ---- depthwise rows sy - 1 .. sy + RPP - 2
+#pragma unroll
+        for (int rr = 0; rr < RPP; ++rr) {
+            const int oy = sy - 1 + rr;
+            if (oy < y0 || oy >= y1) continue;  // uniform
+            const float *r0 = s_ring + ((oy - 1 + RING) % RING) * RP + 4 * quad, *r1 = s_ring + ((oy + RING) % RING) * RP + 4 * quad,
+                        *r2 = s_ring + ((oy + 1 + RING) % RING) * RP + 4 * quad;
             for (int px = tid >> 3; px < Wo; px += 32) {
                 f32x4 acc = tb;
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
-                    const float *rr = ky == 0 ? r0 : (ky == 1 ? r1 : r2);
+                    const float *rrp = (ky == 0 ? r0 : (ky == 1 ? r1 : r2)) + px * 36;
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const f32x4 v = *reinterpret_cast<const f32x4 *>(rr + (px + kx) * 36 + 4 * quad);
-                        dw_tap(acc, v, tw[ky * 3 + kx]);
-                    }
+                    for (int kx = 0; kx < 3; ++kx) dw_tap(acc, *reinterpret_cast<const f32x4 *>(rrp + kx * 36), tw[ky * 3 + kx]);
                 }
                 const f32x4 r = {silu_f(acc.x), silu_f(acc.y), silu_f(acc.z), silu_f(acc.w)};
                 *reinterpret_cast<f32x4 *>(out + (((size_t)b * Ho + oy) * Wo + px) * 32 + 4 * quad) = r;
                 se_acc(psum, r);
             }
         }
-        __syncthreads();  // the next stem row overwrites the ring slot the filter just read
+        __syncthreads();  // the next phase overwrites ring slots the filter just read
     }
+    ll4 *s_red = reinterpret_cast<ll4 *>(s_sd);  // [256]: over the ring (free by now: the loop ends with a barrier)
     s_red[tid] = psum;
     __syncthreads();
     if (tid < 8) {
@@ -358,6 +369,7 @@ __global__ __launch_bounds__(256) void k_stem_dw(const uint8_t *__restrict__ img
     }
     // the band that completes the image computes the first block's squeeze-excite gate (se_gate_image; the ring is free by now)
     if (se.sp) {
+        __syncthreads();
         if (se_arrive(se.cnt + b, (unsigned)n_bands, reinterpret_cast<unsigned *>(s_sd)))
             se_gate_image_sp<256>(part + (size_t)b * n_bands * 32, n_bands, 32, se, se.gate + (size_t)b * 32, s_sd + 4);
     }

@@ -81,6 +81,44 @@ def test_config3_batch_512_vs_oracle():
     assert np.array_equal(d_u8.cpu().numpy(), u8)
 
 
+@pytest.mark.parametrize("kind", ["bench", "parity"])
+def test_hip_embedding_is_as_close_to_the_f64_value_as_the_oracle_is(kind):
+    """The third point under the 1e-5 bar: the same network evaluated in f64 (oracle/pb_oracle_effnet_f64.c).
+
+    Both f32 evaluations -- the oracle's naive loops and the HIP path's matrix-core sums -- approximate that value with
+    independent rounding, so per image their errors are two draws from the same distribution: over bench.py's 512 images the
+    ratio hip / oracle has median 1.0 and reaches 3 on individual images whose oracle draw happened to be small (measured,
+    profiles/r05_embed_f64.txt), while the maxima and medians over a set agree to a few per cent.  Asserted, saturated images
+    INCLUDED and no carve-out:
+      * over the set: max|hip - f64| <= 1.5 max|oracle - f64|, median likewise;
+      * per image:    max|hip - f64| <= 1.5 max|oracle - f64| + 1e-6 (the floor is ~8 ulp of an output near 1: what one f32
+        evaluation of this network scatters by on an unsaturated image);
+      * the same two over the saturated images alone (where tests/embed_tol.py widens the hip-vs-oracle bar to 2e-4: the
+        measured worst case there is 1.1e-5 for the HIP path and 1.3e-5 for the oracle).
+    bench: bench.py's images (the raw synthetic byte stream); parity: synth.synthetic_images (brightness windows; ~16 % saturate)."""
+    n = 512
+    blob = W.synthetic_blob(synth.SEED_WEIGHTS, 128, 128, 256)
+    if kind == "bench":
+        imgs = synth.fill_synthetic(synth.SEED_IMAGES, 0, n * 128 * 128 * 3).reshape(n, 128, 128, 3)
+    else:
+        imgs = synth.synthetic_images(synth.SEED_IMAGES, 0, n, 128, 128)
+    nthr = min(64, os.cpu_count() or 8)
+    emb = capi.Embedder(blob, max_batch=512)
+    _, f = emb.embed(imgs)
+    _, ref_f = oracle.mlhash_batch(blob, imgs, 256, nthreads=nthr)
+    f64 = oracle.effnet_batch_f64(blob, imgs, 256, nthreads=nthr)
+    e_hip = np.abs(f.astype(np.float64) - f64).max(axis=1)
+    e_orc = np.abs(ref_f.astype(np.float64) - f64).max(axis=1)
+    sat = np.abs(f64).max(axis=1) >= 0.999
+    assert e_hip.max() <= 1.5 * e_orc.max(), (e_hip.max(), e_orc.max())
+    assert np.median(e_hip) <= 1.5 * np.median(e_orc), (np.median(e_hip), np.median(e_orc))
+    assert np.all(e_hip <= 1.5 * e_orc + 1e-6), (e_hip[e_hip > 1.5 * e_orc + 1e-6], e_orc[e_hip > 1.5 * e_orc + 1e-6])
+    if kind == "parity":
+        assert sat.sum() >= 32  # the set does exercise saturation
+        assert e_hip[sat].max() <= 1.5 * e_orc[sat].max() and e_hip[sat].max() <= 5e-5, (e_hip[sat].max(), e_orc[sat].max())
+    assert e_hip[~sat].max() <= 1e-5  # the absolute bar, against the true value, where no output saturates
+
+
 def test_embed_device_then_append_device_on_default_streams():
     # The pipeline the header advertises (embed_batch_device -> pb_index_append_device) with NOTHING configured: the
     # embedder and the index each own a non-blocking stream.  pb_embed_batch_device waits for its stream by default,
