@@ -1811,7 +1811,7 @@ int pb_embed_tune_ms(pb_embedder *e, double *ms) {
 namespace {
 // serialised picks: header {magic "PBTN", format, H, W, D, n_entries} then entries {map, key id, bucket, v[6]}.  `format` changes
 // whenever an encoding of gemm_cfg / dw_cfg / front_cfg changes meaning (a new kernel form, a renumbered shape).
-constexpr uint32_t TUNE_MAGIC = 0x4E544250u, TUNE_FORMAT = 4u;
+constexpr uint32_t TUNE_MAGIC = 0x4E544250u, TUNE_FORMAT = 5u;
 struct TuneHdr {
     uint32_t magic, format, H, W, D, n;
 };

@@ -341,11 +341,13 @@ def test_host_buffer_call_larger_than_max_batch_pipelines_its_chunks():
     assert np.array_equal(u8, u8_ref[:9])
 
 
-@pytest.mark.parametrize("switch", ["PB_NO_BLOCK_FUSION", "PB_NO_TAIL_FUSION", "PB_NO_GEMM_T", "PB_NO_GEMM_STREAM", "PB_NO_BAND", "PB_FORCE_BAND", "PB_FOLD_SE"])
+@pytest.mark.parametrize("switch", ["PB_NO_BLOCK_FUSION", "PB_NO_TAIL_FUSION", "PB_NO_GEMM_T", "PB_NO_GEMM_STREAM", "PB_NO_BAND", "PB_FORCE_BAND", "PB_FOLD_SE",
+                                    "PB_STEM_RPP"])
 def test_round3_kernel_forms_give_the_same_bits(monkeypatch, switch):
     # Each switch (read at pb_embed_create) takes one of round 3's kernel forms out of -- or forces it into -- the forward:
     # the whole-block kernel of the 4 x 4 maps, the pooling / tanh + quantiser epilogues, the fragment-ordered GEMM, the
-    # streaming GEMM of the thin early project layers, the LDS-ring front kernel, the squeeze-excite tails.  At a batch where the forms are in use (512: one workgroup of the
+    # streaming GEMM of the thin early project layers, the LDS-ring front kernel, the squeeze-excite tails; round 5: one stem row per phase in
+    # k_stem_dw.  At a batch where the forms are in use (512: one workgroup of the
     # whole-block kernel per CU) and at small ones the embedding must not change in a single bit.
     blob = W.synthetic_blob(synth.SEED_WEIGHTS, 128, 128, 256)
     imgs = synth.synthetic_scenes(synth.SEED_IMAGES, 4000, 512, 128, 128)
