@@ -1281,13 +1281,15 @@ void destroy(pb_embedder *e) {
 // efficientnet.rs:20 on the device for a BATCH of host RGB8 images of individual sizes: resize_to_fill(W, H, Triangle) of image
 // i into d_dst[i][H][W][3] (image 0.25.x semantics; kernels in pb_embed_kernels.h; the tests compare with a CPU restatement bit
 // for bit).  The reference does this per image on a crawler worker (crawler.rs:68-119 -> indexed_image.rs:71 ->
-// efficientnet.rs:19-29); here the batch is cut into sub-batches of <= STAGE_BYTES of source pixels and pipelined over two
+// efficientnet.rs:19-29); here the batch is cut into sub-batches of <= STAGE_BYTES of source pixels (and <= STAGE_TMP_FLOATS of
+// vertical-pass scratch) and pipelined over two
 // staging slots: the host packs sub-batch j + 1 into pinned memory (split over four threads) while the copy engine moves
 // sub-batch j and the resize kernels -- TWO launches per sub-batch, over a descriptor array -- run on the embedder's stream.
 // Nothing waits for the GPU except a slot's reuse; the kernels are queued on e->stream, so a forward pass queued after this
 // call is ordered behind them.  On an error the caller drains (drain_streams).
 constexpr size_t STAGE_BYTES = 48u << 20;
 constexpr uint32_t STAGE_MAX_IMAGES = 1024;
+constexpr size_t STAGE_TMP_FLOATS = 64u << 20;  // 256 MB of vertical-pass scratch per sub-batch (48 MB of 256 x 256 sources need 96 MB)
 
 void drain_streams(pb_embedder *e) {
     (void)hipStreamSynchronize(e->h2d_stream);
@@ -1376,6 +1378,9 @@ int prepare_images(pb_embedder *e, const uint8_t *const *rgb, const uint32_t *wi
             PB_CHECK(w >= 1 && h >= 1 && w <= 65535 && h <= 65535, PB_ERR_INVALID, "image %u: size %ux%u outside 1..65535", i1, w, h);
             const size_t sb = (size_t)w * h * 3;
             if (i1 > i0 && src_total + sb > STAGE_BYTES) break;
+            // the vertical pass's scratch is H * w * 3 floats per image -- 4 H / h times the source bytes: a sub-batch of wide, short
+            // images is cut by ITS size too (a single image over the cap still gets a sub-batch of its own, as with the source bytes)
+            if (i1 > i0 && tmp_total + (size_t)H * w * 3 > STAGE_TMP_FLOATS) break;
             // src/math/utils.rs resize_dimensions(.., fill = true)
             const double wratio = (double)W / (double)w, hratio = (double)H / (double)h;
             const double ratio = wratio > hratio ? wratio : hratio;
@@ -1811,9 +1816,10 @@ int pb_embed_tune_ms(pb_embedder *e, double *ms) {
 namespace {
 // serialised picks: header {magic "PBTN", format, H, W, D, n_entries} then entries {map, key id, bucket, v[6]}.  `format` changes
 // whenever an encoding of gemm_cfg / dw_cfg / front_cfg changes meaning (a new kernel form, a renumbered shape).
-constexpr uint32_t TUNE_MAGIC = 0x4E544250u, TUNE_FORMAT = 5u;
+constexpr uint32_t TUNE_MAGIC = 0x4E544250u, TUNE_FORMAT = 6u;
 struct TuneHdr {
     uint32_t magic, format, H, W, D, n;
+    uint32_t p3_min_k, reserved;  // which layers are P3 layers is part of what a gemm entry's numbers MEAN (format 6)
 };
 struct TuneEntry {
     uint32_t map, key;
@@ -1857,7 +1863,7 @@ int pb_embed_get_tuning(pb_embedder *e, uint8_t *out, size_t cap, size_t *len) {
     *len = need;
     if (!out) return PB_OK;
     PB_CHECK(cap >= need, PB_ERR_INVALID, "pb_embed_get_tuning: buffer of %zu bytes, %zu needed", cap, need);
-    const TuneHdr h{TUNE_MAGIC, TUNE_FORMAT, e->H, e->W, e->D, (uint32_t)ent.size()};
+    const TuneHdr h{TUNE_MAGIC, TUNE_FORMAT, e->H, e->W, e->D, (uint32_t)ent.size(), (uint32_t)e->p3_min_k, 0u};
     memcpy(out, &h, sizeof h);
     if (!ent.empty()) memcpy(out + sizeof h, ent.data(), ent.size() * sizeof(TuneEntry));
     return PB_OK;
@@ -1876,9 +1882,57 @@ int pb_embed_set_tuning(pb_embedder *e, const uint8_t *data, size_t len) {
     PB_CHECK(len == sizeof h + (size_t)h.n * sizeof(TuneEntry), PB_ERR_FORMAT, "tuning data: %zu bytes for %u entries", len, h.n);
     std::vector<TuneEntry> ent(h.n);
     if (h.n) memcpy(ent.data(), data + sizeof h, (size_t)h.n * sizeof(TuneEntry));
-    for (const TuneEntry &t : ent)  // all or nothing
+    PB_CHECK(h.p3_min_k == (uint32_t)e->p3_min_k, PB_ERR_FORMAT, "tuning data: made with P3 layers from K = %u on, this embedder has %d", h.p3_min_k, e->p3_min_k);
+    // Every entry is checked before any is accepted (all or nothing): the numbers go straight into launch geometry, and a stale or
+    // damaged block must not become a grid that leaves output columns unwritten (a column-tile count that does not divide the
+    // layer's) or a shape that is not built (which would fail every later call of that bucket).
+    auto find_gemm = [&](const void *p, bool *frag_key) -> const Gemm * {
+        auto hit = [&](const Gemm &g) { if (g.wt == p) { *frag_key = false; return true; } if (g.wt2 && g.wt2 == p) { *frag_key = true; return true; } return false; };
+        for (const Block &bl : e->blocks) {
+            if (bl.has_expand && hit(bl.expand)) return &bl.expand;
+            if (hit(bl.project)) return &bl.project;
+        }
+        if (hit(e->head)) return &e->head;
+        if (hit(e->fc)) return &e->fc;
+        return nullptr;
+    };
+    for (const TuneEntry &t : ent) {
         PB_CHECK(t.map <= 2u && tune_key_ptr(e, t.key) && t.bucket >= 1 && (t.bucket & (t.bucket - 1)) == 0, PB_ERR_FORMAT,
                  "tuning data: entry for layer %u / map %u does not belong to this model", t.key, t.map);
+        if (t.map == 0) {
+            bool frag = false;
+            const Gemm *g = find_gemm(tune_key_ptr(e, t.key), &frag);
+            PB_CHECK(g, PB_ERR_FORMAT, "tuning data: GEMM entry for key %u, which is not a GEMM layer", t.key);
+            const int tiles = g->Npad / 16;
+            if (g->p3) {  // enc = 4096 nw + 16 mr + nr, for the store epilogue (key wt) or the head / Linear epilogues (key wt2)
+                const int nr = t.v[0] & 15, mr = (t.v[0] >> 4) & 15, nw = t.v[0] >> 12;
+                const int epi = !frag ? 0 : (g == &e->head ? 1 : 2);
+                bool built = false;
+                for (int gate = 0; gate < 2 && !built; ++gate) built = p3_has(nr, mr, nw, epi, gate != 0, (g->K & 31) != 0);
+                PB_CHECK(nr >= 1 && tiles % nr == 0 && built, PB_ERR_FORMAT, "tuning data: P3 GEMM shape NR%d MR%d NW%d is not built for layer %u (%d column tiles)", nr,
+                         mr, nw, t.key, tiles);
+            } else if (frag) {  // the pooling head of the f32 chain: (waves, column tiles per workgroup)
+                PB_CHECK((t.v[0] == 4 || t.v[0] == 8) && t.v[1] >= 1 && t.v[1] <= 8 && tiles % t.v[1] == 0, PB_ERR_FORMAT,
+                         "tuning data: head shape NW%d NR%d does not fit layer %u", t.v[0], t.v[1], t.key);
+            } else {  // the f32 forms: (form code, column tiles per workgroup)
+                const int c = t.v[0], nr = t.v[1];
+                const bool form = c == 1 || c == 2 || c == 4 || c == -1 || c == 100 || c == 304 || c == 308 || c == 1008 || c == 1016 || c == 1032 || c == 1064;
+                PB_CHECK(form && nr >= 1 && nr <= 8 && tiles % nr == 0 && (c < 1000 || nr == tiles) && (c != 100 || nr == 1) && ((c != 304 && c != 308) || g->wt2),
+                         PB_ERR_FORMAT, "tuning data: GEMM form %d with %d column tiles per workgroup does not fit layer %u (%d tiles)", c, nr, t.key, tiles);
+            }
+        } else if (t.map == 1) {  // depthwise geometry: ranges of the three kernels' launch shapes
+            bool in_range = t.v[0] >= 0 && t.v[0] <= 2;
+            for (int j = 1; j < 6; ++j) in_range = in_range && t.v[j] >= 0 && t.v[j] <= 65536;
+            // (the launch is grid (n_tiles, B, zsplit) x block cqpb * slots in all three kernels)
+            PB_CHECK(in_range && (long)t.v[2] * t.v[3] >= 1 && (long)t.v[2] * t.v[3] <= 1024 && t.v[1] >= 1 && t.v[4] >= 1,
+                     PB_ERR_FORMAT, "tuning data: depthwise geometry of layer %u out of range", t.key);
+        } else {
+            const int c = t.v[0];
+            const bool small = c >= 0x1000 && c < 0x2000 && (((c >> 8) & 15) == 1 || ((c >> 8) & 15) == 4) && (((c >> 4) & 15) == 2 || ((c >> 4) & 15) == 3) && (c & 7) <= 2;
+            const bool band = c >= 0x2000 && c <= 0x2000 + 16 && ((c - 0x2000) & (c - 0x2000 - 1)) == 0 && c > 0x2000;
+            PB_CHECK(c == 0 || c == 1 || small || band || (c > 1 && c < 0x1000), PB_ERR_FORMAT, "tuning data: front form %d of layer %u is not a form of this build", c, t.key);
+        }
+    }
     for (const TuneEntry &t : ent) {
         const std::pair<const void *, long> key(tune_key_ptr(e, t.key), (long)t.bucket);
         if (t.map == 0) e->gemm_cfg[key] = std::make_pair(t.v[0], t.v[1]);

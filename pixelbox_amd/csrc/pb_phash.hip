@@ -145,6 +145,7 @@ int phash_one(pb_phasher *p, const uint8_t *rgb, uint32_t w, uint32_t h, uint8_t
 // source pixels: sources packed into one pinned block (one transfer), the Gaussian weights and windows of every image computed
 // on the host (libm expf, as for one image) into one block, a descriptor per image; ONE wait per sub-batch.
 constexpr size_t PH_STAGE_BYTES = 64u << 20;
+constexpr size_t PH_STAGE_TMP_FLOATS = 64u << 20;  // 256 MB of vertical-pass scratch per sub-batch
 constexpr uint32_t PH_STAGE_IMAGES = 1024;
 
 template <typename T>
@@ -182,6 +183,7 @@ int phash_batch(pb_phasher *p, const uint8_t *const *rgb, const uint32_t *widths
             PB_CHECK(w >= 1 && h >= 1 && w <= 65535 && h <= 65535, PB_ERR_INVALID, "pb_phash_batch_images: image %u: size %ux%u outside 1..65535", i1, w, h);
             const size_t sb = (size_t)w * h * 3;
             if (i1 > i0 && src_total + sb > PH_STAGE_BYTES) break;
+            if (i1 > i0 && tmp_total + (size_t)16 * w * 3 > PH_STAGE_TMP_FLOATS) break;  // scratch: <= 16 rows x w x 3 floats per image (wide, short sources)
             pbp::PhashDesc d{};
             d.w = w; d.h = h;
             fit16(w, h, &d.w2, &d.h2);

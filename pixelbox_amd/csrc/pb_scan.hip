@@ -885,8 +885,17 @@ int search_chunk(pb_index *ix, uint32_t cq, uint32_t k, double max_dist, const f
             const auto t0 = std::chrono::steady_clock::now();
             uint32_t spins = 0;
             bool late = false;
-            auto wait_tag = [&](uint32_t slot) -> bool {  // tag first, payload after it (loads stay in order)
-                while (__atomic_load_n(&g[4 * slot + 3], __ATOMIC_ACQUIRE) != want) {
+            // one snapshot of a granule's four words; valid iff its fourth word, un-mixed, is this call's sequence number
+            // (sel_put_granule: a granule carries a check of its own payload, so a torn or half-arrived one is simply not valid yet)
+            struct Snap { uint32_t w[4]; };
+            auto snap = [&](uint32_t slot, Snap &s) -> bool {
+                const volatile uint32_t *p = g + 4 * slot;
+                s.w[3] = __atomic_load_n(&g[4 * slot + 3], __ATOMIC_ACQUIRE);
+                s.w[0] = p[0]; s.w[1] = p[1]; s.w[2] = p[2];
+                return (s.w[3] ^ granule_mix(s.w[0], s.w[1], s.w[2])) == want;
+            };
+            auto wait_granule = [&](uint32_t slot, Snap &s) -> bool {
+                while (!snap(slot, s)) {
                     if (late) return false;
                     __builtin_ia32_pause();
                     if (((++spins & 4095u) == 0u || ix->poll_timeout_us < 100) &&
@@ -897,23 +906,27 @@ int search_chunk(pb_index *ix, uint32_t cq, uint32_t k, double max_dist, const f
                 }
                 return true;
             };
-            auto unpack = [&]() {
+            auto unpack = [&](const Snap &g0, const Snap &g1) {
                 ResultHdr &h = ix->h_res_hdr[0];
-                h.count = g[0];
-                h.status = g[1];
-                h.n_cand = g[2];
-                memcpy(&h.o_max, &g[4], 4);
-                memcpy(&h.ck, &g[5], 4);
+                h.count = g0.w[0];
+                h.status = g0.w[1];
+                h.n_cand = g0.w[2];
+                memcpy(&h.o_max, &g1.w[0], 4);
+                memcpy(&h.ck, &g1.w[1], 4);
             };
-            bool ok = wait_tag(0) && wait_tag(1);
+            auto take = [&](uint32_t i, const Snap &s) {
+                ix->h_res_ids[i] = (int64_t)(((uint64_t)s.w[1] << 32) | s.w[0]);
+                memcpy(&ix->h_res_dist[i], &s.w[2], 4);
+            };
+            Snap g0, g1, gi;
+            bool ok = wait_granule(0, g0) && wait_granule(1, g1);
             if (ok) {
-                unpack();
+                unpack(g0, g1);
                 const uint32_t n = std::min<uint32_t>(ix->h_res_hdr[0].count, PB_MAX_K);
                 for (uint32_t i = 0; i < n && ok; ++i) {
-                    ok = wait_tag(2 + i);
+                    ok = wait_granule(2 + i, gi);
                     if (!ok) break;
-                    ix->h_res_ids[i] = (int64_t)(((uint64_t)g[4 * (2 + i) + 1] << 32) | g[4 * (2 + i)]);
-                    memcpy(&ix->h_res_dist[i], &g[4 * (2 + i) + 2], 4);
+                    take(i, gi);
                 }
             }
             if (ok) {
@@ -922,18 +935,19 @@ int search_chunk(pb_index *ix, uint32_t cq, uint32_t k, double max_dist, const f
             }
             // the granules did not arrive in time (a GPU shared with ingest or another process): counted
             // (pb_index_get_stats); three in a row put the next 256 one-query calls on the stream wait, then polling gets
-            // another chance.  After the stream wait every granule is there.
+            // another chance.  After the stream wait every granule is there -- and still has to carry this call's number.
             ++ix->stats.stamp_timeouts;
             if (++ix->stamp_timeouts_row >= 3) {
                 ix->stamp_timeouts_row = 0;
                 ix->no_poll_calls = 256;
             }
             PB_HIP(hipStreamSynchronize(ix->stream));
-            unpack();
+            PB_CHECK(snap(0, g0) && snap(1, g1), PB_ERR_INTERNAL, "one-query call: result header granules do not carry this call's sequence number after the stream wait");
+            unpack(g0, g1);
             const uint32_t n = std::min<uint32_t>(ix->h_res_hdr[0].count, PB_MAX_K);
             for (uint32_t i = 0; i < n; ++i) {
-                ix->h_res_ids[i] = (int64_t)(((uint64_t)g[4 * (2 + i) + 1] << 32) | g[4 * (2 + i)]);
-                memcpy(&ix->h_res_dist[i], &g[4 * (2 + i) + 2], 4);
+                PB_CHECK(snap(2 + i, gi), PB_ERR_INTERNAL, "one-query call: result granule %u does not carry this call's sequence number after the stream wait", i);
+                take(i, gi);
             }
             return PB_OK;
         }

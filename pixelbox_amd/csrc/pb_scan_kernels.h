@@ -1023,13 +1023,25 @@ __device__ __forceinline__ void block_bitonic_sort(uint64_t *s, int n) {
 // (profiles/r04_scan_stamps.txt).
 // One-query calls answered into pinned host memory (done_flag != nullptr) publish their results as 16-byte GRANULES
 // {payload[3], tag}: one store instruction of one lane each, so a granule arrives whole, and the host accepts a granule once
-// its tag equals the call's sequence number -- no fence between the result stores and a separate completion flag (which cost
-// the store round trip over PCIe, ~2 us at the end of every query), no flag.  Granule 0: {count, status, n_cand}, 1: {o_max,
-// ck, 0}, 2 + i: {id low, id high, distance} of result i.  The host reads the tag first (search_chunk in pb_scan.hip).
+// its tag (fourth word ^ granule_mix(payload), below) equals the call's sequence number -- no fence between the result stores and a
+// separate completion flag (which cost the store round trip over PCIe, ~2 us at the end of every query), no flag.  Granule 0:
+// {count, status, n_cand}, 1: {o_max, ck, 0}, 2 + i: {id low, id high, distance} of result i.
+// A granule is SELF-VALIDATING: its fourth word is tag ^ granule_mix(payload), so a reader that sees the words of two
+// different stores in one granule -- the store split on its way, or the tag word landing first, neither of which the architecture
+// rules out even though a 16-byte store of one lane has been observed to arrive whole on gfx950 -- finds a word that is not its
+// call's sequence number and keeps polling; stale payload under a fresh tag passes with probability 2^-32.  The host takes one
+// snapshot of the four words, checks it, and uses the payload of THAT snapshot (search_chunk, pb_scan.hip).
+__host__ __device__ __forceinline__ uint32_t granule_mix(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t h = a * 0x9E3779B1u;
+    h ^= (b + 0x7F4A7C15u) * 0x85EBCA6Bu;
+    h = (h << 13) | (h >> 19);
+    h ^= (c + 0x165667B1u) * 0xC2B2AE35u;
+    return h ^ (h >> 16);
+}
 __device__ __forceinline__ void sel_put_granule(uint32_t *base, uint32_t slot, uint32_t a, uint32_t b, uint32_t c, uint32_t tag) {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     u32x4 g;
-    g.x = a; g.y = b; g.z = c; g.w = tag;
+    g.x = a; g.y = b; g.z = c; g.w = tag ^ granule_mix(a, b, c);
     *reinterpret_cast<u32x4 *>(base + 4 * (size_t)slot) = g;
 }
 constexpr int SEL_SLOTS = F_MAX_WG * F_KWG / SEL_BLOCK;  // list slots per thread (16)
@@ -1278,7 +1290,11 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
         ck = 3.0f;
         for (int w = 0; w < SEL_BLOCK / WAVE; ++w) ck = fminf(ck, s_ck[w]);
         const float o_max = fmaxf(fmaxf(cut, dmax), P.thr0) + P.m;  // no unexamined row's exact cos reaches this
-        bool ok = !overflow && s_u[4] == n_rows;  // every row of the table was evaluated by exactly one workgroup of the filter pass
+        // the rows the workgroups report add up to the table (u32: a table is < 2^32 rows).  A NECESSARY condition only: it catches a
+        // tile that nobody read or that two workgroups read (the failure class of a dynamic partition), not a tile read twice
+        // while another full tile was skipped -- which the partitions here cannot produce (a ticket or chunk number is handed
+        // out once by an atomic; what went wrong in round 4 was a chunk past the region's end hiding a valid one: a lost tile)
+        bool ok = !overflow && s_u[4] == n_rows;
         if (n_out == P.k) {
             ok = ok && (o_max <= ck * (1.0f - 1e-6f));
         } else {
