@@ -44,6 +44,10 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-clustered", action="store_true", help="skip the embedding-like table sub-leg of the sweep")
+    ap.add_argument("--settle-min-seconds", type=float, default=2.5, help="one GPU: the settling loop runs at least this long")
+    ap.add_argument("--settle-seconds", type=float, default=8.0,
+                    help="one GPU: at most this long repeating one untimed step until its time has settled (0: off); see `settle` in the line")
     ap.add_argument("--rows", type=int, default=10_000_000, help="total index rows (BASELINE: 10M)")
     ap.add_argument("--dim", type=int, default=256)
     ap.add_argument("--queries", type=int, default=64, help="independent batch-1 queries per step")
@@ -318,6 +322,34 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    # Settling (untimed, before the W warm-up steps).  A table streams 2.5-6.5 % slower WHILE the kernel driver scrubs memory that a
+    # process has just released -- the test suite that ran before this bench on the same box, for one: 150 GB written and freed cost
+    # the next ~2 s (profiles/r05_placement.txt; round 4 read these as "slow allocations").  The same step is repeated until the
+    # median of its last six runs is within 0.3 % of the fastest run seen and that minimum is at least six steps old, for at most
+    # --settle-seconds; what it saw goes into the line.  One GPU only (a rank-local loop would unbalance the collective path).
+    settle = None
+    if not distributed and args.settle_seconds > 0:
+        ts = []
+        t_s0 = time.perf_counter()
+        best_at = 0
+        while True:
+            t1 = time.perf_counter()
+            sh.search(qbytes[0], k, args.max_dist)
+            ts.append(time.perf_counter() - t1)
+            if ts[-1] <= min(ts):
+                best_at = len(ts) - 1
+            # (a backlog can hold a table at a steady +1.5-2.5 % for seconds -- a plateau looks settled -- so the loop also runs for
+            # at least --settle-min-seconds: the scrubbing of what a test suite released is over by then)
+            if (time.perf_counter() - t_s0 >= args.settle_min_seconds and len(ts) >= 12 and len(ts) - 1 - best_at >= 6 and
+                    float(np.median(ts[-6:])) <= 1.003 * min(ts)):
+                break
+            if time.perf_counter() - t_s0 > args.settle_seconds:
+                break
+        settle = {"steps": len(ts), "seconds": round(time.perf_counter() - t_s0, 3), "ms_first": round(ts[0] * 1e3, 3),
+                  "ms_slowest_after_first": round(max(ts[1:]) * 1e3, 3), "ms_fastest": round(min(ts) * 1e3, 3),
+                  "ms_median_last6": round(float(np.median(ts[-6:])) * 1e3, 3),
+                  "note": "untimed repeats of one step before the warm-up steps, until the step time has settled (driver scrubbing of "
+                          "memory released by earlier processes slows every table for a second or two: profiles/r05_placement.txt)"}
     for s in range(args.warmup):
         sh.search(qbytes[s], k, args.max_dist)
     sh.index.stats(reset=True)
@@ -461,6 +493,11 @@ def main():
         del sh
         sh = None
         sweep = bench_sweep(args, torch, local_rank)
+        if not args.no_clustered:
+            try:
+                sweep["clustered"] = bench_clustered(args, torch, local_rank)
+            except capi.PixelboxError as e:
+                sweep["clustered"] = {"error": str(e)}
 
     embed = None
     if not args.no_embed:
@@ -509,6 +546,10 @@ def main():
             out["roofline"]["n_sweep"] = sweep["n_sweep"]
             out["roofline"]["evicted_between_passes"] = sweep["evicted"]
             out["scan_1m"] = sweep["scan_1m"]
+            if "clustered" in sweep:
+                out["roofline"]["clustered_table"] = sweep["clustered"]
+        if settle is not None:
+            out["settle"] = settle
         if weak is not None:
             out["weak_scaling"] = weak
         if concurrent is not None:
@@ -533,6 +574,67 @@ def latest_profile(tag: str):
 
     paths = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{tag}.json")), reverse=True)
     return os.path.relpath(paths[0], ROOT) if paths else None
+
+
+def bench_clustered(args, torch, device):
+    """The headline's launch over an EMBEDDING-LIKE table (SURVEY.md 8(d), config 2's clustered variant): bytes =
+    quantise(tanh(0.5 N(0, 1))) drawn by inverse-CDF sampling at 8-bit resolution (a 256-entry table maps a uniform byte to its
+    quantile), 10M rows built on the device (torch as buffer plumbing) and appended device-to-device; the 64 queries are rows of the
+    table (each has an exact duplicate at distance ~0) with a few bytes nudged (near-duplicates).  The filter pass's time depends on
+    the data only through how often a wave's buffer of passing keys fills up (profiles/r05_placement.txt, content probe: a table in
+    which EVERY row ties costs 33-42 % more and certifies half its queries; bytes in the wire are the same), so the uniform-random
+    headline and this leg bracket what a real `semantic_hashes` table does."""
+    from statistics import NormalDist
+
+    from pixelbox_amd import capi
+
+    d, k, B = args.dim, args.k, args.queries
+    rows = args.rows
+    nd = NormalDist()
+    lut = np.empty(256, dtype=np.uint8)
+    for u in range(256):
+        f = np.float32(np.tanh(0.5 * nd.inv_cdf((u + 0.5) / 256.0)))
+        t = min(max(float(f) * 128.0, -128.0), 128.0)
+        lut[u] = 128 + (127 if t >= 127.0 else (-128 if t <= -128.0 else int(t)))  # efficientnet.rs:39
+    dev = f"cuda:{device}"
+    g = torch.Generator(device=dev)
+    g.manual_seed(0x5EED0009)
+    lut_t = torch.from_numpy(lut).to(dev)
+    ix = capi.Index(d, rows, device)
+    chunk = 1_000_000
+    first_rows = None
+    for r0 in range(0, rows, chunk):
+        n = min(chunk, rows - r0)
+        u = torch.randint(0, 256, (n, d), dtype=torch.uint8, device=dev, generator=g)
+        t = lut_t[u.long()].contiguous()
+        if first_rows is None:
+            first_rows = t[:4096].cpu().numpy()
+        torch.cuda.synchronize()
+        ix.append_device(np.arange(r0 + 1, r0 + n + 1, dtype=np.int64), t.data_ptr())
+    del u, t
+    ix.set_option(capi.PB_OPT_SEARCH_PATH, 2)
+    rng = np.random.default_rng(11)
+    steps = []
+    for s in range(3):
+        q = first_rows[rng.choice(4096, B, replace=False)].copy()
+        for i in range(B // 2):  # half of them near-duplicates: four bytes moved by one
+            j = rng.choice(d, 4, replace=False)
+            q[i, j] = np.clip(q[i, j].astype(np.int32) + 1, 0, 255).astype(np.uint8)
+        steps.append(q)
+    res = ix.search(steps[0], k, args.max_dist)
+    ix.stats(reset=True)
+    ix.set_option(capi.PB_OPT_PROFILE, 1)
+    for s in range(1, 3):
+        res = ix.search(steps[s], k, args.max_dist)
+    ix.set_option(capi.PB_OPT_PROFILE, 0)
+    st = ix.stats()
+    ms = st.profiled_ms / max(1, st.profiled_launches)
+    gbs = st.profiled_bytes / (st.profiled_ms * 1e-3) / 1e9
+    return {"rows": rows, "table": "quantise(tanh(0.5 N(0,1))) per byte (inverse-CDF sampling), queries = rows of the table, half of them with four "
+                                   "bytes nudged", "kernel_ms_per_64_passes": round(ms, 4), "GB/s": round(gbs, 1),
+            "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4), "queries": int(st.queries), "filter_certified": int(st.fast_path),
+            "second_chance": int(st.second_chance), "exhaustive": int(st.fallback),
+            "first_result_dist_of_last_query": float(res[1][B - 1][0]) if res[2][B - 1] else None}
 
 
 def bench_sweep(args, torch, device):

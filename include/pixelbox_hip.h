@@ -55,9 +55,8 @@ typedef struct pb_index pb_index;
  * image_id order (the order SQLite scans the rowid B-tree in).  dim is fixed per index; the reference
  * does not enforce blob length (engine.rs:585 zip-truncates) -- documented deviation: other lengths
  * are rejected.  `device` is the HIP device ordinal.
- * Placement: where the driver puts a multi-GB buffer decides how fast it streams (3-4 % between two allocations of one
- * process, for as long as they live).  PB_INDEX_PLACEMENT_TRIES=n in the environment (an experiment, off by default) makes
- * the call allocate a large 256-byte-row table n times, time the filter pass over each and keep the fastest. */
+ * (A table streams 2.5-6.5 % slower WHILE the driver scrubs memory that some process has just released -- tens of GB written
+ * and freed cost the next second or two -- and at its full rate afterwards: a property of the moment, not of the allocation.) */
 int pb_index_create(pb_index **out, int device, uint32_t dim, uint64_t capacity_rows);
 /* Same table for the reference's other two blob distances: the `phashes` table has
  * the semantic_hashes schema (engine.rs:106-109) and the UDFs byte_distance / hamming_distance are registered

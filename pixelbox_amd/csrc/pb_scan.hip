@@ -1439,72 +1439,18 @@ int pb_index_create(pb_index **out, int device, uint32_t dim, uint64_t capacity_
         PB_HIP(hipMalloc(&ix->d_lut, 256 * sizeof(float)));
         PB_HIP(hipMemcpy(ix->d_lut, ix->lut, 256 * sizeof(float), hipMemcpyHostToDevice));
         { int rcw = alloc_workspace(ix); if (rcw) return rcw; }
-        {   // The table.  Where the driver puts a multi-GB buffer decides how fast the filter pass streams it: a process that
-            // creates six 2.56 GB tables measures 22.7 ms per 64 passes over some and 23.4-23.6 over others, and a table keeps its
-            // rate on every stream for as long as it lives (profiles/r04_scan_stamps.txt).  PB_INDEX_PLACEMENT_TRIES=n (2..4; an
-            // EXPERIMENT, off by default) allocates a 256-byte-row table of 256 MB or more n times (while that many fit in half the
-            // free memory), fills each candidate with pseudo-random bytes (a table of constant bytes is scanned at half rate
-            // whatever its placement), runs THE FILTER PASS ITSELF over it twice -- the looped launch, 64 queries nothing can pass;
-            // the first run also brings an idling GPU up to its clocks -- and keeps the fastest.  Measured: it removes the bad draws
-            // (23.3-23.6 ms) but not the good ones' margin -- with three candidates every table ends at 23.0, the first allocation
-            // alone is a coin between 22.7 and 23.3 -- so the default stays one allocation.
+        {   // The table: ONE allocation, wherever the driver puts it.  (Round 4 found "slow tables" -- 23.3-23.6 ms per 64 passes over
+            // some, 22.7 over others -- read them as a property of the buffer's placement and built a best-of-n allocation behind
+            // PB_INDEX_PLACEMENT_TRIES.  Round 5 timed ONE table again and again from process start (profiles/placement_timeline.py,
+            // profiles/r05_placement.txt): a table is slow WHILE the kernel driver scrubs memory some process has just released -- 150 GB
+            // written and freed make the next two seconds 2.5-6.5 % slower, for every table, and then the same table runs at 22.7 -- and
+            // the candidates that the best-of-n probe freed were themselves such a release.  The knob is gone; bench.py waits for a
+            // settled step time before its warm-up steps instead.)
             const size_t bytes = (capacity_rows + 64) * (size_t)dim;
-            int tries = getenv("PB_INDEX_PLACEMENT_TRIES") ? atoi(getenv("PB_INDEX_PLACEMENT_TRIES")) : 1;
-            size_t free_b = 0, total_b = 0;
-            PB_HIP(hipMemGetInfo(&free_b, &total_b));
-            if (dim != 256 || bytes < (256ull << 20) || (double)bytes * tries > 0.5 * (double)free_b) tries = 1;
-            tries = std::max(1, std::min(tries, 4));
-            uint8_t *cand[4] = {nullptr, nullptr, nullptr, nullptr};
-            float cand_ms[4] = {0.f, 0.f, 0.f, 0.f};
-            int n_cand = 0, best = 0;
-            int rc_alloc = PB_OK;
-            // passes per probe launch: 64 up to 10M rows (~23 ms), fewer over larger tables (never under 8)
-            const int NQP = (int)std::max<uint64_t>(8, std::min<uint64_t>(64, 640000000ull / std::max<uint64_t>(1, capacity_rows)));
-            if (tries > 1) {
-                std::vector<QParams> pq(NQP);
-                memset(pq.data(), 0, NQP * sizeof(QParams));
-                for (QParams &p : pq) {
-                    p.max_dist = 1e3;
-                    p.sqrt_sa = 1.0f;
-                    p.den_a = 1.0f;
-                    p.thr0 = 2.0f;  // no cosine reaches it
-                    p.k = 1;
-                }
-                PB_HIP(hipMemcpy(ix->d_qp, pq.data(), NQP * sizeof(QParams), hipMemcpyHostToDevice));
-                PB_HIP(hipMemset(ix->d_queries, 0x80, (size_t)NQP * 256));
+            if (hipMalloc(&ix->d_rows, bytes) != hipSuccess) {
+                (void)hipGetLastError();
+                return pb::fail(PB_ERR_HIP, "pb_index_create: hipMalloc of %zu bytes for the table failed", bytes);
             }
-            for (int t = 0; t < tries; ++t) {
-                if (hipMalloc(&cand[t], bytes) != hipSuccess) {
-                    (void)hipGetLastError();
-                    if (t == 0) rc_alloc = pb::fail(PB_ERR_HIP, "pb_index_create: hipMalloc of %zu bytes for the table failed", bytes);
-                    break;
-                }
-                ++n_cand;
-                if (tries == 1) break;
-                hipLaunchKernelGGL(k_fill_synth, dim3(ix->n_cu * 8), dim3(256), 0, ix->stream, 0x9E3779B97F4A7C15ull, 0ull, (uint64_t)(bytes / 8),
-                                   reinterpret_cast<uint64_t *>(cand[t]));
-                for (int r = 0; r < 2; ++r) {
-                    if (r == 1) (void)hipEventRecord(ix->ev0, ix->stream);
-                    hipLaunchKernelGGL((k_scan_filter<16, 8, true, F_WAVES, 0, true, false, false, true, 4>), dim3(ix->n_cu, 1), dim3(F_WAVES * 64), 0,
-                                       ix->stream, (const uint8_t *)cand[t], (uint64_t)capacity_rows, (const uint8_t *)ix->d_queries,
-                                       (const QParams *)ix->d_qp, ix->d_lists, ix->d_hdrs, 0, NQP, (uint8_t *)nullptr, (QParams *)nullptr, QArg256{},
-                                       (uint32_t *)nullptr, StealGeo{});
-                }
-                (void)hipEventRecord(ix->ev1, ix->stream);
-                if (hipEventSynchronize(ix->ev1) != hipSuccess || hipEventElapsedTime(&cand_ms[t], ix->ev0, ix->ev1) != hipSuccess) {
-                    (void)hipGetLastError();
-                    cand_ms[t] = 1e30f;  // a pass that cannot be timed never wins; the allocation itself is fine
-                }
-                if (cand_ms[t] < cand_ms[best]) best = t;
-                if (ix->env_trace_cert)
-                    fprintf(stderr, "pb_index_create: table candidate %d: %.3f ms per %d passes = %.1f GB/s\n", t, cand_ms[t], NQP,
-                            (double)NQP * capacity_rows * dim / (cand_ms[t] * 1e-3) / 1e9);
-            }
-            if (getenv("PB_INDEX_PLACEMENT_KEEP_FIRST")) best = 0;  // experiments: time every candidate, keep the first
-            for (int t = 0; t < n_cand; ++t)
-                if (t != best) (void)hipFree(cand[t]);
-            if (rc_alloc) return rc_alloc;
-            ix->d_rows = cand[best];
         }
         return PB_OK;
     };

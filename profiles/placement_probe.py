@@ -8,6 +8,30 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from pixelbox_amd import capi, synth
 
+import ctypes as C
+if os.environ.get("PB_PROBE_FRAGMENT"):
+    # what a box that has run other jobs looks like to the allocator: many blocks of 1-8 MB over most of the memory, every other one
+    # freed (the survivors stay allocated for the life of this process), so that a 2.56 GB table is pieced together from the holes
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipFree.argtypes = [C.c_void_p]
+    rng = np.random.default_rng(7)
+    total_gb = float(os.environ.get("PB_PROBE_FRAGMENT_GB", "120"))
+    blocks, tot = [], 0
+    while tot < total_gb * (1 << 30):
+        sz = int(rng.integers(1, 9)) << 20
+        p_ = C.c_void_p()
+        if hip.hipMalloc(C.byref(p_), sz) != 0:
+            break
+        blocks.append(p_)
+        tot += sz
+    keep = []
+    for i, b in enumerate(blocks):
+        if i & 1:
+            hip.hipFree(b)
+        else:
+            keep.append(b)
+    print(f"fragmented: {len(blocks)} blocks of 1-8 MB ({tot / 2**30:.1f} GB), every other one freed", flush=True)
 rows = int(os.environ.get("PB_PROBE_ROWS", "10000000"))
 n_tab = int(os.environ.get("PB_PROBE_TABLES", "6"))
 q = synth.fill_synthetic(synth.SEED_QUERY, 0, 4 * 64 * 256).reshape(4, 64, 256)
