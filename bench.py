@@ -956,11 +956,63 @@ def bench_ingest_images(args, torch, device, forward_ips):
                            "pcie_bound_images_per_s": round(h2d / per, 1), "forward_rate_images_per_s": round(forward_ips, 1),
                            "frac_of_min_bound": round(ips / bound, 3)}
         del index, images, batches, pool
-    res["note"] = ("host images -> resize_to_fill on the GPU (two launches per sub-batch of <= 48 MB) -> forward -> device-to-device insert; PCIe "
+    del embs
+    res["with_decoders"] = bench_ingest_staged(device, forward_ips, h2d, blob)
+    res["note"] = ("host images -> resize_to_fill on the GPU (one fused launch per sub-batch of <= 48 MB) -> forward -> device-to-device insert; PCIe "
                    "inclusive, never `value`.  Images in ordinary (pageable) memory, packed into pinned staging by four host threads per call "
                    "(streaming stores) and copied once per sub-batch; that pass is one more trip of every byte through host memory, which is "
                    "what bounds the 256 x 256 case below the forward rate (profiles/ingest_probe.py)")
     return res
+
+
+def bench_ingest_staged(device, forward_ips, h2d, blob):
+    """The same hot loop with DECODERS in it, driven natively (profiles/micro/ingest_staged.cpp, compiled here with g++; host threads, no
+    interpreter): 8 embedders (an embed thread each) x 1-2 decoder threads each; a decoder's output -- a copy of a pool image: the bytes
+    its last pass would store -- goes either into a buffer of its own that pb_embed_batch_images_device then packs into pinned staging
+    (`own_buffers`), or straight into the embedder's staging slot (pb_embed_stage_acquire / _release / _close / _commit: `staged`, round 5);
+    hashes appended device-to-device to one index.  The decoders' pass is INSIDE both numbers (the Python leg above starts from images
+    that already exist)."""
+    import shutil
+    import subprocess
+    import tempfile
+
+    from pixelbox_amd import capi
+
+    root = os.path.dirname(os.path.abspath(__file__))
+    gxx = shutil.which("g++")
+    if not gxx:
+        return {"error": "no g++ on this box"}
+    tmp = tempfile.mkdtemp(prefix="pb_ingest_")
+    try:
+        wpath = os.path.join(tmp, "w.pbxw")
+        with open(wpath, "wb") as f:
+            f.write(blob)
+        exe = os.path.join(tmp, "ingest_staged")
+        libdir = os.path.dirname(capi.LIB_PATH)
+        subprocess.check_call([gxx, "-O2", "-std=c++17", "-pthread", "-I", os.path.join(root, "include"),
+                               os.path.join(root, "profiles", "micro", "ingest_staged.cpp"), "-o", exe, "-L", libdir, "-lpixelbox_hip",
+                               f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        env = dict(os.environ, HIP_VISIBLE_DEVICES=str(device)) if device else dict(os.environ)
+        out = {"threads": "8 embedders x (1 embed thread + 1 or 2 decoder threads)", "batch": 512}
+        for (h, w, n, dec) in ((256, 256, 131072, 1), (480, 640, 16384, 2)):
+            per = h * w * 3
+            bound = min(h2d / per, forward_ips)
+            entry = {"images": n, "bytes_per_image": per, "pcie_bound_images_per_s": round(h2d / per, 1),
+                     "forward_rate_images_per_s": round(forward_ips, 1)}
+            for mode, name in ((1, "staged"), (0, "own_buffers")):
+                p = subprocess.run([exe, wpath, str(n), str(w), str(h), "8", str(dec), str(mode)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                   env=env, timeout=300)
+                if p.returncode != 0:
+                    entry[name] = {"error": p.stderr.decode(errors="replace")[-300:]}
+                    continue
+                r = json.loads(p.stdout.decode().strip().splitlines()[-1])
+                entry[name] = {"images_per_s": round(r["images_per_s"], 1), "frac_of_min_bound": round(r["images_per_s"] / bound, 3)}
+            out[f"{w}x{h}"] = entry
+        return out
+    except (subprocess.CalledProcessError, subprocess.TimeoutExpired, OSError, ValueError) as e:
+        return {"error": str(e)[:300]}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def bench_end_to_end(args, torch, rank, world, device, distributed):

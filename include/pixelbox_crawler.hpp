@@ -18,6 +18,11 @@
 // (pixelbox_sharded.hpp) uses it to assign image ids and store the hashes on shard g device-to-device
 // (pb_sharded_append_device), so that N GPUs embed and insert concurrently with no host hop for the hashes.
 //
+// Staged decoding (round 5): given a StagedDecoder (a decoder that writes where it is told: pixelbox_host.hpp) the workers write their
+// pixels ONCE, into the pinned staging block of the embedder the image goes to (pb_embed_stage_acquire / _release), and the embed
+// thread closes and commits the batch (pb_embed_stage_close / _commit) -- no packing pass, the transfer is one command per batch;
+// phash runs on the same pinned pixels between close and commit.  Same records as the Decoder path (tests/cpp/crawler_demo.cpp).
+//
 // Shutdown: like the reference's detached workers, which stop when the Receiver is dropped (`TrySendError::Disconnected`,
 // crawler.rs:97-101), every thread here leaves as soon as the stage is cancelled -- by the destructor, by cancel(), or by an
 // embed thread that failed.  A failure (a pb_* call returning an error throws pixelbox::Error on the embed thread) is
@@ -29,6 +34,7 @@
 #include <deque>
 #include <filesystem>
 #include <functional>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -44,7 +50,8 @@ class Crawler {
                                                                       "tiff", "pnm", "webp", "ico",  "tga",  "exr"};  // crawler.rs:7
 
     // records of one finished batch + its hashes in the memory of embedder `model_index`'s GPU (uint8[batch][dim], valid for
-    // the duration of the call); may set IndexedImage::id.  Runs on that embedder's thread: sinks of different embedders
+    // the duration of the call; row i = record i; NULL when the records do not line up with the device buffer -- a staged batch that
+    // held an undecodable file -- and the sink must use the records' own visual_hash); may set IndexedImage::id.  Runs on that embedder's thread: sinks of different embedders
     // run concurrently.  Throwing pixelbox::Error stops the stage.
     using BatchSink = std::function<void(size_t model_index, std::vector<IndexedImage> &batch, const uint8_t *d_hashes)>;
 
@@ -56,6 +63,13 @@ class Crawler {
         : models_(std::move(models)), hasher_(hasher), decode_(std::move(decode)), max_batch_(max_batch), sink_(std::move(sink)) {
         for (const Embedder *m : models_) max_batch_ = std::min(max_batch_, m->max_batch());  // a batch must fit every embedder's workspace
         if (models_.empty()) throw Error(PB_ERR_INVALID, "Crawler: no embedder");
+    }
+    // the same stage with decoders that write into the embedders' staging slots (see the header comment)
+    Crawler(std::vector<const Embedder *> models, const PHasher *hasher, StagedDecoder decode, uint32_t max_batch = 512, BatchSink sink = nullptr)
+        : models_(std::move(models)), hasher_(hasher), decode_(nullptr), max_batch_(max_batch), sink_(std::move(sink)), staged_decode_(std::move(decode)) {
+        for (const Embedder *m : models_) max_batch_ = std::min(max_batch_, m->max_batch());
+        if (models_.empty()) throw Error(PB_ERR_INVALID, "Crawler: no embedder");
+        if (!staged_decode_) throw Error(PB_ERR_INVALID, "Crawler: null staged decoder");
     }
     ~Crawler() {
         cancel();
@@ -92,8 +106,10 @@ class Crawler {
         embedders_left_ = models_.size();
         out_closed_ = false;
         stats_ = Stats{};
+        staged_.assign(models_.size(), StagedState{});
+        next_model_ = 0;
         threads_.emplace_back([this, folders] { glob_thread(folders); });
-        for (size_t i = 0; i < num_workers; ++i) threads_.emplace_back([this] { decode_worker(); });
+        for (size_t i = 0; i < num_workers; ++i) threads_.emplace_back([this] { staged_decode_ ? staged_worker() : decode_worker(); });
         for (size_t m = 0; m < models_.size(); ++m) threads_.emplace_back([this, m] { embed_thread(m); });
     }
 
@@ -191,9 +207,174 @@ class Crawler {
         if (--decoders_left_ == 0) cv_decoded_.notify_all();
     }
 
+    // ---- staged decoding: a worker writes into the staging slot of embedder m (images go round robin over the embedders)
+    struct StagedMeta {
+        std::string filename, path;
+        uint32_t w = 0, h = 0;
+        bool valid = false;  // acquired AND decoded (an image whose decoder failed after it got room stays in the batch and is dropped afterwards)
+    };
+    struct StagedState {
+        std::map<uint32_t, std::vector<StagedMeta>> meta;  // generation -> records by position in the batch
+        size_t pending = 0;                                 // images acquired into batches that are not closed yet
+        bool want_commit = false;                           // a worker found the open batch full
+    };
+
+    void staged_worker() {
+        try {
+            for (;;) {
+                std::string path;
+                size_t m;
+                {
+                    std::unique_lock<std::mutex> lk(mu_);
+                    cv_files_.wait(lk, [&] { return !files_.empty() || files_done_ || cancelled_; });
+                    if (files_.empty() || cancelled_) break;
+                    path = std::move(files_.front());
+                    files_.pop_front();
+                    m = next_model_++ % models_.size();
+                }
+                std::optional<std::vector<uint8_t>> bytes = read_file(path);
+                uint64_t ticket = 0;
+                bool acquired = false;
+                uint32_t iw = 0, ih = 0;
+                const PixelAlloc alloc = [&](uint32_t w, uint32_t h) -> uint8_t * {
+                    for (;;) {
+                        uint8_t *px = nullptr;
+                        const int rc = pb_embed_stage_acquire(models_[m]->raw(), w, h, &px, &ticket);
+                        if (rc == PB_OK) {
+                            acquired = true;
+                            iw = w;
+                            ih = h;
+                            std::lock_guard<std::mutex> lk(mu_);
+                            ++staged_[m].pending;
+                            return px;
+                        }
+                        if (rc != PB_STAGE_FULL) check(rc);
+                        std::unique_lock<std::mutex> lk(mu_);  // the open batch is full: the embed thread closes it
+                        if (cancelled_) return nullptr;
+                        staged_[m].want_commit = true;
+                        cv_decoded_.notify_all();
+                        cv_space_.wait_for(lk, std::chrono::milliseconds(2));
+                        if (cancelled_) return nullptr;
+                    }
+                };
+                const bool ok = bytes && staged_decode_(*bytes, alloc);
+                {
+                    std::lock_guard<std::mutex> lk(mu_);
+                    if (ok && acquired) ++stats_.decoded;
+                    else ++stats_.skipped;  // crawler.rs:78: anything that does not decode is dropped silently
+                    if (acquired) {
+                        std::vector<StagedMeta> &v = staged_[m].meta[(uint32_t)(ticket >> 32)];
+                        const size_t pos = (size_t)(ticket & 0xFFFFu);
+                        if (v.size() <= pos) v.resize(pos + 1);
+                        StagedMeta &mt = v[pos];
+                        mt.path = path;
+                        const size_t slash = path.find_last_of('/');
+                        mt.filename = slash == std::string::npos ? path : path.substr(slash + 1);
+                        mt.w = iw;
+                        mt.h = ih;
+                        mt.valid = ok;
+                    }
+                }
+                if (acquired) {
+                    check(pb_embed_stage_release(models_[m]->raw(), ticket));
+                    std::lock_guard<std::mutex> lk(mu_);
+                    cv_decoded_.notify_all();
+                }
+            }
+        } catch (const std::exception &ex) {
+            std::lock_guard<std::mutex> lk(mu_);
+            if (error_.empty()) error_ = ex.what();
+            cancelled_ = true;
+            cv_files_.notify_all();
+            cv_space_.notify_all();
+        }
+        std::lock_guard<std::mutex> lk(mu_);
+        if (--decoders_left_ == 0) {}
+        cv_decoded_.notify_all();
+    }
+
+    void staged_embed_loop(size_t m) {
+        const Embedder &model = *models_[m];
+        std::vector<uint32_t> ws(model.max_batch()), hs(model.max_batch());
+        std::vector<const uint8_t *> ptrs(model.max_batch());
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                // a batch goes when it is full, when a worker found it full, when the workers are done, or when something has waited 5 ms
+                cv_decoded_.wait_for(lk, std::chrono::milliseconds(5), [&] {
+                    return staged_[m].pending >= max_batch_ || staged_[m].want_commit || decoders_left_ == 0 || cancelled_;
+                });
+                if (cancelled_) break;
+                if (staged_[m].pending == 0) {
+                    if (decoders_left_ == 0) break;
+                    continue;
+                }
+            }
+            std::unique_lock<std::recursive_mutex> own(model.exclusive());
+            uint32_t n = 0, gen = 0;
+            check(pb_embed_stage_close(model.raw(), &n, &gen, ws.data(), hs.data(), ptrs.data()));
+            std::vector<StagedMeta> metas;
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                staged_[m].pending -= std::min<size_t>(staged_[m].pending, n);
+                staged_[m].want_commit = false;
+                auto it = staged_[m].meta.find(gen);
+                if (it != staged_[m].meta.end()) {
+                    metas = std::move(it->second);
+                    staged_[m].meta.erase(it);
+                }
+                if (n) {
+                    ++stats_.batches;
+                    stats_.largest_batch = std::max<uint64_t>(stats_.largest_batch, n);
+                }
+            }
+            if (n == 0) continue;
+            metas.resize(n);
+            std::vector<std::vector<uint8_t>> phashes;
+            if (hasher_) {  // on the pinned pixels, before the commit gives the block back
+                std::vector<const uint8_t *> pp(ptrs.begin(), ptrs.begin() + n);
+                std::vector<uint32_t> pw(ws.begin(), ws.begin() + n), ph(hs.begin(), hs.begin() + n);
+                phashes = image_hashes::phash_batch(*hasher_, pp, pw, ph);
+            }
+            std::vector<uint8_t> hashes((size_t)n * model.dim());
+            const uint8_t *d_hashes = nullptr;
+            check(pb_embed_stage_commit(model.raw(), hashes.data(), &d_hashes));
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                cv_space_.notify_all();  // workers that found the batch full: the other slot is open for them (or this one is free again)
+            }
+            std::vector<IndexedImage> recs;
+            recs.reserve(n);
+            // the sink stores the batch's hashes device-to-device by POSITION: with a sink every position must be a record, so a
+            // batch that holds an undecodable image goes to the sink from the host copy of its valid rows' positions only if all are valid
+            bool all_valid = true;
+            for (uint32_t i = 0; i < n; ++i) all_valid = all_valid && metas[i].valid;
+            for (uint32_t i = 0; i < n; ++i) {
+                if (!metas[i].valid) continue;
+                IndexedImage r;
+                r.filename = std::move(metas[i].filename);
+                r.path = std::move(metas[i].path);
+                r.resolution = {ws[i], hs[i]};
+                if (hasher_) r.phash = std::move(phashes[i]);
+                r.visual_hash = std::vector<uint8_t>(hashes.begin() + (size_t)i * model.dim(), hashes.begin() + (size_t)(i + 1) * model.dim());
+                recs.push_back(std::move(r));
+            }
+            if (sink_) sink_(m, recs, all_valid ? d_hashes : nullptr);
+            own.unlock();
+            for (IndexedImage &r : recs) {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_space_.wait(lk, [&] { return out_.size() < MAX_PENDING_TX || cancelled_; });
+                if (cancelled_) return;
+                out_.push_back(std::move(r));
+                cv_out_.notify_one();
+            }
+        }
+    }
+
     void embed_thread(size_t m) {  // the GPU half: whatever is pending, up to max_batch images per forward pass
         try {
-            embed_loop(m);
+            if (staged_decode_) staged_embed_loop(m);
+            else embed_loop(m);
         } catch (const std::exception &ex) {  // pixelbox::Error from a pb_* call, bad_alloc, ...: never out of a std::thread
             std::lock_guard<std::mutex> lk(mu_);
             if (error_.empty()) error_ = ex.what();
@@ -262,6 +443,9 @@ class Crawler {
     Decoder decode_;
     uint32_t max_batch_;
     BatchSink sink_;
+    StagedDecoder staged_decode_;
+    std::vector<StagedState> staged_;
+    size_t next_model_ = 0;
     mutable std::mutex mu_;
     std::condition_variable cv_files_, cv_decoded_, cv_out_, cv_space_;
     std::deque<std::string> files_;

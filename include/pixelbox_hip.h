@@ -284,6 +284,30 @@ int pb_mlhash(pb_embedder *e, const uint8_t *rgb, uint8_t *out, size_t out_len);
 int pb_embed_batch_images_device(pb_embedder *e, const uint8_t *const *rgb, const uint32_t *widths, const uint32_t *heights, uint32_t n,
                                  uint8_t *out_u8, const uint8_t **d_out_u8);
 
+/* ---- staging slots for decoders (round 5).  The reference's workers decode a file into a buffer of the decoder's
+ * own and hash it at once (crawler.rs:68-119, indexed_image.rs:47-91); pb_embed_batch_images* take such buffers and PACK them into
+ * the embedder's pinned staging before the transfer -- one more pass of every pixel through host memory.  Here a decode worker asks
+ * the embedder where to put the pixels and writes them once:
+ *   pb_embed_stage_acquire(e, w, h, &pixels, &ticket)   room for a w x h RGB8 image (rows top to bottom, 3 bytes per pixel, w * 3 per
+ *        row) in the batch being filled; thread-safe, any number of workers; PB_STAGE_FULL (> 0, not an error) when the batch cannot
+ *        take the image (max_batch images, the slot's bytes -- 48 MB unless PB_OPT_EMBED_STAGE_BYTES says otherwise -- or 256 MB of resize
+ *        scratch reached): close + commit it, acquire again.
+ *        Blocks while both slots are busy (one closed and not yet committed, the other full).
+ *   pb_embed_stage_release(e, ticket)                   the pixels are written.
+ *   pb_embed_stage_close(e, &n, &generation, widths, heights, pixels)   one thread (the embed thread): no more images join the batch;
+ *        waits until every acquired image has been released; returns the batch's images in acquisition order (ticket & 0xFFFF = the
+ *        image's position, ticket >> 32 = generation) -- their pixel pointers stay valid until the commit returns, for whatever
+ *        else wants them on the host (phash).  widths / heights / pixels: room for max_batch entries each, or null.
+ *   pb_embed_stage_commit(e, out_u8, &d_out_u8)         the closed batch: ONE transfer of the block, resize_to_fill + network as
+ *        pb_embed_batch_images_device (same bits), hashes to out_u8 (host, optional) and in the embedder's own device buffer
+ *        (*d_out_u8, valid until the next call on this embedder); returns with the forward pass complete and the slot free again.
+ * Decoders fill one slot while the other is being committed. */
+#define PB_STAGE_FULL 1
+int pb_embed_stage_acquire(pb_embedder *e, uint32_t w, uint32_t h, uint8_t **pixels, uint64_t *ticket);
+int pb_embed_stage_release(pb_embedder *e, uint64_t ticket);
+int pb_embed_stage_close(pb_embedder *e, uint32_t *n, uint32_t *generation, uint32_t *widths, uint32_t *heights, const uint8_t **pixels);
+int pb_embed_stage_commit(pb_embedder *e, uint8_t *out_u8, const uint8_t **d_out_u8);
+
 /* The same for images of ANY size: efficientnet.rs:19-29 `image_to_tensor` in full -- the image crate's
  * `resize_to_fill(W, H, FilterType::Triangle)` (scale to cover, separable triangle filter through an f32
  * intermediate, centre crop; image 0.25.x semantics, restated -- the crate is not part of the reference tree, so
@@ -303,6 +327,8 @@ int pb_pinned_free(void *p);
 
 #define PB_OPT_EMBED_STREAM 3 /* value = hipStream_t the forward pass is launched on (0 = the embedder's own stream) */
 #define PB_OPT_EMBED_ASYNC 4  /* 1: pb_embed_batch_device returns with the forward pass queued (see its stream contract); default 0 */
+#define PB_OPT_EMBED_STAGE_BYTES 5 /* capacity of each of the two staging slots of pb_embed_stage_* in bytes (default 48 MB = 244 images of 256 x 256);
+                                      takes effect the next time a slot is opened */
 int pb_embed_set_option(pb_embedder *e, int option, int64_t value);
 
 /* The embedder picks a kernel form per (layer, batch-size bucket) by timing the candidates at first use (all forms give the

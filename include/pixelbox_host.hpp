@@ -20,6 +20,7 @@
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <functional>
 #include <map>
 #include <memory>
@@ -122,6 +123,16 @@ inline std::vector<std::vector<uint8_t>> phash_batch(const PHasher &hasher, cons
     for (size_t i = 0; i < imgs.size(); ++i) res[i].assign(out.begin() + i * 32, out.begin() + i * 32 + nb[i]);
     return res;
 }
+// ... of pixel blocks that are not RgbImages (the staging slots of pb_embed_stage_close)
+inline std::vector<std::vector<uint8_t>> phash_batch(const PHasher &hasher, const std::vector<const uint8_t *> &ptrs, const std::vector<uint32_t> &ws,
+                                                     const std::vector<uint32_t> &hs) {
+    std::vector<uint32_t> nb(ptrs.size());
+    std::vector<uint8_t> out(ptrs.size() * 32);
+    check(pb_phash_batch_images(hasher.raw(), ptrs.data(), ws.data(), hs.data(), (uint32_t)ptrs.size(), out.data(), nb.data()));
+    std::vector<std::vector<uint8_t>> res(ptrs.size());
+    for (size_t i = 0; i < ptrs.size(); ++i) res[i].assign(out.begin() + i * 32, out.begin() + i * 32 + nb[i]);
+    return res;
+}
 // pub fn mlhash(img:&DynamicImage) -> Vec<u8>   (the model is an explicit handle instead of a lazy static)
 // Any image size: `resize_to_fill(W, H, Triangle)` of efficientnet.rs:20 runs on the GPU (pb_mlhash_image); an
 // image that already has the model's input size goes straight in, as in the image crate.
@@ -172,7 +183,13 @@ struct IndexedImage {
 // P5 grey, maxval <= 255) -- "pnm" is one of the twelve extensions the crawler accepts (crawler.rs:7) and needs no codec.
 using Decoder = std::function<std::optional<RgbImage>(const std::vector<uint8_t> &bytes)>;
 
-inline std::optional<RgbImage> decode_pnm(const std::vector<uint8_t> &b) {
+// A decoder that writes where it is told (round 5: pb_embed_stage_*): it parses the header, asks `alloc(w, h)` for room -- w * h * 3
+// bytes, rows top to bottom; null: give up -- and writes the RGB8 rows there.  false: not an image of this decoder's kind, or alloc
+// said no.  (The image crate's `ImageDecoder::read_image(buf)` has this shape.)
+using PixelAlloc = std::function<uint8_t *(uint32_t w, uint32_t h)>;
+using StagedDecoder = std::function<bool(const std::vector<uint8_t> &bytes, const PixelAlloc &alloc)>;
+
+inline bool decode_pnm_into(const std::vector<uint8_t> &b, const PixelAlloc &alloc) {
     size_t pos = 0;
     auto token = [&]() -> std::string {
         for (;;) {  // whitespace and # comments
@@ -188,23 +205,37 @@ inline std::optional<RgbImage> decode_pnm(const std::vector<uint8_t> &b) {
         return t;
     };
     const std::string magic = token();
-    if (magic != "P6" && magic != "P5") return std::nullopt;
+    if (magic != "P6" && magic != "P5") return false;
     const std::string ws = token(), hs = token(), ms = token();
-    if (ws.empty() || hs.empty() || ms.empty()) return std::nullopt;
+    if (ws.empty() || hs.empty() || ms.empty()) return false;
     const long w = std::strtol(ws.c_str(), nullptr, 10), h = std::strtol(hs.c_str(), nullptr, 10), mx = std::strtol(ms.c_str(), nullptr, 10);
-    if (w < 1 || h < 1 || w > 65535 || h > 65535 || mx < 1 || mx > 255) return std::nullopt;
+    if (w < 1 || h < 1 || w > 65535 || h > 65535 || mx < 1 || mx > 255) return false;
     ++pos;  // the single whitespace byte after maxval
     const size_t ch = magic == "P6" ? 3 : 1, need = (size_t)w * h * ch;
-    if (pos + need > b.size()) return std::nullopt;
-    RgbImage img;
-    img.width = (uint32_t)w;
-    img.height = (uint32_t)h;
-    img.pixels.resize((size_t)w * h * 3);
+    if (pos + need > b.size()) return false;
+    uint8_t *px = alloc((uint32_t)w, (uint32_t)h);
+    if (!px) return false;
+    if (ch == 3 && mx == 255) {
+        std::memcpy(px, b.data() + pos, need);  // the common case: the file's samples are the pixels
+        return true;
+    }
     for (size_t i = 0; i < (size_t)w * h; ++i)
         for (size_t c = 0; c < 3; ++c) {
             const uint32_t v = b[pos + i * ch + (ch == 3 ? c : 0)];
-            img.pixels[3 * i + c] = (uint8_t)(mx == 255 ? v : (v * 255 + mx / 2) / mx);
+            px[3 * i + c] = (uint8_t)(mx == 255 ? v : (v * 255 + mx / 2) / mx);
         }
+    return true;
+}
+
+inline std::optional<RgbImage> decode_pnm(const std::vector<uint8_t> &b) {
+    RgbImage img;
+    const bool ok = decode_pnm_into(b, [&](uint32_t w, uint32_t h) {
+        img.width = w;
+        img.height = h;
+        img.pixels.resize((size_t)w * h * 3);
+        return img.pixels.data();
+    });
+    if (!ok) return std::nullopt;
     return img;
 }
 

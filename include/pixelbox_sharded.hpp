@@ -168,7 +168,9 @@ class ShardedEngine {
             while (a < rows.size()) {
                 size_t b = a + 1;
                 while (b < rows.size() && rows[b] == rows[b - 1] + 1) ++b;
-                const int rc = pb_sharded_append_device(idx_.get(), (int)g, ids.data() + a, d_hashes + (size_t)rows[a] * dim_, b - a);
+                // (d_hashes null: the stage could not line the records up with the device buffer -- a staged batch that held an
+                // undecodable file -- and the host copies go in)
+                const int rc = d_hashes ? pb_sharded_append_device(idx_.get(), (int)g, ids.data() + a, d_hashes + (size_t)rows[a] * dim_, b - a) : PB_ERR_INVALID;
                 if (rc == PB_ERR_CAPACITY || rc == PB_ERR_INVALID) {  // this shard cannot take the run: the host path places it
                     std::vector<uint8_t> host((b - a) * (size_t)dim_);
                     for (size_t i = a; i < b; ++i) {

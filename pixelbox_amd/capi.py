@@ -26,6 +26,7 @@ PB_OPT_APPEND_ASYNC = 12
 PB_OPT_EXACT_QN = 13
 PB_OPT_SECOND_CHANCE = 14
 PB_OPT_EMBED_STREAM = 3  # pb_embed_set_option: stream handle to launch on (0 = the embedder's own)
+PB_OPT_EMBED_STAGE_BYTES = 5  # pb_embed_set_option: bytes per staging slot of pb_embed_stage_*
 PB_OPT_EMBED_ASYNC = 4   # pb_embed_set_option: 1 = pb_embed_batch_device returns with the forward pass queued (default 0: waits)
 PB_OPT_SCAN_LAUNCH = 8  # 0: one launch per query; 1: queries side by side in one grid; 2 (default): one launch, queries one after the other
 PB_METRIC_COSINE, PB_METRIC_BYTE, PB_METRIC_HAMMING = 0, 1, 2
@@ -40,7 +41,8 @@ SYMBOLS = [
     "pb_index_search", "pb_index_search_device", "pb_index_search_packed", "pb_topk_merge_packed", "pb_topk_merge", "pb_index_read", "pb_index_fill_synthetic",
     "pb_index_set_option", "pb_index_get_stats",
     "pb_embed_create", "pb_embed_destroy", "pb_embed_info", "pb_embed_batch", "pb_embed_batch_device", "pb_mlhash",
-    "pb_mlhash_image", "pb_embed_batch_images", "pb_embed_batch_images_device", "pb_resize_to_fill",
+    "pb_mlhash_image", "pb_embed_batch_images", "pb_embed_batch_images_device", "pb_embed_stage_acquire", "pb_embed_stage_release", "pb_embed_stage_close",
+    "pb_embed_stage_commit", "pb_resize_to_fill",
     "pb_embed_set_option", "pb_pinned_alloc", "pb_pinned_free", "pb_embed_tune_ms", "pb_embed_get_tuning", "pb_embed_set_tuning", "pb_fill_synthetic", "pb_fill_synthetic_images", "pb_fill_synthetic_scenes",
     "pb_phash_create", "pb_phash_destroy", "pb_phash_image", "pb_phash_batch_images", "pb_phash_small_image",
 ]
@@ -123,6 +125,10 @@ def lib():
         L.pb_mlhash_image.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, u8p, C.c_size_t]
         L.pb_embed_batch_images.argtypes = [vp, C.POINTER(u8p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint32, u8p, C.POINTER(C.c_float)]
         L.pb_embed_batch_images_device.argtypes = [vp, C.POINTER(u8p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint32, u8p, C.POINTER(vp)]
+        L.pb_embed_stage_acquire.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(vp), C.POINTER(C.c_uint64)]
+        L.pb_embed_stage_release.argtypes = [vp, C.c_uint64]
+        L.pb_embed_stage_close.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(vp)]
+        L.pb_embed_stage_commit.argtypes = [vp, u8p, C.POINTER(vp)]
         L.pb_resize_to_fill.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, u8p]
         L.pb_embed_set_option.argtypes = [vp, C.c_int, C.c_int64]
         L.pb_pinned_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
@@ -486,6 +492,35 @@ class Embedder:
         d = C.c_void_p(0)
         _check(lib().pb_embed_batch_images_device(self._h, ptrs, ws, hs, n, _p(host_copy, C.c_uint8) if host_copy is not None else None, C.byref(d)))
         return int(d.value or 0)
+
+    # -- staging slots (pb_embed_stage_*): the decoder writes its pixels into the embedder's pinned block
+    def stage_acquire(self, w: int, h: int):
+        """-> (numpy view [h, w, 3] of the room inside the pinned block, ticket), or None when the open batch is full (PB_STAGE_FULL)."""
+        px, ticket = C.c_void_p(0), C.c_uint64(0)
+        rc = lib().pb_embed_stage_acquire(self._h, w, h, C.byref(px), C.byref(ticket))
+        if rc == 1:
+            return None
+        _check(rc)
+        buf = (C.c_uint8 * (w * h * 3)).from_address(px.value)
+        return np.frombuffer(buf, dtype=np.uint8).reshape(h, w, 3), int(ticket.value)
+
+    def stage_release(self, ticket: int):
+        _check(lib().pb_embed_stage_release(self._h, ticket))
+
+    def stage_close(self):
+        """-> (n, generation, widths, heights): the batch is closed; its pixel blocks stay valid until stage_commit returns."""
+        n, gen = C.c_uint32(0), C.c_uint32(0)
+        ws = (C.c_uint32 * self.max_batch)()
+        hs = (C.c_uint32 * self.max_batch)()
+        _check(lib().pb_embed_stage_close(self._h, C.byref(n), C.byref(gen), ws, hs, None))
+        return int(n.value), int(gen.value), list(ws[: n.value]), list(hs[: n.value])
+
+    def stage_commit(self, n: int, host_copy: bool = True):
+        """-> (uint8 [n, D] hashes or None, device pointer of the same hashes)"""
+        out = np.empty((n, self.d), dtype=np.uint8) if host_copy else None
+        d = C.c_void_p(0)
+        _check(lib().pb_embed_stage_commit(self._h, _p(out, C.c_uint8) if out is not None else None, C.byref(d)))
+        return out, int(d.value or 0)
 
     def resize_to_fill(self, rgb: np.ndarray) -> np.ndarray:
         rgb = np.ascontiguousarray(rgb, dtype=np.uint8)

@@ -4,6 +4,7 @@
 // Linear(1280, D) exactly as resources/train.py:30-46,167-174 exports them.
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -91,6 +92,7 @@ struct pb_embedder {
     int opt_async = 0;    // PB_OPT_EMBED_ASYNC
     int trace_tune = 0;   // PB_TRACE_TUNE (1: chosen forms, 2: every candidate), PB_NO_STEM_FUSION: read once at create
     bool no_stem_fusion = false;
+    bool no_resize_fusion = false, resize_attr_set = false;  // PB_NO_RESIZE_FUSION: the two-kernel resize (k_resize_v + k_resize_h) always
     int stem_rpp = 0;  // PB_STEM_RPP: stem rows per phase of k_stem_dw (0: the default)
     unsigned *d_se_cnt = nullptr;  // [max_batch] arrival counters of the squeeze-excite tails (zero between launches)
     bool fold_se = false;          // PB_FOLD_SE=1: the gates of the first six blocks come from the producing kernels' tails instead of k_se
@@ -124,6 +126,24 @@ struct pb_embedder {
     float *d_tmp = nullptr;
     size_t d_tmp_cap = 0;
     std::mutex mu;
+    // ---- decoder-facing staging (pb_embed_stage_*): decode workers write pixels straight into pinned slot memory
+    struct StageSlot {
+        uint8_t *h = nullptr, *d = nullptr;  // pinned host block and its device twin
+        size_t cap = 0;
+        ResizeDesc *h_desc = nullptr, *d_desc = nullptr;
+        int state = 0;             // 0 free, 1 open (acquire hands out room), 2 closed (waiting for its writers / being committed)
+        uint32_t n = 0, gen = 0;   // images handed out; generation (part of every ticket of this filling)
+        int writers = 0;           // acquired, not yet released
+        size_t bytes = 0, tmp = 0;
+        std::vector<uint32_t> w, hgt;
+        std::vector<size_t> off;
+    };
+    StageSlot st[2];
+    std::mutex st_mu;
+    std::condition_variable st_cv;
+    size_t st_bytes_want = 0;          // PB_OPT_EMBED_STAGE_BYTES (0: STAGE_BYTES)
+    int st_open = -1, st_closed = -1;  // slot being filled / slot closed and not yet committed
+    uint32_t st_gen = 0;
 };
 
 namespace {
@@ -1252,6 +1272,12 @@ int forward_device(pb_embedder *e, const uint8_t *d_rgb, int n, uint8_t *d_u8, f
 
 void destroy(pb_embedder *e) {
     for (void *p : e->allocs) (void)hipFree(p);
+    for (auto &sl : e->st) {
+        if (sl.h) (void)hipHostFree(sl.h);
+        if (sl.h_desc) (void)hipHostFree(sl.h_desc);
+        (void)hipFree(sl.d);
+        (void)hipFree(sl.d_desc);
+    }
     for (int i = 0; i < 2; ++i) {
         (void)hipFree(e->d_src[i]);
         (void)hipFree(e->d_desc[i]);
@@ -1356,6 +1382,56 @@ void pack_parallel(uint8_t *dst, const uint8_t *const *src, const size_t *bytes,
     for (int k = 0; k < started; ++k) th[k].join();
 }
 
+// the two passes of resize_to_fill for m staged images: one fused launch when every image's row of vertical sums fits the LDS asked
+// for (k_resize_fused), else the vertical pass into the f32 scratch and the horizontal pass from it (k_resize_v, k_resize_h) -- same bytes
+size_t resize_fused_lds(const pb_embedder *e, const ResizeDesc *h_desc, uint32_t m) {  // 0: the two-kernel path
+    size_t span = 0;  // the widest image that is resampled bounds every row's column span
+    for (uint32_t i = 0; i < m; ++i)
+        if (h_desc[i].resample) span = std::max<size_t>(span, h_desc[i].w);
+    const size_t lds = std::max<size_t>(span * 3 * sizeof(float), 16);
+    return (!e->no_resize_fusion && lds <= 96 * 1024) ? lds : 0;
+}
+int launch_resize(pb_embedder *e, const uint8_t *d_src, const ResizeDesc *d_desc, const ResizeDesc *h_desc, uint32_t m, uint32_t max_w, size_t tmp_total,
+                  uint8_t *d_dst) {
+    const uint32_t W = e->W, H = e->H;
+    const size_t lds = resize_fused_lds(e, h_desc, m);
+    if (lds) {
+        if (lds > 48 * 1024 && !e->resize_attr_set) {
+            PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_resize_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            e->resize_attr_set = true;
+        }
+        hipLaunchKernelGGL(k_resize_fused, dim3(H, m), dim3(256), lds, e->stream, d_src, d_desc, W, H, d_dst);
+        PB_HIP(hipGetLastError());
+        return PB_OK;
+    }
+    if (tmp_total) {
+        hipLaunchKernelGGL(k_resize_v, dim3((max_w + 255) / 256, H, m), dim3(256), 0, e->stream, d_src, d_desc, e->d_tmp);
+        PB_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_resize_h, dim3((W * H + 255) / 256, m), dim3(256), 0, e->stream, d_src, e->d_tmp, d_desc, W, H, d_dst);
+    PB_HIP(hipGetLastError());
+    return PB_OK;
+}
+
+// geometry of `resize_to_fill(W, H)` for a w x h source: src/math/utils.rs resize_dimensions(.., fill = true) + src/dynimage.rs
+// resize_to_fill's centre crop (efficientnet.rs:20)
+int resize_geometry(uint32_t W, uint32_t H, uint32_t w, uint32_t h, ResizeDesc *out) {
+    const double wratio = (double)W / (double)w, hratio = (double)H / (double)h;
+    const double ratio = wratio > hratio ? wratio : hratio;
+    const double a = std::round((double)w * ratio), b2 = std::round((double)h * ratio);
+    ResizeDesc d{};
+    d.w = w; d.h = h;
+    d.w2 = a < 1.0 ? 1u : (uint32_t)a;
+    d.h2 = b2 < 1.0 ? 1u : (uint32_t)b2;
+    PB_CHECK(d.w2 >= W && d.h2 >= H, PB_ERR_INVALID, "resize_to_fill: %ux%u does not cover %ux%u", d.w2, d.h2, W, H);
+    d.cx = d.cy = 0;
+    if ((uint64_t)W * d.h2 > (uint64_t)d.w2 * H) d.cy = (d.h2 - H) / 2;  // centre crop along the dimension that overshoots
+    else d.cx = (d.w2 - W) / 2;
+    d.resample = (d.w2 == w && d.h2 == h) ? 0u : 1u;  // imageops::resize: same dimensions -> copy
+    *out = d;
+    return PB_OK;
+}
+
 int prepare_images(pb_embedder *e, const uint8_t *const *rgb, const uint32_t *widths, const uint32_t *heights, uint32_t n, uint8_t *d_dst) {
     const uint32_t W = e->W, H = e->H;
     for (int b = 0; b < 2; ++b) {
@@ -1381,20 +1457,8 @@ int prepare_images(pb_embedder *e, const uint8_t *const *rgb, const uint32_t *wi
             // the vertical pass's scratch is H * w * 3 floats per image -- 4 H / h times the source bytes: a sub-batch of wide, short
             // images is cut by ITS size too (a single image over the cap still gets a sub-batch of its own, as with the source bytes)
             if (i1 > i0 && tmp_total + (size_t)H * w * 3 > STAGE_TMP_FLOATS) break;
-            // src/math/utils.rs resize_dimensions(.., fill = true)
-            const double wratio = (double)W / (double)w, hratio = (double)H / (double)h;
-            const double ratio = wratio > hratio ? wratio : hratio;
-            const double a = std::round((double)w * ratio), b2 = std::round((double)h * ratio);
             ResizeDesc d;
-            d.w = w; d.h = h;
-            d.w2 = a < 1.0 ? 1u : (uint32_t)a;
-            d.h2 = b2 < 1.0 ? 1u : (uint32_t)b2;
-            PB_CHECK(d.w2 >= W && d.h2 >= H, PB_ERR_INVALID, "resize_to_fill: %ux%u does not cover %ux%u", d.w2, d.h2, W, H);
-            // src/dynimage.rs resize_to_fill: centre crop along the dimension that overshoots
-            d.cx = d.cy = 0;
-            if ((uint64_t)W * d.h2 > (uint64_t)d.w2 * H) d.cy = (d.h2 - H) / 2;
-            else d.cx = (d.w2 - W) / 2;
-            d.resample = (d.w2 == w && d.h2 == h) ? 0u : 1u;  // imageops::resize: same dimensions -> copy
+            { int rcd = resize_geometry(W, H, w, h, &d); if (rcd) return rcd; }
             d.slot = i1;
             d.src_off = src_total;
             d.tmp_off = tmp_total;
@@ -1419,7 +1483,7 @@ int prepare_images(pb_embedder *e, const uint8_t *const *rgb, const uint32_t *wi
             PB_HIP(hipMalloc(reinterpret_cast<void **>(&e->d_src[slot]), cap));
             e->stage_cap[slot] = cap;
         }
-        if (tmp_total > e->d_tmp_cap) {
+        if (tmp_total > e->d_tmp_cap && !resize_fused_lds(e, hd, m)) {  // (the fused resize needs no scratch image)
             drain_streams(e);
             (void)hipFree(e->d_tmp);
             e->d_tmp = nullptr;
@@ -1443,12 +1507,7 @@ int prepare_images(pb_embedder *e, const uint8_t *const *rgb, const uint32_t *wi
         PB_HIP(hipEventRecord(e->ev_copied[slot], e->h2d_stream));
         e->stage_used[slot] = true;
         PB_HIP(hipStreamWaitEvent(e->stream, e->ev_copied[slot], 0));
-        if (tmp_total) {
-            hipLaunchKernelGGL(k_resize_v, dim3((max_w + 255) / 256, H, m), dim3(256), 0, e->stream, e->d_src[slot], e->d_desc[slot], e->d_tmp);
-            PB_HIP(hipGetLastError());
-        }
-        hipLaunchKernelGGL(k_resize_h, dim3((W * H + 255) / 256, m), dim3(256), 0, e->stream, e->d_src[slot], e->d_tmp, e->d_desc[slot], W, H, d_dst);
-        PB_HIP(hipGetLastError());
+        { int rcr = launch_resize(e, e->d_src[slot], e->d_desc[slot], hd, m, max_w, tmp_total, d_dst); if (rcr) return rcr; }
         PB_HIP(hipEventRecord(e->ev_resized[slot], e->stream));
         i0 = i1;
     }
@@ -1478,6 +1537,7 @@ int pb_embed_create(pb_embedder **out, int device, const void *weights_blob, siz
     if (const char *tp = getenv("PB_TUNE_PICK")) e->tune_pick = atoi(tp);
     if (const char *tt = getenv("PB_TRACE_TUNE")) e->trace_tune = tt[0] == '3' ? 3 : (tt[0] == '2' ? 2 : 1);  // 3: + host-side staging times
     e->no_stem_fusion = getenv("PB_NO_STEM_FUSION") != nullptr;
+    e->no_resize_fusion = getenv("PB_NO_RESIZE_FUSION") != nullptr;
     if (const char *v = getenv("PB_STEM_RPP")) e->stem_rpp = atoi(v) == 1 ? 1 : 2;
     e->fold_se = getenv("PB_FOLD_SE") != nullptr;
     e->no_gemm_t = getenv("PB_NO_GEMM_T") != nullptr;
@@ -1746,6 +1806,160 @@ int pb_embed_batch_images(pb_embedder *e, const uint8_t *const *rgb, const uint3
     return rc;
 }
 
+// ---- decoder-facing staging (include/pixelbox_hip.h: pb_embed_stage_*).  Reference loop being replaced: crawler.rs:68-119 ->
+// indexed_image.rs:47-91 (decode into a buffer of the decoder's own, then hash one image at a time).
+int pb_embed_stage_acquire(pb_embedder *e, uint32_t w, uint32_t h, uint8_t **pixels, uint64_t *ticket) {
+    PB_CHECK(e && pixels && ticket, PB_ERR_INVALID, "pb_embed_stage_acquire: null pointer");
+    PB_CHECK(w >= 1 && h >= 1 && w <= 65535 && h <= 65535, PB_ERR_INVALID, "pb_embed_stage_acquire: size %ux%u outside 1..65535", w, h);
+    const size_t sb = ((size_t)w * h * 3 + 15) & ~(size_t)15, tmp = (size_t)e->H * w * 3;
+    std::unique_lock<std::mutex> lk(e->st_mu);
+    if (e->st_open < 0) {  // open the next slot (they alternate); it may still be in its commit
+        const int s = e->st_closed == 0 ? 1 : (e->st_closed == 1 ? 0 : (int)(e->st_gen & 1u));
+        e->st_cv.wait(lk, [&] { return e->st[s].state == 0 || e->st_open >= 0; });
+        if (e->st_open < 0) {
+            pb_embedder::StageSlot &sl = e->st[s];
+            const size_t want = e->st_bytes_want ? e->st_bytes_want : STAGE_BYTES;
+            if (!sl.h || sl.cap < want) {  // first use, or PB_OPT_EMBED_STAGE_BYTES asked for more (the slot is free: nobody holds room in it)
+                pb::DeviceGuard guard(e->device);
+                PB_CHECK(guard.ok, PB_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+                if (sl.h) (void)hipHostFree(sl.h);
+                (void)hipFree(sl.d);
+                sl.h = nullptr; sl.d = nullptr; sl.cap = 0;
+                PB_HIP(hipHostMalloc(reinterpret_cast<void **>(&sl.h), want, hipHostMallocDefault));
+                PB_HIP(hipMalloc(reinterpret_cast<void **>(&sl.d), want));
+                if (!sl.h_desc) PB_HIP(hipHostMalloc(reinterpret_cast<void **>(&sl.h_desc), STAGE_MAX_IMAGES * sizeof(ResizeDesc), hipHostMallocDefault));
+                if (!sl.d_desc) PB_HIP(hipMalloc(reinterpret_cast<void **>(&sl.d_desc), STAGE_MAX_IMAGES * sizeof(ResizeDesc)));
+                sl.cap = want;
+            }
+            sl.state = 1;
+            sl.n = 0;
+            sl.bytes = sl.tmp = 0;
+            sl.writers = 0;
+            sl.gen = ++e->st_gen;
+            sl.w.clear(); sl.hgt.clear(); sl.off.clear();
+            e->st_open = s;
+        }
+    }
+    pb_embedder::StageSlot &sl = e->st[e->st_open];
+    const uint32_t lim = std::min<uint32_t>(e->max_batch, STAGE_MAX_IMAGES);
+    if (sl.n == 0 && sb > sl.cap) {  // one image larger than the block: the (empty) slot grows to hold it
+        pb::DeviceGuard guard(e->device);
+        PB_CHECK(guard.ok, PB_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+        (void)hipHostFree(sl.h);
+        (void)hipFree(sl.d);
+        sl.h = nullptr; sl.d = nullptr; sl.cap = 0;
+        PB_HIP(hipHostMalloc(reinterpret_cast<void **>(&sl.h), sb, hipHostMallocDefault));
+        PB_HIP(hipMalloc(reinterpret_cast<void **>(&sl.d), sb));
+        sl.cap = sb;
+    }
+    if (sl.n >= lim || sl.bytes + sb > sl.cap || (sl.n > 0 && sl.tmp + tmp > STAGE_TMP_FLOATS)) return PB_STAGE_FULL;
+    *pixels = sl.h + sl.bytes;
+    *ticket = ((uint64_t)sl.gen << 32) | ((uint64_t)e->st_open << 16) | sl.n;
+    sl.w.push_back(w); sl.hgt.push_back(h); sl.off.push_back(sl.bytes);
+    sl.bytes += sb;
+    sl.tmp += tmp;
+    ++sl.n;
+    ++sl.writers;
+    return PB_OK;
+}
+
+int pb_embed_stage_release(pb_embedder *e, uint64_t ticket) {
+    PB_CHECK(e, PB_ERR_INVALID, "pb_embed_stage_release: null embedder");
+    const int s = (int)((ticket >> 16) & 0xFFFFu);
+    std::lock_guard<std::mutex> lk(e->st_mu);
+    PB_CHECK(s < 2 && e->st[s].gen == (uint32_t)(ticket >> 32) && e->st[s].state != 0 && e->st[s].writers > 0, PB_ERR_INVALID,
+             "pb_embed_stage_release: stale ticket");
+    --e->st[s].writers;
+    e->st_cv.notify_all();
+    return PB_OK;
+}
+
+int pb_embed_stage_close(pb_embedder *e, uint32_t *n, uint32_t *generation, uint32_t *widths, uint32_t *heights, const uint8_t **pixels) {
+    PB_CHECK(e && n, PB_ERR_INVALID, "pb_embed_stage_close: null pointer");
+    std::unique_lock<std::mutex> lk(e->st_mu);
+    PB_CHECK(e->st_closed < 0, PB_ERR_INVALID, "pb_embed_stage_close: the batch closed before has not been committed (or aborted)");
+    *n = 0;
+    if (generation) *generation = 0;
+    if (e->st_open < 0) return PB_OK;
+    const int s = e->st_open;
+    pb_embedder::StageSlot &sl = e->st[s];
+    sl.state = 2;
+    e->st_open = -1;
+    e->st_closed = s;
+    e->st_cv.wait(lk, [&] { return sl.writers == 0; });
+    *n = sl.n;
+    if (generation) *generation = sl.gen;
+    for (uint32_t i = 0; i < sl.n; ++i) {
+        if (widths) widths[i] = sl.w[i];
+        if (heights) heights[i] = sl.hgt[i];
+        if (pixels) pixels[i] = sl.h + sl.off[i];
+    }
+    if (sl.n == 0) {  // nothing in it: free again at once
+        sl.state = 0;
+        e->st_closed = -1;
+        e->st_cv.notify_all();
+    }
+    return PB_OK;
+}
+
+int pb_embed_stage_commit(pb_embedder *e, uint8_t *out_u8, const uint8_t **d_out_u8) {
+    PB_CHECK(e, PB_ERR_INVALID, "pb_embed_stage_commit: null embedder");
+    int s;
+    {
+        std::lock_guard<std::mutex> lk(e->st_mu);
+        s = e->st_closed;
+    }
+    if (d_out_u8) *d_out_u8 = e->d_out_u8;
+    if (s < 0) return PB_OK;
+    pb_embedder::StageSlot &sl = e->st[s];
+    int rc;
+    {
+        std::lock_guard<std::mutex> lock(e->mu);
+        pb::DeviceGuard guard(e->device);
+        auto body = [&]() -> int {
+            const uint32_t m = sl.n, W = e->W, H = e->H;
+            size_t tmp_total = 0;
+            uint32_t max_w = 1;
+            for (uint32_t i = 0; i < m; ++i) {
+                ResizeDesc d;
+                int rcd = resize_geometry(W, H, sl.w[i], sl.hgt[i], &d);
+                if (rcd) return rcd;
+                d.slot = i;
+                d.src_off = sl.off[i];
+                d.tmp_off = tmp_total;
+                if (d.resample) tmp_total += ((size_t)H * sl.w[i] * 3 + 3) & ~(size_t)3;
+                max_w = std::max(max_w, sl.w[i]);
+                sl.h_desc[i] = d;
+            }
+            if (tmp_total > e->d_tmp_cap && !resize_fused_lds(e, sl.h_desc, m)) {
+                drain_streams(e);
+                (void)hipFree(e->d_tmp);
+                e->d_tmp = nullptr;
+                e->d_tmp_cap = 0;
+                PB_HIP(hipMalloc(reinterpret_cast<void **>(&e->d_tmp), tmp_total * sizeof(float)));
+                e->d_tmp_cap = tmp_total;
+            }
+            // ONE transfer of the block the decoders wrote (no packing pass), then the two resize kernels and the forward pass
+            PB_HIP(hipMemcpyAsync(sl.d, sl.h, sl.bytes, hipMemcpyHostToDevice, e->stream));
+            PB_HIP(hipMemcpyAsync(sl.d_desc, sl.h_desc, m * sizeof(ResizeDesc), hipMemcpyHostToDevice, e->stream));
+            { int rcr = launch_resize(e, sl.d, sl.d_desc, sl.h_desc, m, max_w, tmp_total, e->d_img); if (rcr) return rcr; }
+            int rcf = forward_device(e, e->d_img, (int)m, e->d_out_u8, e->d_out_f32);
+            if (rcf) return rcf;
+            if (out_u8) PB_HIP(hipMemcpyAsync(out_u8, e->d_out_u8, (size_t)m * e->D, hipMemcpyDeviceToHost, e->stream));
+            PB_HIP(hipStreamSynchronize(e->stream));
+            return PB_OK;
+        };
+        rc = body();
+        if (rc) drain_streams(e);
+    }
+    std::lock_guard<std::mutex> lk(e->st_mu);  // the block has been read (or the call failed): the slot is free again either way
+    sl.state = 0;
+    sl.n = 0;
+    e->st_closed = -1;
+    e->st_cv.notify_all();
+    return rc;
+}
+
 int pb_embed_batch_images_device(pb_embedder *e, const uint8_t *const *rgb, const uint32_t *widths, const uint32_t *heights, uint32_t n,
                                  uint8_t *out_u8, const uint8_t **d_out_u8) {
     PB_CHECK(e, PB_ERR_INVALID, "pb_embed_batch_images_device: null embedder");
@@ -1955,6 +2169,12 @@ int pb_embed_set_option(pb_embedder *e, int option, int64_t value) {
     if (option == PB_OPT_EMBED_ASYNC) {
         PB_CHECK(value == 0 || value == 1, PB_ERR_INVALID, "PB_OPT_EMBED_ASYNC: 0 or 1");
         e->opt_async = (int)value;
+        return PB_OK;
+    }
+    if (option == PB_OPT_EMBED_STAGE_BYTES) {
+        PB_CHECK(value >= (1 << 20) && value <= (1ll << 31), PB_ERR_INVALID, "PB_OPT_EMBED_STAGE_BYTES: 1 MB .. 2 GB");
+        std::lock_guard<std::mutex> lk(e->st_mu);
+        e->st_bytes_want = ((size_t)value + 4095) & ~(size_t)4095;  // taken by a slot the next time it is opened empty
         return PB_OK;
     }
     return pb::fail(PB_ERR_INVALID, "pb_embed_set_option: unknown option %d", option);

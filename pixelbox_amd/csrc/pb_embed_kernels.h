@@ -2027,6 +2027,90 @@ __global__ __launch_bounds__(256) void k_resize_h(const uint8_t *__restrict__ sr
     o[0] = to_u8(t0); o[1] = to_u8(t1); o[2] = to_u8(t2);
 }
 
+// Both passes of one output row in ONE workgroup (round 5): the vertical pass of the source columns the row's horizontal windows
+// touch goes into LDS instead of the f32 scratch image (H x w x 3 floats per image written and read back: 400 of the 530 MB the two
+// kernels move for 512 images of 256 x 256), the horizontal pass reads it from there.  Same operations in the same order on the same
+// values as k_resize_v + k_resize_h (a scratch value is formed by the same loop and read back unchanged), so the same bytes; the
+// filter weights of the row are formed once per workgroup instead of once per thread.  The host uses it when the widest span of a
+// sub-batch fits the LDS it asks for (s_span floats x 3), else the two-kernel path.  grid = (H, images); block = 256.
+__global__ __launch_bounds__(256) void k_resize_fused(const uint8_t *__restrict__ src_base, const ResizeDesc *__restrict__ desc, uint32_t W,
+                                                      uint32_t H, uint8_t *__restrict__ dst_base) {
+    extern __shared__ __attribute__((aligned(16))) float s_rs[];  // [span][3] vertical sums, then nothing else
+    __shared__ float s_wv[64];
+    const ResizeDesc d = desc[blockIdx.y];
+    const uint32_t y = blockIdx.x;
+    uint8_t *orow = dst_base + ((size_t)d.slot * W * H + (size_t)y * W) * 3;
+    if (!d.resample) {  // same-size source: crop only
+        const uint8_t *p = src_base + d.src_off + ((size_t)(d.cy + y) * d.w + d.cx) * 3;
+        for (uint32_t i = threadIdx.x; i < W * 3; i += 256) orow[i] = p[i];
+        return;
+    }
+    const uint8_t *src = src_base + d.src_off;
+    // the source columns this row's horizontal windows cover: [xlo, xhi)
+    int l0, r0, l1, r1;
+    float in0, sr0;
+    resize_window(d.cx, d.w, d.w2, l0, r0, in0, sr0);
+    resize_window(d.cx + W - 1, d.w, d.w2, l1, r1, in0, sr0);
+    const int xlo = l0, xhi = r1;
+    // vertical weights of this output row (the same values every thread of k_resize_v forms for itself)
+    int left, right;
+    float input, sratio;
+    resize_window(d.cy + y, d.h, d.h2, left, right, input, sratio);
+    const int nv = right - left;
+    if (nv <= 64) {
+        float sum = 0.0f;
+        for (int i = left; i < right; ++i) sum = sum + triangle_kernel(((float)i - input) / sratio);
+        if ((int)threadIdx.x < nv) s_wv[threadIdx.x] = triangle_kernel(((float)(left + (int)threadIdx.x) - input) / sratio) / sum;
+        __syncthreads();
+        for (int x = xlo + (int)threadIdx.x; x < xhi; x += 256) {
+            float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;
+            for (int i = 0; i < nv; ++i) {
+                const float wgt = s_wv[i];
+                const uint8_t *p = src + ((size_t)(left + i) * d.w + x) * 3;
+                const float m0 = (float)p[0] * wgt, m1 = (float)p[1] * wgt, m2 = (float)p[2] * wgt;
+                t0 = t0 + m0; t1 = t1 + m1; t2 = t2 + m2;
+            }
+            float *o = s_rs + (size_t)(x - xlo) * 3;
+            o[0] = t0; o[1] = t1; o[2] = t2;
+        }
+    } else {  // a very tall source: more taps than the weight table holds -- every thread forms them, as k_resize_v does
+        float sum = 0.0f;
+        for (int i = left; i < right; ++i) sum = sum + triangle_kernel(((float)i - input) / sratio);
+        for (int x = xlo + (int)threadIdx.x; x < xhi; x += 256) {
+            float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;
+            for (int i = left; i < right; ++i) {
+                const float wgt = triangle_kernel(((float)i - input) / sratio) / sum;
+                const uint8_t *p = src + ((size_t)i * d.w + x) * 3;
+                const float m0 = (float)p[0] * wgt, m1 = (float)p[1] * wgt, m2 = (float)p[2] * wgt;
+                t0 = t0 + m0; t1 = t1 + m1; t2 = t2 + m2;
+            }
+            float *o = s_rs + (size_t)(x - xlo) * 3;
+            o[0] = t0; o[1] = t1; o[2] = t2;
+        }
+    }
+    __syncthreads();
+    for (uint32_t xo = threadIdx.x; xo < W; xo += 256) {
+        int hl, hr;
+        float hin, hsr;
+        resize_window(d.cx + xo, d.w, d.w2, hl, hr, hin, hsr);
+        float sum = 0.0f;
+        for (int k = hl; k < hr; ++k) sum = sum + triangle_kernel(((float)k - hin) / hsr);
+        float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;
+        for (int k = hl; k < hr; ++k) {
+            const float wgt = triangle_kernel(((float)k - hin) / hsr) / sum;
+            const float *p = s_rs + (size_t)(k - xlo) * 3;
+            const float m0 = p[0] * wgt, m1 = p[1] * wgt, m2 = p[2] * wgt;
+            t0 = t0 + m0; t1 = t1 + m1; t2 = t2 + m2;
+        }
+        auto to_u8 = [](float t) -> uint8_t {
+            t = t < 0.0f ? 0.0f : (t > 255.0f ? 255.0f : t);
+            return (uint8_t)roundf(t);  // f32::round: half away from zero
+        };
+        uint8_t *o = orow + (size_t)xo * 3;
+        o[0] = to_u8(t0); o[1] = to_u8(t1); o[2] = to_u8(t2);
+    }
+}
+
 // tanh + u8 quantiser (efficientnet.rs:39) on the Linear(1280, D) outputs (computed by k_gemm1x1, bias included)
 __global__ void k_tanh_quant(const float *__restrict__ pre, long n, float *__restrict__ out_f32,
                              uint8_t *__restrict__ out_u8) {

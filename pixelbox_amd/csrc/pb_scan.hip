@@ -1423,7 +1423,12 @@ int pb_index_create(pb_index **out, int device, uint32_t dim, uint64_t capacity_
         hipDeviceProp_t prop;
         PB_HIP(hipGetDeviceProperties(&prop, device));
         ix->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        PB_HIP(hipStreamCreateWithFlags(&ix->own_stream, hipStreamNonBlocking));
+        {   // the index's own stream at the device's highest priority: its launches are small (an append's copy + norms, a query's
+            // filter pass) and must not queue behind the embedders' forward passes when a crawler and queries share the GPU
+            int pr_lo = 0, pr_hi = 0;
+            PB_HIP(hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi));
+            PB_HIP(hipStreamCreateWithPriority(&ix->own_stream, hipStreamNonBlocking, pr_hi));
+        }
         ix->stream = ix->own_stream;
         PB_HIP(hipEventCreate(&ix->ev0));
         PB_HIP(hipEventCreate(&ix->ev1));

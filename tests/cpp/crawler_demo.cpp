@@ -1,6 +1,7 @@
 // crawler_demo.cpp -- the reference's indexing flow written against the C++ host mirror: Crawler::start_indexing ->
 // drain the channel into Engine::insert_image_from_memory (engine.rs:177-205), then Engine::query_by_image_hash_from_file
-// (engine.rs:352-361).  argv: weights.pbxw folder query.pnm out.txt workers
+// (engine.rs:352-361).  argv: weights.pbxw folder query.pnm out.txt workers [staged: 1 = the decoders write into the embedder's
+// staging slots (pb_embed_stage_*), 0 / absent = decoders with buffers of their own]
 #include <cstdio>
 #include <fstream>
 
@@ -27,7 +28,10 @@ int main(int argc, char **argv) {
         pixelbox::Embedder model(blob.data(), blob.size(), 64);
         pixelbox::PHasher hasher;
         pixelbox::Engine engine(model.dim(), 4096);
-        pixelbox::Crawler crawler(model, &hasher, pixelbox::decode_pnm, 64);
+        const bool staged = argc > 6 && std::atoi(argv[6]) != 0;
+        pixelbox::Crawler crawler = staged ? pixelbox::Crawler(std::vector<const pixelbox::Embedder *>{&model}, &hasher,
+                                                               pixelbox::StagedDecoder(pixelbox::decode_pnm_into), 64)
+                                           : pixelbox::Crawler(model, &hasher, pixelbox::decode_pnm, 64);
         crawler.start_indexing({argv[2]}, (size_t)std::atoi(argv[5]));
         std::vector<pixelbox::IndexedImage> got;
         pixelbox::IndexedImage img;

@@ -153,8 +153,10 @@ def _write_pnm(path, img):
         f.write(np.ascontiguousarray(img, dtype=np.uint8).tobytes())
 
 
-def test_crawler_stage_and_query_by_file(tmp_path):
-    """SURVEY 8f rank 2 + row a7: files on disk -> decode workers -> ONE batched GPU resize + embed (+ phash) -> bounded channel
+@pytest.mark.parametrize("staged", [0, 1])
+def test_crawler_stage_and_query_by_file(tmp_path, staged):
+    """staged = 1: the decode workers write their pixels into the embedder's staging slots (pb_embed_stage_*, round 5) -- same records.
+    SURVEY 8f rank 2 + row a7: files on disk -> decode workers -> ONE batched GPU resize + embed (+ phash) -> bounded channel
     -> Engine::insert_image_from_memory; then Engine::query_by_image_hash_from_file (engine.rs:352-361).  Hashes against
     the oracle (resize restatement + network + phash restatement), the allow-list and the skip rule against crawler.rs."""
     rng = np.random.default_rng(5)
@@ -183,7 +185,7 @@ def test_crawler_stage_and_query_by_file(tmp_path):
                            "-L", libdir, "-lpixelbox_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
     qpath = next(root.rglob(query_name))
     out = tmp_path / "out.txt"
-    subprocess.check_call([str(exe), str(tmp_path / "w.pbxw"), str(root), str(qpath), str(out), "4"])
+    subprocess.check_call([str(exe), str(tmp_path / "w.pbxw"), str(root), str(qpath), str(out), "4", str(staged)])
     lines = out.read_text().splitlines()
     head = dict(zip(lines[0].split()[::2], map(int, lines[0].split()[1::2])))
     assert head["matched"] == 38 and head["decoded"] == 37 and head["skipped"] == 1 and head["indexed"] == 37
