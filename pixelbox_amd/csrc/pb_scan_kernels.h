@@ -2006,6 +2006,41 @@ __global__ __launch_bounds__(M_BLOCK) void k_merge_lists(
 constexpr int MQ_MAXQ = 64;
 constexpr int MQ_WAVES = 4;
 constexpr int MQ_BINS = 256;
+// The sample pass's histogram of cos_filter (it only steers tau: efficiency, never correctness).  Rounds 1-4 used 256 equal bins over
+// [0, 1]: the queries of a DENSE cluster -- a k-th best cosine of 0.993-0.9995 with thousands of rows at 0.99+, 11 % of the end-to-end
+// leg's queries (profiles/e2e_uncertified_probe.py) -- found their whole candidate set in the top bin, were gated as "near-duplicate
+// floods" and took the exhaustive pass although their tie sets hold 100-106 rows.  Round 5: equal bins of 1/128 below 0.875 (112 of
+// them) and LOGARITHMIC bins in 1 - cos above it -- eight per octave from 2^-3 down to 2^-21 (144 of them), read straight off the
+// float's exponent and top three mantissa bits -- so that the resolution follows the density where embeddings cluster.
+__host__ __device__ __forceinline__ int mq_bin(float cs) {
+    if (cs < 0.875f) {
+        const int b = (int)(cs * 128.0f);
+        return b < 0 ? 0 : b;
+    }
+    float u = 1.0f - cs;
+    u = u > 4.76837158203125e-07f ? u : 4.76837158203125e-07f;  // 2^-21
+#ifdef __HIP_DEVICE_COMPILE__
+    const int key = (int)(__float_as_uint(u) >> 20);
+#else
+    uint32_t ub;
+    memcpy(&ub, &u, 4);
+    const int key = (int)(ub >> 20);
+#endif
+    const int b = 112 + (991 - key);  // u just below 2^-3: key 991 -> bin 112; u = 2^-21: key 848 -> bin 255
+    return b < 112 ? 112 : (b > 255 ? 255 : b);
+}
+// lower cosine edge of bin b: every value in bins >= b is >= this
+__host__ __device__ __forceinline__ float mq_bin_edge(int b) {
+    if (b < 112) return (float)b / 128.0f;
+    const uint32_t hi = (uint32_t)(1104 - b) << 20;  // upper edge of the bin in 1 - cos
+#ifdef __HIP_DEVICE_COMPILE__
+    return 1.0f - __uint_as_float(hi);
+#else
+    float f;
+    memcpy(&f, &hi, 4);
+    return 1.0f - f;
+#endif
+}
 constexpr int MQ_CAP = 4096;
 constexpr int MQ_SAMPLE = 32;
 constexpr int MQ_HPITCH = 65;  // LDS histogram: [bin pair][query] with a 65-word pitch, two 16-bit counters per word
@@ -2137,8 +2172,7 @@ __global__ __launch_bounds__(MQ_WAVES * WAVE) void k_scan_multi(
                     const int num = 4 * acc[qt][r] + sa2[qt] + cr[r];
                     const float cs = (float)num * rsb[r] * rs_a[qt];
                     if (cs >= q_tau[qt] && q < n_q) {
-                        int bin = count_mode ? 0 : (int)(cs * (float)MQ_BINS);
-                        bin = bin < 0 ? 0 : (bin >= MQ_BINS ? MQ_BINS - 1 : bin);
+                        const int bin = count_mode ? 0 : mq_bin(cs);
                         atomicAdd(&s_hist[(bin >> 1) * MQ_HPITCH + q], 1u << (16 * (bin & 1)));
                     }
                 }
@@ -2526,14 +2560,14 @@ __global__ void k_mq_pick_tau(const uint32_t *__restrict__ ghist, const QParams 
         acc += __shfl(incl, WAVE - 1);
     }
     if (lane == 0) {
-        float t = found >= 0 ? (float)found / (float)MQ_BINS - 2e-6f : 0.0f;
+        float t = found >= 0 ? mq_bin_edge(found) - 2e-6f : 0.0f;
         // never <= 0: the collect pass's group bound (4 max acc' + max cr) / min W bounds a row's value only while that
         // numerator is non-negative, i.e. for thresholds above zero (thr0 is >= 2 M + 2e-6 by construction, make_qparams;
         // the clamp states it here: a query that needs rows with a cosine below it ends in the exhaustive pass through
         // its failed certificate)
         t = fmaxf(t, fmaxf(qp[q].thr0, 1e-6f));
         if ((uint64_t)cum * MQ_SAMPLE > (uint64_t)MQ_CAP) {
-            float h = found_k >= 0 ? (float)found_k / (float)MQ_BINS - 4e-6f - qp[q].m : 0.0f;
+            float h = found_k >= 0 ? mq_bin_edge(found_k) - 4e-6f - qp[q].m : 0.0f;
             h = h > 0.0f && h < 0.999f ? h : 0.0f;
             t = 2.0f + h;
         }
