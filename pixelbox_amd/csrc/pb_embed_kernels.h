@@ -353,6 +353,9 @@ __global__ __launch_bounds__(256) void k_stem_dw(const uint8_t *__restrict__ img
                     for (int kx = 0; kx < 3; ++kx) dw_tap(acc, *reinterpret_cast<const f32x4 *>(rrp + kx * 36), tw[ky * 3 + kx]);
                 }
                 const f32x4 r = {silu_f(acc.x), silu_f(acc.y), silu_f(acc.z), silu_f(acc.w)};
+#if defined(PB_STEM_ABL) && (PB_STEM_ABL & 1)
+                if (r.x == 12345.678f)  // ablation: no output stores
+#endif
                 *reinterpret_cast<f32x4 *>(out + (((size_t)b * Ho + oy) * Wo + px) * 32 + 4 * quad) = r;
                 se_acc(psum, r);
             }
@@ -1750,6 +1753,9 @@ __global__ __launch_bounds__(256) void k_mbconv_small(
 #pragma unroll
             for (int j = 0; j < TX; ++j) {
                 const f32x4 r4 = {silu_f(acc[j].x), silu_f(acc[j].y), silu_f(acc[j].z), silu_f(acc[j].w)};
+#if defined(PB_SM_ABL) && (PB_SM_ABL & 1)
+                if (r4.x == 12345.678f)  // ablation: no output stores
+#endif
                 *reinterpret_cast<f32x4 *>(op + (size_t)j * E) = r4;
                 se_acc(q4, r4);
             }

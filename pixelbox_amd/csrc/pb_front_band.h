@@ -27,6 +27,12 @@
 // store group (stride 2: two runs of four).  PLS is a multiple of 4, so ring rows differ by multiples of 16 slots and the
 // rows a 16-lane read group straddles (maps 16 pixels wide) keep their slots distinct modulo the 16 slots of a bank row.
 //
+// Output stores (round 5): the filter phase leaves a wave with ONE channel quad of 64 pixels -- stored from there, a store instruction
+// touches 64 separate 16-byte pieces 4 E bytes apart, and blocks 1 and 2 (201 / 302 MB of output) ran at the rate of those stores, not
+// of their arithmetic (ablation builds, profiles/r05_front_band_ablation.txt: everything but the stores removed: 162 -> 152 us; the
+// stores removed too: 65).  The step's 64 x 16 results are now staged in LDS and stored after the step's closing barrier, four
+// lanes per pixel: a pixel's 64 bytes leave in one piece, and the stores issue under the next step's expand phase.
+//
 // Same arithmetic as the kernels it replaces (k order of the expand chain, (ky, kx) tap order with one fused
 // multiply-add per tap, 2^-24 fixed-point SE sums): bit-identical outputs, whatever the band count.
 #pragma once
@@ -56,7 +62,9 @@ struct FrontBandGeom {
     static constexpr int NP0 = R0 * WT;         // pairs of the priming rows
     static constexpr int TPW0 = (NP0 + 3) / 4;
     static constexpr int NQ = 4;                // channel quads per workgroup: one 16-channel MFMA tile
-    static constexpr size_t LDS_BYTES = (size_t)RR * NQ * PLS * 16;
+    static constexpr int STG_PITCH = 5;         // float4 per staged pixel: 16 channels + one float4 of padding (conflict-free both ways)
+    static constexpr size_t RING_BYTES = (size_t)RR * NQ * PLS * 16;
+    static constexpr size_t LDS_BYTES = RING_BYTES + (size_t)64 * STG_PITCH * 16;  // + the step's 64 x 16 outputs staged for the stores
     static_assert(RPS * Wo == 64, "a step is 64 output pixels per channel quad");
     static_assert(NP % 4 == 0, "pairs of a step divide over the 4 waves of a channel tile");
     static_assert(W % S == 0 && PLS % 4 == 0, "geometry");
@@ -81,7 +89,8 @@ __global__ __launch_bounds__(256, PB_BAND_WAVES) void k_front_band(
     constexpr int TPW = G::TPW, NQ = G::NQ;
     constexpr int PF = TPW * KC <= 4 ? TPW : (TPW < 2 ? TPW : 2);  // pairs per group: their operands are in flight ahead of use
     static_assert(TPW % PF == 0, "groups of PF pairs");
-    extern __shared__ __attribute__((aligned(16))) f32x4 s_ring[];  // [RR][NQ][PLS]
+    extern __shared__ __attribute__((aligned(16))) f32x4 s_ring[];  // [RR][NQ][PLS], then the store staging [64 pixels][STG_PITCH]
+    f32x4 *s_stage = s_ring + RR * NQ * PLS;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: what it indexes stays in SGPRs
     const int li = lane & 15, kq = lane >> 4;
@@ -148,6 +157,10 @@ __global__ __launch_bounds__(256, PB_BAND_WAVES) void k_front_band(
         f32x4 acc[PF];
 #pragma unroll
         for (int jj = 0; jj < PF; ++jj) acc[jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#if defined(PB_BAND_ABL) && (PB_BAND_ABL & 8)
+#pragma unroll
+        for (int jj = 0; jj < PF; ++jj) acc[jj] = xg[jj][0];  // ablation: no expand MFMAs (the operands are still loaded and consumed)
+#else
 #pragma unroll
         for (int s2 = 0; s2 < KC; ++s2)
 #pragma unroll
@@ -158,6 +171,7 @@ __global__ __launch_bounds__(256, PB_BAND_WAVES) void k_front_band(
                     const float av = e == 0 ? a.x : (e == 1 ? a.y : (e == 2 ? a.z : a.w));
                     acc[jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s2][e], av, acc[jj], 0, 0, 0);
                 }
+#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int jj = 0; jj < PF; ++jj) load_pair(next_first, g + 4 * (jn + jj), xg[jj]);
@@ -168,7 +182,11 @@ __global__ __launch_bounds__(256, PB_BAND_WAVES) void k_front_band(
             const int r = p / WT, pt = p % WT;
             const unsigned rs = (unsigned)(rel_first + r) % (unsigned)RR;
             f32x4 v;
+#if defined(PB_BAND_ABL) && (PB_BAND_ABL & 32)
+            v.x = acc[jj].x + bev.x; v.y = acc[jj].y + bev.y; v.z = acc[jj].z + bev.z; v.w = acc[jj].w + bev.w;  // ablation: no SiLU
+#else
             v.x = silu_f(acc[jj].x + bev.x); v.y = silu_f(acc[jj].y + bev.y); v.z = silu_f(acc[jj].z + bev.z); v.w = silu_f(acc[jj].w + bev.w);
+#endif
             s_ring[rs * (unsigned)(NQ * PLS) + wr_slot + (unsigned)pt * WR_TILE] = v;
         }
         if constexpr (CHECK) {
@@ -190,7 +208,20 @@ __global__ __launch_bounds__(256, PB_BAND_WAVES) void k_front_band(
     const int oyl = lane / Wo, ox = lane % Wo;
     const f32x4 *tq = dw_wq + (size_t)(e0 / 4 + q) * (KS * KS);
     const f32x4 dbv = *reinterpret_cast<const f32x4 *>(dw_b + e0 + 4 * q);  // wave-uniform
-    float *op = out + ((size_t)(b * Ho + oy_b + oyl) * Wo + ox) * E + e0 + 4 * q;
+    // store role (after the step's closing barrier): lane = (pixel 16 wave + lane / 4 of the step, channel quad lane % 4)
+    const int sp_px = 16 * wave + (lane >> 2), sp_q = lane & 3;
+    float *op = out + ((size_t)(b * Ho + oy_b + sp_px / Wo) * Wo + sp_px % Wo) * E + e0 + 4 * sp_q;
+    const f32x4 *stg_rd = s_stage + sp_px * G::STG_PITCH + sp_q;
+    f32x4 *stg_wr = s_stage + lane * G::STG_PITCH + q;
+    auto flush_stage = [&]() __attribute__((always_inline)) {
+#if defined(PB_BAND_ABL) && (PB_BAND_ABL & 2)
+        const f32x4 r4 = *stg_rd;
+        if (r4.x == 12345.678f) *reinterpret_cast<f32x4 *>(op) = r4;  // ablation: no output stores
+#else
+        *reinterpret_cast<f32x4 *>(op) = *stg_rd;
+#endif
+        op += (size_t)RPS * Wo * E;
+    };
     const unsigned rd_col = (unsigned)(q * PLS + ox);  // + compile-time slot offset of kx
     ll4 psum = {0, 0, 0, 0};
 
@@ -241,7 +272,15 @@ __global__ __launch_bounds__(256, PB_BAND_WAVES) void k_front_band(
             unsigned rb = (unsigned)(sbase + oyl * S);
             rb = rb >= (unsigned)RR ? rb - RR : rb;
             f32x4 acc = dbv;
-            if constexpr (KS * KS <= 9) {
+#if defined(PB_BAND_ABL) && (PB_BAND_ABL & 16)
+            constexpr bool NO_TAPS = true;
+#else
+            constexpr bool NO_TAPS = false;
+#endif
+            if constexpr (NO_TAPS) {  // ablation: one window read, no taps
+                const f32x4 v0 = s_ring[rb * (unsigned)(NQ * PLS) + rd_col];
+                acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+            } else if constexpr (KS * KS <= 9) {
                 // 3x3: the 36 tap values stay in scalar registers for the whole kernel (loop-invariant scalar loads)
 #pragma unroll
                 for (int ky = 0; ky < KS; ++ky) {
@@ -287,22 +326,30 @@ __global__ __launch_bounds__(256, PB_BAND_WAVES) void k_front_band(
                     asm volatile("" : "+v"(acc.x), "+v"(acc.y), "+v"(acc.z), "+v"(acc.w));
                 }
             }
-            const f32x4 r4 = {silu_f(acc.x), silu_f(acc.y), silu_f(acc.z), silu_f(acc.w)};
-#if defined(PB_BAND_ABL) && (PB_BAND_ABL & 2)
-            if (r4.x == 12345.678f) *reinterpret_cast<f32x4 *>(op) = r4;  // ablation: no output stores
+#if defined(PB_BAND_ABL) && (PB_BAND_ABL & 32)
+            const f32x4 r4 = acc;
 #else
-            *reinterpret_cast<f32x4 *>(op) = r4;
+            const f32x4 r4 = {silu_f(acc.x), silu_f(acc.y), silu_f(acc.z), silu_f(acc.w)};
+#endif
+#ifdef PB_BAND_DIRECT_STORE  // comparison build: rounds 3-4's stores, a channel quad of 64 pixels per wave
+            *reinterpret_cast<f32x4 *>(out + ((size_t)(b * Ho + oy_b + t * RPS + oyl) * Wo + ox) * E + e0 + 4 * q) = r4;
+#else
+            *stg_wr = r4;  // stored after the closing barrier (flush_stage)
 #endif
 #if defined(PB_BAND_ABL) && (PB_BAND_ABL & 4)
             psum.x += __float_as_int(r4.x) ^ __float_as_int(r4.y) ^ __float_as_int(r4.z) ^ __float_as_int(r4.w);  // ablation: no fixed-point SE sums
 #else
             se_acc(psum, r4);
 #endif
-            op += (size_t)RPS * Wo * E;
         }
         sbase += RN;
         sbase = sbase >= RR ? sbase - RR : sbase;
         __syncthreads();
+        // the step's outputs leave now: four lanes per pixel, under the next step's expand phase (the staging block is rewritten by
+        // the next filter phase, i.e. behind the next step's first barrier, which this wave reaches after these reads)
+#ifndef PB_BAND_DIRECT_STORE
+        flush_stage();
+#endif
     }
     // ---- SE partial of this (image, band, quad): exact integer sum over the 64 lanes
 #pragma unroll
