@@ -216,7 +216,11 @@ __device__ __forceinline__ void stem_tile(const StemFrag &f, const uint8_t *rows
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8s, f.w[c][2]), __builtin_bit_cast(bf16x8s, px), acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8s, f.w[c][1]), __builtin_bit_cast(bf16x8s, px), acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8s, f.w[c][0]), __builtin_bit_cast(bf16x8s, px), acc, 0, 0, 0);
+#if defined(PB_STEM_ABL) && (PB_STEM_ABL & 2)
+        out[c] = (f32x4){acc.x + f.bv[c].x, acc.y + f.bv[c].y, acc.z + f.bv[c].z, acc.w + f.bv[c].w};  // ablation: no SiLU behind the stem
+#else
         out[c] = (f32x4){silu_f(acc.x + f.bv[c].x), silu_f(acc.y + f.bv[c].y), silu_f(acc.z + f.bv[c].z), silu_f(acc.w + f.bv[c].w)};
+#endif
     }
 }
 
@@ -299,13 +303,41 @@ __global__ __launch_bounds__(256) void k_stem_dw(const uint8_t *__restrict__ img
     // input rows 2 (y0 - 1) - 1 .. 2 y1 + 1 -> staged rows 0 .. ; rows outside the image are zero bytes
     const int iy0 = 2 * (y0 - 1) - 1;
     const int n_in = 2 * (y1 - y0 + 2) + 1;
-    const int row_dwords = W * 3 / 4;
-    for (int i = tid; i < n_in * (row_dwords + 1); i += 256) {
-        const int r = i / (row_dwords + 1), dq = i - r * (row_dwords + 1);  // dq = 0: the pad dword
-        const int iy = iy0 + r;
-        uint32_t u = 0;
-        if (dq > 0 && iy >= 0 && iy < H) u = *reinterpret_cast<const uint32_t *>(img + ((size_t)b * H + iy) * W * 3 + 4 * (dq - 1));
-        *reinterpret_cast<uint32_t *>(s_in + (size_t)r * RSB + 4 * dq) = u;
+    {
+        // The band's input rows are ONE contiguous block of the image (rows iy0 .. iy0 + n_in - 1, W * 3 bytes each; W * 3 is a multiple
+        // of 96, so rows start 16-byte aligned): 16-byte pieces, ALL of a thread's loads requested before its first LDS store.  (Rounds
+        // 1-4 copied a dword per loop turn with a runtime division in the index, and hipcc waited for each turn's load before the next
+        // turn's: 14 dependent round trips of ~1.5 us per workgroup -- with everything else of the kernel removed it still took 57 of
+        // its 108 us, profiles/r05_stem.txt.)  A piece lands in its staged row behind the 4 pad bytes (the pad dword itself is zeroed
+        // by the thread that stores the row's first piece); rows outside the image are zero.
+        typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+        const int row_pieces = W * 3 / 16;            // 16-byte pieces per row
+        const int n_pieces = n_in * row_pieces;
+        constexpr int MAXP = 8;                       // pieces per thread and trip (8 x 256 x 16 B = 32 KB per trip: a band of 37 rows of 384 B in one)
+        const uint8_t *src0 = img + ((size_t)b * H) * W * 3;
+        for (int base = 0; base < n_pieces; base += MAXP * 256) {
+            u32x4v v[MAXP];
+            int rr[MAXP], cc[MAXP];
+#pragma unroll
+            for (int j = 0; j < MAXP; ++j) {
+                const int i = base + j * 256 + tid;
+                const int r = i / row_pieces, c = i - r * row_pieces;
+                rr[j] = r;
+                cc[j] = c;
+                const int iy = iy0 + r;
+                v[j] = (u32x4v){0u, 0u, 0u, 0u};
+                if (i < n_pieces && iy >= 0 && iy < H) v[j] = *reinterpret_cast<const u32x4v *>(src0 + ((size_t)iy * row_pieces + c) * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < MAXP; ++j) {
+                const int i = base + j * 256 + tid;
+                if (i < n_pieces) {
+                    uint32_t *d = reinterpret_cast<uint32_t *>(s_in + (size_t)rr[j] * RSB + 4 + 16 * cc[j]);  // 4-byte aligned: RSB = 4 (mod 16)
+                    d[0] = v[j].x; d[1] = v[j].y; d[2] = v[j].z; d[3] = v[j].w;
+                    if (cc[j] == 0) d[-1] = 0u;  // the row's pad dword (bytes 1..3 = pixel -1)
+                }
+            }
+        }
     }
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: what it indexes stays in SGPRs
     const int li = lane & 15, kq = lane >> 4;
@@ -330,7 +362,11 @@ __global__ __launch_bounds__(256) void k_stem_dw(const uint8_t *__restrict__ img
             float *ring = s_ring + ((row + RING) % RING) * RP;
             for (int tx = wave; tx < tiles; tx += 4) {
                 f32x4 r[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#if defined(PB_STEM_ABL) && (PB_STEM_ABL & 32)
+                if (in_img) r[0].x = (float)rows0[96 * tx + lane];  // ablation: no stem tile (one byte read)
+#else
                 if (in_img) stem_tile(f, rows0 + 96 * tx, r);
+#endif
                 float *rp = ring + (tx * 16 + li + 1) * 36 + 4 * kq;
 #pragma unroll
                 for (int c = 0; c < 2; ++c) *reinterpret_cast<f32x4 *>(rp + 16 * c) = r[c];
@@ -346,18 +382,30 @@ __global__ __launch_bounds__(256) void k_stem_dw(const uint8_t *__restrict__ img
                         *r2 = s_ring + ((oy + 1 + RING) % RING) * RP + 4 * quad;
             for (int px = tid >> 3; px < Wo; px += 32) {
                 f32x4 acc = tb;
+#if defined(PB_STEM_ABL) && (PB_STEM_ABL & 4)
+                dw_tap(acc, *reinterpret_cast<const f32x4 *>(r1 + px * 36 + 36), tw[4]);  // ablation: one tap
+#else
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
                     const float *rrp = (ky == 0 ? r0 : (ky == 1 ? r1 : r2)) + px * 36;
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) dw_tap(acc, *reinterpret_cast<const f32x4 *>(rrp + kx * 36), tw[ky * 3 + kx]);
                 }
+#endif
+#if defined(PB_STEM_ABL) && (PB_STEM_ABL & 8)
+                const f32x4 r = acc;  // ablation: no SiLU behind the filter
+#else
                 const f32x4 r = {silu_f(acc.x), silu_f(acc.y), silu_f(acc.z), silu_f(acc.w)};
+#endif
 #if defined(PB_STEM_ABL) && (PB_STEM_ABL & 1)
                 if (r.x == 12345.678f)  // ablation: no output stores
 #endif
                 *reinterpret_cast<f32x4 *>(out + (((size_t)b * Ho + oy) * Wo + px) * 32 + 4 * quad) = r;
+#if defined(PB_STEM_ABL) && (PB_STEM_ABL & 16)
+                psum.x += __float_as_int(r.x) ^ __float_as_int(r.y) ^ __float_as_int(r.z) ^ __float_as_int(r.w);  // ablation: no fixed-point sums
+#else
                 se_acc(psum, r);
+#endif
             }
         }
         __syncthreads();  // the next phase overwrites ring slots the filter just read
