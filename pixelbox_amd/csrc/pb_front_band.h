@@ -266,6 +266,12 @@ __global__ __launch_bounds__(256, PB_BAND_WAVES) void k_front_band(
             const int jn = last ? 0 : j0 + PF;
             expand_group(iy_first, rel_first, j0, xq, next_first, jn, std::true_type{});
         }
+#ifndef PB_BAND_DIRECT_STORE
+        // the PREVIOUS step's outputs leave now, four lanes per pixel, behind this step's operand requests: nothing this wave waits
+        // for before the next step's expand phase was issued after them (the staging block is rewritten by the filter phase below,
+        // i.e. behind the barrier this wave reaches after these reads)
+        if (t > 0) flush_stage();
+#endif
         __syncthreads();
         // ---- filter phase
         {
@@ -345,12 +351,10 @@ __global__ __launch_bounds__(256, PB_BAND_WAVES) void k_front_band(
         sbase += RN;
         sbase = sbase >= RR ? sbase - RR : sbase;
         __syncthreads();
-        // the step's outputs leave now: four lanes per pixel, under the next step's expand phase (the staging block is rewritten by
-        // the next filter phase, i.e. behind the next step's first barrier, which this wave reaches after these reads)
-#ifndef PB_BAND_DIRECT_STORE
-        flush_stage();
-#endif
     }
+#ifndef PB_BAND_DIRECT_STORE
+    if (n_steps > 0) flush_stage();  // the last step's
+#endif
     // ---- SE partial of this (image, band, quad): exact integer sum over the 64 lanes
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) {
