@@ -4,31 +4,35 @@
 # scan launches and for the embed forward; MFMA busy and the SQ wave-cycle split for the embed forward), summarised on the
 # box.  Outputs: gpurun_out/<tag>/; the summaries are then copied to profiles/<tag>_*.
 # PMC passes profile SHORT commands (scan legs only / profiles/embed_probe.py): a counter pass over the whole bench, with
-# its thousands of dispatches (1M-image end-to-end leg, tuning loops), takes tens of minutes.
+# its thousands of dispatches (1M-image end-to-end leg, tuning loops), takes tens of minutes.  Every command runs under `timeout`
+# (a hung command would otherwise hold the box until gpurun's own limit).
 set -x
 TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/$TAG; mkdir -p $O
-cd $R && python -m pytest tests -q -m gpu > $O/gpu_tests_full.txt 2>&1; grep -E "passed|failed" $O/gpu_tests_full.txt > $O/gpu_tests.txt
+cd $R && timeout 1500 python -m pytest tests -q -m gpu > $O/gpu_tests_full.txt 2>&1; grep -E "passed|failed" $O/gpu_tests_full.txt > $O/gpu_tests.txt
 cd /tmp; export TMPDIR=/tmp
-python3 $R/bench.py > $O/bench.json 2> $O/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/full -o full -- python3 $R/bench.py > $O/bench_under_rocprof.json 2> $O/full.err
+timeout 900 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/full -o full -- python3 $R/bench.py > $O/bench_under_rocprof.json 2> $O/full.err
 # the headline legs alone (default steps): the LOOPQ filter instance's average in this stats file is the 10M-row launches only
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/head -o head -- python3 $R/bench.py --no-embed --e2e-images 0 --no-sweep --no-cpu-baseline > $O/bench_headline_under_rocprof.json 2> $O/head.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/head -o head -- python3 $R/bench.py --no-embed --e2e-images 0 --no-sweep --no-cpu-baseline > $O/bench_headline_under_rocprof.json 2> $O/head.err
 cp $(find $O/head -name "head_kernel_stats.csv") $O/headline_kernel_stats.csv; rm -rf $O/head
 SCAN="--no-embed --e2e-images 0 --no-sweep --no-cpu-baseline --steps 2 --warmup 1"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 $R/bench.py $SCAN > /dev/null 2> $O/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 $R/bench.py $SCAN > /dev/null 2> $O/pmc_write.err
+timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 $R/bench.py $SCAN > /dev/null 2> $O/pmc_fetch.err
+timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 $R/bench.py $SCAN > /dev/null 2> $O/pmc_write.err
 python3 $R/profiles/summarize_pmc.py $O/scan_pmc.json FETCH_SIZE=$(find $O/pmc_fetch -name f_counter_collection.csv) WRITE_SIZE=$(find $O/pmc_write -name w_counter_collection.csv) > $O/summarize_pmc.txt 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/epmc_fetch -o f -- python3 $R/profiles/embed_probe.py > /dev/null 2> $O/epmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/epmc_write -o w -- python3 $R/profiles/embed_probe.py > /dev/null 2> $O/epmc_write.err
+timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/epmc_fetch -o f -- python3 $R/profiles/embed_probe.py > /dev/null 2> $O/epmc_fetch.err
+timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/epmc_write -o w -- python3 $R/profiles/embed_probe.py > /dev/null 2> $O/epmc_write.err
 python3 $R/profiles/summarize_embed_pmc.py $O/embed_pmc.json FETCH_SIZE=$(find $O/epmc_fetch -name f_counter_collection.csv) WRITE_SIZE=$(find $O/epmc_write -name w_counter_collection.csv) > $O/summarize_embed_pmc.txt 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma -o m -- python3 $R/profiles/embed_probe.py > /dev/null 2> $O/pmc_mfma.err
+timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma -o m -- python3 $R/profiles/embed_probe.py > /dev/null 2> $O/pmc_mfma.err
 python3 $R/profiles/summarize_mfma.py $O/mfma_pmc.json $(find $O/pmc_mfma -name m_counter_collection.csv) > $O/summarize_mfma.txt 2>&1
 rm -rf $O/pmc_fetch $O/pmc_write $O/epmc_fetch $O/epmc_write $O/pmc_mfma
 cp $(find $O/full -name "full_kernel_stats.csv") $O/full_kernel_stats.csv; rm -rf $O/full
 cd $R
-python3 profiles/embed_error.py 64 > $O/embed_error.txt 2>&1
-python3 profiles/mlhash_latency.py > $O/mlhash_latency.txt 2>&1
-python3 profiles/single_call_probe.py > $O/single_call.txt 2>&1
-python3 profiles/exact_probe.py > $O/exact_probe.txt 2>&1
+timeout 300 python3 profiles/embed_error.py 64 > $O/embed_error.txt 2>&1
+timeout 300 python3 profiles/mlhash_latency.py > $O/mlhash_latency.txt 2>&1
+timeout 300 python3 profiles/single_call_probe.py > $O/single_call.txt 2>&1
+timeout 300 python3 profiles/exact_probe.py > $O/exact_probe.txt 2>&1
+timeout 200 bash profiles/embed_kernel_trace.sh gpurun_out/$TAG/layers512 > /dev/null 2>&1; cp $O/layers512/layers.txt $O/embed_layers.txt
+timeout 200 bash profiles/embed_batch_trace.sh 1 gpurun_out/$TAG/layers1 > /dev/null 2>&1; cp $O/layers1/layers_b1.txt $O/embed_layers_batch1.txt
+timeout 300 python3 profiles/embed_f64.py > $O/embed_f64.txt 2>&1
 du -sh $O; ls $O
