@@ -35,7 +35,9 @@ typedef enum pb_status {
     PB_ERR_NOMEM = -3,     /* host or device allocation failed */
     PB_ERR_CAPACITY = -4,  /* index is full (capacity_rows reached) */
     PB_ERR_FORMAT = -5,    /* malformed weight blob */
-    PB_ERR_INTERNAL = -6
+    PB_ERR_INTERNAL = -6,
+    PB_ERR_RANGE = -7      /* embed: an activation left the domain of the fixed-point squeeze-excite sums (|x| >= 128 after a depthwise
+                              SiLU); the call's outputs are not valid.  No such value occurs in a batch-normalised EfficientNet. */
 } pb_status;
 
 #define PB_MAX_K 256u /* reference: LIMIT 100 (engine.rs:314,381) */

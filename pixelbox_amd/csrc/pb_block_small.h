@@ -49,6 +49,7 @@ struct BlockW {
     const void *wp3;    // P3 project layers (pb_gemm_p3.h): the three bf16 planes in fragment order, [E / 32][NT16][3][64 lanes] x 16 B; else null
     const float *bp;    // [16 NT16] project bias
     int nt16;           // 16-column tiles of the project weights' padded width
+    const long long *range_slot;  // se_range_check: the word that holds the address of the embedder's range flag (buf_part - 1)
     unsigned long long *dbg;  // ABL 32 (stamped diagnostic build): [workgroup][wave][16] cycle sums per phase; else unused
 };
 
@@ -237,8 +238,10 @@ __global__ __launch_bounds__(512) void k_block_small(const float *__restrict__ x
         for (int it = tid; it < G * NQ; it += 512) {
             const int im = it / NQ, cq = it - im * NQ;
             ll4 t = {0, 0, 0, 0};
+            int qmax = 0;  // largest converted output seen (se_range_check)
 #pragma unroll 8
-            for (int p = 0; p < P; ++p) se_acc(t, *reinterpret_cast<const f32x4 *>(s_dwo + (im * P + p) * DP + 4 * cq));
+            for (int p = 0; p < P; ++p) se_acc(t, qmax, *reinterpret_cast<const f32x4 *>(s_dwo + (im * P + p) * DP + 4 * cq));
+            se_range_check(qmax, w.range_slot);
             const f32x4 m = {(float)((double)t.x * sc), (float)((double)t.y * sc), (float)((double)t.z * sc), (float)((double)t.w * sc)};
             *reinterpret_cast<f32x4 *>(s_m + im * E + 4 * cq) = m;
         }

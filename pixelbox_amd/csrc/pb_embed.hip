@@ -76,7 +76,8 @@ struct pb_embedder {
     uint8_t *d_img = nullptr;
     float *buf_x[2] = {nullptr, nullptr};
     float *buf_e = nullptr, *buf_dw = nullptr, *buf_gate = nullptr, *buf_pool = nullptr;
-    long long *buf_part = nullptr;  // SE pooling partial sums, 2^-24 fixed point
+    long long *buf_part = nullptr;  // SE pooling partial sums, 2^-24 fixed point; buf_part[-1] holds the address of *h_range (se_range_check)
+    unsigned *h_range = nullptr;    // pinned host word a kernel raises when an activation leaves the fixed-point domain (|x| >= 128)
     float *d_out_f32 = nullptr;
     uint8_t *d_out_u8 = nullptr;
     int n_cu = 256;
@@ -1055,6 +1056,7 @@ int launch_block_t(pb_embedder *e, const Block &bl, const float *x, int n, float
     w.we2 = bl.expand.wt4; w.be = bl.expand.bias; w.dwc = bl.dw_wc; w.bd = bl.dw_b;
     w.w1 = bl.se_w1; w.b1 = bl.se_b1; w.w2t = bl.se_w2t; w.b2 = bl.se_b2;
     w.wp2 = bl.project.wt4; w.wp3 = bl.project.wt3; w.bp = bl.project.bias; w.nt16 = bl.project.Npad / 16;
+    w.range_slot = e->buf_part - 1;
     hipLaunchKernelGGL(kern, dim3((n + G - 1) / G), dim3(512), GEO::LDS_BYTES, e->stream, x, w, out, n);
     PB_HIP(hipGetLastError());
     return PB_OK;
@@ -1272,6 +1274,7 @@ int forward_device(pb_embedder *e, const uint8_t *d_rgb, int n, uint8_t *d_u8, f
 
 void destroy(pb_embedder *e) {
     for (void *p : e->allocs) (void)hipFree(p);
+    if (e->h_range) (void)hipHostFree(e->h_range);
     for (auto &sl : e->st) {
         if (sl.h) (void)hipHostFree(sl.h);
         if (sl.h_desc) (void)hipHostFree(sl.h_desc);
@@ -1582,7 +1585,16 @@ int pb_embed_create(pb_embedder **out, int device, const void *weights_blob, siz
         if ((rc = dalloc(e, &e->buf_x[0], B * max_x)) || (rc = dalloc(e, &e->buf_x[1], B * max_x))) return rc;
         if ((rc = dalloc(e, &e->buf_e, B * max_e)) || (rc = dalloc(e, &e->buf_dw, B * max_dw))) return rc;
         e->part_floats_per_image = max_part;
-        if ((rc = dalloc(e, &e->buf_part, B * max_part)) || (rc = dalloc(e, &e->buf_gate, B * std::max<size_t>(1152, e->D)))) return rc;
+        if ((rc = dalloc(e, &e->buf_part, B * max_part + 2)) || (rc = dalloc(e, &e->buf_gate, B * std::max<size_t>(1152, e->D)))) return rc;
+        {  // 16-byte header in front of the partial sums: the address of the range word, for the kernels that write them
+            PB_HIP(hipHostMalloc(reinterpret_cast<void **>(&e->h_range), sizeof(unsigned), hipHostMallocMapped));
+            *e->h_range = 0u;
+            void *d_flag = nullptr;
+            PB_HIP(hipHostGetDevicePointer(&d_flag, e->h_range, 0));
+            const long long hdr[2] = {0, (long long)reinterpret_cast<uintptr_t>(d_flag)};
+            PB_HIP(hipMemcpy(e->buf_part, hdr, sizeof(hdr), hipMemcpyHostToDevice));
+            e->buf_part += 2;
+        }
         if ((rc = dalloc(e, &e->buf_pool, B * 1280))) return rc;
         if ((rc = dalloc(e, &e->d_se_cnt, B))) return rc;
         PB_HIP(hipMemset(e->d_se_cnt, 0, B * sizeof(unsigned)));
@@ -1624,6 +1636,18 @@ int pb_embed_info(const pb_embedder *e, uint32_t *h, uint32_t *w, uint32_t *d, u
     return PB_OK;
 }
 
+// After a stream wait: did a kernel of the forward passes behind it see a depthwise output outside the domain of the fixed-point
+// squeeze-excite sums (se_range_check, pb_embed_common.h)?  Such a batch's hashes are wrong; the call fails instead of returning them.
+static int range_status(pb_embedder *e) {
+    if (e->h_range && __atomic_load_n(e->h_range, __ATOMIC_ACQUIRE)) {
+        __atomic_store_n(e->h_range, 0u, __ATOMIC_RELEASE);
+        PB_CHECK(false, PB_ERR_RANGE,
+                 "embed: a depthwise activation of 128 or more left the domain of the 2^-24 fixed-point squeeze-excite sums; the batch's outputs are not valid "
+                 "(with PB_OPT_EMBED_ASYNC the batch may be an earlier one on this embedder)");
+    }
+    return PB_OK;
+}
+
 int pb_embed_batch_device(pb_embedder *e, const uint8_t *d_rgb, uint32_t n, uint8_t *d_out_u8, float *d_out_f32) {
     PB_CHECK(e, PB_ERR_INVALID, "pb_embed_batch_device: null embedder");
     PB_CHECK(n <= e->max_batch, PB_ERR_INVALID, "pb_embed_batch_device: n = %u > max_batch %u", n, e->max_batch);
@@ -1637,8 +1661,11 @@ int pb_embed_batch_device(pb_embedder *e, const uint8_t *d_rgb, uint32_t n, uint
     // owns a stream of its own).  PB_OPT_EMBED_ASYNC = 1 returns with the forward pass queued on the embedder's
     // stream instead: the consumer must then run on that same stream (PB_OPT_EMBED_STREAM + PB_OPT_STREAM) or
     // wait for it.
-    if (!e->opt_async) PB_HIP(hipStreamSynchronize(e->stream));
-    return PB_OK;
+    if (!e->opt_async) {
+        PB_HIP(hipStreamSynchronize(e->stream));
+        return range_status(e);
+    }
+    return range_status(e);  // of the batches queued before this one (their waits are the caller's)
 }
 
 // host copy split over a few threads (one thread moves ~10 GB/s: 2.5 ms for a chunk of 512 images, longer than its forward)
@@ -1688,7 +1715,7 @@ int pb_embed_batch(pb_embedder *e, const uint8_t *rgb, uint32_t n, uint8_t *out_
             PB_HIP(hipMemcpyAsync(out_u8, e->d_out_u8, (size_t)n * e->D, hipMemcpyDeviceToHost, e->stream));
             if (out_f32) PB_HIP(hipMemcpyAsync(out_f32, e->d_out_f32, (size_t)n * e->D * sizeof(float), hipMemcpyDeviceToHost, e->stream));
             PB_HIP(hipStreamSynchronize(e->stream));
-            return PB_OK;
+            return range_status(e);
         };
         const int rc = body();
         if (rc) (void)hipStreamSynchronize(e->stream);  // a copy may still be reading `rgb` / writing the outputs: not after the call has returned
@@ -1749,6 +1776,7 @@ int pb_embed_batch(pb_embedder *e, const uint8_t *rgb, uint32_t n, uint8_t *out_
     for (uint32_t i0 = 0; i0 < n && !rc; i0 += chunk, slot ^= 1) rc = run_chunk(slot, i0, std::min(chunk, n - i0));
     if (!rc) rc = hand_over(slot);
     if (!rc) rc = hand_over(slot ^ 1);
+    if (!rc) rc = range_status(e);
     if (rc) {  // drain: nothing of this call may still be in flight when it returns
         (void)hipStreamSynchronize(e->h2d_stream);
         (void)hipStreamSynchronize(e->stream);
@@ -1947,7 +1975,7 @@ int pb_embed_stage_commit(pb_embedder *e, uint8_t *out_u8, const uint8_t **d_out
             if (rcf) return rcf;
             if (out_u8) PB_HIP(hipMemcpyAsync(out_u8, e->d_out_u8, (size_t)m * e->D, hipMemcpyDeviceToHost, e->stream));
             PB_HIP(hipStreamSynchronize(e->stream));
-            return PB_OK;
+            return range_status(e);
         };
         rc = body();
         if (rc) drain_streams(e);
@@ -1976,7 +2004,7 @@ int pb_embed_batch_images_device(pb_embedder *e, const uint8_t *const *rgb, cons
         if ((rc = forward_device(e, e->d_img, (int)n, e->d_out_u8, e->d_out_f32))) return rc;
         if (out_u8) PB_HIP(hipMemcpyAsync(out_u8, e->d_out_u8, (size_t)n * e->D, hipMemcpyDeviceToHost, e->stream));
         PB_HIP(hipStreamSynchronize(e->stream));
-        return PB_OK;
+        return range_status(e);
     };
     const int rc = body();
     if (rc) drain_streams(e);

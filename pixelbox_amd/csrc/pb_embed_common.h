@@ -31,9 +31,11 @@ __device__ __forceinline__ float dpp_shr1(float v) {
 // (round 5; rounds 1-4: rint() through v_rndne + v_cvt + a magnitude test per quad with an i64 conversion behind it --
 // 7.5 vector instructions per element where the depthwise phases are issue-bound, now 4).  The 2^-24 grid is this
 // library's own definition (the oracle sums f32), so which way a tie rounds is immaterial; what matters is that every
-// form goes through this one function.  Domain: |o| < 128 (2^31 / 2^24).  A depthwise output beyond that -- none in any
-// model seen: these are post-SiLU activations of a batch-normalised network, O(1-10) -- enters the pooled sum as whatever
-// the instruction returns for an out-of-range input, the same in every form and batch size (deterministic, no trap).
+// form goes through this one function.  Domain: |o| < 128 (2^31 / 2^24).  Beyond it the instruction saturates, the pooled
+// mean would be wrong and nothing downstream could tell, so se_acc also keeps the largest converted value it has seen (v_max3_i32:
+// half an instruction per element) and the accumulating kernel ends with se_range_check: a saturated conversion raises a
+// word in pinned host memory that the entry point reads after its stream wait -> PB_ERR_RANGE, never a silent answer.
+// (No model seen comes near: these are post-SiLU activations of a batch-normalised network, O(1-10).)
 struct ll4 {
     long long x, y, z, w;
 };
@@ -42,11 +44,23 @@ __device__ __forceinline__ int se_fix(float o) {
     asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(q) : "v"(o * 16777216.0f));
     return q;
 }
-__device__ __forceinline__ void se_acc(ll4 &s, const f32x4 &o) {
-    s.x += (long long)se_fix(o.x);
-    s.y += (long long)se_fix(o.y);
-    s.z += (long long)se_fix(o.z);
-    s.w += (long long)se_fix(o.w);
+__device__ __forceinline__ void se_acc(ll4 &s, int &qmax, const f32x4 &o) {
+    const int qx = se_fix(o.x), qy = se_fix(o.y), qz = se_fix(o.z), qw = se_fix(o.w);
+    s.x += (long long)qx;
+    s.y += (long long)qy;
+    s.z += (long long)qz;
+    s.w += (long long)qw;
+#ifndef PB_NO_SE_RANGE  // (comparison build: what the tracking costs -- nothing measurable, two v_max3_i32 per quad)
+    qmax = max(max(qmax, qx), qy);
+    qmax = max(max(qmax, qz), qw);
+#endif
+}
+// `flag_slot` holds the DEVICE-VISIBLE ADDRESS of the embedder's range word (pinned host memory) as an integer: for the kernels
+// that write pooled partial sums it is part[-1] (the buffer has a 16-byte header, pb_embed_create), for k_block_small a field.
+// A conversion that saturated is INT_MAX, which no in-range value reaches (the largest f32 below 2^31 is 2^31 - 128); the inputs
+// are post-SiLU (>= -0.28), so the negative end cannot be reached; +inf saturates too, a NaN converts to 0 and is not seen here.
+__device__ __forceinline__ void se_range_check(int qmax, const long long *flag_slot) {
+    if (qmax == 0x7fffffff) *reinterpret_cast<unsigned *>(static_cast<uintptr_t>(*flag_slot)) = 1u;
 }
 __device__ __forceinline__ void se_add(ll4 &s, const ll4 &o) {
     s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;

@@ -349,6 +349,7 @@ __global__ __launch_bounds__(256) void k_stem_dw(const uint8_t *__restrict__ img
     for (int t = 0; t < 9; ++t) tw[t] = *reinterpret_cast<const f32x4 *>(dw_w + t * 32 + quad * 4);
     const f32x4 tb = *reinterpret_cast<const f32x4 *>(dw_b + quad * 4);
     ll4 psum = {0, 0, 0, 0};
+    int qmax = 0;  // largest converted output seen (se_range_check)
     const int tiles = Wo / 16;
     __syncthreads();
     for (int sy = y0 - 1; sy <= y1; sy += RPP) {
@@ -404,12 +405,13 @@ __global__ __launch_bounds__(256) void k_stem_dw(const uint8_t *__restrict__ img
 #if defined(PB_STEM_ABL) && (PB_STEM_ABL & 16)
                 psum.x += __float_as_int(r.x) ^ __float_as_int(r.y) ^ __float_as_int(r.z) ^ __float_as_int(r.w);  // ablation: no fixed-point sums
 #else
-                se_acc(psum, r);
+                se_acc(psum, qmax, r);
 #endif
             }
         }
         __syncthreads();  // the next phase overwrites ring slots the filter just read
     }
+    se_range_check(qmax, part - 1);
     ll4 *s_red = reinterpret_cast<ll4 *>(s_sd);  // [256]: over the ring (free by now: the loop ends with a barrier)
     s_red[tid] = psum;
     __syncthreads();
@@ -1059,6 +1061,7 @@ __global__ __launch_bounds__(256) void k_dwconv(const float *__restrict__ in, in
     const int strips_x = (Wo + TX - 1) / TX;
     const int n_strips = Ho * strips_x;
     ll4 psum = {0, 0, 0, 0};
+    int qmax = 0;  // largest converted output seen (se_range_check)
     const int st_begin = tile * strips_per_tile;
     const int st_end = (st_begin + strips_per_tile) < n_strips ? (st_begin + strips_per_tile) : n_strips;
     for (int st = st_begin + slot; st < st_end; st += slots) {
@@ -1094,10 +1097,11 @@ __global__ __launch_bounds__(256) void k_dwconv(const float *__restrict__ in, in
             if (x0 + t < Wo) {
                 f32x4 o = {silu_f(acc[t].x), silu_f(acc[t].y), silu_f(acc[t].z), silu_f(acc[t].w)};
                 *reinterpret_cast<f32x4 *>(ob + ((size_t)y * Wo + x0 + t) * C) = o;
-                se_acc(psum, o);
+                se_acc(psum, qmax, o);
             }
         }
     }
+    se_range_check(qmax, part - 1);
     s_red[threadIdx.x] = psum;
     __syncthreads();
     if (slot == 0) {
@@ -1142,6 +1146,7 @@ __global__ __launch_bounds__(256) void k_dwconv_roll(const float *__restrict__ i
     const int y_begin = band * rows_per_band;
     const int y_end = (y_begin + rows_per_band) < Ho ? (y_begin + rows_per_band) : Ho;
     ll4 psum = {0, 0, 0, 0};
+    int qmax = 0;  // largest converted output seen (se_range_check)
     f32x4 win[KS][NX];
     auto load_row = [&](int iy, f32x4 (&dst)[NX]) {
         const bool rv = iy >= 0 && iy < H;
@@ -1177,7 +1182,7 @@ __global__ __launch_bounds__(256) void k_dwconv_roll(const float *__restrict__ i
                 if (x0 + t < Wo) {
                     f32x4 o = {silu_f(acc[t].x), silu_f(acc[t].y), silu_f(acc[t].z), silu_f(acc[t].w)};
                     *reinterpret_cast<f32x4 *>(ob + ((size_t)y * Wo + x0 + t) * C) = o;
-                    se_acc(psum, o);
+                    se_acc(psum, qmax, o);
                 }
             }
             if (y + 1 < y_end) {  // slide the window down by S rows
@@ -1190,6 +1195,7 @@ __global__ __launch_bounds__(256) void k_dwconv_roll(const float *__restrict__ i
             }
         }
     }
+    se_range_check(qmax, part - 1);
     s_red[threadIdx.x] = psum;
     __syncthreads();
     if (sx == 0) {
@@ -1234,6 +1240,7 @@ __global__ __launch_bounds__(256) void k_dwconv_lds(const float *__restrict__ in
     const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + c0);
     float *ob = out + (size_t)b * Ho * Wo * C + c0;
     ll4 psum = {0, 0, 0, 0};
+    int qmax = 0;  // largest converted output seen (se_range_check)
     for (int o = slot; o < Ho * Wo; o += slots) {
         const int oy = o / Wo, ox = o % Wo;
         f32x4 acc = bv;
@@ -1248,8 +1255,9 @@ __global__ __launch_bounds__(256) void k_dwconv_lds(const float *__restrict__ in
             }
         const f32x4 r = {silu_f(acc.x), silu_f(acc.y), silu_f(acc.z), silu_f(acc.w)};
         *reinterpret_cast<f32x4 *>(ob + (size_t)o * C) = r;
-        se_acc(psum, r);
+        se_acc(psum, qmax, r);
     }
+    se_range_check(qmax, part - 1);
     s_red[tid] = psum;
     __syncthreads();
     if (slot == 0) {
@@ -1408,6 +1416,7 @@ __global__ __launch_bounds__(256, NC == 1 ? 4 : 2) void k_front_roll(
     ll4 psum[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) psum[c] = (ll4){0, 0, 0, 0};
+    int qmax = 0;  // largest converted output seen (se_range_check)
     // prime: rows oy_b*S - PAD .. + (KS - S - 1) go to ring[S ..]; the loop shifts them down before use
     const int iy_first = oy_b * S - PAD;
 #pragma unroll
@@ -1488,10 +1497,11 @@ __global__ __launch_bounds__(256, NC == 1 ? 4 : 2) void k_front_roll(
             for (int c = 0; c < NC; ++c) {
                 const f32x4 r = {silu_f(o[c].x), silu_f(o[c].y), silu_f(o[c].z), silu_f(o[c].w)};
                 *reinterpret_cast<f32x4 *>(op + 16 * c) = r;
-                se_acc(psum[c], r);
+                se_acc(psum[c], qmax, r);
             }
         }
     }
+    se_range_check(qmax, part - 1);
     // SE partial of this (strip, band): sum over the 16 columns of the row (exact integer adds)
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -1543,6 +1553,7 @@ __global__ __launch_bounds__(256) void k_mbconv_small(
     float *s_dw = s_e + G * Hp * Wp * NT;       // [KS * KS][NT]
     float *s_b = s_dw + KS * KS * NT;           // [NT] expand bias, [NT] depthwise bias
     const int tid = threadIdx.x;
+    int qmax = 0;  // largest converted output seen (se_range_check)
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: what it indexes stays in SGPRs
     const int li = lane & 15, kq = lane >> 4;
     const int e0 = blockIdx.z * NT;
@@ -1805,7 +1816,7 @@ __global__ __launch_bounds__(256) void k_mbconv_small(
                 if (r4.x == 12345.678f)  // ablation: no output stores
 #endif
                 *reinterpret_cast<f32x4 *>(op + (size_t)j * E) = r4;
-                se_acc(q4, r4);
+                se_acc(q4, qmax, r4);
             }
             atomicAdd(&s_se[sp][g2][4 * cq + 0], (unsigned long long)q4.x);
             atomicAdd(&s_se[sp][g2][4 * cq + 1], (unsigned long long)q4.y);
@@ -1828,6 +1839,7 @@ __global__ __launch_bounds__(256) void k_mbconv_small(
         st_[7] += 1;
 #endif
     }
+    se_range_check(qmax, part - 1);
 #ifdef PB_SM_STAMP_E
     if (lane == 0 && E == PB_SM_STAMP_E && KS == PB_SM_STAMP_KS && S == 1) {
         const size_t w_ = ((size_t)(blockIdx.z * gridDim.x + blockIdx.x) * 4 + wave) & 65535;

@@ -224,6 +224,7 @@ __global__ __launch_bounds__(256, PB_BAND_WAVES) void k_front_band(
     };
     const unsigned rd_col = (unsigned)(q * PLS + ox);  // + compile-time slot offset of kx
     ll4 psum = {0, 0, 0, 0};
+    int qmax = 0;  // largest converted output seen (se_range_check)
 
     // ---- priming rows (ring positions 0 .. R0-1) of the band
     if constexpr (G::NP0 > 0) {
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(256, PB_BAND_WAVES) void k_front_band(
 #if defined(PB_BAND_ABL) && (PB_BAND_ABL & 4)
             psum.x += __float_as_int(r4.x) ^ __float_as_int(r4.y) ^ __float_as_int(r4.z) ^ __float_as_int(r4.w);  // ablation: no fixed-point SE sums
 #else
-            se_acc(psum, r4);
+            se_acc(psum, qmax, r4);
 #endif
         }
         sbase += RN;
@@ -355,6 +356,7 @@ __global__ __launch_bounds__(256, PB_BAND_WAVES) void k_front_band(
 #ifndef PB_BAND_DIRECT_STORE
     if (n_steps > 0) flush_stage();  // the last step's
 #endif
+    se_range_check(qmax, part - 1);
     // ---- SE partial of this (image, band, quad): exact integer sum over the 64 lanes
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) {

@@ -34,5 +34,5 @@ timeout 300 python3 profiles/single_call_probe.py > $O/single_call.txt 2>&1
 timeout 300 python3 profiles/exact_probe.py > $O/exact_probe.txt 2>&1
 timeout 200 bash profiles/embed_kernel_trace.sh gpurun_out/$TAG/layers512 > /dev/null 2>&1; cp $O/layers512/layers.txt $O/embed_layers.txt
 timeout 200 bash profiles/embed_batch_trace.sh 1 gpurun_out/$TAG/layers1 > /dev/null 2>&1; cp $O/layers1/layers_b1.txt $O/embed_layers_batch1.txt
-timeout 300 python3 profiles/embed_f64.py > $O/embed_f64.txt 2>&1
+timeout 300 python3 profiles/embed_f64.py 512 bench > $O/embed_f64.txt 2>&1; timeout 300 python3 profiles/embed_f64.py 512 parity >> $O/embed_f64.txt 2>&1
 du -sh $O; ls $O

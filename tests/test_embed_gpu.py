@@ -241,6 +241,36 @@ def test_bad_blobs_fail_loudly():
         emb.embed_device(1, 3, 1)  # n > max_batch
 
 
+@pytest.mark.parametrize("tensor", ["stem.w", "b2.dw.b", "b7.dw.b", "b13.dw.b"])
+def test_activation_outside_the_fixed_point_domain_fails_loudly(tensor):
+    # the squeeze-excite pooled sums are 2^-24 fixed point with 32-bit addends: |depthwise output| < 128 (pb_embed_common.h).  A
+    # model that leaves the domain must get PB_ERR_RANGE from the call -- never a hash computed from a saturated sum -- whichever
+    # kernel the layer runs in (stem + block 0; band front; small-map front; whole-block kernel), and the embedder stays usable.
+    blob = W.synthetic_blob(synth.SEED_WEIGHTS, 128, 128, 256)
+    h, w, d, tensors = W.parse_blob(blob)
+    raw = bytearray(blob)
+    pos = W.HEADER_BYTES
+    for name, shape, _ in W.tensor_specs(d):
+        n = int(np.prod(shape))
+        if name == tensor:
+            t = np.frombuffer(bytes(raw[pos : pos + 4 * n]), dtype="<f4").copy()
+            t = t * np.float32(2000.0) if name == "stem.w" else t + np.float32(500.0)  # SiLU(x + 500) ~ x + 500
+            raw[pos : pos + 4 * n] = t.astype("<f4").tobytes()
+        pos += 4 * n
+    imgs = synth.synthetic_images(synth.SEED_IMAGES, 0, 5, 128, 128)
+    for n_img in (1, 5):
+        bad = capi.Embedder(bytes(raw), max_batch=8)
+        with pytest.raises(capi.PixelboxError) as ei:
+            bad.embed(imgs[:n_img])
+        assert ei.value.code == capi.PB_ERR_RANGE, (tensor, n_img, str(ei.value))
+    good = capi.Embedder(blob, max_batch=8)
+    u8, _ = good.embed(imgs)
+    with pytest.raises(capi.PixelboxError):
+        bad.embed(imgs)
+    u8b, _ = good.embed(imgs)  # another embedder's failure leaves this one alone
+    assert np.array_equal(u8, u8b)
+
+
 def test_embed_then_search_end_to_end():
     # config 1 in miniature: embed synthetic images, store the hashes, query with image #0's hash -> id(#0) first
     blob = W.synthetic_blob(synth.SEED_WEIGHTS, 128, 128, 256)
