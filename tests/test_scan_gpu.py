@@ -793,8 +793,25 @@ def test_full_size_10m_properties():
     order = np.lexsort((cand_ids, cand_d))[:100]
     assert np.array_equal(ids_a, cand_ids[order])
     assert np.array_equal(d_a.view(np.uint32), cand_d[order].view(np.uint32))
-    # (b) plant duplicates beyond the synthetic ids
+    # the metric's size uses the launch form whose partition is timing-dependent (chunked stealing, lead / shift geometry chosen
+    # for this size): 150 one-query calls, every one certified by the filter pass (rows_seen: every row exactly once) and equal
+    # to the oracle's answer above, plus three other queries 50 times each against their own first answer (= the exhaustive pass)
     ix.set_option(capi.PB_OPT_SEARCH_PATH, AUTO)
+    before = ix.stats()
+    for rep in range(150):
+        ids_r, d_r = ix.search_one(q)
+        assert np.array_equal(ids_r, ids_a) and np.array_equal(d_r.view(np.uint32), d_a.view(np.uint32)), rep
+    after = ix.stats()
+    assert after.fast_path - before.fast_path == 150 and after.fallback == before.fallback
+    for s in (1, 2, 3):
+        q2 = synth.fill_synthetic(synth.SEED_QUERY, s * d, d)
+        ix.set_option(capi.PB_OPT_SEARCH_PATH, EXACT)
+        ids_e, d_e = ix.search_one(q2)
+        ix.set_option(capi.PB_OPT_SEARCH_PATH, AUTO)
+        for rep in range(50):
+            ids_r, d_r = ix.search_one(q2)
+            assert np.array_equal(ids_r, ids_e) and np.array_equal(d_r.view(np.uint32), d_e.view(np.uint32)), (s, rep)
+    # (b) plant duplicates beyond the synthetic ids
     ix.append([n + 5, n + 6, n + 7], np.tile(q, (3, 1)))
     ids_c, d_c = ix.search_one(q)
     assert ids_c[:3].tolist() == [n + 5, n + 6, n + 7]
