@@ -46,7 +46,7 @@ def parse(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-clustered", action="store_true", help="skip the embedding-like table sub-leg of the sweep")
     ap.add_argument("--settle-min-seconds", type=float, default=2.5, help="one GPU: the settling loop runs at least this long")
-    ap.add_argument("--settle-seconds", type=float, default=8.0,
+    ap.add_argument("--settle-seconds", type=float, default=15.0,
                     help="one GPU: at most this long repeating one untimed step until its time has settled (0: off); see `settle` in the line")
     ap.add_argument("--rows", type=int, default=10_000_000, help="total index rows (BASELINE: 10M)")
     ap.add_argument("--dim", type=int, default=256)
@@ -332,6 +332,7 @@ def main():
         ts = []
         t_s0 = time.perf_counter()
         best_at = 0
+        table_bytes = float(len(sh.index)) * d
         while True:
             t1 = time.perf_counter()
             sh.search(qbytes[0], k, args.max_dist)
@@ -342,10 +343,18 @@ def main():
             # at least --settle-min-seconds: the scrubbing of what a test suite released is over by then)
             if (time.perf_counter() - t_s0 >= args.settle_min_seconds and len(ts) >= 12 and len(ts) - 1 - best_at >= 6 and
                     float(np.median(ts[-6:])) <= 1.003 * min(ts)):
-                break
+                # ... and a plateau can outlast that when the release was large (another tenant's job on a shared pool: the run of
+                # gpurun_out/bench_timed.json settled at 23.63 ms = 0.866 after 3.9 s and the same process streamed the same size at
+                # 0.890 twenty seconds later).  An HBM-sized table (>= 1 GB) whose steady rate is under 0.885 of the peak -- every idle
+                # box of five rounds measured 0.895-0.904 -- is therefore watched on, up to --settle-seconds; `below_idle_rate_at_exit`
+                # says whether the wait ran out.  The timed region is what it always was: K steps after W warm-up steps.
+                idle = table_bytes < 1e9 or table_bytes * B / float(np.median(ts[-6:])) >= 0.885 * 8e12
+                if idle:
+                    break
             if time.perf_counter() - t_s0 > args.settle_seconds:
                 break
         settle = {"steps": len(ts), "seconds": round(time.perf_counter() - t_s0, 3), "ms_first": round(ts[0] * 1e3, 3),
+                  "below_idle_rate_at_exit": bool(table_bytes >= 1e9 and table_bytes * B / float(np.median(ts[-6:])) < 0.885 * 8e12),
                   "ms_slowest_after_first": round(max(ts[1:]) * 1e3, 3), "ms_fastest": round(min(ts) * 1e3, 3),
                   "ms_median_last6": round(float(np.median(ts[-6:])) * 1e3, 3),
                   "note": "untimed repeats of one step before the warm-up steps, until the step time has settled (driver scrubbing of "
