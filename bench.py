@@ -1003,7 +1003,7 @@ def bench_ingest_staged(device, forward_ips, h2d, blob):
                                f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         env = dict(os.environ, HIP_VISIBLE_DEVICES=str(device)) if device else dict(os.environ)
         out = {"threads": "8 embedders x (1 embed thread + 1 or 2 decoder threads)", "batch": 512}
-        for (h, w, n, dec) in ((256, 256, 131072, 1), (480, 640, 16384, 2)):
+        for (h, w, n, dec) in ((256, 256, 131072, 1), (480, 640, 65536, 2)):
             per = h * w * 3
             bound = min(h2d / per, forward_ips)
             entry = {"images": n, "bytes_per_image": per, "pcie_bound_images_per_s": round(h2d / per, 1),
