@@ -46,7 +46,7 @@ def parse(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-clustered", action="store_true", help="skip the embedding-like table sub-leg of the sweep")
     ap.add_argument("--settle-min-seconds", type=float, default=2.5, help="one GPU: the settling loop runs at least this long")
-    ap.add_argument("--settle-seconds", type=float, default=15.0,
+    ap.add_argument("--settle-seconds", type=float, default=40.0,
                     help="one GPU: at most this long repeating one untimed step until its time has settled (0: off); see `settle` in the line")
     ap.add_argument("--rows", type=int, default=10_000_000, help="total index rows (BASELINE: 10M)")
     ap.add_argument("--dim", type=int, default=256)

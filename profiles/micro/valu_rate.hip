@@ -7,7 +7,7 @@
 #include <cstdio>
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int ITERS = 2048, REP = 4;
-enum Op { MUL, ADD_CHAIN, PK_MUL, PK_MUL_BCAST, PK_FMA_SGPR, PK_ADD_CHAIN, CVT_UB, PK_MUL_ADD_PAIR, FMA };
+enum Op { MUL, ADD_CHAIN, PK_MUL, PK_MUL_BCAST, PK_FMA_SGPR, PK_ADD_CHAIN, CVT_UB, PK_MUL_ADD_PAIR, FMA, EXP, RCP, SILU, CVT_RPI, EXP_MUL };
 template <int OP, int N_ACC>
 __global__ __launch_bounds__(256) void k(float *out, float a, float b, unsigned w) {
     f32x2 acc[N_ACC];
@@ -25,6 +25,21 @@ __global__ __launch_bounds__(256) void k(float *out, float a, float b, unsigned 
                 if constexpr (OP == PK_MUL_BCAST) asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel_hi:[1,0]" : "+v"(acc[i]) : "v"(m));
                 if constexpr (OP == PK_FMA_SGPR) asm volatile("v_pk_fma_f32 %0, %0, %1, %0 op_sel_hi:[1,0,1]" : "+v"(acc[i]) : "s"(m));
                 if constexpr (OP == CVT_UB) asm volatile("v_cvt_f32_ubyte1 %0, %1" : "=v"(acc[i].x) : "v"(ww));
+                if constexpr (OP == EXP) asm volatile("v_exp_f32 %0, %0" : "+v"(acc[i].x));
+                if constexpr (OP == RCP) asm volatile("v_rcp_f32 %0, %0" : "+v"(acc[i].x));
+                if constexpr (OP == EXP_MUL) {  // does a full-rate instruction of the same wave hide under a transcendental?
+                    asm volatile("v_exp_f32 %0, %0" : "+v"(acc[i].x));
+                    asm volatile("v_mul_f32 %0, %0, %1" : "+v"(acc[i].y) : "v"(m.x));
+                }
+                if constexpr (OP == CVT_RPI) asm volatile("v_cvt_rpi_i32_f32 %0, %1" : "=v"(acc[i].y) : "v"(acc[i].x));
+                if constexpr (OP == SILU) {  // silu_f of pb_embed_common.h: x * rcp(1 + exp2(x * -log2 e)), five instructions
+                    float t, u;
+                    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(t) : "v"(acc[i].x), "v"(m.y));
+                    asm volatile("v_exp_f32 %0, %0" : "+v"(t));
+                    asm volatile("v_add_f32 %0, 1.0, %1" : "=v"(u) : "v"(t));
+                    asm volatile("v_rcp_f32 %0, %0" : "+v"(u));
+                    asm volatile("v_mul_f32 %0, %0, %1" : "+v"(acc[i].x) : "v"(u));
+                }
                 if constexpr (OP == PK_MUL_ADD_PAIR) {
                     f32x2 p;
                     asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(p) : "v"(m), "v"(acc[(i + 1) % N_ACC]));
@@ -64,6 +79,11 @@ int main() {
     row<PK_FMA_SGPR, 8>("v_pk_fma_f32 with an SGPR pair, 8 independent", d, 1);
     row<PK_ADD_CHAIN, 1>("v_pk_mul_f32, dependent chain", d, 1);
     row<CVT_UB, 8>("v_cvt_f32_ubyte1, 8 independent", d, 1);
+    row<EXP, 8>("v_exp_f32, 8 independent", d, 1);
+    row<RCP, 8>("v_rcp_f32, 8 independent", d, 1);
+    row<CVT_RPI, 8>("v_cvt_rpi_i32_f32, 8 independent", d, 1);
+    row<EXP_MUL, 8>("v_exp_f32 + independent v_mul_f32, per PAIR", d, 1);
+    row<SILU, 8>("SiLU (mul, exp, add, rcp, mul), 8 independent, per VALUE", d, 1);
     row<PK_MUL_ADD_PAIR, 4>("v_pk_mul + dependent v_pk_add, 4 chains", d, 2);
     row<PK_MUL_ADD_PAIR, 2>("v_pk_mul + dependent v_pk_add, 2 chains", d, 2);
     return 0;

@@ -25,6 +25,25 @@ if hog > 0:
     for b in bl:
         hip.hipFree(b)
     print(f"hog: {len(bl)} GB allocated and freed at t = {time.perf_counter() - T0:.2f} s", flush=True)
+if os.environ.get("PB_DRAIN"):
+    # does ALLOCATING (never touching) the free memory make the driver finish its scrubbing first?
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipFree.argtypes = [C.c_void_p]
+    hip.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    fr, tot = C.c_size_t(), C.c_size_t()
+    hip.hipMemGetInfo(C.byref(fr), C.byref(tot))
+    t_d = time.perf_counter()
+    bl = []
+    for i in range(max(0, (fr.value >> 30) - 8)):
+        p_ = C.c_void_p()
+        if hip.hipMalloc(C.byref(p_), 1 << 30) != 0:
+            break
+        bl.append(p_)
+    hip.hipDeviceSynchronize()
+    for b in bl:
+        hip.hipFree(b)
+    print(f"drain: {len(bl)} GB of {fr.value >> 30} free allocated untouched and freed in {time.perf_counter() - t_d:.2f} s", flush=True)
 rows = 10_000_000
 ix = capi.Index(256, rows)
 ix.fill_synthetic(synth.SEED_INDEX, 0, rows, 1)
