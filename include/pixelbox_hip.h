@@ -275,7 +275,10 @@ int pb_embed_batch(pb_embedder *e, const uint8_t *rgb, uint32_t n, uint8_t *out_
 int pb_embed_batch_device(pb_embedder *e, const uint8_t *d_rgb, uint32_t n, uint8_t *d_out_u8,
                           float *d_out_f32);
 
-/* mlhash(img) -> Vec<u8> for one image: writes D bytes to out (out_len must be >= D). */
+/* mlhash(img) -> Vec<u8> for one image: writes D bytes to out (out_len must be >= D).
+ * One-image calls (this, pb_embed_batch with n = 1, pb_mlhash_image) replay the forward pass as one hipGraph from the third call on
+ * (input copy + ~50 kernels + output copies captured once on the embedder's stream; same results; PB_NO_GRAPH=1 in the environment at
+ * pb_embed_create launches them one by one). */
 int pb_mlhash(pb_embedder *e, const uint8_t *rgb, uint8_t *out, size_t out_len);
 
 /* pb_embed_batch_images for n <= max_batch images whose hashes are wanted IN DEVICE MEMORY as well: *d_out_u8 receives a

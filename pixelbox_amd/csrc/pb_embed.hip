@@ -78,6 +78,17 @@ struct pb_embedder {
     float *buf_e = nullptr, *buf_dw = nullptr, *buf_gate = nullptr, *buf_pool = nullptr;
     long long *buf_part = nullptr;  // SE pooling partial sums, 2^-24 fixed point; buf_part[-1] holds the address of *h_range (se_range_check)
     unsigned *h_range = nullptr;    // pinned host word a kernel raises when an activation leaves the fixed-point domain (|x| >= 128)
+    // pb_mlhash / pb_embed_batch with ONE image: input copy + the ~50 launches of the forward + output copies as one replayed hipGraph
+    // (a dependent launch costs 3.1 us on a stream and 1.9 us as a graph node: profiles/micro/launch_floor.hip).  Captured at the third
+    // one-image call whose predecessor ran no timing loop; dropped when the stream, the picks or anything else it froze changes.
+    hipGraphExec_t g1_exec[2] = {nullptr, nullptr};  // [0] with the input copy (pb_mlhash), [1] without (pb_mlhash_image: the resize kernel has left the image in d_img)
+    hipStream_t g1_stream = nullptr;   // the stream they were captured on
+    uint8_t *g1_in = nullptr;          // pinned: the image
+    uint8_t *g1_out_u8 = nullptr;      // pinned: D bytes
+    float *g1_out_f32 = nullptr;       // pinned: D floats
+    int g1_quiet_calls = 0;            // consecutive one-image calls that ran no timing loop
+    unsigned long tune_runs = 0;       // timing loops entered so far (TuneTimer)
+    bool g1_off = false;               // PB_NO_GRAPH=1, or a capture failed once
     float *d_out_f32 = nullptr;
     uint8_t *d_out_u8 = nullptr;
     int n_cu = 256;
@@ -190,7 +201,7 @@ bool tune_take(pb_embedder *e, float ms, float best_ms) {
 struct TuneTimer {
     pb_embedder *e;
     std::chrono::steady_clock::time_point t0;
-    explicit TuneTimer(pb_embedder *e_) : e(e_), t0(std::chrono::steady_clock::now()) { ++e->tune_depth; }
+    explicit TuneTimer(pb_embedder *e_) : e(e_), t0(std::chrono::steady_clock::now()) { ++e->tune_depth; ++e->tune_runs; }
     ~TuneTimer() {
         if (--e->tune_depth == 0) e->tune_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
@@ -1275,6 +1286,11 @@ int forward_device(pb_embedder *e, const uint8_t *d_rgb, int n, uint8_t *d_u8, f
 void destroy(pb_embedder *e) {
     for (void *p : e->allocs) (void)hipFree(p);
     if (e->h_range) (void)hipHostFree(e->h_range);
+    for (auto &ge : e->g1_exec)
+        if (ge) (void)hipGraphExecDestroy(ge);
+    if (e->g1_in) (void)hipHostFree(e->g1_in);
+    if (e->g1_out_u8) (void)hipHostFree(e->g1_out_u8);
+    if (e->g1_out_f32) (void)hipHostFree(e->g1_out_f32);
     for (auto &sl : e->st) {
         if (sl.h) (void)hipHostFree(sl.h);
         if (sl.h_desc) (void)hipHostFree(sl.h_desc);
@@ -1540,6 +1556,7 @@ int pb_embed_create(pb_embedder **out, int device, const void *weights_blob, siz
     if (const char *tp = getenv("PB_TUNE_PICK")) e->tune_pick = atoi(tp);
     if (const char *tt = getenv("PB_TRACE_TUNE")) e->trace_tune = tt[0] == '3' ? 3 : (tt[0] == '2' ? 2 : 1);  // 3: + host-side staging times
     e->no_stem_fusion = getenv("PB_NO_STEM_FUSION") != nullptr;
+    e->g1_off = getenv("PB_NO_GRAPH") != nullptr;
     e->no_resize_fusion = getenv("PB_NO_RESIZE_FUSION") != nullptr;
     if (const char *v = getenv("PB_STEM_RPP")) e->stem_rpp = atoi(v) == 1 ? 1 : 2;
     e->fold_se = getenv("PB_FOLD_SE") != nullptr;
@@ -1696,6 +1713,72 @@ static void parallel_copy(uint8_t *dst, const uint8_t *src, size_t bytes) {
     for (int i = 0; i < started; ++i) th[i].join();
 }
 
+static void g1_drop(pb_embedder *e) {
+    for (auto &ge : e->g1_exec) {
+        if (ge) (void)hipGraphExecDestroy(ge);
+        ge = nullptr;
+    }
+    e->g1_quiet_calls = 0;
+}
+
+// One image through the replayed graph.  rgb = null: the image is in d_img already (queued on the embedder's stream by the resize).
+// *used = 0: no graph (not yet / not possible), the caller takes the plain path.
+static int one_image_graph(pb_embedder *e, const uint8_t *rgb, uint8_t *out_u8, float *out_f32, int *used) {
+    *used = 0;
+    const size_t img_bytes = (size_t)e->H * e->W * 3;
+    const int kind = rgb ? 0 : 1;
+    if ((e->g1_exec[0] || e->g1_exec[1]) && e->g1_stream != e->stream) g1_drop(e);
+    if (!e->g1_exec[kind]) {
+        if (e->g1_quiet_calls < 2 || e->fold_se) return PB_OK;  // the kernel forms of this bucket are picked and warm by then
+        if (!e->g1_in) {
+            PB_HIP(hipHostMalloc(reinterpret_cast<void **>(&e->g1_in), img_bytes, hipHostMallocDefault));
+            PB_HIP(hipHostMalloc(reinterpret_cast<void **>(&e->g1_out_u8), e->D, hipHostMallocDefault));
+            PB_HIP(hipHostMalloc(reinterpret_cast<void **>(&e->g1_out_f32), e->D * sizeof(float), hipHostMallocDefault));
+        }
+        // capture: the same calls the plain path makes, on the same stream.  Anything that cannot be captured (a timing loop that
+        // was not expected, a runtime that refuses a call) ends the capture, switches the graph off for this embedder and leaves
+        // the call to the plain path -- never an error of its own.
+        const unsigned long tuned_before = e->tune_runs;
+        hipGraph_t g = nullptr;
+        if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeRelaxed) != hipSuccess) {
+            (void)hipGetLastError();
+            e->g1_off = true;
+            return PB_OK;
+        }
+        bool ok = kind == 1 || hipMemcpyAsync(e->d_img, e->g1_in, img_bytes, hipMemcpyHostToDevice, e->stream) == hipSuccess;
+        ok = ok && forward_device(e, e->d_img, 1, e->d_out_u8, e->d_out_f32) == PB_OK;
+        ok = ok && hipMemcpyAsync(e->g1_out_u8, e->d_out_u8, e->D, hipMemcpyDeviceToHost, e->stream) == hipSuccess;
+        ok = ok && hipMemcpyAsync(e->g1_out_f32, e->d_out_f32, e->D * sizeof(float), hipMemcpyDeviceToHost, e->stream) == hipSuccess;
+        const hipError_t ec = hipStreamEndCapture(e->stream, &g);
+        ok = ok && ec == hipSuccess && g != nullptr && e->tune_runs == tuned_before;
+        if (ok) ok = hipGraphInstantiate(&e->g1_exec[kind], g, nullptr, nullptr, 0) == hipSuccess;
+        if (g) (void)hipGraphDestroy(g);
+        (void)hipGetLastError();
+        if (!ok) {
+            e->g1_exec[kind] = nullptr;
+            e->g1_off = true;
+            (void)hipStreamSynchronize(e->stream);
+            return PB_OK;
+        }
+        e->g1_stream = e->stream;
+    }
+    *used = 1;
+    if (kind == 0) memcpy(e->g1_in, rgb, img_bytes);
+    auto body = [&]() -> int {
+        PB_HIP(hipGraphLaunch(e->g1_exec[kind], e->stream));
+        PB_HIP(hipStreamSynchronize(e->stream));
+        return range_status(e);
+    };
+    const int rc = body();
+    if (rc) {
+        (void)hipStreamSynchronize(e->stream);
+        return rc;
+    }
+    memcpy(out_u8, e->g1_out_u8, e->D);
+    if (out_f32) memcpy(out_f32, e->g1_out_f32, e->D * sizeof(float));
+    return PB_OK;
+}
+
 int pb_embed_batch(pb_embedder *e, const uint8_t *rgb, uint32_t n, uint8_t *out_u8, float *out_f32) {
     PB_CHECK(e, PB_ERR_INVALID, "pb_embed_batch: null embedder");
     PB_CHECK(n == 0 || (rgb && out_u8), PB_ERR_INVALID, "pb_embed_batch: null buffer");
@@ -1707,7 +1790,13 @@ int pb_embed_batch(pb_embedder *e, const uint8_t *rgb, uint32_t n, uint8_t *out_
     // the output copy of chunk i - 1 (a third stream) run beside the forward pass of chunk i.  (Cutting a single chunk in two
     // to hide half of its copies was measured and is slower: 148 k against 168 k images/s at 512 -- the half-batches' forwards
     // lose more than the hidden copies save.)
+    if (n == 1 && !e->g1_off) {
+        int used = 0;
+        const int rc = one_image_graph(e, rgb, out_u8, out_f32, &used);
+        if (used) return rc;  // else: not captured (yet): the plain path below
+    }
     if (n <= e->max_batch) {  // one chunk: nothing to overlap, one stream, no events
+        const unsigned long tuned_before = e->tune_runs;
         auto body = [&]() -> int {
             PB_HIP(hipMemcpyAsync(e->d_img, rgb, n * img_bytes, hipMemcpyHostToDevice, e->stream));
             int rc = forward_device(e, e->d_img, (int)n, e->d_out_u8, e->d_out_f32);
@@ -1719,6 +1808,7 @@ int pb_embed_batch(pb_embedder *e, const uint8_t *rgb, uint32_t n, uint8_t *out_
         };
         const int rc = body();
         if (rc) (void)hipStreamSynchronize(e->stream);  // a copy may still be reading `rgb` / writing the outputs: not after the call has returned
+        if (n == 1) e->g1_quiet_calls = (!rc && e->tune_runs == tuned_before) ? e->g1_quiet_calls + 1 : 0;
         return rc;
     }
     const uint32_t chunk = e->max_batch;
@@ -1800,6 +1890,16 @@ int pb_embed_batch_images(pb_embedder *e, const uint8_t *const *rgb, const uint3
     // chunks of max_batch images through two input slots: the staging + resize of chunk c + 1 is queued while the forward pass
     // of chunk c runs (the host's packing and the copy engine's transfers hide under it); outputs land in pinned memory on a
     // third stream and are handed over when their slot comes round again, as in pb_embed_batch
+    if (n == 1 && !e->g1_off && (e->g1_exec[1] || e->g1_quiet_calls >= 2)) {  // pb_mlhash_image: resize, then the forward as one replayed graph
+        int used = 0;
+        int rc1 = prepare_images(e, rgb, widths, heights, 1, e->d_img);
+        if (!rc1) rc1 = one_image_graph(e, nullptr, out_u8, out_f32, &used);
+        if (rc1 || used) {
+            if (rc1) drain_streams(e);
+            return rc1;
+        }
+    }
+    const unsigned long tuned_before = e->tune_runs;
     uint8_t *d_in[2] = {e->d_img, e->d_img_b}, *d_u8[2] = {e->d_out_u8, e->d_out_u8_b};
     float *d_f[2] = {e->d_out_f32, e->d_out_f32_b};
     uint32_t first[2] = {0, 0}, count[2] = {0, 0};
@@ -1830,7 +1930,9 @@ int pb_embed_batch_images(pb_embedder *e, const uint8_t *const *rgb, const uint3
     for (uint32_t i0 = 0; i0 < n && !rc; i0 += e->max_batch, slot ^= 1) rc = run_chunk(slot, i0, std::min(e->max_batch, n - i0));
     if (!rc) rc = hand_over(slot);
     if (!rc) rc = hand_over(slot ^ 1);
+    if (!rc) rc = range_status(e);
     if (rc) drain_streams(e);  // nothing of this call may still be in flight when it returns
+    if (n == 1) e->g1_quiet_calls = (!rc && e->tune_runs == tuned_before) ? e->g1_quiet_calls + 1 : 0;
     return rc;
 }
 
@@ -2114,6 +2216,7 @@ int pb_embed_get_tuning(pb_embedder *e, uint8_t *out, size_t cap, size_t *len) {
 int pb_embed_set_tuning(pb_embedder *e, const uint8_t *data, size_t len) {
     PB_CHECK(e && data, PB_ERR_INVALID, "pb_embed_set_tuning: null pointer");
     std::lock_guard<std::mutex> lock(e->mu);
+    g1_drop(e);  // the one-image graph froze the picks it was captured with
     TuneHdr h;
     PB_CHECK(len >= sizeof h, PB_ERR_FORMAT, "tuning data: %zu bytes is shorter than its header", len);
     memcpy(&h, data, sizeof h);
@@ -2192,6 +2295,7 @@ int pb_embed_set_option(pb_embedder *e, int option, int64_t value) {
     std::lock_guard<std::mutex> lock(e->mu);
     if (option == PB_OPT_EMBED_STREAM) {
         e->stream = value ? reinterpret_cast<hipStream_t>(value) : e->own_stream;
+        g1_drop(e);  // the one-image graph was captured on the other stream
         return PB_OK;
     }
     if (option == PB_OPT_EMBED_ASYNC) {

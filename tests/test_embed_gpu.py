@@ -263,12 +263,43 @@ def test_activation_outside_the_fixed_point_domain_fails_loudly(tensor):
         with pytest.raises(capi.PixelboxError) as ei:
             bad.embed(imgs[:n_img])
         assert ei.value.code == capi.PB_ERR_RANGE, (tensor, n_img, str(ei.value))
+        with pytest.raises(capi.PixelboxError) as ei:  # the entry points that resize on the GPU
+            bad.mlhash_image(np.ascontiguousarray(imgs[0][:100, :90])) if n_img == 1 else bad.embed_images([imgs[i] for i in range(n_img)])
+        assert ei.value.code == capi.PB_ERR_RANGE
     good = capi.Embedder(blob, max_batch=8)
     u8, _ = good.embed(imgs)
     with pytest.raises(capi.PixelboxError):
         bad.embed(imgs)
     u8b, _ = good.embed(imgs)  # another embedder's failure leaves this one alone
     assert np.array_equal(u8, u8b)
+
+
+def test_one_image_calls_replay_a_graph_and_keep_the_bits(monkeypatch):
+    # pb_mlhash / pb_embed_batch with one image replay the whole forward as one hipGraph from the third quiet call on (pb_embed.hip,
+    # one_image_graph: a dependent launch is 3.1 us on a stream, 1.9 us as a graph node).  Same bits as the plain launches of an
+    # embedder created with PB_NO_GRAPH=1, for every image; the graph is dropped and re-captured when the picks are replaced; a batch
+    # call in between does not disturb it; an out-of-domain model still fails the call.
+    blob = W.synthetic_blob(synth.SEED_WEIGHTS, 128, 128, 256)
+    imgs = synth.synthetic_images(synth.SEED_IMAGES, 4000, 12, 128, 128)
+    monkeypatch.setenv("PB_NO_GRAPH", "1")
+    plain = capi.Embedder(blob, max_batch=8)
+    monkeypatch.delenv("PB_NO_GRAPH")
+    g = capi.Embedder(blob, max_batch=8)
+    want = [plain.embed(imgs[i : i + 1]) for i in range(12)]
+    for rnd in range(2):
+        for i in range(12):
+            u8, f = g.embed(imgs[i : i + 1])
+            assert np.array_equal(u8, want[i][0]) and np.array_equal(f.view(np.uint32), want[i][1].view(np.uint32)), (rnd, i)
+            assert np.array_equal(g.mlhash(imgs[i]), want[i][0][0])
+            assert np.array_equal(g.mlhash_image(imgs[i]), want[i][0][0])  # exact size: passes through the resize path, same graph for the forward
+            odd = np.ascontiguousarray(imgs[i][:101, :77])
+            assert np.array_equal(g.mlhash_image(odd), plain.mlhash_image(odd))
+        u8b, fb = g.embed(imgs[:5])  # a batch call between one-image calls
+        assert np.array_equal(u8b, np.concatenate([w[0] for w in want[:5]]))
+        g.set_tuning(g.get_tuning())  # drops the graph: the next calls run plainly, then capture again
+    ref_u8, ref_f = oracle.mlhash_batch(blob, imgs, 256, nthreads=8)
+    assert_embeddings_close(np.concatenate([w[1] for w in want]), ref_f)
+    assert_bytes_match(np.concatenate([w[0] for w in want]), ref_u8, ref_f)
 
 
 def test_embed_then_search_end_to_end():
