@@ -853,9 +853,11 @@ def bench_embed(args, torch, device, distributed):
                                 "pb_embed_set_tuning carry the picks to a fresh embedder (another process), which then starts without the loops "
                                 "(the first calls still carry the kernels' code load)"}
     del emb2
+    for i in range(12):  # one-image calls replay a graph from the third quiet call on (pb_embed.hip, one_image_graph): past its capture
+        emb.mlhash(host_imgs[i % 8])
     t0 = time.perf_counter()
-    for i in range(10):
-        emb.mlhash(host_imgs[i])
+    for i in range(50):
+        emb.mlhash(host_imgs[i % 8])
     res["host_buffers"] = {"images_per_s": round(nb / (host_ms * 1e-3), 1), "ms_per_batch": round(host_ms, 4),
                            "images_per_s_8_chunks": round(8 * nb / (many_ms * 1e-3), 1),
                            "images_per_s_8_chunks_pinned_input": round(8 * nb / (pinned_ms * 1e-3), 1),
@@ -864,7 +866,7 @@ def bench_embed(args, torch, device, distributed):
                                    "512 through a two-slot pipeline (input copy, forward and output copy of neighbouring chunks on three streams; "
                                    "pageable input staged through pinned buffers by a four-thread host copy, outputs landing in pinned buffers); "
                                    "images_per_s / images_per_s_8_chunks read pageable caller memory"}
-    res["mlhash_latency_ms"] = round((time.perf_counter() - t0) * 1e3 / 10, 4)
+    res["mlhash_latency_ms"] = round((time.perf_counter() - t0) * 1e3 / 50, 4)
     if int(os.environ.get("RANK", "0")) == 0 and not args.no_cpu_baseline:
         from oracle import capi as oracle
 

@@ -1520,12 +1520,21 @@ int prepare_images(pb_embedder *e, const uint8_t *const *rgb, const uint32_t *wi
                 fprintf(stderr, "prepare_images: sub-batch of %u images, %.1f MB packed in %.3f ms\n", m, src_total / 1e6,
                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count());
         }
-        if (e->stage_used[slot]) PB_HIP(hipStreamWaitEvent(e->h2d_stream, e->ev_resized[slot], 0));  // the kernels that read d_src[slot] last
-        PB_HIP(hipMemcpyAsync(e->d_src[slot], e->h_stage_img[slot], src_total, hipMemcpyHostToDevice, e->h2d_stream));
-        PB_HIP(hipMemcpyAsync(e->d_desc[slot], hd, m * sizeof(ResizeDesc), hipMemcpyHostToDevice, e->h2d_stream));
-        PB_HIP(hipEventRecord(e->ev_copied[slot], e->h2d_stream));
-        e->stage_used[slot] = true;
-        PB_HIP(hipStreamWaitEvent(e->stream, e->ev_copied[slot], 0));
+        if (n == 1) {
+            // one image (pb_mlhash_image): nothing to overlap, so the copies go on the embedder's stream itself -- no event hand-over
+            // between two streams in front of the resize kernel (the events are still recorded: a later batch call waits on them)
+            PB_HIP(hipMemcpyAsync(e->d_src[slot], e->h_stage_img[slot], src_total, hipMemcpyHostToDevice, e->stream));
+            PB_HIP(hipMemcpyAsync(e->d_desc[slot], hd, m * sizeof(ResizeDesc), hipMemcpyHostToDevice, e->stream));
+            PB_HIP(hipEventRecord(e->ev_copied[slot], e->stream));
+            e->stage_used[slot] = true;
+        } else {
+            if (e->stage_used[slot]) PB_HIP(hipStreamWaitEvent(e->h2d_stream, e->ev_resized[slot], 0));  // the kernels that read d_src[slot] last
+            PB_HIP(hipMemcpyAsync(e->d_src[slot], e->h_stage_img[slot], src_total, hipMemcpyHostToDevice, e->h2d_stream));
+            PB_HIP(hipMemcpyAsync(e->d_desc[slot], hd, m * sizeof(ResizeDesc), hipMemcpyHostToDevice, e->h2d_stream));
+            PB_HIP(hipEventRecord(e->ev_copied[slot], e->h2d_stream));
+            e->stage_used[slot] = true;
+            PB_HIP(hipStreamWaitEvent(e->stream, e->ev_copied[slot], 0));
+        }
         { int rcr = launch_resize(e, e->d_src[slot], e->d_desc[slot], hd, m, max_w, tmp_total, d_dst); if (rcr) return rcr; }
         PB_HIP(hipEventRecord(e->ev_resized[slot], e->stream));
         i0 = i1;

@@ -9,11 +9,17 @@
 set -x
 TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/$TAG; mkdir -p $O
-cd $R && timeout 1500 python -m pytest tests -q -m gpu > $O/gpu_tests_full.txt 2>&1; grep -E "passed|failed" $O/gpu_tests_full.txt > $O/gpu_tests.txt
+# the plain bench FIRST, on a device that streams at its idle rate (wait_quiet.py: a box can arrive, or be left by our own test suite, with
+# minutes of driver scrubbing ahead of it); then the tests; then the profiled runs, each behind the same wait
 cd /tmp; export TMPDIR=/tmp
+timeout 400 python3 $R/profiles/wait_quiet.py > $O/wait_quiet.txt 2>&1
 timeout 900 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
+cd $R && timeout 1500 python -m pytest tests -q -m gpu > $O/gpu_tests_full.txt 2>&1; grep -E "passed|failed" $O/gpu_tests_full.txt > $O/gpu_tests.txt
+cd /tmp
+timeout 400 python3 $R/profiles/wait_quiet.py >> $O/wait_quiet.txt 2>&1
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/full -o full -- python3 $R/bench.py > $O/bench_under_rocprof.json 2> $O/full.err
 # the headline legs alone (default steps): the LOOPQ filter instance's average in this stats file is the 10M-row launches only
+timeout 400 python3 $R/profiles/wait_quiet.py >> $O/wait_quiet.txt 2>&1
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/head -o head -- python3 $R/bench.py --no-embed --e2e-images 0 --no-sweep --no-cpu-baseline > $O/bench_headline_under_rocprof.json 2> $O/head.err
 cp $(find $O/head -name "head_kernel_stats.csv") $O/headline_kernel_stats.csv; rm -rf $O/head
 SCAN="--no-embed --e2e-images 0 --no-sweep --no-cpu-baseline --steps 2 --warmup 1"
