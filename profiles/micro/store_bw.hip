@@ -16,6 +16,22 @@ __global__ __launch_bounds__(256) void k_copy(f32x4 *out, const f32x4 *in, size_
     const f32x4 *s = in + (size_t)blockIdx.x * per_wg + threadIdx.x;
     for (size_t i = 0; i < per_wg; i += 256) o[i] = s[i];
 }
+// the copy with non-temporal loads, non-temporal stores, or both (read-once / write-once streams beside each other)
+template <bool NTL, bool NTS>
+__global__ __launch_bounds__(256) void k_copy_nt(f32x4 *out, const f32x4 *in, size_t per_wg) {
+    f32x4 *o = out + (size_t)blockIdx.x * per_wg + threadIdx.x;
+    const f32x4 *s = in + (size_t)blockIdx.x * per_wg + threadIdx.x;
+    for (size_t i = 0; i < per_wg; i += 1024) {
+        f32x4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = NTL ? __builtin_nontemporal_load(s + i + 256 * j) : s[i + 256 * j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (NTS) __builtin_nontemporal_store(v[j], o + i + 256 * j);
+            else o[i + 256 * j] = v[j];
+        }
+    }
+}
 // strided pieces: each lane group of 4 writes 64 B of a `pitch`-byte record (the band kernel's NHWC pattern: 16 channels of E)
 __global__ __launch_bounds__(256) void k_store_pieces(float *out, size_t recs_per_wg, int pitch_f, int piece) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -42,6 +58,19 @@ int main() {
             printf("%4zu MB, %5d workgroups: store %7.1f us = %5.2f TB/s written;  copy %7.1f us = %5.2f TB/s written (+ as much read)\n", mb, wgs, ms_s * 1e3,
                    by / ms_s / 1e9, ms_c * 1e3, by / ms_c / 1e9);
         }
+    }
+    for (size_t mb : {200, 300, 600}) {
+        const int wgs = 8192;
+        const size_t n4 = (mb << 20) / 16, per = n4 / wgs / 1024 * 1024;
+        float ms[4] = {0, 0, 0, 0};
+        for (int rep = 0; rep < 3; ++rep) {
+#define RUN(I, NTL, NTS) CK(hipEventRecord(e0)); hipLaunchKernelGGL((k_copy_nt<NTL, NTS>), dim3(wgs), dim3(256), 0, 0, a, b, per); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms[I], e0, e1));
+            RUN(0, false, false) RUN(1, true, false) RUN(2, false, true) RUN(3, true, true)
+#undef RUN
+        }
+        const double by = (double)per * wgs * 16;
+        printf("%4zu MB copied, four loads in flight per lane: plain %6.1f us = %4.2f TB/s each way; nt loads %6.1f us = %4.2f; nt stores %6.1f us = %4.2f; both %6.1f us = %4.2f\n", mb,
+               ms[0] * 1e3, by / ms[0] / 1e9, ms[1] * 1e3, by / ms[1] / 1e9, ms[2] * 1e3, by / ms[2] / 1e9, ms[3] * 1e3, by / ms[3] / 1e9);
     }
     // NHWC pieces: 200 MB of 384-byte records, six launches-in-one? no: one launch per 64-byte piece, and all six pieces concurrently
     for (int pitch : {96, 144}) {
