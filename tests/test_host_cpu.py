@@ -174,6 +174,9 @@ def test_option_constants_of_the_python_binding_match_the_header():
             assert defs[name] == value, (name, defs[name], value)
             checked += 1
     assert checked >= 8
+    # status codes: an enum in the header, not #defines
+    enum = dict((m.group(1), int(m.group(2))) for m in re.finditer(r"\b(PB_(?:OK|ERR_[A-Z]+))\s*=\s*(-?\d+)", hdr))
+    assert enum.get("PB_OK") == 0 and enum.get("PB_ERR_RANGE") == capi.PB_ERR_RANGE == -7 and len(set(enum.values())) == len(enum)
 
 
 # ---- bench.py launch logic (`python bench.py --gpus 8` launched plainly must not exit) -------------
