@@ -334,6 +334,9 @@ int pb_pinned_free(void *p);
 #define PB_OPT_EMBED_ASYNC 4  /* 1: pb_embed_batch_device returns with the forward pass queued (see its stream contract); default 0 */
 #define PB_OPT_EMBED_STAGE_BYTES 5 /* capacity of each of the two staging slots of pb_embed_stage_* in bytes (default 48 MB = 244 images of 256 x 256);
                                       takes effect the next time a slot is opened */
+#define PB_OPT_EMBED_FRONT_SUB 6 /* images per sub-batch of the network's front (stem .. the last block with a large expanded map: blocks 0-4
+                                    at 128 x 128): their maps then stay in the 256 MiB Infinity Cache between writer and reader.  0 = one
+                                    pass over the whole batch (the default: every split measured slower at 128 x 128, profiles/r06_front_sub.txt); bits do not depend on it */
 int pb_embed_set_option(pb_embedder *e, int option, int64_t value);
 
 /* The embedder picks a kernel form per (layer, batch-size bucket) by timing the candidates at first use (all forms give the

@@ -106,6 +106,11 @@ struct pb_embedder {
     bool no_stem_fusion = false;
     bool no_resize_fusion = false, resize_attr_set = false;  // PB_NO_RESIZE_FUSION: the two-kernel resize (k_resize_v + k_resize_h) always
     int stem_rpp = 0;  // PB_STEM_RPP: stem rows per phase of k_stem_dw (0: the default)
+    // the front of the network over sub-batches (forward_device): blocks [0, front_blocks) run front_sub images at a time, the last of
+    // them writing its output map of all images to buf_front.  PB_FRONT_SUB (0: off), PB_FRONT_BLOCKS; PB_OPT_EMBED_FRONT_SUB
+    size_t front_blocks = 0, front_out_per_image = 0;
+    int front_sub = 0;
+    float *buf_front = nullptr;
     unsigned *d_se_cnt = nullptr;  // [max_batch] arrival counters of the squeeze-excite tails (zero between launches)
     bool fold_se = false;          // PB_FOLD_SE=1: the gates of the first six blocks come from the producing kernels' tails instead of k_se
                                    // launches (measured: +0.04 ms per batch-512 forward and per batch-1 forward -- see SeTail; off by default)
@@ -1111,7 +1116,35 @@ int launch_se(pb_embedder *e, const Block &bl, int n_tiles, int n, int hw, int s
     return PB_OK;
 }
 
+// stem + the first `nb` blocks (all of them: nb = blocks.size()) of n images.  The last of those blocks writes to `out_last` when
+// that is given, otherwise the blocks ping-pong over buf_x as always; *x_out is where the next block finds its input.
+int forward_blocks(pb_embedder *e, const uint8_t *d_rgb, int n, size_t nb, float *out_last, const float **x_out, int *H_out, int *W_out);
+int forward_rest(pb_embedder *e, const float *x_in, int n, size_t first, int H, int W, uint8_t *d_u8, float *d_f32);
+
+// The leading blocks' maps are the big ones (128 x 128 input, batch 512: the depthwise outputs of blocks 0-4 are 268, 201, 302, 75
+// and 126 MB, each written by one kernel and read back by the next).  With front_sub > 0 (PB_OPT_EMBED_FRONT_SUB; off by default: it
+// measured slower, see pb_embed_create) stem .. block front_blocks - 1 run over sub-batches whose maps would stay inside the 256 MiB
+// Infinity Cache between their writer and their reader, the rest of the network over the whole batch.  A host-side loop: every
+// kernel computes an image's values from that image alone, so the bits are those of the one-pass form.
 int forward_device(pb_embedder *e, const uint8_t *d_rgb, int n, uint8_t *d_u8, float *d_f32) {
+    int H = 0, W = 0, rc;
+    const float *x = nullptr;
+    const size_t fb = std::min<size_t>(e->front_blocks, e->blocks.size());
+    const int sub = e->front_sub;
+    if (fb > 0 && sub > 0 && n > sub && e->buf_front) {
+        for (int s = 0; s < n; s += sub) {
+            const int m = std::min(sub, n - s);
+            if ((rc = forward_blocks(e, d_rgb + (size_t)s * e->H * e->W * 3, m, fb, e->buf_front + (size_t)s * e->front_out_per_image, &x, &H, &W))) return rc;
+        }
+        return forward_rest(e, e->buf_front, n, fb, H, W, d_u8, d_f32);
+    }
+    if ((rc = forward_blocks(e, d_rgb, n, e->blocks.size(), nullptr, &x, &H, &W))) return rc;
+    return forward_rest(e, x, n, e->blocks.size(), H, W, d_u8, d_f32);
+}
+
+int run_block(pb_embedder *e, const Block &bl, const float *x, float *out, int n, int H, int W, bool stem_fused, int stem_bands);
+
+int forward_blocks(pb_embedder *e, const uint8_t *d_rgb, int n, size_t nb, float *out_last, const float **x_out, int *H_out, int *W_out) {
     int H = (int)e->H / 2, W = (int)e->W / 2;
     // arrival counters of the squeeze-excite tails: every tail leaves them zero; cleared anyway (a failed launch must not poison the next forward)
     if (e->fold_se) PB_HIP(hipMemsetAsync(e->d_se_cnt, 0, (size_t)n * sizeof(unsigned), e->stream));
@@ -1149,77 +1182,107 @@ int forward_device(pb_embedder *e, const uint8_t *d_rgb, int n, uint8_t *d_u8, f
         PB_HIP(hipGetLastError());
     }
     int cur = 0;
-    for (const Block &bl : e->blocks) {
-        const float *x = e->buf_x[cur];
-        const int Ho = (H + bl.stride - 1) / bl.stride, Wo = (W + bl.stride - 1) / bl.stride;
-        // the unfused form of the block: front (expand + depthwise + pooled sums), squeeze-excite gates, project GEMM
-        auto run_unfused = [&]() -> int {
-            int rc;
-            int part_tiles = 0;
-            bool folded = false;  // the gate was computed in the tail of the kernel that produced the pooled sums
-            if (fuse_stem && &bl == &b0) {
-                part_tiles = stem_bands;  // depthwise output and SE partials are already in buf_dw / buf_part
-                folded = e->fold_se && b0.sp <= 16;  // ... and the gate, written by the band that completed the image
-            } else if (bl.has_expand) {
-                if ((rc = run_front(e, bl, x, n, H, W, Ho, Wo, &part_tiles, &folded))) return rc;
-            } else {
-                DwGeom g0;
-                if ((rc = launch_dw(e, bl, x, n, H, W, e->buf_dw, Ho, Wo, &g0))) return rc;
-                part_tiles = g0.n_tiles;
-            }
-            struct { int n_tiles; } g{part_tiles};
-            // block = (channel quads rounded up to a wave multiple) x (groups of 16 squeeze units)
-            const int se_qp = ((bl.e / 4 + 63) / 64) * 64;
-            const long Mo = (long)n * Ho * Wo;
-            if (!folded && (rc = launch_se(e, bl, g.n_tiles, n, Ho * Wo, se_qp))) return rc;
-            if ((rc = launch_gemm(e, e->buf_dw, Mo, bl.project, e->buf_gate, Ho * Wo, bl.residual ? x : nullptr, 0,
-                                  e->buf_x[cur ^ 1])))
-                return rc;
-            return PB_OK;
-        };
-        int rc;
-        if (const int shape = block_shape(e, bl, H, W)) {
-            // one kernel for the whole block, or the unfused form -- identical bits; which is faster depends on the batch (the
-            // fused kernel runs two images per CU at a fixed ~110 us: it wins from about one workgroup per CU on), so both are
-            // timed once per (block, batch bucket)
-            const std::pair<const void *, long> key(&bl, tune_bucket(n));
-            auto it = e->front_cfg.find(key);
-            if (it == e->front_cfg.end()) {
-                TuneTimer tt(e);
-                if ((rc = run_unfused())) return rc;  // lets the unfused kernels pick their own forms first
-                float best_ms = 1e30f;
-                int best = 0;
-                for (int cand = 0; cand < 2; ++cand) {
-                    // one untimed run first: a kernel's first launch carries its code load (the first of the three 5 x 5 blocks
-                    // kept losing to the unfused form by exactly that)
-                    if ((rc = cand ? launch_block(e, bl, shape, x, n, e->buf_x[cur ^ 1]) : run_unfused())) return rc;
-                    PB_HIP(hipEventRecord(e->tune_e0, e->stream));
-                    for (int rep = 0; rep < 2; ++rep)
-                        if ((rc = cand ? launch_block(e, bl, shape, x, n, e->buf_x[cur ^ 1]) : run_unfused())) return rc;
-                    PB_HIP(hipEventRecord(e->tune_e1, e->stream));
-                    PB_HIP(hipEventSynchronize(e->tune_e1));
-                    float ms = 0.f;
-                    PB_HIP(hipEventElapsedTime(&ms, e->tune_e0, e->tune_e1));
-                    if (e->trace_tune) fprintf(stderr, "block e%d k%d n%d: %s %.1f us\n", bl.e, bl.k, n, cand ? "one kernel" : "front + se + project", ms * 500.f);
-                    if (tune_take(e, ms, best_ms)) {
-                        best_ms = ms;
-                        best = cand;
-                    }
-                }
-                it = e->front_cfg.emplace(key, best).first;
-            }
-            if ((rc = it->second ? launch_block(e, bl, shape, x, n, e->buf_x[cur ^ 1]) : run_unfused())) return rc;
-        } else if ((rc = run_unfused())) {
-            return rc;
-        }
+    const float *x = e->buf_x[0];
+    for (size_t bi = 0; bi < nb; ++bi) {
+        const Block &bl = e->blocks[bi];
+        float *out = (bi + 1 == nb && out_last) ? out_last : e->buf_x[cur ^ 1];
+        int rc = run_block(e, bl, x, out, n, H, W, fuse_stem && bi == 0, stem_bands);
+        if (rc) return rc;
+        x = out;
         cur ^= 1;
-        H = Ho;
-        W = Wo;
+        H = (H + bl.stride - 1) / bl.stride;
+        W = (W + bl.stride - 1) / bl.stride;
     }
+    *x_out = x;
+    *H_out = H;
+    *W_out = W;
+    return PB_OK;
+}
+
+// one MBConv block of n images: x [n][H][W][cin] -> out [n][Ho][Wo][cout]; stem_fused: the depthwise output and the pooled sums of
+// block 0 are already in buf_dw / buf_part (k_stem_dw)
+int run_block(pb_embedder *e, const Block &bl, const float *x, float *out, int n, int H, int W, bool stem_fused, int stem_bands) {
+    const int Ho = (H + bl.stride - 1) / bl.stride, Wo = (W + bl.stride - 1) / bl.stride;
+    // the unfused form of the block: front (expand + depthwise + pooled sums), squeeze-excite gates, project GEMM
+    auto run_unfused = [&]() -> int {
+        int rc;
+        int part_tiles = 0;
+        bool folded = false;  // the gate was computed in the tail of the kernel that produced the pooled sums
+        if (stem_fused) {
+            part_tiles = stem_bands;  // depthwise output and SE partials are already in buf_dw / buf_part
+            folded = e->fold_se && bl.sp <= 16;  // ... and the gate, written by the band that completed the image
+        } else if (bl.has_expand) {
+            if ((rc = run_front(e, bl, x, n, H, W, Ho, Wo, &part_tiles, &folded))) return rc;
+        } else {
+            DwGeom g0;
+            if ((rc = launch_dw(e, bl, x, n, H, W, e->buf_dw, Ho, Wo, &g0))) return rc;
+            part_tiles = g0.n_tiles;
+        }
+        struct { int n_tiles; } g{part_tiles};
+        // block = (channel quads rounded up to a wave multiple) x (groups of 16 squeeze units)
+        const int se_qp = ((bl.e / 4 + 63) / 64) * 64;
+        const long Mo = (long)n * Ho * Wo;
+        if (!folded && (rc = launch_se(e, bl, g.n_tiles, n, Ho * Wo, se_qp))) return rc;
+        if ((rc = launch_gemm(e, e->buf_dw, Mo, bl.project, e->buf_gate, Ho * Wo, bl.residual ? x : nullptr, 0,
+                              out)))
+            return rc;
+        return PB_OK;
+    };
+    int rc;
+    if (const int shape = block_shape(e, bl, H, W)) {
+        // one kernel for the whole block, or the unfused form -- identical bits; which is faster depends on the batch (the
+        // fused kernel runs two images per CU at a fixed ~110 us: it wins from about one workgroup per CU on), so both are
+        // timed once per (block, batch bucket)
+        const std::pair<const void *, long> key(&bl, tune_bucket(n));
+        auto it = e->front_cfg.find(key);
+        if (it == e->front_cfg.end()) {
+            TuneTimer tt(e);
+            if ((rc = run_unfused())) return rc;  // lets the unfused kernels pick their own forms first
+            float best_ms = 1e30f;
+            int best = 0;
+            for (int cand = 0; cand < 2; ++cand) {
+                // one untimed run first: a kernel's first launch carries its code load (the first of the three 5 x 5 blocks
+                // kept losing to the unfused form by exactly that)
+                if ((rc = cand ? launch_block(e, bl, shape, x, n, out) : run_unfused())) return rc;
+                PB_HIP(hipEventRecord(e->tune_e0, e->stream));
+                for (int rep = 0; rep < 2; ++rep)
+                    if ((rc = cand ? launch_block(e, bl, shape, x, n, out) : run_unfused())) return rc;
+                PB_HIP(hipEventRecord(e->tune_e1, e->stream));
+                PB_HIP(hipEventSynchronize(e->tune_e1));
+                float ms = 0.f;
+                PB_HIP(hipEventElapsedTime(&ms, e->tune_e0, e->tune_e1));
+                if (e->trace_tune) fprintf(stderr, "block e%d k%d n%d: %s %.1f us\n", bl.e, bl.k, n, cand ? "one kernel" : "front + se + project", ms * 500.f);
+                if (tune_take(e, ms, best_ms)) {
+                    best_ms = ms;
+                    best = cand;
+                }
+            }
+            it = e->front_cfg.emplace(key, best).first;
+        }
+        if ((rc = it->second ? launch_block(e, bl, shape, x, n, out) : run_unfused())) return rc;
+    } else if ((rc = run_unfused())) {
+        return rc;
+    }
+    return PB_OK;
+}
+
+int forward_rest(pb_embedder *e, const float *x_in, int n, size_t first, int H, int W, uint8_t *d_u8, float *d_f32) {
+    // the ping-pong continues on whichever of buf_x the input is not
+    const float *xr = x_in;
+    for (size_t bi = first; bi < e->blocks.size(); ++bi) {
+        const Block &bl = e->blocks[bi];
+        float *out = xr == e->buf_x[0] ? e->buf_x[1] : e->buf_x[0];
+        int rc = run_block(e, bl, xr, out, n, H, W, false, 0);
+        if (rc) return rc;
+        xr = out;
+        H = (H + bl.stride - 1) / bl.stride;
+        W = (W + bl.stride - 1) / bl.stride;
+    }
+    const float *const xh = xr;
     const long M = (long)n * H * W;
     if (H * W == 16 && e->head.p3 && e->fc.p3 && !e->no_tail_fusion) {
         // P3 head + Linear with the same fused epilogues (pool in the head's accumulators; tanh + quantiser behind the Linear)
-        int rc = launch_p3_tuned(e, 1, p3_args(e->buf_x[cur], M, e->head, nullptr, 16, nullptr, 1, e->buf_pool, 1.0f / 16.0f), e->head.wt2, "head + pool");
+        int rc = launch_p3_tuned(e, 1, p3_args(xh, M, e->head, nullptr, 16, nullptr, 1, e->buf_pool, 1.0f / 16.0f), e->head.wt2, "head + pool");
         if (rc) return rc;
         return launch_p3_tuned(e, 2, p3_args(e->buf_pool, n, e->fc, nullptr, 1, nullptr, 0, d_f32, 0.f, d_u8), e->fc.wt2, "linear + tanh + quantiser");
     }
@@ -1230,8 +1293,8 @@ int forward_device(pb_embedder *e, const uint8_t *d_rgb, int n, uint8_t *d_u8, f
         const std::pair<const void *, long> key(e->head.wt2, tune_bucket(M));
         auto it = e->gemm_cfg.find(key);
         auto launch_head = [&](int nr, int nw) {
-            if (nw == 8) launch_gemm_t<false, 8, 1>(nr, e->stream, e->buf_x[cur], M, e->head, nullptr, 16, nullptr, 1, e->buf_pool, 1.0f / 16.0f);
-            else launch_gemm_t<false, 4, 1>(nr, e->stream, e->buf_x[cur], M, e->head, nullptr, 16, nullptr, 1, e->buf_pool, 1.0f / 16.0f);
+            if (nw == 8) launch_gemm_t<false, 8, 1>(nr, e->stream, xh, M, e->head, nullptr, 16, nullptr, 1, e->buf_pool, 1.0f / 16.0f);
+            else launch_gemm_t<false, 4, 1>(nr, e->stream, xh, M, e->head, nullptr, 16, nullptr, 1, e->buf_pool, 1.0f / 16.0f);
         };
         if (it == e->gemm_cfg.end()) {
             TuneTimer tt(e);
@@ -1268,7 +1331,7 @@ int forward_device(pb_embedder *e, const uint8_t *d_rgb, int n, uint8_t *d_u8, f
         PB_HIP(hipGetLastError());
         return PB_OK;
     }
-    int rc = launch_gemm(e, e->buf_x[cur], M, e->head, nullptr, 1, nullptr, 1, e->buf_e);
+    int rc = launch_gemm(e, xh, M, e->head, nullptr, 1, nullptr, 1, e->buf_e);
     if (rc) return rc;
     hipLaunchKernelGGL(k_avgpool, dim3((1280 + 255) / 256, n), dim3(256), 0, e->stream, e->buf_e, H * W, 1280,
                        1.0f / (float)(H * W), e->buf_pool);
@@ -1607,6 +1670,32 @@ int pb_embed_create(pb_embedder **out, int device, const void *weights_blob, siz
             w = wo;
         }
         max_e = std::max(max_e, h * w * 1280);
+        {   // front sub-batches: the leading blocks up to the last whose depthwise output is >= 128 KB per image (blocks 0-4 at
+            // 128 x 128), in sub-batches whose largest block working set (input + depthwise output + output map) fits ~100 MB
+            size_t hh = h2, ww = w2, fb = 0, per = 0, ws = 0;
+            std::vector<size_t> out_per, ws_per;
+            for (const Block &bl : e->blocks) {
+                const size_t ho = (hh + bl.stride - 1) / bl.stride, wo = (ww + bl.stride - 1) / bl.stride;
+                out_per.push_back(ho * wo * (size_t)bl.cout);
+                ws_per.push_back((hh * ww * (size_t)bl.cin + ho * wo * (size_t)bl.e + ho * wo * (size_t)bl.cout) * sizeof(float));
+                if (ho * wo * (size_t)bl.e * sizeof(float) >= 128 * 1024) fb = out_per.size();
+                hh = ho;
+                ww = wo;
+            }
+            if (const char *v = getenv("PB_FRONT_BLOCKS")) fb = std::min<size_t>((size_t)std::max(0, atoi(v)), e->blocks.size());
+            for (size_t i = 0; i < fb; ++i) ws = std::max(ws, ws_per[i]);
+            per = fb ? out_per[fb - 1] : 0;
+            // measured (profiles/r06_front_sub.txt): at 128 x 128, batch 512, every split is SLOWER than one pass (sub 256: +0.03 ms, 128: +0.16,
+            // 64: +0.54 over 1.98) -- the front kernels are not paced by where their maps come from, and smaller grids pay their fill and
+            // drain more often.  So the default is off; the option stays for other shapes and for A/B runs.
+            (void)ws;
+            int sub = 0;
+            if (const char *v = getenv("PB_FRONT_SUB")) sub = std::max(0, atoi(v));
+            e->front_blocks = fb;
+            e->front_out_per_image = per;
+            e->front_sub = sub;
+            if (fb && (rc = dalloc(e, &e->buf_front, B * per))) return rc;
+        }
         if ((rc = dalloc(e, &e->d_img, B * e->H * e->W * 3))) return rc;
         if ((rc = dalloc(e, &e->buf_x[0], B * max_x)) || (rc = dalloc(e, &e->buf_x[1], B * max_x))) return rc;
         if ((rc = dalloc(e, &e->buf_e, B * max_e)) || (rc = dalloc(e, &e->buf_dw, B * max_dw))) return rc;
@@ -2316,6 +2405,11 @@ int pb_embed_set_option(pb_embedder *e, int option, int64_t value) {
         PB_CHECK(value >= (1 << 20) && value <= (1ll << 31), PB_ERR_INVALID, "PB_OPT_EMBED_STAGE_BYTES: 1 MB .. 2 GB");
         std::lock_guard<std::mutex> lk(e->st_mu);
         e->st_bytes_want = ((size_t)value + 4095) & ~(size_t)4095;  // taken by a slot the next time it is opened empty
+        return PB_OK;
+    }
+    if (option == PB_OPT_EMBED_FRONT_SUB) {
+        PB_CHECK(value >= 0 && value <= (int64_t)e->max_batch, PB_ERR_INVALID, "PB_OPT_EMBED_FRONT_SUB: 0 (off) .. max_batch images");
+        e->front_sub = (int)value;
         return PB_OK;
     }
     return pb::fail(PB_ERR_INVALID, "pb_embed_set_option: unknown option %d", option);

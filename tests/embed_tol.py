@@ -4,12 +4,15 @@ f32 implementations of the 82-layer network differ from an f64 evaluation by ~1.
 largest pre-tanh value) -- measured for torch-CPU, the C oracle and the HIP path alike -- so two f32
 implementations agree to 1e-5 exactly when the image's pre-tanh values stay below ~3.8, i.e. when no output
 saturates (max |f| < 0.999).  Images that drive outputs into saturation (flat white/black, very bright
-images) have proportionally larger rounding noise and get 2e-4.  The u8 quantiser itself is always bit-exact.
+images) have proportionally larger rounding noise: measured against the f64 evaluation of the same weights
+(profiles/r05_embed_f64.txt, test_hip_embedding_is_as_close_to_the_f64_value_as_the_oracle_is) the worst such image is
+1.1e-5 off for the HIP path and 1.3e-5 for the oracle, so two f32 evaluations can be 2.4e-5 apart; they get 5e-5
+(round 5 allowed 2e-4).  The u8 quantiser itself is always bit-exact.
 """
 import numpy as np
 
 TOL = 1e-5
-TOL_SATURATED = 2e-4
+TOL_SATURATED = 5e-5
 
 
 def per_image_tol(ref_f: np.ndarray) -> np.ndarray:

@@ -2,7 +2,7 @@
 (oracle/pb_oracle_effnet.c) and the torch-generated golden fixtures.
 
 Bar (embedding floats are "parity unpinned" against tract, which is absent):
-  floats within 1e-5 of the oracle on images whose outputs do not saturate (2e-4 on saturating ones, e.g.
+  floats within 1e-5 of the oracle on images whose outputs do not saturate (5e-5 on saturating ones, e.g.
   flat black/white, where pre-tanh values are ~10x larger and f32 rounding scales with them -- see
   tests/embed_tol.py); the u8 quantiser (efficientnet.rs:39) bit-exact on
   the GPU's own floats; bytes identical to the oracle's except where the oracle's float sits within the
@@ -93,7 +93,7 @@ def test_hip_embedding_is_as_close_to_the_f64_value_as_the_oracle_is(kind):
       * over the set: max|hip - f64| <= 1.5 max|oracle - f64|, median likewise;
       * per image:    max|hip - f64| <= 1.5 max|oracle - f64| + 1e-6 (the floor is ~8 ulp of an output near 1: what one f32
         evaluation of this network scatters by on an unsaturated image);
-      * the same two over the saturated images alone (where tests/embed_tol.py widens the hip-vs-oracle bar to 2e-4: the
+      * the same two over the saturated images alone (where tests/embed_tol.py widens the hip-vs-oracle bar to 5e-5: the
         measured worst case there is 1.1e-5 for the HIP path and 1.3e-5 for the oracle).
     bench: bench.py's images (the raw synthetic byte stream); parity: synth.synthetic_images (brightness windows; ~16 % saturate)."""
     n = 512
@@ -176,6 +176,22 @@ def test_hash_is_bitwise_independent_of_batch_size():
         u8_s, f_s = emb.embed(sub)
         assert np.array_equal(f_s.view(np.uint32), f[: len(sub)].view(np.uint32)), mb
         assert np.array_equal(u8_s, u8[: len(sub)]), mb
+
+
+@pytest.mark.parametrize("sub", [16, 40])
+def test_front_of_the_network_over_sub_batches_gives_the_same_bits(sub):
+    # PB_OPT_EMBED_FRONT_SUB: stem .. block 4 run `sub` images at a time (ragged last group included), blocks 5-15 and
+    # the tail over the whole batch.  A host-side loop over the same kernels: same bits as the one-pass form.
+    blob = W.synthetic_blob(synth.SEED_WEIGHTS, 128, 128, 256)
+    imgs = synth.synthetic_images(synth.SEED_IMAGES, 900, 100, 128, 128)
+    emb = capi.Embedder(blob, max_batch=128)
+    u8, f = emb.embed(imgs)
+    emb.set_option(capi.PB_OPT_EMBED_FRONT_SUB, sub)
+    u8_s, f_s = emb.embed(imgs)
+    assert np.array_equal(f_s.view(np.uint32), f.view(np.uint32))
+    assert np.array_equal(u8_s, u8)
+    with pytest.raises(capi.PixelboxError):
+        emb.set_option(capi.PB_OPT_EMBED_FRONT_SUB, 129)
 
 
 def test_mlhash_is_deterministic_like_the_reference_test():
