@@ -79,12 +79,17 @@ class Crawler {
 
     // stop everything: waiting threads wake up and leave, recv() returns false once the channel is empty
     void cancel() {
-        std::lock_guard<std::mutex> lk(mu_);
-        cancelled_ = true;
-        cv_files_.notify_all();
-        cv_decoded_.notify_all();
-        cv_out_.notify_all();
-        cv_space_.notify_all();
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            cancelled_ = true;
+            cv_files_.notify_all();
+            cv_decoded_.notify_all();
+            cv_out_.notify_all();
+            cv_space_.notify_all();
+        }
+        // an embed thread parked in pb_embed_stage_close (a decoder that holds a ticket and is slow, or stuck) gets its call back
+        if (staged_decode_)
+            for (const auto &mdl : models_) (void)pb_embed_stage_abort(mdl->raw());
     }
     // message of the first failure on an embed thread ("" = none); the stage is cancelled when one occurs
     std::string error() const {
@@ -107,6 +112,8 @@ class Crawler {
         out_closed_ = false;
         stats_ = Stats{};
         staged_.assign(models_.size(), StagedState{});
+        if (staged_decode_)  // nothing of an earlier run (of this Crawler or of another user of the embedder) joins this run's first batch
+            for (const auto &mdl : models_) check(pb_embed_stage_abort(mdl->raw()));
         next_model_ = 0;
         threads_.emplace_back([this, folders] { glob_thread(folders); });
         for (size_t i = 0; i < num_workers; ++i) threads_.emplace_back([this] { staged_decode_ ? staged_worker() : decode_worker(); });
@@ -215,8 +222,38 @@ class Crawler {
     };
     struct StagedState {
         std::map<uint32_t, std::vector<StagedMeta>> meta;  // generation -> records by position in the batch
-        size_t pending = 0;                                 // images acquired into batches that are not closed yet
+        // images acquired into batches that are not closed yet, PER GENERATION: a worker counts its image after the acquire has
+        // returned, which may be after the embed thread closed that very batch -- a single counter clipped at zero then stays one too
+        // high for ever and the loop never sees `nothing pending`
+        std::map<uint32_t, size_t> pending_gen;
+        uint32_t closed_through = 0;                        // generations <= this one are closed: late counts for them are dropped
         bool want_commit = false;                           // a worker found the open batch full
+        size_t pending() const {
+            size_t t = 0;
+            for (const auto &kv : pending_gen) t += kv.second;
+            return t;
+        }
+        void count(uint32_t gen) {
+            if (gen > closed_through) ++pending_gen[gen];
+        }
+        void closed(uint32_t gen) {
+            closed_through = std::max(closed_through, gen);
+            pending_gen.erase(pending_gen.begin(), pending_gen.upper_bound(gen));
+        }
+    };
+    // whatever happens between a successful acquire and the release (a throwing StagedDecoder -- it is a std::function --, bad_alloc
+    // in the bookkeeping), the ticket goes back: an unreleased ticket parks the embed thread inside pb_embed_stage_close for ever
+    struct TicketGuard {
+        Crawler *c;
+        size_t m = 0;
+        uint64_t ticket = 0;
+        bool armed = false;
+        ~TicketGuard() {
+            if (!armed) return;
+            (void)pb_embed_stage_release(c->models_[m]->raw(), ticket);  // the record of this position stays `not valid`
+            std::lock_guard<std::mutex> lk(c->mu_);
+            c->cv_decoded_.notify_all();
+        }
     };
 
     void staged_worker() {
@@ -236,16 +273,20 @@ class Crawler {
                 uint64_t ticket = 0;
                 bool acquired = false;
                 uint32_t iw = 0, ih = 0;
+                TicketGuard guard{this, m};
                 const PixelAlloc alloc = [&](uint32_t w, uint32_t h) -> uint8_t * {
                     for (;;) {
                         uint8_t *px = nullptr;
+                        if (acquired) return nullptr;  // one image per file: a decoder that asks twice gets no second room
                         const int rc = pb_embed_stage_acquire(models_[m]->raw(), w, h, &px, &ticket);
                         if (rc == PB_OK) {
                             acquired = true;
+                            guard.ticket = ticket;
+                            guard.armed = true;
                             iw = w;
                             ih = h;
                             std::lock_guard<std::mutex> lk(mu_);
-                            ++staged_[m].pending;
+                            staged_[m].count((uint32_t)(ticket >> 32));
                             return px;
                         }
                         if (rc != PB_STAGE_FULL) check(rc);
@@ -276,6 +317,7 @@ class Crawler {
                     }
                 }
                 if (acquired) {
+                    guard.armed = false;
                     check(pb_embed_stage_release(models_[m]->raw(), ticket));
                     std::lock_guard<std::mutex> lk(mu_);
                     cv_decoded_.notify_all();
@@ -297,26 +339,35 @@ class Crawler {
         const Embedder &model = *models_[m];
         std::vector<uint32_t> ws(model.max_batch()), hs(model.max_batch());
         std::vector<const uint8_t *> ptrs(model.max_batch());
+        // Whatever THIS run leaves in the staging (a cancel with an open batch, a failure between close and commit) is discarded on
+        // every way out -- break, return, exception; start_indexing does the same before the workers of the next run exist (not
+        // here: this thread starts beside them, and a worker may already have its room in the first batch).
+        struct StageReset {
+            pb_embedder *e;
+            ~StageReset() { (void)pb_embed_stage_abort(e); }
+        } stage_reset{model.raw()};
         for (;;) {
             {
                 std::unique_lock<std::mutex> lk(mu_);
                 // a batch goes when it is full, when a worker found it full, when the workers are done, or when something has waited 5 ms
                 cv_decoded_.wait_for(lk, std::chrono::milliseconds(5), [&] {
-                    return staged_[m].pending >= max_batch_ || staged_[m].want_commit || decoders_left_ == 0 || cancelled_;
+                    return staged_[m].pending() >= max_batch_ || staged_[m].want_commit || decoders_left_ == 0 || cancelled_;
                 });
                 if (cancelled_) break;
-                if (staged_[m].pending == 0) {
+                if (staged_[m].pending() == 0 && !staged_[m].want_commit) {
                     if (decoders_left_ == 0) break;
                     continue;
                 }
             }
             std::unique_lock<std::recursive_mutex> own(model.exclusive());
             uint32_t n = 0, gen = 0;
-            check(pb_embed_stage_close(model.raw(), &n, &gen, ws.data(), hs.data(), ptrs.data()));
+            const int rc_close = pb_embed_stage_close(model.raw(), &n, &gen, ws.data(), hs.data(), ptrs.data());
+            if (rc_close == PB_STAGE_ABORTED) continue;  // cancel() discarded the staging while this thread waited for the writers
+            check(rc_close);
             std::vector<StagedMeta> metas;
             {
                 std::lock_guard<std::mutex> lk(mu_);
-                staged_[m].pending -= std::min<size_t>(staged_[m].pending, n);
+                if (gen) staged_[m].closed(gen);
                 staged_[m].want_commit = false;
                 auto it = staged_[m].meta.find(gen);
                 if (it != staged_[m].meta.end()) {

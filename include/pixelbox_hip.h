@@ -296,8 +296,8 @@ int pb_embed_batch_images_device(pb_embedder *e, const uint8_t *const *rgb, cons
  *   pb_embed_stage_acquire(e, w, h, &pixels, &ticket)   room for a w x h RGB8 image (rows top to bottom, 3 bytes per pixel, w * 3 per
  *        row) in the batch being filled; thread-safe, any number of workers; PB_STAGE_FULL (> 0, not an error) when the batch cannot
  *        take the image (max_batch images, the slot's bytes -- 48 MB unless PB_OPT_EMBED_STAGE_BYTES says otherwise -- or 256 MB of resize
- *        scratch reached): close + commit it, acquire again.
- *        Blocks while both slots are busy (one closed and not yet committed, the other full).
+ *        scratch reached): close + commit it, acquire again (the reference crawler's workers poll).  The call only BLOCKS when no batch is
+ *        open and the slot whose turn it is has not come back from its commit (or from an abort with writers still in it).
  *   pb_embed_stage_release(e, ticket)                   the pixels are written.
  *   pb_embed_stage_close(e, &n, &generation, widths, heights, pixels)   one thread (the embed thread): no more images join the batch;
  *        waits until every acquired image has been released; returns the batch's images in acquisition order (ticket & 0xFFFF = the
@@ -306,12 +306,20 @@ int pb_embed_batch_images_device(pb_embedder *e, const uint8_t *const *rgb, cons
  *   pb_embed_stage_commit(e, out_u8, &d_out_u8)         the closed batch: ONE transfer of the block, resize_to_fill + network as
  *        pb_embed_batch_images_device (same bits), hashes to out_u8 (host, optional) and in the embedder's own device buffer
  *        (*d_out_u8, valid until the next call on this embedder); returns with the forward pass complete and the slot free again.
+ *   pb_embed_stage_abort(e)                             discards what the staging holds: the batch being filled and a batch closed and
+ *        not yet committed (a batch inside pb_embed_stage_commit is left to that call).  Tickets handed out for them stay releasable
+ *        (and must still be released: a slot with writers in it is free again at its last release); a pb_embed_stage_close blocked on
+ *        such writers returns PB_STAGE_ABORTED (> 0, not an error) with *n = 0.  What a cancelled or failed run must call before the
+ *        embedder's staging is used again: without it a batch closed and never committed fails every later close (PB_ERR_INVALID),
+ *        and an open batch's stale pixels would join the next run's first batch.  Never blocks.
  * Decoders fill one slot while the other is being committed. */
 #define PB_STAGE_FULL 1
+#define PB_STAGE_ABORTED 2
 int pb_embed_stage_acquire(pb_embedder *e, uint32_t w, uint32_t h, uint8_t **pixels, uint64_t *ticket);
 int pb_embed_stage_release(pb_embedder *e, uint64_t ticket);
 int pb_embed_stage_close(pb_embedder *e, uint32_t *n, uint32_t *generation, uint32_t *widths, uint32_t *heights, const uint8_t **pixels);
 int pb_embed_stage_commit(pb_embedder *e, uint8_t *out_u8, const uint8_t **d_out_u8);
+int pb_embed_stage_abort(pb_embedder *e);
 
 /* The same for images of ANY size: efficientnet.rs:19-29 `image_to_tensor` in full -- the image crate's
  * `resize_to_fill(W, H, FilterType::Triangle)` (scale to cover, separable triangle filter through an f32

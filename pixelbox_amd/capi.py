@@ -44,7 +44,7 @@ SYMBOLS = [
     "pb_index_set_option", "pb_index_get_stats",
     "pb_embed_create", "pb_embed_destroy", "pb_embed_info", "pb_embed_batch", "pb_embed_batch_device", "pb_mlhash",
     "pb_mlhash_image", "pb_embed_batch_images", "pb_embed_batch_images_device", "pb_embed_stage_acquire", "pb_embed_stage_release", "pb_embed_stage_close",
-    "pb_embed_stage_commit", "pb_resize_to_fill",
+    "pb_embed_stage_commit", "pb_embed_stage_abort", "pb_resize_to_fill",
     "pb_embed_set_option", "pb_pinned_alloc", "pb_pinned_free", "pb_embed_tune_ms", "pb_embed_get_tuning", "pb_embed_set_tuning", "pb_fill_synthetic", "pb_fill_synthetic_images", "pb_fill_synthetic_scenes",
     "pb_phash_create", "pb_phash_destroy", "pb_phash_image", "pb_phash_batch_images", "pb_phash_small_image",
 ]
@@ -131,6 +131,7 @@ def lib():
         L.pb_embed_stage_release.argtypes = [vp, C.c_uint64]
         L.pb_embed_stage_close.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(vp)]
         L.pb_embed_stage_commit.argtypes = [vp, u8p, C.POINTER(vp)]
+        L.pb_embed_stage_abort.argtypes = [vp]
         L.pb_resize_to_fill.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, u8p]
         L.pb_embed_set_option.argtypes = [vp, C.c_int, C.c_int64]
         L.pb_pinned_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
@@ -514,8 +515,15 @@ class Embedder:
         n, gen = C.c_uint32(0), C.c_uint32(0)
         ws = (C.c_uint32 * self.max_batch)()
         hs = (C.c_uint32 * self.max_batch)()
-        _check(lib().pb_embed_stage_close(self._h, C.byref(n), C.byref(gen), ws, hs, None))
+        rc = lib().pb_embed_stage_close(self._h, C.byref(n), C.byref(gen), ws, hs, None)
+        if rc == 2:  # PB_STAGE_ABORTED: stage_abort took the batch while this call waited for its writers
+            return 0, 0, [], []
+        _check(rc)
         return int(n.value), int(gen.value), list(ws[: n.value]), list(hs[: n.value])
+
+    def stage_abort(self):
+        """Discards the open batch and a batch closed and not committed (a cancelled or failed run calls this)."""
+        _check(lib().pb_embed_stage_abort(self._h))
 
     def stage_commit(self, n: int, host_copy: bool = True):
         """-> (uint8 [n, D] hashes or None, device pointer of the same hashes)"""

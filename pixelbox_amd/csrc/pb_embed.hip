@@ -148,7 +148,8 @@ struct pb_embedder {
         uint8_t *h = nullptr, *d = nullptr;  // pinned host block and its device twin
         size_t cap = 0;
         ResizeDesc *h_desc = nullptr, *d_desc = nullptr;
-        int state = 0;             // 0 free, 1 open (acquire hands out room), 2 closed (waiting for its writers / being committed)
+        int state = 0;             // 0 free, 1 open (acquire hands out room), 2 closed (waiting for its writers / being committed),
+                                   // 3 discarded by pb_embed_stage_abort with writers still in it (free when the last one releases)
         uint32_t n = 0, gen = 0;   // images handed out; generation (part of every ticket of this filling)
         int writers = 0;           // acquired, not yet released
         size_t bytes = 0, tmp = 0;
@@ -161,6 +162,8 @@ struct pb_embedder {
     size_t st_bytes_want = 0;          // PB_OPT_EMBED_STAGE_BYTES (0: STAGE_BYTES)
     int st_open = -1, st_closed = -1;  // slot being filled / slot closed and not yet committed
     uint32_t st_gen = 0;
+    uint32_t st_abort_seq = 0;         // pb_embed_stage_abort calls so far (a close that waits for writers gives up when it changes)
+    bool st_committing = false;        // pb_embed_stage_commit is reading the closed slot (abort leaves that slot to it)
 };
 
 namespace {
@@ -2097,7 +2100,36 @@ int pb_embed_stage_release(pb_embedder *e, uint64_t ticket) {
     std::lock_guard<std::mutex> lk(e->st_mu);
     PB_CHECK(s < 2 && e->st[s].gen == (uint32_t)(ticket >> 32) && e->st[s].state != 0 && e->st[s].writers > 0, PB_ERR_INVALID,
              "pb_embed_stage_release: stale ticket");
-    --e->st[s].writers;
+    if (--e->st[s].writers == 0 && e->st[s].state == 3) {  // the last writer of a discarded batch: the slot is free again
+        e->st[s].state = 0;
+        e->st[s].n = 0;
+    }
+    e->st_cv.notify_all();
+    return PB_OK;
+}
+
+int pb_embed_stage_abort(pb_embedder *e) {
+    PB_CHECK(e, PB_ERR_INVALID, "pb_embed_stage_abort: null embedder");
+    std::lock_guard<std::mutex> lk(e->st_mu);
+    ++e->st_abort_seq;
+    auto discard = [&](int s) {
+        pb_embedder::StageSlot &sl = e->st[s];
+        if (sl.state == 0) return;
+        if (sl.writers > 0) {
+            sl.state = 3;  // its writers still hold pointers into the block: nobody gets room in it before the last release
+        } else {
+            sl.state = 0;
+            sl.n = 0;
+        }
+    };
+    if (e->st_open >= 0) {
+        discard(e->st_open);
+        e->st_open = -1;
+    }
+    if (e->st_closed >= 0 && !e->st_committing) {
+        discard(e->st_closed);
+        e->st_closed = -1;
+    }
     e->st_cv.notify_all();
     return PB_OK;
 }
@@ -2114,7 +2146,9 @@ int pb_embed_stage_close(pb_embedder *e, uint32_t *n, uint32_t *generation, uint
     sl.state = 2;
     e->st_open = -1;
     e->st_closed = s;
-    e->st_cv.wait(lk, [&] { return sl.writers == 0; });
+    const uint32_t seq = e->st_abort_seq;
+    e->st_cv.wait(lk, [&] { return sl.writers == 0 || e->st_abort_seq != seq; });
+    if (e->st_abort_seq != seq) return PB_STAGE_ABORTED;  // pb_embed_stage_abort has taken the batch
     *n = sl.n;
     if (generation) *generation = sl.gen;
     for (uint32_t i = 0; i < sl.n; ++i) {
@@ -2136,6 +2170,7 @@ int pb_embed_stage_commit(pb_embedder *e, uint8_t *out_u8, const uint8_t **d_out
     {
         std::lock_guard<std::mutex> lk(e->st_mu);
         s = e->st_closed;
+        if (s >= 0) e->st_committing = true;
     }
     if (d_out_u8) *d_out_u8 = e->d_out_u8;
     if (s < 0) return PB_OK;
@@ -2184,6 +2219,7 @@ int pb_embed_stage_commit(pb_embedder *e, uint8_t *out_u8, const uint8_t **d_out
     sl.state = 0;
     sl.n = 0;
     e->st_closed = -1;
+    e->st_committing = false;
     e->st_cv.notify_all();
     return rc;
 }

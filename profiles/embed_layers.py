@@ -36,7 +36,7 @@ def main(path, batch):
     tail_gemms = 0
     tot_us = tot_fl = tot_gap = 0.0
     by = {}
-    print(f"{'kernel':38s} {'block':>5s} {'us':>8s} {'GFLOP':>8s} {'TFLOP/s':>8s} {'of peak':>7s} {'gap us':>7s}")
+    print(f"{'kernel':38s} {'block':>5s} {'us':>8s} {'GFLOP':>8s} {'TFLOP/s':>8s} {'of peak':>7s} {'gap us':>7s} {'MB':>7s}")
     prev_end = None
     for r in rows[s : s + 90]:
         n = r["Kernel_Name"]
@@ -46,11 +46,14 @@ def main(path, batch):
         fam = short.split("<")[0]
         dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1000
         fl, label = 0.0, ""
+        by_ = 0.0  # algorithmic activation bytes per image this launch reads + writes (f32 maps; weights not counted)
         if fam in ("k_stem", "k_stem_dw"):
             fl, label = stem_fl, "stem"
+            by_ = 128 * 128 * 3 + 64 * 64 * 32 * 4
             if fam == "k_stem_dw":  # + the first block's depthwise
                 b, hh, ww, ho, wo = geo[0]
                 fl += 2 * ho * wo * b.kernel * b.kernel * b.expanded
+                by_ = 128 * 128 * 3 + ho * wo * b.expanded * 4
         elif bi < len(geo):
             b, hh, ww, ho, wo = geo[bi]
             label = f"b{bi}"
@@ -61,24 +64,31 @@ def main(path, batch):
             gated = "true" in short
             if fam == "k_gemm_p3":  # <NR, MR, GATE, NW, EPI, DIRECT, KT>: the project layers are the gated ones
                 gated = short.split("<")[1].split(",")[2].strip() == "true"
+            resid = b.stride == 1 and b.cin == b.cout
             if fam == "k_block_small":
                 fl = f_exp + f_dw + f_se + f_proj
+                by_ = 4 * (hh * ww * b.cin + ho * wo * b.cout)
                 bi += 1
             elif fam in ("k_front_band", "k_front_roll", "k_mbconv_small"):
                 fl = f_exp + f_dw
+                by_ = 4 * (hh * ww * b.cin + ho * wo * b.expanded)
             elif fam in ("k_dwconv", "k_dwconv_roll", "k_dwconv_lds"):
                 fl = f_dw
+                by_ = 4 * (hh * ww * b.expanded + ho * wo * b.expanded)
             elif fam == "k_se":
                 fl = f_se
             elif fam == "k_gemm_stream" or (fam in ("k_gemm1x1", "k_gemm_t", "k_gemm_p3", "k_gemm_thin") and gated):
                 fl = f_proj
+                by_ = 4 * (ho * wo * b.expanded + ho * wo * b.cout * (2 if resid else 1))
                 bi += 1
             elif fam in ("k_gemm1x1", "k_gemm_t", "k_gemm_p3", "k_gemm_thin"):
                 fl = f_exp  # the expand GEMM of an unfused front
+                by_ = 4 * (hh * ww * b.cin + hh * ww * b.expanded)
         else:
             label = "tail"
             if fam in ("k_gemm1x1", "k_gemm_t", "k_gemm_p3"):
                 fl = 2 * 16 * 320 * 1280 if tail_gemms == 0 else 2 * 1280 * 256  # head conv (+ pool), then the Linear
+                by_ = 4 * (16 * 320 + 1280) if tail_gemms == 0 else 4 * (1280 + 256) + 256
                 tail_gemms += 1
         fl *= batch
         tot_us += dur
@@ -88,7 +98,7 @@ def main(path, batch):
         gap = (int(r["Start_Timestamp"]) - prev_end) / 1000 if prev_end is not None else 0.0  # idle time since the previous kernel ended
         prev_end = int(r["End_Timestamp"])
         tot_gap += gap
-        print(f"{short[:38]:38s} {label:>5s} {dur:8.1f} {fl / 1e9:8.2f} {tf:8.1f} {tf / PEAK_TF:7.3f} {gap:7.1f}")
+        print(f"{short[:38]:38s} {label:>5s} {dur:8.1f} {fl / 1e9:8.2f} {tf:8.1f} {tf / PEAK_TF:7.3f} {gap:7.1f} {by_ * batch / 1e6:7.1f}")
         if "k_tanh_quant" in n or ("k_gemm_t" in n and short.rstrip(">").endswith(", 2")):
             break
         if fam == "k_gemm_p3" and short.split("<")[1].split(",")[4].strip() == "2":  # the Linear + tanh + quantiser epilogue

@@ -7,17 +7,21 @@ saturates (max |f| < 0.999).  Images that drive outputs into saturation (flat wh
 images) have proportionally larger rounding noise: measured against the f64 evaluation of the same weights
 (profiles/r05_embed_f64.txt, test_hip_embedding_is_as_close_to_the_f64_value_as_the_oracle_is) the worst such image is
 1.1e-5 off for the HIP path and 1.3e-5 for the oracle, so two f32 evaluations can be 2.4e-5 apart; they get 5e-5
-(round 5 allowed 2e-4).  The u8 quantiser itself is always bit-exact.
+(round 5 allowed 2e-4 for all of them).  One class keeps 2e-4: images that drive an output to exactly +-1.0 in f32
+(pre-tanh values beyond ~9: the flat black / flat white fixtures, 14.2 on flat black) -- there torch-CPU and the C oracle, two
+f32 CPU evaluations of the same weights, already differ by 1.05e-4 (tests/golden/embed_128_256.npz, image 3), on
+outputs near |x| ~ 1 whose inputs carry 14x the rounding noise.  The u8 quantiser itself is always bit-exact.
 """
 import numpy as np
 
 TOL = 1e-5
-TOL_SATURATED = 5e-5
+TOL_SATURATED = 5e-5   # some output >= 0.999
+TOL_PINNED = 2e-4      # some output exactly +-1.0 in f32
 
 
 def per_image_tol(ref_f: np.ndarray) -> np.ndarray:
-    sat = np.abs(ref_f).max(axis=1) >= 0.999
-    return np.where(sat, TOL_SATURATED, TOL)
+    top = np.abs(ref_f).max(axis=1)
+    return np.where(top >= 1.0, TOL_PINNED, np.where(top >= 0.999, TOL_SATURATED, TOL))
 
 
 def assert_embeddings_close(f: np.ndarray, ref_f: np.ndarray):

@@ -215,6 +215,37 @@ def test_crawler_stage_and_query_by_file(tmp_path, staged):
     assert lines[-1] == "missing 0"
 
 
+def test_staged_crawler_survives_a_throwing_decoder_a_cancel_and_restarts_clean(tmp_path):
+    """a StagedDecoder that throws with a ticket in hand must not park the embed thread in pb_embed_stage_close; a
+    cancelled or failed run must leave the embedder's staging usable (pb_embed_stage_abort), with no stale pixels in the next
+    run's first batch.  The program runs under a timeout: a hang is the failure this test is about.  crawler.rs:68-119."""
+    rng = np.random.default_rng(11)
+    blob = W.synthetic_blob(synth.SEED_WEIGHTS, 64, 64, 32)
+    (tmp_path / "w.pbxw").write_bytes(blob)
+    good, bad = tmp_path / "good", tmp_path / "bad"
+    good.mkdir()
+    bad.mkdir()
+    for i in range(45):
+        img = rng.integers(0, 256, size=(64 + i % 7, 64 + i % 5, 3), dtype=np.uint8)
+        _write_pnm(good / f"g{i:02d}.pnm", img)
+        _write_pnm(bad / f"b{i:02d}.pnm", rng.integers(0, 256, size=(70, 66, 3), dtype=np.uint8))
+    exe = tmp_path / "crawler_faults_demo"
+    libdir = os.path.dirname(capi.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "crawler_faults_demo.cpp"), "-o", str(exe),
+                           "-L", libdir, "-lpixelbox_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
+    out = tmp_path / "out.txt"
+    subprocess.run([str(exe), str(tmp_path / "w.pbxw"), str(good), str(bad), str(out)], check=True, timeout=240)
+    lines = out.read_text().splitlines()
+    assert lines[0] == "plain 45"
+    assert lines[1].startswith("poisoned error=1 ")
+    assert lines[2] == "restart0 error=0 same=1 n=45"
+    assert lines[3] == "cancelled0 error=0"
+    assert lines[4] == "restart1 error=0 same=1 n=45"
+    assert lines[5] == "cancelled1 error=0"
+    assert lines[6] == "abi second_close=-1 after_abort=0 n=0 release_late=0"
+
+
 @pytest.mark.parametrize("devices", ["0", "0,0", "0,0,0", "0,0,0,0,0,0,0,0"])
 def test_sharded_engine_ingests_device_to_device_with_an_embed_thread_per_shard(tmp_path, devices):
     """VERDICT r2 row x1 (BASELINE configs[4], product form): ONE process, a shard + an embedder per entry of the device list,
