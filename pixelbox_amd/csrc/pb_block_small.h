@@ -41,6 +41,7 @@ namespace pbe {
 
 struct BlockW {
     const float *we2;   // expand weights, fragments by k-step (Gemm::wt4): [CIN / 16][E / 16][64 lanes][4 e]
+    const void *we3;    // P3 expand layers (pb_gemm_p3.h): the three bf16 planes in fragment order, [CIN / 32][E / 16][3][64 lanes] x 16 B; else null
     const float *be;    // [E] expand bias
     const float *dwc;   // [E][KS * KS rounded up to 4] depthwise taps per channel
     const float *bd;    // [E] depthwise bias
@@ -72,7 +73,12 @@ struct BlockGeom {
 
 // ABL (timing experiments only, results invalid): 1 no expand MFMAs, 2 no filter taps, 4 no squeeze-excite, 8 no project MFMAs,
 // 16 the expand / project weights of the first group / chunk re-read throughout (no L2 traffic for them)
-template <int KS, int CIN, int E, int COUT, int HW, int G, int SP, bool RESID, int ABL = 0, bool P3 = false>
+// P3E (round 6): the EXPAND layer is a P3 layer too (blocks 12-15: K = 192).  The block input is split ONCE, in the prologue, into the
+// three bf16 planes of its 6 k-steps (a lane keeps 2 row tiles x 6 steps x 12 registers: the split costs nothing per channel group --
+// the consumer-side split the producers' pre-split planes of round 5's experiment could not give), a group's expand is 72 bf16 MFMAs
+// per SIMD (1 152 clocks) where the f32 chain took 96 f32 MFMAs (3 072), and the weight planes come straight from memory through a
+// three-step register ring.  Arithmetic: p3_step per k-step, steps ascending -- the same bits as k_gemm_p3 on this layer.
+template <int KS, int CIN, int E, int COUT, int HW, int G, int SP, bool RESID, int ABL = 0, bool P3 = false, bool P3E = false>
 __global__ __launch_bounds__(512) void k_block_small(const float *__restrict__ x, BlockW w, float *__restrict__ out, int n_img) {
     using GEO = BlockGeom<KS, CIN, E, COUT, HW, G, SP, P3>;
     constexpr int P = GEO::P, R = GEO::R, PT = GEO::PT, GC = GEO::GC, QG = GEO::QG, NG = GEO::NG, KC = GEO::KC, NT = GEO::NT;
@@ -105,23 +111,61 @@ __global__ __launch_bounds__(512) void k_block_small(const float *__restrict__ x
     // NEXT group right after its last MFMA of this group (in place: the requests spread over the MFMA phase and have the
     // epilogue, both barriers and the filter phase to land).
     constexpr int PTW = PT * GC / 4;
+    constexpr int KS32 = CIN / 32;  // P3E: k-steps of 32
+    static_assert(!P3E || (CIN % 32 == 0 && KS32 % 3 == 0), "P3E: whole k-steps, whole turns of the three-slot weight ring");
     const bool ew = wave < 4;
     const int ect = wave % GC, ept0 = (wave % 4) / GC * PTW;
-    f32x4 xb[PTW][KC];
+    f32x4 xb[P3E ? 1 : PTW][P3E ? 1 : KC];
+    P3Act xp[P3E ? PTW : 1][P3E ? KS32 : 1];
+    if constexpr (P3E) {
+        if (ew) {
 #pragma unroll
-    for (int pt = 0; pt < PTW; ++pt) {
-        const int erow = 16 * (ept0 + pt) + li;
-        int eimg = b0 + erow / P;
-        if (eimg >= n_img) eimg = n_img - 1;  // a padded slot repeats the last image, stores nothing
-        const float *xrow = x + ((size_t)eimg * P + erow % P) * CIN + 4 * kk;
+            for (int pt = 0; pt < PTW; ++pt) {
+                const int erow = 16 * (ept0 + pt) + li;
+                int eimg = b0 + erow / P;
+                if (eimg >= n_img) eimg = n_img - 1;  // a padded slot repeats the last image, stores nothing
+                const float *xrow = x + ((size_t)eimg * P + erow % P) * CIN + 8 * kk;
+                f32x4 xr[KS32][2];
 #pragma unroll
-        for (int s = 0; s < KC; ++s) xb[pt][s] = *reinterpret_cast<const f32x4 *>(xrow + 16 * s);
+                for (int s = 0; s < KS32; ++s) {
+                    xr[s][0] = *reinterpret_cast<const f32x4 *>(xrow + 32 * s);
+                    xr[s][1] = *reinterpret_cast<const f32x4 *>(xrow + 32 * s + 4);
+                }
+#pragma unroll
+                for (int s = 0; s < KS32; ++s) xp[pt][s] = p3_split8(xr[s][0], xr[s][1]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int pt = 0; pt < PTW; ++pt) {
+            const int erow = 16 * (ept0 + pt) + li;
+            int eimg = b0 + erow / P;
+            if (eimg >= n_img) eimg = n_img - 1;  // a padded slot repeats the last image, stores nothing
+            const float *xrow = x + ((size_t)eimg * P + erow % P) * CIN + 4 * kk;
+#pragma unroll
+            for (int s = 0; s < KC; ++s) xb[pt][s] = *reinterpret_cast<const f32x4 *>(xrow + 16 * s);
+        }
     }
-    f32x4 aw[KC], bev;
+    f32x4 aw[P3E ? 1 : KC], bev;
     const float *awp = w.we2 + ((size_t)ect * 64 + lane) * 4;  // + (s * ET + g * GC) * 256
-    if (ew) {
+    // P3E: plane p of (k-step s, tile t) is fragment ((s * ET + t) * 3 + p) of 64 lanes x 16 bytes; the ring holds steps s, s + 1, s + 2
+    // (slot = s % 3); steps 0 and 1 of the first group are requested here, every later step two steps ahead of its MFMAs
+    u32x4 wr[P3E ? 3 : 1][3];
+    const u32x4 *wq3 = reinterpret_cast<const u32x4 *>(w.we3) + lane;
+    auto load_w3 = [&](int s, int tile, auto slotc) __attribute__((always_inline)) {
+        constexpr int SLOT = decltype(slotc)::value;
+        const u32x4 *src = wq3 + ((size_t)s * ET + tile) * 192;
 #pragma unroll
-        for (int s = 0; s < KC; ++s) aw[s] = *reinterpret_cast<const f32x4 *>(awp + (size_t)s * ET * 256);
+        for (int pl = 0; pl < 3; ++pl) wr[SLOT][pl] = src[pl * 64];
+    };
+    if (ew) {
+        if constexpr (P3E) {
+            load_w3(0, ect, std::integral_constant<int, 0>{});
+            load_w3(1, ect, std::integral_constant<int, 1>{});
+        } else {
+#pragma unroll
+            for (int s = 0; s < KC; ++s) aw[s] = *reinterpret_cast<const f32x4 *>(awp + (size_t)s * ET * 256);
+        }
         bev = *reinterpret_cast<const f32x4 *>(w.be + 16 * ect + 4 * kk);
     }
     // ---- depthwise role: wave = (image dimg, output row dpy), lane = (channel dc of the group, strip dh of 4 output pixels).
@@ -152,6 +196,34 @@ __global__ __launch_bounds__(512) void k_block_small(const float *__restrict__ x
             f32x4 acc[PTW];
 #pragma unroll
             for (int pt = 0; pt < PTW; ++pt) acc[pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if constexpr (P3E) {
+                auto step3 = [&](auto sc) __attribute__((always_inline)) {
+                    constexpr int S = decltype(sc)::value, SLOT = S % 3, SN = S + 2;
+                    // the step two ahead (of the next group past this group's last) into the slot step S - 1 has just left
+                    if constexpr (SN < KS32) load_w3(SN, g * GC + ect, std::integral_constant<int, SN % 3>{});
+                    else load_w3(SN - KS32, gn + ect, std::integral_constant<int, SN % 3>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (!(ABL & 1) || S == 0) {
+#define PB_BLK_EPASS(WP_, AP_) \
+    _Pragma("unroll") for (int pt = 0; pt < PTW; ++pt) acc[pt] = p3_mfma(wr[SLOT][WP_], xp[pt][S].AP_, acc[pt]);
+                        PB_BLK_EPASS(2, h)
+                        PB_BLK_EPASS(1, m)
+                        PB_BLK_EPASS(1, h)
+                        PB_BLK_EPASS(0, l)
+                        PB_BLK_EPASS(0, m)
+                        PB_BLK_EPASS(0, h)
+#undef PB_BLK_EPASS
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                static_assert(KS32 == 6, "P3E: six k-steps (CIN = 192)");
+                step3(std::integral_constant<int, 0>{});
+                step3(std::integral_constant<int, 1>{});
+                step3(std::integral_constant<int, 2>{});
+                step3(std::integral_constant<int, 3>{});
+                step3(std::integral_constant<int, 4>{});
+                step3(std::integral_constant<int, 5>{});
+            } else {
 #pragma unroll
             for (int s = 0; s < ((ABL & 1) ? 1 : KC); ++s) {
 #pragma unroll
@@ -167,6 +239,7 @@ __global__ __launch_bounds__(512) void k_block_small(const float *__restrict__ x
                 __builtin_amdgcn_sched_barrier(0);
                 aw[s] = *reinterpret_cast<const f32x4 *>(awp + ((size_t)s * ET + gn) * 256);
                 __builtin_amdgcn_sched_barrier(0);
+            }
             }
             stamp(2);
             const f32x4 bq = bev;

@@ -114,7 +114,7 @@ struct pb_embedder {
     unsigned *d_se_cnt = nullptr;  // [max_batch] arrival counters of the squeeze-excite tails (zero between launches)
     bool fold_se = false;          // PB_FOLD_SE=1: the gates of the first six blocks come from the producing kernels' tails instead of k_se
                                    // launches (measured: +0.04 ms per batch-512 forward and per batch-1 forward -- see SeTail; off by default)
-    bool block_attr_set[2] = {false, false};  // k_block_small's LDS size attribute requested (5 x 5 residual form, 3 x 3 / 320 form)
+    bool block_attr_set[4] = {false, false, false, false};  // k_block_small's LDS size attribute requested (5 x 5 residual form, 3 x 3 / 320 form)
     bool no_block_fusion = false;  // PB_NO_BLOCK_FUSION: the 4 x 4 blocks as front + k_se + project GEMM (A/B runs)
     bool no_tail_fusion = false;   // PB_NO_TAIL_FUSION: head conv, k_avgpool, FC GEMM and k_tanh_quant as four launches (A/B runs)
     bool no_gemm_stream = false;   // PB_NO_GEMM_STREAM: leave k_gemm_stream out of the per-layer timing loops (A/B runs)
@@ -122,6 +122,7 @@ struct pb_embedder {
     bool no_band = false, force_band = false;  // PB_NO_BAND / PB_FORCE_BAND: leave out / always take the LDS-ring front kernel where it applies (A/B runs, bit comparisons)
     int tune_pick = 0;    // PB_TUNE_PICK: 0 fastest candidate (default); 1 slowest; 2 a pseudo-random one -- test hook: every form must give the same bits
     uint32_t tune_rng = 12345u;
+    int p3e_min_k = 192;  // p3e_layer(): the expand layers of blocks 12-15 are P3 layers too; PB_P3E_MIN_K, PB_NO_P3E (PB_NO_P3 switches both off)
     int p3_min_k = 240;   // p3_layer(): the project layers of blocks 5-15, the head and the Linear are P3 layers (pb_gemm_p3.h); PB_P3_MIN_K, PB_NO_P3
     std::map<std::pair<const void *, long>, std::pair<int, int>> gemm_cfg;  // (layer weights, rows) -> (MR, NR), measured; MR < 0: eight-wave form
     std::map<std::pair<const void *, long>, DwGeom> dw_cfg;
@@ -278,6 +279,9 @@ int make_gemm(pb_embedder *e, Gemm *g, const float *w, const float *b, int N, in
 // tile's own matrix instructions (the 40-column project of block 4 is bound by its 126 MB of activations either way and ran
 // 44 us as a P3 layer against 39 us on the f32 chain).
 bool p3_layer(const pb_embedder *e, int K, int N) { return K >= e->p3_min_k && K % 8 == 0 && (N + 15) / 16 >= 5; }
+// EXPAND layers as P3 layers (round 6): whole k-steps of 32 and K >= 192 -- the 192 -> 1152 expands of blocks 12-15, whose f32 chain was
+// 38 % of the whole-block kernel (k_block_small: the block input is split once per workgroup; pb_block_small.h, P3E).
+bool p3e_layer(const pb_embedder *e, int K, int N) { return K >= e->p3e_min_k && K % 32 == 0 && (N + 15) / 16 >= 5; }
 
 size_t blob_floats(int D) {
     size_t n = 32 * 27 + 32;
@@ -348,7 +352,7 @@ int load_weights(pb_embedder *e, const uint8_t *blob, size_t len) {
             bl.residual = bl.stride == 1 && bl.cin == bl.cout;
             const int E = bl.e, S = bl.sq, KK = st.k * st.k;
             if (bl.has_expand) {
-                if ((rc = make_gemm(e, &bl.expand, p, p + (size_t)E * bl.cin, E, bl.cin, false, bl.stride == 1))) return rc;
+                if ((rc = make_gemm(e, &bl.expand, p, p + (size_t)E * bl.cin, E, bl.cin, p3e_layer(e, bl.cin, E), bl.stride == 1))) return rc;
                 p += (size_t)E * bl.cin + E;
             }
             {  // dw [E][k][k] -> [k*k][E]
@@ -803,6 +807,7 @@ SeTail se_tail(pb_embedder *e, const Block &bl, int Ho, int Wo) {
 // ---- fused MBConv front (expand + depthwise in one kernel, expanded rows in registers) -------------------------
 bool front_eligible(const Block &bl) {
     const int kc = bl.expand.Kpad / 16;
+    if (bl.expand.p3) return false;  // k_front_roll expands on the f32 chain
     if (!bl.has_expand || bl.e % 48 || bl.expand.Kpad % 16 || bl.cin % 4) return false;
     return (bl.k == 3 && bl.stride == 2 && (kc == 1 || kc == 3)) || (bl.k == 3 && bl.stride == 1 && kc == 2) ||
            (bl.k == 5 && bl.stride == 2 && kc == 2) || (bl.k == 5 && bl.stride == 1 && kc == 3);
@@ -843,6 +848,7 @@ int launch_front(pb_embedder *e, const Block &bl, int cfg, const float *x, int B
 // ---- fused MBConv front for small maps (k_mbconv_small): cfg = 0x1000 + 256 * mr + 16 * nr + 8 * regs + log2(groups per workgroup)
 bool small_eligible(const Block &bl, int H, int W, int nr, int mr) {
     const int P = H * W;
+    if (bl.expand.p3) return false;  // k_mbconv_small expands on the f32 chain
     if (!bl.has_expand || H != W || bl.e % (16 * nr) || bl.expand.Kpad % 16 || bl.cin % 4) return false;
     if (!((P == 256 && mr == 4) || (P == 64 && mr == 1) || (P == 16 && mr == 1))) return false;  // two row tiles per wave never won
     if (P == 256) return (bl.k == 5 && bl.stride == 1) || (bl.k == 3 && bl.stride == 2);
@@ -910,7 +916,7 @@ struct BandShape {
 const BandShape BAND_SHAPES[] = {{3, 2, 16, 4, 2}, {3, 1, 24, 2, 2}, {5, 2, 24, 2, 4}, {5, 1, 40, 1, 4}, {3, 2, 40, 1, 8}};
 
 const BandShape *band_shape(const Block &bl, int H, int W) {
-    if (!bl.has_expand || !bl.dw_wq || bl.e % 16 || H != W) return nullptr;
+    if (!bl.has_expand || !bl.dw_wq || bl.e % 16 || H != W || bl.expand.p3) return nullptr;
     for (const BandShape &bs : BAND_SHAPES)
         if (bs.ks == bl.k && bs.s == bl.stride && bs.cin == bl.cin && bs.wt * 16 == W) return &bs;
     return nullptr;
@@ -1062,17 +1068,18 @@ int run_front(pb_embedder *e, const Block &bl, const float *x, int n, int H, int
 
 // forward for n images already on the device; results to device buffers
 // ---- a whole MBConv block of a 4 x 4 map in one kernel (k_block_small, pb_block_small.h)
-template <int KS, int CIN, int E, int COUT, int HW, int G, int SP, bool RESID, bool P3>
+template <int KS, int CIN, int E, int COUT, int HW, int G, int SP, bool RESID, bool P3, bool P3E = false>
 int launch_block_t(pb_embedder *e, const Block &bl, const float *x, int n, float *out) {
     using GEO = BlockGeom<KS, CIN, E, COUT, HW, G, SP, P3>;
-    auto kern = k_block_small<KS, CIN, E, COUT, HW, G, SP, RESID, 0, P3>;
+    auto kern = k_block_small<KS, CIN, E, COUT, HW, G, SP, RESID, 0, P3, P3E>;
     static_assert(GEO::LDS_BYTES <= 160 * 1024, "one CU's LDS");
-    if (!e->block_attr_set[RESID ? 0 : 1]) {  // once per embedder and instantiation (the attribute is per device function and context)
+    bool &attr_set = e->block_attr_set[(RESID ? 0 : 1) + (P3E ? 2 : 0)];
+    if (!attr_set) {  // once per embedder and instantiation (the attribute is per device function and context)
         PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEO::LDS_BYTES));
-        e->block_attr_set[RESID ? 0 : 1] = true;
+        attr_set = true;
     }
     BlockW w{};
-    w.we2 = bl.expand.wt4; w.be = bl.expand.bias; w.dwc = bl.dw_wc; w.bd = bl.dw_b;
+    w.we2 = bl.expand.wt4; w.we3 = bl.expand.wt3; w.be = bl.expand.bias; w.dwc = bl.dw_wc; w.bd = bl.dw_b;
     w.w1 = bl.se_w1; w.b1 = bl.se_b1; w.w2t = bl.se_w2t; w.b2 = bl.se_b2;
     w.wp2 = bl.project.wt4; w.wp3 = bl.project.wt3; w.bp = bl.project.bias; w.nt16 = bl.project.Npad / 16;
     w.range_slot = e->buf_part - 1;
@@ -1084,7 +1091,7 @@ int launch_block_t(pb_embedder *e, const Block &bl, const float *x, int n, float
 // 0: not a shape the fused kernel is built for
 int block_shape(const pb_embedder *e, const Block &bl, int H, int W) {
     if (e->no_block_fusion || !bl.has_expand || bl.stride != 1 || !bl.expand.wt4 || !bl.project.wt4 || !bl.dw_wc) return 0;
-    if (bl.expand.p3) return 0;  // the whole-block kernel expands on the f32 MFMA
+    if (bl.expand.p3 && !bl.project.p3) return 0;  // (a combination only an A/B switch produces: not instantiated)
     if (H == 4 && W == 4 && bl.cin == 192 && bl.e == 1152 && bl.sp == 48) {
         if (bl.k == 5 && bl.cout == 192 && bl.residual) return 1;
         if (bl.k == 3 && bl.cout == 320 && !bl.residual) return 2;
@@ -1094,10 +1101,17 @@ int block_shape(const pb_embedder *e, const Block &bl, int H, int W) {
 
 int launch_block(pb_embedder *e, const Block &bl, int shape, const float *x, int n, float *out) {
     // the project phase follows the layer's arithmetic (P3 or the f32 chain)
-    if (shape == 1) return bl.project.p3 ? launch_block_t<5, 192, 1152, 192, 4, 2, 48, true, true>(e, bl, x, n, out)
-                                         : launch_block_t<5, 192, 1152, 192, 4, 2, 48, true, false>(e, bl, x, n, out);
-    if (shape == 2) return bl.project.p3 ? launch_block_t<3, 192, 1152, 320, 4, 2, 48, false, true>(e, bl, x, n, out)
-                                         : launch_block_t<3, 192, 1152, 320, 4, 2, 48, false, false>(e, bl, x, n, out);
+    // the expand and project phases follow their layers' arithmetic (P3 or the f32 chain)
+    if (shape == 1) {
+        if (bl.expand.p3) return launch_block_t<5, 192, 1152, 192, 4, 2, 48, true, true, true>(e, bl, x, n, out);
+        return bl.project.p3 ? launch_block_t<5, 192, 1152, 192, 4, 2, 48, true, true>(e, bl, x, n, out)
+                             : launch_block_t<5, 192, 1152, 192, 4, 2, 48, true, false>(e, bl, x, n, out);
+    }
+    if (shape == 2) {
+        if (bl.expand.p3) return launch_block_t<3, 192, 1152, 320, 4, 2, 48, false, true, true>(e, bl, x, n, out);
+        return bl.project.p3 ? launch_block_t<3, 192, 1152, 320, 4, 2, 48, false, true>(e, bl, x, n, out)
+                             : launch_block_t<3, 192, 1152, 320, 4, 2, 48, false, false>(e, bl, x, n, out);
+    }
     return PB_ERR_INTERNAL;
 }
 
@@ -1627,7 +1641,9 @@ int pb_embed_create(pb_embedder **out, int device, const void *weights_blob, siz
     e->device = device;
     e->max_batch = max_batch;
     if (const char *pk = getenv("PB_P3_MIN_K")) e->p3_min_k = atoi(pk);  // A/B runs; the default is part of the arithmetic's definition
-    if (getenv("PB_NO_P3")) e->p3_min_k = 1 << 30;
+    if (const char *pk = getenv("PB_P3E_MIN_K")) e->p3e_min_k = atoi(pk);
+    if (getenv("PB_NO_P3E")) e->p3e_min_k = 1 << 30;
+    if (getenv("PB_NO_P3")) e->p3_min_k = e->p3e_min_k = 1 << 30;
     if (const char *tp = getenv("PB_TUNE_PICK")) e->tune_pick = atoi(tp);
     if (const char *tt = getenv("PB_TRACE_TUNE")) e->trace_tune = tt[0] == '3' ? 3 : (tt[0] == '2' ? 2 : 1);  // 3: + host-side staging times
     e->no_stem_fusion = getenv("PB_NO_STEM_FUSION") != nullptr;
