@@ -180,6 +180,151 @@ __global__ __launch_bounds__(512) void k_block_small(const float *__restrict__ x
     float *ddst = s_dwo + (dimg * P + dpy * HW + 4 * dh) * DP + dc;  // + px * DP + CH * g
     float *ewin = s_scr + (16 * ept0 + li) * WP + 16 * ect + 4 * kk;  // + 16 pt * WP
     stamp(0);
+    if constexpr (P3E) {
+        // ---- the group loop as a two-stage pipeline (round 6): in turn `it` waves 0-3 EXPAND group it while waves 4-7 FILTER group it - 1;
+        // one barrier per turn.  (The serial form -- expand by four waves, barrier, filter by eight, barrier -- left the matrix pipe idle
+        // during every filter and waves 4-7 idle during every expand: 4.7 k clocks per group of which 2.3 k expand; profiles/r06_block_small.txt.)
+        // No second window buffer is needed: group g's window lives in dwo's columns of group g + 1 (pitch DP; free until filter g + 1
+        // writes them, by which time filter g has read it), the last group's in the scratch window (pitch WP).  Turn `it` then touches:
+        // expand -> columns of it + 1; filter -> reads columns of it, writes columns of it - 1: disjoint.
+        // Each role has a loop of its own (NG + 1 turns and barriers each): in one loop with a branch per turn the expand role's 180
+        // resident registers (input planes, weight ring) counted as live through the filter role's code too -- 61 spills.
+        if (ew) {
+            for (int it = 0; it <= NG; ++it) {
+                if (it < NG) {
+                    const int g = it;
+                    const int gn = ((ABL & 16) ? 0 : (g + 1 < NG ? g + 1 : g)) * GC;  // ABL 16: every group re-reads the first group's weights
+                    float *const wbase = g + 1 < NG ? s_dwo + CH * (g + 1) : s_scr;
+                    const int wpitch = g + 1 < NG ? DP : WP;
+                    f32x4 acc[PTW];
+#pragma unroll
+                    for (int pt = 0; pt < PTW; ++pt) acc[pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    auto step3 = [&](auto sc) __attribute__((always_inline)) {
+                        constexpr int S = decltype(sc)::value, SLOT = S % 3, SN = S + 2;
+                        // the step two ahead (of the next group past this group's last) into the slot step S - 1 has just left
+                        if constexpr (SN < KS32) load_w3(SN, g * GC + ect, std::integral_constant<int, SN % 3>{});
+                        else load_w3(SN - KS32, gn + ect, std::integral_constant<int, SN % 3>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (!(ABL & 1) || S == 0) {
+#define PB_BLK_EPASS(WP_, AP_) \
+    _Pragma("unroll") for (int pt = 0; pt < PTW; ++pt) acc[pt] = p3_mfma(wr[SLOT][WP_], xp[pt][S].AP_, acc[pt]);
+                            PB_BLK_EPASS(2, h)
+                            PB_BLK_EPASS(1, m)
+                            PB_BLK_EPASS(1, h)
+                            PB_BLK_EPASS(0, l)
+                            PB_BLK_EPASS(0, m)
+                            PB_BLK_EPASS(0, h)
+#undef PB_BLK_EPASS
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    };
+                    static_assert(KS32 == 6, "P3E: six k-steps (CIN = 192)");
+                    step3(std::integral_constant<int, 0>{});
+                    step3(std::integral_constant<int, 1>{});
+                    step3(std::integral_constant<int, 2>{});
+                    step3(std::integral_constant<int, 3>{});
+                    step3(std::integral_constant<int, 4>{});
+                    step3(std::integral_constant<int, 5>{});
+                    stamp(2);
+                    const f32x4 bq = bev;
+                    bev = *reinterpret_cast<const f32x4 *>(w.be + 16 * (gn + ect) + 4 * kk);
+                    float *ew2 = wbase + (16 * ept0 + li) * wpitch + 16 * ect + 4 * kk;
+#pragma unroll
+                    for (int pt = 0; pt < PTW; ++pt) {
+                        f32x4 v = acc[pt];
+                        v.x = silu_f(v.x + bq.x); v.y = silu_f(v.y + bq.y); v.z = silu_f(v.z + bq.z); v.w = silu_f(v.w + bq.w);
+                        *reinterpret_cast<f32x4 *>(ew2 + 16 * pt * wpitch) = v;
+                    }
+                    stamp(3);
+                }
+                __syncthreads();
+                stamp(6);
+            }
+        } else {
+            // taps of the group this wave filters NEXT turn are requested a whole turn ahead into the OTHER of two register sets (the
+            // turns alternate sets; a copy at the end of the turn would wait for the loads there -- and behind the expand waves' 18
+            // weight requests per group on the same address path they take most of a turn)
+            f32x4 tqs[2][KKP / 4];
+            float bds[2] = {0.f, 0.f};
+#ifndef PB_BLK_NO_PRIO
+            __builtin_amdgcn_s_setprio(3);  // this role is the longer stage and shares its SIMD's issue with an MFMA stream (see below)
+#endif
+            auto turn = [&](int it, auto parc) __attribute__((always_inline)) {
+                constexpr int CUR = decltype(parc)::value, NXT = CUR ^ 1;
+                f32x4 (&tq)[KKP / 4] = tqs[CUR];
+                const float bdv = bds[CUR];
+                if (it < NG && (!(ABL & 64) || it < 2)) {  // ABL 64: the taps of the first two groups for every group (no tap requests later)
+                    const f32x4 *tp = reinterpret_cast<const f32x4 *>(w.dwc + (size_t)(it * CH + dc) * KKP);
+#pragma unroll
+                    for (int t = 0; t < KKP / 4; ++t) tqs[NXT][t] = tp[t];
+                    bds[NXT] = w.bd[it * CH + dc];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (it >= 1) {
+                    const int g = it - 1;
+                    const float *const wbase = g + 1 < NG ? s_dwo + CH * (g + 1) : s_scr;
+                    const int wpitch = g + 1 < NG ? DP : WP;
+                    static_assert(HW == 4 && G == 2, "P3E: one image's two output rows per filter wave");
+                    // wave 4 + v: image v / 2, output rows 2 (v % 2) and 2 (v % 2) + 1 -- the image's 16 window values are read once
+                    // (one burst of LDS reads, one latency) and serve both rows
+                    const int fv = wave - 4, fimg = fv >> 1;
+                    const float *fwin = wbase + (fimg * P) * wpitch + dc;
+                    float in[HW][HW];
+#pragma unroll
+                    for (int iy = 0; iy < HW; ++iy)
+#pragma unroll
+                        for (int ix = 0; ix < HW; ++ix) in[iy][ix] = fwin[(iy * HW + ix) * wpitch];
+                    float o[2][4];
+                    // the output rows are compile-time constants in each of the two copies: every tap that falls outside the map is gone
+                    // at compile time (on a 4 x 4 map 51 % of a 5 x 5 filter's taps are padding), no branch per filter row
+                    auto rows = [&](auto fpyc) __attribute__((always_inline)) {
+                        constexpr int FPY0 = decltype(fpyc)::value;
+#pragma unroll
+                        for (int h2 = 0; h2 < 2; ++h2) {
+#pragma unroll
+                            for (int px = 0; px < 4; ++px) o[h2][px] = bdv;
+#pragma unroll
+                            for (int ky = 0; ky < ((ABL & 2) ? 1 : KS); ++ky) {
+                                const int iy = FPY0 + h2 + ky - PAD;
+                                if (iy < 0 || iy >= HW) continue;
+#pragma unroll
+                                for (int px = 0; px < 4; ++px)
+#pragma unroll
+                                    for (int kx = 0; kx < KS; ++kx) {
+                                        const int ix = px + kx - PAD;
+                                        if (ix < 0 || ix >= HW) continue;
+                                        const int t = ky * KS + kx;
+                                        const f32x4 qv = tq[t >> 2];
+                                        const float wv = (t & 3) == 0 ? qv.x : ((t & 3) == 1 ? qv.y : ((t & 3) == 2 ? qv.z : qv.w));
+                                        o[h2][px] = __builtin_fmaf(in[iy][ix], wv, o[h2][px]);
+                                    }
+                            }
+                        }
+                    };
+                    if (fv & 1) rows(std::integral_constant<int, 2>{});
+                    else rows(std::integral_constant<int, 0>{});
+                    const int fpy0 = 2 * (fv & 1);
+                    // (the window of group g is read; its outputs go to the columns filter g - 1's window occupied)
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        float *fdst = s_dwo + (fimg * P + (fpy0 + h2) * HW) * DP + dc + CH * g;
+#pragma unroll
+                        for (int px = 0; px < 4; ++px) fdst[px * DP] = silu_f(o[h2][px]);
+                    }
+                }
+                stamp(5);
+                __syncthreads();
+                stamp(6);
+            };
+            static_assert(NG % 2 == 0, "NG + 1 turns: pairs, then one");
+            for (int it = 0; it < NG; it += 2) {
+                turn(it, std::integral_constant<int, 1>{});      // turn 0 filters nothing and requests group 0's taps into set 0
+                turn(it + 1, std::integral_constant<int, 0>{});
+            }
+            turn(NG, std::integral_constant<int, 1>{});
+            __builtin_amdgcn_s_setprio(0);
+        }
+    } else {
     for (int g = 0; g < NG; ++g) {
         f32x4 tq[KKP / 4];
         float bdv;
@@ -196,34 +341,6 @@ __global__ __launch_bounds__(512) void k_block_small(const float *__restrict__ x
             f32x4 acc[PTW];
 #pragma unroll
             for (int pt = 0; pt < PTW; ++pt) acc[pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if constexpr (P3E) {
-                auto step3 = [&](auto sc) __attribute__((always_inline)) {
-                    constexpr int S = decltype(sc)::value, SLOT = S % 3, SN = S + 2;
-                    // the step two ahead (of the next group past this group's last) into the slot step S - 1 has just left
-                    if constexpr (SN < KS32) load_w3(SN, g * GC + ect, std::integral_constant<int, SN % 3>{});
-                    else load_w3(SN - KS32, gn + ect, std::integral_constant<int, SN % 3>{});
-                    __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (!(ABL & 1) || S == 0) {
-#define PB_BLK_EPASS(WP_, AP_) \
-    _Pragma("unroll") for (int pt = 0; pt < PTW; ++pt) acc[pt] = p3_mfma(wr[SLOT][WP_], xp[pt][S].AP_, acc[pt]);
-                        PB_BLK_EPASS(2, h)
-                        PB_BLK_EPASS(1, m)
-                        PB_BLK_EPASS(1, h)
-                        PB_BLK_EPASS(0, l)
-                        PB_BLK_EPASS(0, m)
-                        PB_BLK_EPASS(0, h)
-#undef PB_BLK_EPASS
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                };
-                static_assert(KS32 == 6, "P3E: six k-steps (CIN = 192)");
-                step3(std::integral_constant<int, 0>{});
-                step3(std::integral_constant<int, 1>{});
-                step3(std::integral_constant<int, 2>{});
-                step3(std::integral_constant<int, 3>{});
-                step3(std::integral_constant<int, 4>{});
-                step3(std::integral_constant<int, 5>{});
-            } else {
 #pragma unroll
             for (int s = 0; s < ((ABL & 1) ? 1 : KC); ++s) {
 #pragma unroll
@@ -239,7 +356,6 @@ __global__ __launch_bounds__(512) void k_block_small(const float *__restrict__ x
                 __builtin_amdgcn_sched_barrier(0);
                 aw[s] = *reinterpret_cast<const f32x4 *>(awp + ((size_t)s * ET + gn) * 256);
                 __builtin_amdgcn_sched_barrier(0);
-            }
             }
             stamp(2);
             const f32x4 bq = bev;
@@ -289,6 +405,7 @@ __global__ __launch_bounds__(512) void k_block_small(const float *__restrict__ x
         stamp(5);
         __syncthreads();
         stamp(6);
+    }
     }
     // ---- squeeze-excite (k_se's arithmetic and order).  Wave w owns the units jj = w, w + 8, ...: their FC1 weights for every
     // block of 64 quads are requested before the pooled means are formed (one L2 round trip under that pass).

@@ -81,6 +81,8 @@ int main(int argc, char **argv) {
             run<5, 192, true, 1, true, true>("5x5 P3+P3E -expand mfma", n);
             run<5, 192, true, 16, true, true>("5x5 P3+P3E weights from L1", n);
             run<5, 192, true, 2, true, true>("5x5 P3+P3E -taps", n);
+            run<5, 192, true, 64, true, true>("5x5 P3+P3E -tap loads", n);
+            run<5, 192, true, 64 + 32, true, true>("5x5 P3+P3E -tap loads stamped", n);
             run<5, 192, true, 4, true, true>("5x5 P3+P3E -se", n);
             run<5, 192, true, 8, true, true>("5x5 P3+P3E -project mfma", n);
             run<5, 192, true, 15, true, true>("5x5 P3+P3E -all", n);
