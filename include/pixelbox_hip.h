@@ -345,6 +345,9 @@ int pb_pinned_free(void *p);
 #define PB_OPT_EMBED_FRONT_SUB 6 /* images per sub-batch of the network's front (stem .. the last block with a large expanded map: blocks 0-4
                                     at 128 x 128): their maps then stay in the 256 MiB Infinity Cache between writer and reader.  0 = one
                                     pass over the whole batch (the default: every split measured slower at 128 x 128, profiles/r06_front_sub.txt); bits do not depend on it */
+#define PB_OPT_EMBED_DUAL 7 /* batch size from which a forward pass runs as two half-batches side by side (the second on a stream and a workspace of the
+                               embedder's own, joined back into the caller's stream before the call's outputs are touched): the halves' launches
+                               fill each other's ramp-ups, drains and latency-bound stretches.  0 = never.  Bits do not depend on it */
 int pb_embed_set_option(pb_embedder *e, int option, int64_t value);
 
 /* The embedder picks a kernel form per (layer, batch-size bucket) by timing the candidates at first use (all forms give the

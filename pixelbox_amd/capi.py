@@ -28,6 +28,7 @@ PB_OPT_SECOND_CHANCE = 14
 PB_OPT_EMBED_STREAM = 3  # pb_embed_set_option: stream handle to launch on (0 = the embedder's own)
 PB_OPT_EMBED_STAGE_BYTES = 5
 PB_OPT_EMBED_FRONT_SUB = 6
+PB_OPT_EMBED_DUAL = 7
 PB_ERR_RANGE = -7  # embed: an activation left the domain of the fixed-point squeeze-excite sums (pixelbox_hip.h)  # pb_embed_set_option: bytes per staging slot of pb_embed_stage_*
 PB_OPT_EMBED_ASYNC = 4   # pb_embed_set_option: 1 = pb_embed_batch_device returns with the forward pass queued (default 0: waits)
 PB_OPT_SCAN_LAUNCH = 8  # 0: one launch per query; 1: queries side by side in one grid; 2 (default): one launch, queries one after the other

@@ -111,6 +111,20 @@ struct pb_embedder {
     size_t front_blocks = 0, front_out_per_image = 0;
     int front_sub = 0;
     float *buf_front = nullptr;
+    // Two half-batches side by side (round 6; forward_device): a forward is a chain of 42 dependent launches, each with its own ramp-up,
+    // drain and -- the squeeze-excite kernels, 12 launches, 94 us -- latency-bound stretches where most CUs idle.  From `dual_min`
+    // images on the batch is cut in two; the second half runs on a stream and a workspace of its own, so the halves' launches fill
+    // each other's tails.  Same kernels on the same per-image values: same bits.  PB_DUAL=0 / PB_OPT_EMBED_DUAL switch it.
+    struct WsSet {
+        float *buf_x[2] = {nullptr, nullptr}, *buf_e = nullptr, *buf_dw = nullptr, *buf_gate = nullptr, *buf_pool = nullptr, *buf_front = nullptr;
+        long long *buf_part = nullptr;
+        unsigned *d_se_cnt = nullptr;
+    } ws2;
+    bool ws2_ready = false;
+    int dual_min = 1024;               // measured (profiles/r06_dual.txt): 1024 images 3.71 -> 3.63 ms, 512: 1.921 -> 1.919 (nothing), 128: 0.89 -> 1.03 (worse); 0: off
+    hipStream_t dual_stream = nullptr;
+    hipEvent_t dual_e0 = nullptr, dual_e1 = nullptr;
+    size_t ws_max_x = 0, ws_max_e = 0, ws_max_dw = 0;  // per-image workspace sizes (floats), for the second set
     unsigned *d_se_cnt = nullptr;  // [max_batch] arrival counters of the squeeze-excite tails (zero between launches)
     bool fold_se = false;          // PB_FOLD_SE=1: the gates of the first six blocks come from the producing kernels' tails instead of k_se
                                    // launches (measured: +0.04 ms per batch-512 forward and per batch-1 forward -- see SeTail; off by default)
@@ -1143,7 +1157,69 @@ int forward_rest(pb_embedder *e, const float *x_in, int n, size_t first, int H, 
 // measured slower, see pb_embed_create) stem .. block front_blocks - 1 run over sub-batches whose maps would stay inside the 256 MiB
 // Infinity Cache between their writer and their reader, the rest of the network over the whole batch.  A host-side loop: every
 // kernel computes an image's values from that image alone, so the bits are those of the one-pass form.
+int forward_one(pb_embedder *e, const uint8_t *d_rgb, int n, uint8_t *d_u8, float *d_f32);
+int ws2_alloc(pb_embedder *e);
+
+void ws_swap(pb_embedder *e) {
+    pb_embedder::WsSet &w = e->ws2;
+    std::swap(e->buf_x[0], w.buf_x[0]); std::swap(e->buf_x[1], w.buf_x[1]); std::swap(e->buf_e, w.buf_e); std::swap(e->buf_dw, w.buf_dw);
+    std::swap(e->buf_gate, w.buf_gate); std::swap(e->buf_pool, w.buf_pool); std::swap(e->buf_front, w.buf_front);
+    std::swap(e->buf_part, w.buf_part); std::swap(e->d_se_cnt, w.d_se_cnt);
+}
+
 int forward_device(pb_embedder *e, const uint8_t *d_rgb, int n, uint8_t *d_u8, float *d_f32) {
+    if (e->dual_min <= 0 || n < e->dual_min || e->tune_depth > 0) return forward_one(e, d_rgb, n, d_u8, d_f32);
+    int rc;
+    if (!e->ws2_ready && (rc = ws2_alloc(e))) return rc;
+    const int n0 = (n + 1) / 2, n1 = n - n0;
+    const uint8_t *rgb1 = d_rgb + (size_t)n0 * e->H * e->W * 3;
+    uint8_t *u81 = d_u8 + (size_t)n0 * e->D;
+    float *f321 = d_f32 ? d_f32 + (size_t)n0 * e->D : nullptr;
+    hipStream_t s0 = e->stream;
+    // the second half starts where the caller's stream stands NOW (its input is there), not behind the first half
+    PB_HIP(hipEventRecord(e->dual_e0, s0));
+    const unsigned long before = e->tune_runs;
+    if ((rc = forward_one(e, d_rgb, n0, d_u8, d_f32))) return rc;  // first half, on the caller's stream
+    // a call that ran timing loops (the per-layer picks of this batch bucket) finishes one half after the other: a timing loop
+    // must have the device to itself.  So does a split whose halves fall into different buckets.
+    if (e->tune_runs != before || tune_bucket(n0) != tune_bucket(n1)) return forward_one(e, rgb1, n1, u81, f321);
+    PB_HIP(hipStreamWaitEvent(e->dual_stream, e->dual_e0, 0));
+    ws_swap(e);
+    e->stream = e->dual_stream;
+    rc = forward_one(e, rgb1, n1, u81, f321);
+    e->stream = s0;
+    ws_swap(e);
+    if (rc) {
+        (void)hipStreamSynchronize(e->dual_stream);
+        return rc;
+    }
+    PB_HIP(hipEventRecord(e->dual_e1, e->dual_stream));
+    PB_HIP(hipStreamWaitEvent(s0, e->dual_e1, 0));
+    return PB_OK;
+}
+
+// the second workspace: what one half of max_batch images needs (the first half keeps using the embedder's own buffers)
+int ws2_alloc(pb_embedder *e) {
+    pb::DeviceGuard guard(e->device);
+    const size_t B = (e->max_batch + 1) / 2;
+    pb_embedder::WsSet &w = e->ws2;
+    int rc;
+    if ((rc = dalloc(e, &w.buf_x[0], B * e->ws_max_x)) || (rc = dalloc(e, &w.buf_x[1], B * e->ws_max_x))) return rc;
+    if ((rc = dalloc(e, &w.buf_e, B * e->ws_max_e)) || (rc = dalloc(e, &w.buf_dw, B * e->ws_max_dw))) return rc;
+    if ((rc = dalloc(e, &w.buf_part, B * e->part_floats_per_image + 2)) || (rc = dalloc(e, &w.buf_gate, B * std::max<size_t>(1152, e->D)))) return rc;
+    PB_HIP(hipMemcpy(w.buf_part, e->buf_part - 2, 2 * sizeof(long long), hipMemcpyDeviceToDevice));  // the header: the range word's address
+    w.buf_part += 2;
+    if ((rc = dalloc(e, &w.buf_pool, B * 1280)) || (rc = dalloc(e, &w.d_se_cnt, B))) return rc;
+    PB_HIP(hipMemset(w.d_se_cnt, 0, B * sizeof(unsigned)));
+    if (e->front_blocks && (rc = dalloc(e, &w.buf_front, B * e->front_out_per_image))) return rc;
+    PB_HIP(hipStreamCreateWithFlags(&e->dual_stream, hipStreamNonBlocking));
+    PB_HIP(hipEventCreateWithFlags(&e->dual_e0, hipEventDisableTiming));
+    PB_HIP(hipEventCreateWithFlags(&e->dual_e1, hipEventDisableTiming));
+    e->ws2_ready = true;
+    return PB_OK;
+}
+
+int forward_one(pb_embedder *e, const uint8_t *d_rgb, int n, uint8_t *d_u8, float *d_f32) {
     int H = 0, W = 0, rc;
     const float *x = nullptr;
     const size_t fb = std::min<size_t>(e->front_blocks, e->blocks.size());
@@ -1364,6 +1440,9 @@ int forward_rest(pb_embedder *e, const float *x_in, int n, size_t first, int H, 
 }
 
 void destroy(pb_embedder *e) {
+    if (e->dual_stream) (void)hipStreamDestroy(e->dual_stream);
+    if (e->dual_e0) (void)hipEventDestroy(e->dual_e0);
+    if (e->dual_e1) (void)hipEventDestroy(e->dual_e1);
     for (void *p : e->allocs) (void)hipFree(p);
     if (e->h_range) (void)hipHostFree(e->h_range);
     for (auto &ge : e->g1_exec)
@@ -1417,6 +1496,7 @@ constexpr uint32_t STAGE_MAX_IMAGES = 1024;
 constexpr size_t STAGE_TMP_FLOATS = 64u << 20;  // 256 MB of vertical-pass scratch per sub-batch (48 MB of 256 x 256 sources need 96 MB)
 
 void drain_streams(pb_embedder *e) {
+    if (e->dual_stream) (void)hipStreamSynchronize(e->dual_stream);
     (void)hipStreamSynchronize(e->h2d_stream);
     (void)hipStreamSynchronize(e->stream);
     (void)hipStreamSynchronize(e->d2h_stream);
@@ -1651,6 +1731,7 @@ int pb_embed_create(pb_embedder **out, int device, const void *weights_blob, siz
     e->no_resize_fusion = getenv("PB_NO_RESIZE_FUSION") != nullptr;
     if (const char *v = getenv("PB_STEM_RPP")) e->stem_rpp = atoi(v) == 1 ? 1 : 2;
     e->fold_se = getenv("PB_FOLD_SE") != nullptr;
+    if (const char *v = getenv("PB_DUAL")) e->dual_min = atoi(v);  // images from which a forward runs as two concurrent halves (0: never)
     e->no_gemm_t = getenv("PB_NO_GEMM_T") != nullptr;
     e->no_tail_fusion = getenv("PB_NO_TAIL_FUSION") != nullptr;
     e->no_block_fusion = getenv("PB_NO_BLOCK_FUSION") != nullptr;
@@ -1715,6 +1796,7 @@ int pb_embed_create(pb_embedder **out, int device, const void *weights_blob, siz
             e->front_sub = sub;
             if (fb && (rc = dalloc(e, &e->buf_front, B * per))) return rc;
         }
+        e->ws_max_x = max_x; e->ws_max_e = max_e; e->ws_max_dw = max_dw;
         if ((rc = dalloc(e, &e->d_img, B * e->H * e->W * 3))) return rc;
         if ((rc = dalloc(e, &e->buf_x[0], B * max_x)) || (rc = dalloc(e, &e->buf_x[1], B * max_x))) return rc;
         if ((rc = dalloc(e, &e->buf_e, B * max_e)) || (rc = dalloc(e, &e->buf_dw, B * max_dw))) return rc;
@@ -2457,6 +2539,11 @@ int pb_embed_set_option(pb_embedder *e, int option, int64_t value) {
         PB_CHECK(value >= (1 << 20) && value <= (1ll << 31), PB_ERR_INVALID, "PB_OPT_EMBED_STAGE_BYTES: 1 MB .. 2 GB");
         std::lock_guard<std::mutex> lk(e->st_mu);
         e->st_bytes_want = ((size_t)value + 4095) & ~(size_t)4095;  // taken by a slot the next time it is opened empty
+        return PB_OK;
+    }
+    if (option == PB_OPT_EMBED_DUAL) {
+        PB_CHECK(value >= 0 && value <= (int64_t)1 << 20, PB_ERR_INVALID, "PB_OPT_EMBED_DUAL: 0 (off) or the batch size from which a forward runs as two concurrent halves");
+        e->dual_min = (int)value;
         return PB_OK;
     }
     if (option == PB_OPT_EMBED_FRONT_SUB) {

@@ -194,6 +194,25 @@ def test_front_of_the_network_over_sub_batches_gives_the_same_bits(sub):
         emb.set_option(capi.PB_OPT_EMBED_FRONT_SUB, 129)
 
 
+@pytest.mark.parametrize("n", [64, 37, 2])
+def test_two_half_batches_side_by_side_give_the_same_bits(n):
+    # PB_OPT_EMBED_DUAL: from that many images on a forward runs as two halves, the second on a stream and a workspace of the
+    # embedder's own (odd sizes: the halves differ by one image and fall back to one after the other when their tuning buckets
+    # differ).  Same kernels per image: same bits; repeated calls reuse the second workspace behind the right events.
+    blob = W.synthetic_blob(synth.SEED_WEIGHTS, 128, 128, 256)
+    imgs = synth.synthetic_images(synth.SEED_IMAGES, 1200, n, 128, 128)
+    emb = capi.Embedder(blob, max_batch=64)
+    u8, f = emb.embed(imgs)
+    emb.set_option(capi.PB_OPT_EMBED_DUAL, 2)
+    for _ in range(3):
+        u8_d, f_d = emb.embed(imgs)
+        assert np.array_equal(f_d.view(np.uint32), f.view(np.uint32))
+        assert np.array_equal(u8_d, u8)
+    emb.set_option(capi.PB_OPT_EMBED_DUAL, 0)
+    u8_s, _ = emb.embed(imgs[: max(1, n // 2)])
+    assert np.array_equal(u8_s, u8[: max(1, n // 2)])
+
+
 def test_mlhash_is_deterministic_like_the_reference_test():
     # efficientnet.rs:54-67: hamming_distance(mlhash(img), mlhash(img)) == 0
     blob = W.synthetic_blob(synth.SEED_WEIGHTS, 128, 128, 256)
