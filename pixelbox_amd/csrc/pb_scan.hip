@@ -136,6 +136,8 @@ struct pb_index {
     float sc_success = 1.0f;           // running success rate of the second chance on this index (optimistic start)
     uint32_t sc_skipped = 0;           // eligible chunks sent straight to the exhaustive pass since the last attempt
     int opt_exact_qn = 0;              // PB_OPT_EXACT_QN: queries per sweep of the coalesced exhaustive pass (0 = auto: 4 from three queries on, 2 for two)
+    bool env_seed_always = false;  // PB_SEED=1: seeds for HBM-sized tables too (they are for cache-sized ones: run_fast)
+    bool env_no_seed = false;  // PB_NO_SEED: the looped filter launch starts every query at the max_dist floor (no sample pass)
     bool env_no_second_chance = false, env_trace_cert = false;  // PB_NO_SECOND_CHANCE / PB_TRACE_CERT, read once at create
     int opt_path = 0;
     int opt_profile = 0;
@@ -454,6 +456,28 @@ bool loop_mode(const pb_index *ix, uint32_t nq) {
     return ix->opt_mode == 2 && nq > 1 && ix->dim == 256 && (ix->opt_waves == 8 ? (v == 0 || v == 8 || v == 2 || v == 4) : (ix->opt_waves == 4 && v == 0));
 }
 
+template <int QT>
+void launch_multi(pb_index *ix, bool hist, int grid, uint32_t base, uint32_t nq);
+
+// Looped filter launch: every query's starting threshold from ONE shared pass over a 1/32 sample of the table (k_seed_thr,
+// pb_scan_kernels.h) -- without it a wave starts at the max_dist floor and prunes its way up.  PB_NO_SEED=1 for the comparison.
+int seed_thresholds(pb_index *ix, uint32_t nq) {
+    if (ix->env_no_seed || ix->metric != 0 || ix->dim != 256 || nq > (uint32_t)MQ_MAXQ || ix->n_rows < (1u << 16)) return PB_OK;
+    const uint64_t n_tiles = (ix->n_rows + 15) / 16, tiles = (n_tiles + MQ_SAMPLE - 1) / MQ_SAMPLE;
+    PB_HIP(hipMemsetAsync(ix->d_ghist, 0, (size_t)nq * MQ_BINS * sizeof(uint32_t), ix->stream));
+    const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((tiles + MQ_WAVES - 1) / MQ_WAVES, (uint64_t)ix->n_cu));
+    switch ((int)((nq + 15) / 16)) {
+        case 1: launch_multi<1>(ix, true, grid, 0, nq); break;
+        case 2: launch_multi<2>(ix, true, grid, 0, nq); break;
+        case 3: launch_multi<3>(ix, true, grid, 0, nq); break;
+        default: launch_multi<4>(ix, true, grid, 0, nq); break;
+    }
+    PB_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_seed_thr, dim3(nq), dim3(64), 0, ix->stream, ix->d_ghist, ix->d_qp, (int)nq, 1e-5f);
+    PB_HIP(hipGetLastError());
+    return PB_OK;
+}
+
 // fast path for nq staged queries; results + status land in d_res_*
 int run_fast(pb_index *ix, uint32_t nq) {
     int n_wg = filter_grid(ix);
@@ -524,9 +548,14 @@ int run_fast(pb_index *ix, uint32_t nq) {
 #undef PB_ARGQ_ARGS
         PB_HIP(hipGetLastError());
     } else if (cache_sized) {
+        { int rc_s = seed_thresholds(ix, nq); if (rc_s) return rc_s; }
         launch_filter_loop<8, 16, 0, true>(ix, n_wg, 0, nq);
         PB_HIP(hipGetLastError());
     } else if (loop_mode(ix, nq)) {
+        // (HBM-sized tables: the seeds buy nothing -- 64 passes over 10M rows 22.76 against 22.78 ms, the clustered table 22.73-22.82
+        // against 22.78-22.83, and the sample pass costs 0.03 ms of the step; a 1.25M-row shard gains 2 % in the kernel, 1 % in the
+        // step: profiles/r06_seed_thresholds.txt.  PB_SEED=1 seeds here too.)
+        if (ix->env_seed_always) { int rc_s = seed_thresholds(ix, nq); if (rc_s) return rc_s; }
         const int v = ix->opt_variant & 15;
         if (v == 8) launch_filter_loop<8, 8, 1>(ix, n_wg, 0, nq);
         else if (v == 2) launch_filter_loop<8, 16, 0, true>(ix, n_wg, 0, nq);
@@ -1408,6 +1437,8 @@ int pb_index_create(pb_index **out, int device, uint32_t dim, uint64_t capacity_
     ix->device = device;
     ix->dim = dim;
     ix->capacity = capacity_rows;
+    ix->env_no_seed = getenv("PB_NO_SEED") != nullptr;
+    ix->env_seed_always = getenv("PB_SEED") != nullptr;
     ix->env_no_second_chance = getenv("PB_NO_SECOND_CHANCE") != nullptr;  // diagnostics switches
     ix->env_trace_cert = getenv("PB_TRACE_CERT") != nullptr;
     ix->env_exact_lane_rows = getenv("PB_EXACT_LANE_ROWS") != nullptr;

@@ -2575,6 +2575,40 @@ __global__ void k_mq_pick_tau(const uint32_t *__restrict__ ghist, const QParams 
     }
 }
 
+// Seeds of the per-query starting threshold of the looped filter launch (round 6).  k_scan_filter starts every wave at thr0 -- the
+// max_dist floor, which half of a uniform table passes -- and raises it by pruning its buffer (wave_keep_smallest: ~2 us of vector
+// work in an HBM-bound loop, ~6 times per wave and pass on uniform data, more on clustered data: the embedding-like table streamed
+// 6 % slower for it).  The k-th largest cosine of ANY subset of the table is a lower bound on the k-th largest of the whole, so the
+// 1/32 sample's histogram (one shared read of the sample for all queries of the launch: k_scan_multi<.., HIST>) gives every query a
+// threshold only ~k * 32 rows of the whole table pass: bin edge of the sample's k-th largest value, less `slack` (the sample pass
+// forms its cosine with two reciprocal square roots instead of one: a few ulp) and four error margins.  Efficiency only: the seed
+// becomes the query's thr0, which the certificate of k_select_rescore counts among the bounds on unexamined rows (o_max), so a
+// seed that were too high could only fail the certificate, never pass a wrong list.  A sample with fewer than k rows above the
+// old thr0 leaves it alone.
+__global__ void k_seed_thr(const uint32_t *__restrict__ ghist, QParams *__restrict__ qp, int n_q, float slack) {
+    const int q = blockIdx.x;
+    if (q >= n_q) return;
+    const int lane = lane_id();
+    const uint32_t k = qp[q].k;
+    uint32_t acc = 0;
+    int found = -1;
+    for (int chunk = MQ_BINS / WAVE - 1; chunk >= 0 && found < 0; --chunk) {
+        const int bin = chunk * WAVE + (WAVE - 1 - lane);
+        uint32_t incl = ghist[(size_t)q * MQ_BINS + bin];
+        for (int off = 1; off < WAVE; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off);
+            if (lane >= off) incl += o;
+        }
+        const uint64_t hit = __ballot(acc + incl >= k);
+        if (hit) found = chunk * WAVE + (WAVE - 1 - (__ffsll((unsigned long long)hit) - 1));
+        acc += __shfl(incl, WAVE - 1);
+    }
+    if (lane == 0 && found > 0) {
+        const float t = mq_bin_edge(found) - slack - 4.0f * qp[q].m;
+        if (t > qp[q].thr0 && t < 0.9999f) qp[q].thr0 = t;
+    }
+}
+
 // exact re-scoring of one query's candidate list (<= MQ_CAP), sort, top-k, certificate.  One block per query.
 __global__ __launch_bounds__(1024) void k_mq_rescore(
     const uint8_t *__restrict__ rows, const int64_t *__restrict__ ids, const float *__restrict__ norms, int d,
