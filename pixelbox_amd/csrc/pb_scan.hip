@@ -124,6 +124,7 @@ struct pb_index {
     int64_t poll_timeout_us = 20000;  // PB_POLL_TIMEOUT_US: how long a one-query call polls for its result granules before it waits for the stream (tests: 0)
     uint32_t stamp_timeouts_row = 0;  // consecutive stamp time-outs
     uint32_t no_poll_calls = 0;       // one-query calls left on the stream wait after three time-outs in a row
+    uint32_t filter_tile_rows = 32;  // rows per tile of the filter launch just queued (loads in flight x rows per load): the certificate's tile sums
     bool tail_dirty = false;        // a filter launch that uses the counters in d_tail (STEAL / DYN) was queued without the k_select_rescore that clears them
     bool env_loop_static = false;   // PB_LOOP_STATIC: the looped filter launch with fixed tile strides per wave (comparison)
 
@@ -385,6 +386,7 @@ void finish_qparams(const pb_index *ix, float acc, int64_t sum_a, int64_t sum_a2
 template <int LPR, int U, bool NT, int NW, int MAPB>
 void launch_filter_t(pb_index *ix, int n_wg, uint32_t q_base, uint32_t nq) {
     constexpr int HS = (LPR == 16 && U == 8) ? 4 : 0;  // k_scan_filter: load placement
+    ix->filter_tile_rows = U * (64 / LPR);
     hipLaunchKernelGGL((k_scan_filter<LPR, U, NT, NW, MAPB, false, false, false, false, HS>), dim3(n_wg, nq), dim3(NW * 64), 0, ix->stream, ix->d_rows,
                        ix->n_rows, ix->d_queries, ix->d_qp, ix->d_lists, ix->d_hdrs, (int)q_base, 1, (uint8_t *)nullptr,
                        (QParams *)nullptr, QArg256{});
@@ -392,6 +394,7 @@ void launch_filter_t(pb_index *ix, int n_wg, uint32_t q_base, uint32_t nq) {
 // one launch, every workgroup answers the nq queries one after the other (k_scan_filter LOOPQ)
 template <int NW, int U = 8, int MAPB = 0, bool WGT = false>
 void launch_filter_loop(pb_index *ix, int n_wg, uint32_t q_base, uint32_t nq) {
+    ix->filter_tile_rows = U * 4;
     PB_LAUNCH_TIMED((k_scan_filter<16, U, true, NW, MAPB, true, false, false, WGT, (U == 8 ? 4 : 0)>), dim3(n_wg, 1), dim3(NW * 64),
                     (const uint8_t *)ix->d_rows, (uint64_t)ix->n_rows, (const uint8_t *)ix->d_queries, (const QParams *)ix->d_qp, ix->d_lists,
                     ix->d_hdrs, (int)q_base, (int)nq, (uint8_t *)nullptr, (QParams *)nullptr, QArg256{}, (uint32_t *)nullptr, StealGeo{});
@@ -509,6 +512,7 @@ int run_fast(pb_index *ix, uint32_t nq) {
         //   PB_FORCE_TAIL_TICKETS: round 2's form -- fixed strides per wave, the last eighth by one device ticket per wave and
         //     4 tiles (what tables from 4M rows up used until round 4).
         const uint64_t n_super = (ix->n_rows + 31) / 32;
+        ix->filter_tile_rows = 32;  // the ARGQ forms: 8 loads in flight x 4 rows per load
         StealGeo sg{};
         sg.S = (uint32_t)((n_super - n_super / 8) / (uint64_t)n_wg);
         const uint64_t pool = n_super - (uint64_t)sg.S * n_wg;
@@ -578,7 +582,7 @@ int run_fast(pb_index *ix, uint32_t nq) {
     hipLaunchKernelGGL(k_select_rescore, dim3(nq), dim3(SEL_BLOCK), 0, ix->stream, ix->d_rows, ix->d_ids, ix->d_norms,
                        (int)ix->dim, ix->d_queries, ix->d_qp, ix->d_lut, ix->d_lists, ix->d_hdrs, n_wg, ix->r_ids,
                        ix->r_dist, ix->r_hdr, (uint32_t)PB_MAX_K, dyn ? ix->d_tail : nullptr,
-                       ix->poll_pending ? ix->h_done : nullptr, ix->done_seq, (uint32_t)ix->n_rows);
+                       ix->poll_pending ? ix->h_done : nullptr, ix->done_seq, (uint32_t)ix->n_rows, ix->filter_tile_rows);
     PB_HIP(hipGetLastError());
     if (dyn) ix->tail_dirty = false;  // k_select_rescore is queued: it leaves the ticket counters zero
     return PB_OK;

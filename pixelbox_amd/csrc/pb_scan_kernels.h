@@ -74,7 +74,18 @@ struct ListHdr {
     uint32_t rows_seen;  // rows this workgroup evaluated for the query (k_scan_filter): the certificate of k_select_rescore also
                          // requires that the workgroups' counts add up to the table -- the partition of the table over
                          // workgroups is dynamic in some launch forms, and a tile nobody read must cost time, not an answer
+    uint32_t sig_lo, sig_hi;  // sum over the tiles this workgroup evaluated of (tile number + 1)^2, mod 2^64 (round 6): the counts alone
+                              // are a NECESSARY condition -- a tile read twice while another full tile is skipped adds up too -- the
+                              // sums of squares beside them must also come to the closed form for tiles 0 .. n - 1 (tile_sig_expected)
 };
+// sum_{s = 0}^{n - 1} (s + 1)^2 mod 2^64 = n (n + 1) (2 n + 1) / 6 mod 2^64 (the division before the reduction: one factor of 2 and
+// one of 3 are taken out of the three factors first)
+__host__ __device__ inline uint64_t tile_sig_expected(uint64_t n) {
+    uint64_t a = n, b = n + 1, c = 2 * n + 1;
+    if ((a & 1) == 0) a >>= 1; else b >>= 1;  // n (n + 1) is even
+    if (a % 3 == 0) a /= 3; else if (b % 3 == 0) b /= 3; else c /= 3;  // one of n, n + 1, 2 n + 1 is a multiple of 3
+    return a * b * c;
+}
 
 struct ResultHdr {
     uint32_t count;
@@ -528,6 +539,7 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
     __shared__ uint64_t s_buf[NPAR][NW][F_CAPW];
     __shared__ float s_drop[NPAR][NW];
     __shared__ uint32_t s_seen[NPAR][NW];
+    __shared__ unsigned long long s_sig[NPAR][NW];
     __shared__ uint32_t s_ticket[2];
     __shared__ uint32_t s_node[8];  // one-query launch: arrival counters of the list-merging tree (4 pairs, 2 quads, 1 root)
     __shared__ uint32_t s_turn;     // STEAL: the chunk number whose request may go out next
@@ -570,6 +582,7 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
     float dropped = 0.0f;
     int cnt = 0;
     uint32_t rows_seen = 0;  // scalar: rows of the tiles this wave evaluated
+    unsigned long long tile_sig = 0;  // scalar: sum of (tile number + 1)^2 over them, mod 2^64 (ListHdr::sig_*)
     const int k_num = 65025 * D - 510 * P.sum_a;  // num = 4P - 510*S + k_num
     const int k_den = 65025 * D;
 
@@ -687,11 +700,16 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
         if constexpr (WGT) {
             if (lane == 0) wg_pend = atomicAdd(&s_ticket[par], 1u);  // the next ticket, requested ahead of this tile's loads
         }
-        const uint64_t row0 = s * ROWS_IT;
+        uint64_t s_eval = s;  // the tile this turn evaluates (= the tile it was handed, unless a fault is injected)
+#ifdef PB_FAULT_DOUBLE_TILE  // fault injection: tile PB_FAULT_DOUBLE_TILE + 1 is never read, tile PB_FAULT_DOUBLE_TILE is read twice -- the row
+        if (s_eval == (uint64_t)(PB_FAULT_DOUBLE_TILE) + 1) s_eval = (uint64_t)(PB_FAULT_DOUBLE_TILE);  // counts still add up to the table; the sums of squares do not
+#endif
+        const uint64_t row0 = s_eval * ROWS_IT;
 #ifdef PB_FAULT_SKIP_TILE  // fault injection (profiles/r04_scan_stamps.txt): one tile is counted as nobody's
         if (s != (uint64_t)PB_FAULT_SKIP_TILE)
 #endif
         rows_seen += row0 < n_rows ? (uint32_t)(n_rows - row0 < (uint64_t)ROWS_IT ? n_rows - row0 : (uint64_t)ROWS_IT) : 0u;
+        if (row0 < n_rows) tile_sig += (unsigned long long)(s_eval + 1) * (unsigned long long)(s_eval + 1);
         uint4 b[U];
         auto load_row = [&](int u) {
             uint64_t r = row0 + (uint64_t)(u * RPT + g);
@@ -800,6 +818,7 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
         int slot = wave;          // where the list this wave carries sits in s_buf
         float carried = dropped;  // the bound that goes with it
         uint32_t seen = rows_seen;  // and the rows behind it
+        unsigned long long sig = tile_sig;
         uint64_t key = ~0ull;
         bool last = true;
 #pragma unroll
@@ -807,6 +826,7 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
             if (lane == 0) {
                 s_drop[par][slot] = carried;
                 s_seen[par][slot] = seen;
+                s_sig[par][slot] = sig;
             }
             uint32_t pos = 0;
             // release: this wave's list and bound are in LDS before its number is taken; acquire: the partner's are read after
@@ -825,6 +845,7 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
             const uint64_t first_out = __shfl((unsigned long long)key, F_KW);
             carried = fmaxf(s_drop[par][lo], s_drop[par][hi]);
             seen = s_seen[par][lo] + s_seen[par][hi];
+            sig = s_sig[par][lo] + s_sig[par][hi];
             if (first_out != ~0ull) carried = fmaxf(carried, filter_key_cos(first_out));
             if (lv < 2 && lane < F_KW) s_buf[par][lo][lane] = key;
             slot = lo;
@@ -839,6 +860,8 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
                 h.count = (uint32_t)total;
                 h.dropped = carried;
                 h.rows_seen = seen;
+                h.sig_lo = (uint32_t)sig;
+                h.sig_hi = (uint32_t)(sig >> 32);
                 hdrs[(size_t)q * gridDim.x + blockIdx.x] = h;
             }
             PB_STAMP(6);
@@ -847,6 +870,7 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
     if (lane == 0) {
         s_drop[par][wave] = dropped;
         s_seen[par][wave] = rows_seen;
+        s_sig[par][wave] = tile_sig;
     }
     PB_STAMP(4);
     __syncthreads();
@@ -867,8 +891,14 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
             h.count = (uint32_t)total;
             h.dropped = drop;
             uint32_t seen = 0;
-            for (int w = 0; w < NW; ++w) seen += s_seen[par][w];
+            unsigned long long sig = 0;
+            for (int w = 0; w < NW; ++w) {
+                seen += s_seen[par][w];
+                sig += s_sig[par][w];
+            }
             h.rows_seen = seen;
+            h.sig_lo = (uint32_t)sig;
+            h.sig_hi = (uint32_t)(sig >> 32);
             hdrs[(size_t)q * gridDim.x + blockIdx.x] = h;
         }
         PB_STAMP(6);
@@ -983,6 +1013,7 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_dist(const uint8_t *__restri
         h.count = (uint32_t)total;
         h.dropped = 0.0f;
         h.rows_seen = 0u;
+        h.sig_lo = h.sig_hi = 0u;
         hdrs[(size_t)q * gridDim.x + blockIdx.x] = h;
         drop_keys[(size_t)q * gridDim.x + blockIdx.x] = drop;  // every key this workgroup saw and did not list is >= drop
     }
@@ -1051,7 +1082,8 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
     int d, const uint8_t *__restrict__ queries, const QParams *__restrict__ qp,
     const float *__restrict__ lut, const uint64_t *__restrict__ lists, const ListHdr *__restrict__ hdrs,
     int n_lists, int64_t *__restrict__ out_ids, float *__restrict__ out_dist, ResultHdr *__restrict__ out_hdr,
-    uint32_t out_stride, uint32_t *tail_ctr = nullptr, uint32_t *done_flag = nullptr, uint32_t done_seq = 0, uint32_t n_rows = 0) {
+    uint32_t out_stride, uint32_t *tail_ctr = nullptr, uint32_t *done_flag = nullptr, uint32_t done_seq = 0, uint32_t n_rows = 0,
+    uint32_t tile_rows = 32) {
     // the filter launch before this one handed out its tail through these counters (k_scan_filter DYN): clear them
     if (tail_ctr && blockIdx.x == 0 && threadIdx.x < DYN_REGIONS) tail_ctr[threadIdx.x * DYN_CTR_STRIDE] = 0u;
     __shared__ float s_lut[256];
@@ -1061,6 +1093,7 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
     __shared__ float s_red[SEL_BLOCK / WAVE];
     __shared__ float s_ck[SEL_BLOCK / WAVE];
     __shared__ uint32_t s_u[8];
+    __shared__ unsigned long long s_sig64;
     const int q = blockIdx.x;
     const int tid = threadIdx.x;
     PB_SEL_STAMP(0);
@@ -1079,11 +1112,13 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
     }
     float dmax = tid < n_lists ? qh[tid].dropped : 0.0f;
     uint32_t seen = tid < n_lists ? qh[tid].rows_seen : 0u;  // summed below: must come to the whole table
+    unsigned long long sig = tid < n_lists ? ((unsigned long long)qh[tid].sig_hi << 32) | qh[tid].sig_lo : 0ull;  // ... and to the tiles' closed form
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_key);  // lower-bound counts per list head (s_key holds candidates only later)
     s_cnt[tid] = 0u;
     const uint8_t qbyte = tid < d ? queries[(size_t)q * d + tid] : (uint8_t)0;
     s_lut[tid & 255] = lut[tid & 255];
     if (tid < 8) s_u[tid] = 0;
+    if (tid == 8) s_sig64 = 0ull;
     __syncthreads();
     PB_SEL_STAMP(1);
     if (tid < d) s_qf[tid] = s_lut[qbyte];
@@ -1109,11 +1144,13 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
         dmax = fmaxf(dmax, __shfl_xor(dmax, off));
         n_top += (uint32_t)__shfl_xor((int)n_top, off);
         seen += (uint32_t)__shfl_xor((int)seen, off);
+        sig += (unsigned long long)__shfl_xor((long long)sig, off);
     }
     if ((tid & 63) == 0) {
         s_red[tid >> 6] = dmax;
         if (n_top) atomicAdd(&s_u[0], n_top);
         if (seen) atomicAdd(&s_u[4], seen);
+        if (sig) atomicAdd(&s_sig64, sig);
     }
     for (int i = n_topset + tid; i < ((n_topset + 15) & ~15); i += SEL_BLOCK) s_top[i] = -1.0f;  // pad to whole batches of reads
     __syncthreads();
@@ -1294,7 +1331,9 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
         // tile that nobody read or that two workgroups read (the failure class of a dynamic partition), not a tile read twice
         // while another full tile was skipped -- which the partitions here cannot produce (a ticket or chunk number is handed
         // out once by an atomic; what went wrong in round 4 was a chunk past the region's end hiding a valid one: a lost tile)
-        bool ok = !overflow && s_u[4] == n_rows;
+        // ... and (round 6) the sums of squared tile numbers come to the closed form for tiles 0 .. n_tiles - 1: a tile read twice while
+        // another is skipped keeps the row count (full tiles hold the same number of rows) and breaks this one
+        bool ok = !overflow && s_u[4] == n_rows && s_sig64 == tile_sig_expected(((uint64_t)n_rows + (tile_rows - 1)) / tile_rows);
         if (n_out == P.k) {
             ok = ok && (o_max <= ck * (1.0f - 1e-6f));
         } else {
