@@ -124,6 +124,14 @@ struct pb_index {
     int64_t poll_timeout_us = 20000;  // PB_POLL_TIMEOUT_US: how long a one-query call polls for its result granules before it waits for the stream (tests: 0)
     uint32_t stamp_timeouts_row = 0;  // consecutive stamp time-outs
     uint32_t no_poll_calls = 0;       // one-query calls left on the stream wait after three time-outs in a row
+    uint64_t stats_refused_fused = 0;  // one-launch calls that handed over to k_select_rescore (more candidates than threads)
+    bool last_fused = false;  // the filter launch just queued carries the selection / re-scoring itself (k_scan_filter FUSE)
+    int last_n_wg = 0;
+    bool env_no_fuse = true;   // one-query calls as two launches (filter, k_select_rescore) unless PB_FUSE=1: the one-launch form is built, exact and
+                               // measured -- 68.1-68.3 us against 67.1-67.7 per call at 1M rows, 0.381 against 0.381 ms at 10M (profiles/
+                               // r06_one_launch.txt): the second launch's host cost was never on the critical path (it is queued while the
+                               // filter runs), and what the fusion saves at the boundary (~1.3 us) the arrival hand-off and a 512-thread
+                               // selection give back
     uint32_t filter_tile_rows = 32;  // rows per tile of the filter launch just queued (loads in flight x rows per load): the certificate's tile sums
     bool tail_dirty = false;        // a filter launch that uses the counters in d_tail (STEAL / DYN) was queued without the k_select_rescore that clears them
     bool env_loop_static = false;   // PB_LOOP_STATIC: the looped filter launch with fixed tile strides per wave (comparison)
@@ -171,8 +179,9 @@ int alloc_workspace(pb_index *ix) {
         PB_HIP(hipMalloc(&ix->d_xcounts[i], (size_t)Q_CHUNK * lists * sizeof(uint32_t)));
     }
     PB_HIP(hipMalloc(&ix->d_qsel, PIPE_Q * sizeof(uint32_t)));
-    PB_HIP(hipMalloc(&ix->d_tail, (size_t)DYN_REGIONS * DYN_CTR_STRIDE * sizeof(uint32_t)));
-    PB_HIP(hipMemset(ix->d_tail, 0, (size_t)DYN_REGIONS * DYN_CTR_STRIDE * sizeof(uint32_t)));
+    // (+ one stride: the arrival counter of the one-launch one-query call, k_scan_filter FUSE)
+    PB_HIP(hipMalloc(&ix->d_tail, (size_t)(DYN_REGIONS + 1) * DYN_CTR_STRIDE * sizeof(uint32_t)));
+    PB_HIP(hipMemset(ix->d_tail, 0, (size_t)(DYN_REGIONS + 1) * DYN_CTR_STRIDE * sizeof(uint32_t)));
     PB_HIP(hipMalloc(&ix->d_qf, ((size_t)Q_CHUNK * 256 + 16) * sizeof(float)));  // + one piece of slack: k_scan_exact_co fetches one piece ahead
     PB_HIP(hipMalloc(&ix->d_tau, PIPE_Q * sizeof(float)));
     PB_HIP(hipMalloc(&ix->d_cand, (size_t)PIPE_Q * MQ_CAP * sizeof(uint64_t)));
@@ -397,7 +406,7 @@ void launch_filter_loop(pb_index *ix, int n_wg, uint32_t q_base, uint32_t nq) {
     ix->filter_tile_rows = U * 4;
     PB_LAUNCH_TIMED((k_scan_filter<16, U, true, NW, MAPB, true, false, false, WGT, (U == 8 ? 4 : 0)>), dim3(n_wg, 1), dim3(NW * 64),
                     (const uint8_t *)ix->d_rows, (uint64_t)ix->n_rows, (const uint8_t *)ix->d_queries, (const QParams *)ix->d_qp, ix->d_lists,
-                    ix->d_hdrs, (int)q_base, (int)nq, (uint8_t *)nullptr, (QParams *)nullptr, QArg256{}, (uint32_t *)nullptr, StealGeo{});
+                    ix->d_hdrs, (int)q_base, (int)nq, (uint8_t *)nullptr, (QParams *)nullptr, QArg256{}, (uint32_t *)nullptr, StealGeo{}, FuseArgs{});
 }
 
 int filter_u(const pb_index *ix) {
@@ -484,7 +493,7 @@ int seed_thresholds(pb_index *ix, uint32_t nq) {
 // fast path for nq staged queries; results + status land in d_res_*
 int run_fast(pb_index *ix, uint32_t nq) {
     int n_wg = filter_grid(ix);
-    bool dyn = false;
+    bool dyn = false, fused = false;
     // A table that (nearly) fits the 256 MiB Infinity Cache -- a 1.25M-row shard of the 8-GPU split is 320 MB -- is not an
     // HBM stream any more: more loads in flight pay there.  Looped launch, nothing tuned by the caller: 16 loads per lane
     // and two workgroups per CU (profiles/loop_ticket_probe.py: 6.29 -> 6.79 TB/s at 1.25M rows, 5.67 -> 6.59 at 625k; from
@@ -527,16 +536,35 @@ int run_fast(pb_index *ix, uint32_t nq) {
         const bool can_steal = sg.S >= sg.lead * (1u << sg.shift) && n_wg >= 8 && (ix->n_rows >= (2ull << 20) || ix->env_force_steal);
         const bool old_tickets = ix->env_force_tickets;
         if (ix->tail_dirty) {  // an earlier call failed between a ticketed launch and the launch that resets the counters
-            PB_HIP(hipMemsetAsync(ix->d_tail, 0, (size_t)DYN_REGIONS * DYN_CTR_STRIDE * sizeof(uint32_t), ix->stream));
+            PB_HIP(hipMemsetAsync(ix->d_tail, 0, (size_t)(DYN_REGIONS + 1) * DYN_CTR_STRIDE * sizeof(uint32_t), ix->stream));
             ix->tail_dirty = false;
         }
         // (the arguments of every form; the query and its constants ride in ix->argq)
 #define PB_ARGQ_ARGS(TAIL, GEO)                                                                                                    \
     (const uint8_t *)ix->d_rows, (uint64_t)ix->n_rows, (const uint8_t *)ix->d_queries, (const QParams *)ix->d_qp, ix->d_lists, ix->d_hdrs, \
-        0, 1, ix->d_queries, ix->d_qp, ix->argq, TAIL, GEO
+        0, 1, ix->d_queries, ix->d_qp, ix->argq, TAIL, GEO, fa
         const dim3 grid(n_wg, 1), block(F_WAVES * 64);
         const bool pin4 = ix->n_rows >= (4ull << 20);  // load placement (k_scan_filter HS): left to hipcc under 4M rows, pinned above
-        if (old_tickets) {
+        // ONE launch per call (k_scan_filter FUSE): the launch's last workgroup selects, re-scores and certifies.  Its 512 threads
+        // bound the count of the k-th largest list head (n_lists * ceil(k / n_lists) values) -- larger k: the two-launch form.
+        FuseArgs fa{};
+        const uint32_t k_q = ix->argq.p.k;
+        fused = !old_tickets && !ix->env_no_fuse && (uint64_t)n_wg * ((k_q + n_wg - 1) / n_wg) <= (uint64_t)F_BLOCK && n_wg <= F_BLOCK;
+        if (fused) {
+            fa.ids = ix->d_ids; fa.norms = ix->d_norms; fa.lut = ix->d_lut; fa.out_ids = ix->r_ids; fa.out_dist = ix->r_dist; fa.out_hdr = ix->r_hdr;
+            fa.done_flag = ix->poll_pending ? ix->h_done : nullptr;
+            fa.arrive = ix->d_tail + (size_t)DYN_REGIONS * DYN_CTR_STRIDE;
+            fa.out_stride = (uint32_t)PB_MAX_K; fa.done_seq = ix->done_seq; fa.tile_rows = 32;
+        }
+        if (fused && (ix->env_static_tail || !can_steal)) {
+            ix->tail_dirty = true;  // (the arrival counter lives behind the ticket counters: a failed launch leaves it for the memset above)
+            if (!pin4) PB_LAUNCH_TIMED((k_scan_filter<16, 8, true, F_WAVES, 0, false, true, false, true, 0, false, true>), grid, block, PB_ARGQ_ARGS((uint32_t *)nullptr, StealGeo{}));
+            else PB_LAUNCH_TIMED((k_scan_filter<16, 8, true, F_WAVES, 0, false, true, false, true, 4, false, true>), grid, block, PB_ARGQ_ARGS((uint32_t *)nullptr, StealGeo{}));
+        } else if (fused) {
+            ix->tail_dirty = true;
+            if (!pin4) PB_LAUNCH_TIMED((k_scan_filter<16, 8, true, F_WAVES, 0, false, true, false, true, 0, true, true>), grid, block, PB_ARGQ_ARGS(ix->d_tail, sg));
+            else PB_LAUNCH_TIMED((k_scan_filter<16, 8, true, F_WAVES, 0, false, true, false, true, 4, true, true>), grid, block, PB_ARGQ_ARGS(ix->d_tail, sg));
+        } else if (old_tickets) {
             ix->tail_dirty = true;
             PB_LAUNCH_TIMED((k_scan_filter<16, 8, true, F_WAVES, 0, false, true, true, false, 4>), grid, block, PB_ARGQ_ARGS(ix->d_tail, StealGeo{}));
             dyn = true;
@@ -579,6 +607,12 @@ int run_fast(pb_index *ix, uint32_t nq) {
     }
     PB_CT(2);
     if (ix->opt_profile && !ix->timed_by_launch) PB_HIP(hipEventRecord(ix->ev1, ix->stream));
+    ix->last_fused = fused;
+    ix->last_n_wg = n_wg;
+    if (fused) {
+        ix->tail_dirty = false;  // queued: its last workgroup leaves every counter zero
+        return PB_OK;
+    }
     hipLaunchKernelGGL(k_select_rescore, dim3(nq), dim3(SEL_BLOCK), 0, ix->stream, ix->d_rows, ix->d_ids, ix->d_norms,
                        (int)ix->dim, ix->d_queries, ix->d_qp, ix->d_lut, ix->d_lists, ix->d_hdrs, n_wg, ix->r_ids,
                        ix->r_dist, ix->r_hdr, (uint32_t)PB_MAX_K, dyn ? ix->d_tail : nullptr,
@@ -1033,6 +1067,17 @@ int search_chunk(pb_index *ix, uint32_t cq, uint32_t k, double max_dist, const f
         }
         PB_CT(3);
         { int rcw = wait_headers(); if (rcw) return rcw; }
+        if (!use_dist && !use_multi && ix->last_fused && cq == 1 && ix->h_res_hdr[0].status == 2u) {
+            // the one-launch form found more candidates than its last workgroup has threads (status 2): the lists and headers are
+            // in memory, the query is parked in slot 0 (workgroup 0 of that launch) -- the selection kernel of its own finishes the call
+            hipLaunchKernelGGL(k_select_rescore, dim3(1), dim3(SEL_BLOCK), 0, ix->stream, ix->d_rows, ix->d_ids, ix->d_norms, (int)ix->dim,
+                               ix->d_queries, ix->d_qp, ix->d_lut, ix->d_lists, ix->d_hdrs, ix->last_n_wg, ix->r_ids, ix->r_dist, ix->r_hdr,
+                               (uint32_t)PB_MAX_K, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u, (uint32_t)ix->n_rows, ix->filter_tile_rows);
+            PB_HIP(hipGetLastError());
+            ++ix->stats_refused_fused;
+            int rcw = wait_headers();
+            if (rcw) return rcw;
+        }
         PB_CT(4);
         if (ix->opt_profile) {
             int rc2 = use_multi ? account_profile(ix, 1, 1) : account_profile(ix, cq, (ix->opt_mode == 1 || loop_mode(ix, cq) || (use_dist && ix->opt_mode == 2)) ? 1 : cq);
@@ -1441,6 +1486,7 @@ int pb_index_create(pb_index **out, int device, uint32_t dim, uint64_t capacity_
     ix->device = device;
     ix->dim = dim;
     ix->capacity = capacity_rows;
+    ix->env_no_fuse = getenv("PB_FUSE") == nullptr;
     ix->env_no_seed = getenv("PB_NO_SEED") != nullptr;
     ix->env_seed_always = getenv("PB_SEED") != nullptr;
     ix->env_no_second_chance = getenv("PB_NO_SECOND_CHANCE") != nullptr;  // diagnostics switches

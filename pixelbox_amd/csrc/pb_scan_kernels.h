@@ -518,14 +518,41 @@ constexpr int ST_MAXC = 256;  // chunks a workgroup can take (the host picks the
 // by wave 0 AFTER the barrier that ends query i while the other waves are already streaming query i + 1 -- wave 0 simply
 // takes fewer tickets of that query -- so the merge (and the second barrier that protected the buffers) leaves the
 // critical path: it is ~1 % of a pass over 10M rows but ~5 % of one over a 1.25M-row shard (8-GPU strong scaling).
+// FUSE (round 6; the one-query launch with WGT): ONE launch per one-query call.  A workgroup stores its list and header write-through
+// (sc1), drains them, and takes a number at a device-scope arrival counter; the workgroup whose number is the last runs the
+// candidate selection, exact re-scoring and certificate (select_rescore_body<512, true>) itself, reading the others' lists with
+// sc1 loads -- the hand-off form "the workgroup whose add came last" of the MI355X guide (one workgroup per CU, 4- and 8-byte sc1
+// stores, drained before the add; the adding wave loads after its add has returned, the other waves of its workgroup after an
+// LDS word it then sets).  Waves that finished early wait on that LDS word (s_final) to learn whether their workgroup is the one.
+// Against filter launch + k_select_rescore launch: one kernel launch of host time and the launch boundary less per call.
+struct SelArgs;
+template <int BLK, bool FUSED>
+__device__ __forceinline__ void select_rescore_body(const SelArgs &A, const int q, const QParams &P, const uint8_t *__restrict__ qbytes);
+struct FuseArgs {  // (a copy of SelArgs' fields: SelArgs is complete only further down)
+    const int64_t *ids;
+    const float *norms;
+    const float *lut;
+    int64_t *out_ids;
+    float *out_dist;
+    ResultHdr *out_hdr;
+    uint32_t *done_flag;
+    uint32_t *arrive;  // the arrival counter (zero between launches: the last workgroup resets it)
+    uint32_t out_stride, done_seq, tile_rows;
+};
+template <bool FUSE>
+__device__ __forceinline__ void fused_select(const uint8_t *rows, uint64_t n_rows, const uint64_t *lists, const ListHdr *hdrs, uint32_t *tail_ctr,
+                                             const QArg256 &qarg, const FuseArgs &fa);
+
 template <int LPR, int U = 8, bool NT = true, int NW = F_WAVES, int MAPB = 0, bool LOOPQ = false, bool ARGQ = false, bool DYN = false,
-          bool WGT = false, int HS = 0, bool STEAL = false>
+          bool WGT = false, int HS = 0, bool STEAL = false, bool FUSE = false>
 __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__restrict__ rows, uint64_t n_rows,
                                                          const uint8_t *queries, const QParams *qp,
                                                          uint64_t *__restrict__ lists,
                                                          ListHdr *__restrict__ hdrs, int q_base, int nq_loop,
                                                          uint8_t *stage_q, QParams *stage_p, const QArg256 qarg,
-                                                         uint32_t *tail_ctr = nullptr, const StealGeo sg = StealGeo{}) {
+                                                         uint32_t *tail_ctr = nullptr, const StealGeo sg = StealGeo{},
+                                                         const FuseArgs fa = FuseArgs{}) {
+    static_assert(!FUSE || (ARGQ && WGT && NW == 8), "FUSE: the one-query launch with workgroup tickets");
     static_assert(!ARGQ || (LPR == 16 && !LOOPQ), "ARGQ: one 256-byte query per launch");
     static_assert(!STEAL || (WGT && ARGQ), "STEAL: the one-query launch with workgroup tickets");
     static_assert(!DYN || (ARGQ && MAPB == 0), "DYN: the one-query launch only");
@@ -542,6 +569,7 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
     __shared__ unsigned long long s_sig[NPAR][NW];
     __shared__ uint32_t s_ticket[2];
     __shared__ uint32_t s_node[8];  // one-query launch: arrival counters of the list-merging tree (4 pairs, 2 quads, 1 root)
+    __shared__ uint32_t s_final;    // FUSE: 0 not known yet, 1 another workgroup arrives last, 2 this one does: its waves run the selection
     __shared__ uint32_t s_turn;     // STEAL: the chunk number whose request may go out next
     __shared__ uint32_t s_chunk[STEAL ? ST_MAXC : 1];  // STEAL: 1 + the region counter's answer for the workgroup's c-th chunk (0: not there yet)
 
@@ -554,6 +582,7 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
         if (threadIdx.x < 2) s_ticket[threadIdx.x] = 0u;
         if (threadIdx.x < 8) s_node[threadIdx.x] = 0u;
         if (threadIdx.x == 8) s_turn = 0u;
+        if (threadIdx.x == 9) s_final = 0u;
         if constexpr (STEAL)
             for (int i = threadIdx.x; i < ST_MAXC; i += NW * WAVE) s_chunk[i] = 0u;
         __syncthreads();
@@ -854,6 +883,20 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
         if (last) {
             const int total = __popcll(__ballot(lane < F_KWG && key != ~0ull));
             uint64_t *out = lists + ((size_t)q * gridDim.x + blockIdx.x) * F_KWG;
+            if constexpr (FUSE) {
+                // write-through stores (the reader is another CU of this launch), drained before the arrival number is taken
+                if (lane < F_KWG) __hip_atomic_store(out + lane, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                uint32_t *h32 = reinterpret_cast<uint32_t *>(hdrs + ((size_t)q * gridDim.x + blockIdx.x));
+                if (lane < 5) {
+                    const uint32_t v = lane == 0 ? (uint32_t)total : (lane == 1 ? __float_as_uint(carried) : (lane == 2 ? seen : (lane == 3 ? (uint32_t)sig : (uint32_t)(sig >> 32))));
+                    __hip_atomic_store(h32 + lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                uint32_t pos = 0;
+                if (lane == 0) pos = __hip_atomic_fetch_add(fa.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
+                if (lane == 0) __hip_atomic_store(&s_final, pos + 1u == gridDim.x ? 2u : 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
             if (lane < F_KWG) out[lane] = key;  // every slot: the unused ones hold ~0, which is how k_select_rescore tells them
             if (lane == 0) {
                 ListHdr h;
@@ -864,7 +907,13 @@ __global__ __launch_bounds__(NW * WAVE) void k_scan_filter(const uint8_t *__rest
                 h.sig_hi = (uint32_t)(sig >> 32);
                 hdrs[(size_t)q * gridDim.x + blockIdx.x] = h;
             }
+            }
             PB_STAMP(6);
+        }
+        if constexpr (FUSE) {
+            uint32_t v;
+            while ((v = __hip_atomic_load(&s_final, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0u) __builtin_amdgcn_s_sleep(2);
+            if (v == 2u) fused_select<FUSE>(rows, n_rows, lists, hdrs, tail_ctr, qarg, fa);  // wave-uniform over the whole workgroup
         }
     } else {
     if (lane == 0) {
@@ -1075,53 +1124,95 @@ __device__ __forceinline__ void sel_put_granule(uint32_t *base, uint32_t slot, u
     g.x = a; g.y = b; g.z = c; g.w = tag ^ granule_mix(a, b, c);
     *reinterpret_cast<u32x4 *>(base + 4 * (size_t)slot) = g;
 }
-constexpr int SEL_SLOTS = F_MAX_WG * F_KWG / SEL_BLOCK;  // list slots per thread (16)
 constexpr int SEL_RANK_MAX = 256;
-__global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
-    const uint8_t *__restrict__ rows, const int64_t *__restrict__ ids, const float *__restrict__ norms,
-    int d, const uint8_t *__restrict__ queries, const QParams *__restrict__ qp,
-    const float *__restrict__ lut, const uint64_t *__restrict__ lists, const ListHdr *__restrict__ hdrs,
-    int n_lists, int64_t *__restrict__ out_ids, float *__restrict__ out_dist, ResultHdr *__restrict__ out_hdr,
-    uint32_t out_stride, uint32_t *tail_ctr = nullptr, uint32_t *done_flag = nullptr, uint32_t done_seq = 0, uint32_t n_rows = 0,
-    uint32_t tile_rows = 32) {
-    // the filter launch before this one handed out its tail through these counters (k_scan_filter DYN): clear them
-    if (tail_ctr && blockIdx.x == 0 && threadIdx.x < DYN_REGIONS) tail_ctr[threadIdx.x * DYN_CTR_STRIDE] = 0u;
+// Everything k_select_rescore reads and writes besides the query (which comes from memory there and from the kernel argument in the
+// filter launch's own last workgroup: k_scan_filter FUSE).
+struct SelArgs {
+    const uint8_t *rows;
+    const int64_t *ids;
+    const float *norms;
+    const float *lut;
+    const uint64_t *lists;
+    const ListHdr *hdrs;
+    int64_t *out_ids;
+    float *out_dist;
+    ResultHdr *out_hdr;
+    uint32_t *tail_ctr;
+    uint32_t *done_flag;
+    int d, n_lists;
+    uint32_t out_stride, done_seq, n_rows, tile_rows;
+};
+// BLK threads (1 024: the kernel of its own; 512: the filter launch's last workgroup).  FUSED: the lists and headers were written by
+// OTHER workgroups of the same launch with write-through (sc1) stores, drained before each workgroup took its arrival number, and
+// are read here with sc1 loads (MI355X guide, inter-workgroup hand-offs: "the workgroup whose add came last"); the thread count
+// bounds what the body can take -- the k-th-largest count over n_lists * ceil(k / n_lists) <= BLK list heads (the host checks before
+// it picks this form) and one candidate per thread (more than BLK candidates: status 2, the host runs the kernel of its own).
+template <int BLK, bool FUSED>
+__device__ __forceinline__ void select_rescore_body(const SelArgs &A, const int q, const QParams &P, const uint8_t *__restrict__ qbytes) {
+    constexpr int SLOTS = F_MAX_WG * F_KWG / BLK;  // list slots per thread
+    const uint8_t *__restrict__ rows = A.rows;
+    const int64_t *__restrict__ ids = A.ids;
+    const float *__restrict__ norms = A.norms;
+    const int d = A.d, n_lists = A.n_lists;
+    int64_t *__restrict__ out_ids = A.out_ids;
+    float *__restrict__ out_dist = A.out_dist;
+    uint32_t *done_flag = A.done_flag;
+    const uint32_t done_seq = A.done_seq, out_stride = A.out_stride;
+    // the filter launch handed out its tail through these counters (k_scan_filter DYN / STEAL): clear them
+    if (A.tail_ctr && (FUSED || blockIdx.x == 0) && threadIdx.x < DYN_REGIONS) A.tail_ctr[threadIdx.x * DYN_CTR_STRIDE] = 0u;
     __shared__ float s_lut[256];
     __shared__ float s_qf[1024];
+    __shared__ uint8_t s_qf_late[BLK < 1024 ? 1024 - BLK : 1];
     __shared__ __attribute__((aligned(16))) float s_top[SEL_BINS];  // the first j_top filter cosines of every list (-1: unused slot)
     __shared__ __attribute__((aligned(16))) uint64_t s_key[SEL_MAX_CAND];   // candidates (filter keys), then exact keys
-    __shared__ float s_red[SEL_BLOCK / WAVE];
-    __shared__ float s_ck[SEL_BLOCK / WAVE];
+    __shared__ float s_red[BLK / WAVE];
+    __shared__ float s_ck[BLK / WAVE];
     __shared__ uint32_t s_u[8];
     __shared__ unsigned long long s_sig64;
-    const int q = blockIdx.x;
     const int tid = threadIdx.x;
     PB_SEL_STAMP(0);
-    const QParams P = qp[q];
-    const uint64_t *ql = lists + (size_t)q * n_lists * F_KWG;
-    const ListHdr *qh = hdrs + (size_t)q * n_lists;
+    const uint64_t *ql = A.lists + (size_t)q * n_lists * F_KWG;
+    const ListHdr *qh = A.hdrs + (size_t)q * n_lists;
+    auto ld_key = [&](int i) -> uint64_t {
+        if constexpr (FUSED) return __hip_atomic_load(ql + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else return ql[i];
+    };
+    auto ld_u32 = [&](const uint32_t *p2) -> uint32_t {
+        if constexpr (FUSED) return __hip_atomic_load(p2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else return *p2;
+    };
 
     // ---- one round trip: this thread's list slots (slot i = list i / 32, entry i % 32; an unused slot holds ~0) and, on the
     //      first n_lists threads, a list's `dropped` bound
     const int total_slots = n_lists * F_KWG;
-    uint64_t my_key[SEL_SLOTS];
+    uint64_t my_key[SLOTS];
 #pragma unroll
-    for (int j = 0; j < SEL_SLOTS; ++j) {
-        const int i = tid + j * SEL_BLOCK;
-        my_key[j] = i < total_slots ? ql[i] : ~0ull;
+    for (int j = 0; j < SLOTS; ++j) {
+        const int i = tid + j * BLK;
+        my_key[j] = i < total_slots ? ld_key(i) : ~0ull;
     }
-    float dmax = tid < n_lists ? qh[tid].dropped : 0.0f;
-    uint32_t seen = tid < n_lists ? qh[tid].rows_seen : 0u;  // summed below: must come to the whole table
-    unsigned long long sig = tid < n_lists ? ((unsigned long long)qh[tid].sig_hi << 32) | qh[tid].sig_lo : 0ull;  // ... and to the tiles' closed form
+    float dmax = 0.0f;
+    uint32_t seen = 0u;             // summed below: must come to the whole table
+    unsigned long long sig = 0ull;  // ... and to the tiles' closed form
+    if (tid < n_lists) {
+        const uint32_t *h32 = reinterpret_cast<const uint32_t *>(qh + tid);  // {count, dropped, rows_seen, sig_lo, sig_hi}
+        dmax = __uint_as_float(ld_u32(h32 + 1));
+        seen = ld_u32(h32 + 2);
+        sig = ((unsigned long long)ld_u32(h32 + 4) << 32) | ld_u32(h32 + 3);
+    }
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_key);  // lower-bound counts per list head (s_key holds candidates only later)
-    s_cnt[tid] = 0u;
-    const uint8_t qbyte = tid < d ? queries[(size_t)q * d + tid] : (uint8_t)0;
-    s_lut[tid & 255] = lut[tid & 255];
+    for (int i = tid; i < SEL_MAX_CAND; i += BLK) s_cnt[i] = 0u;
+    const uint8_t qbyte = tid < d ? qbytes[tid] : (uint8_t)0;
+    if (BLK < 1024)
+        for (int i = tid + BLK; i < d; i += BLK) s_qf_late[i - BLK] = qbytes[i];  // (d > BLK: the bytes beyond the first BLK, via LDS)
+    s_lut[tid & 255] = A.lut[tid & 255];
     if (tid < 8) s_u[tid] = 0;
     if (tid == 8) s_sig64 = 0ull;
     __syncthreads();
     PB_SEL_STAMP(1);
     if (tid < d) s_qf[tid] = s_lut[qbyte];
+    if (BLK < 1024)
+        for (int i = tid + BLK; i < d; i += BLK) s_qf[i] = s_lut[s_qf_late[i - BLK]];
 
     // ---- lower bound LB on the k-th largest filter cosine: the k-th largest among the first j entries of every (sorted)
     //      list, j = ceil(k / n_lists) -- the k-th largest of a subset is <= the k-th largest of all.  Found by counting:
@@ -1131,8 +1222,8 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
     const int n_topset = n_lists * j_top;
     uint32_t n_top = 0;
 #pragma unroll
-    for (int j = 0; j < SEL_SLOTS; ++j) {
-        const int i = tid + j * SEL_BLOCK;
+    for (int j = 0; j < SLOTS; ++j) {
+        const int i = tid + j * BLK;
         const int e = i % F_KWG;
         if (i < total_slots && e < j_top) {
             const bool live = my_key[j] != ~0ull;
@@ -1152,10 +1243,10 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
         if (seen) atomicAdd(&s_u[4], seen);
         if (sig) atomicAdd(&s_sig64, sig);
     }
-    for (int i = n_topset + tid; i < ((n_topset + 15) & ~15); i += SEL_BLOCK) s_top[i] = -1.0f;  // pad to whole batches of reads
+    for (int i = n_topset + tid; i < ((n_topset + 15) & ~15); i += BLK) s_top[i] = -1.0f;  // pad to whole batches of reads
     __syncthreads();
     dmax = 0.0f;
-    for (int w = 0; w < SEL_BLOCK / WAVE; ++w) dmax = fmaxf(dmax, s_red[w]);
+    for (int w = 0; w < BLK / WAVE; ++w) dmax = fmaxf(dmax, s_red[w]);
     const uint32_t top_total = s_u[0];
     float lb = P.thr0;
     if (top_total >= P.k) {  // uniform
@@ -1163,7 +1254,7 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
         // part t / tp of the set (256 list heads: four parts of 64) and adds {above, equal} as two 16-bit halves into s_cnt
         int lg_tp = 6;
         while ((1 << lg_tp) < n_topset) ++lg_tp;
-        const int vi = tid & ((1 << lg_tp) - 1), part = tid >> lg_tp, n_part = SEL_BLOCK >> lg_tp;
+        const int vi = tid & ((1 << lg_tp) - 1), part = tid >> lg_tp, n_part = BLK >> lg_tp;
         const int len = (((n_topset + n_part - 1) / n_part) + 15) & ~15;  // values per part, whole batches of four 16-byte reads
         if (vi < n_topset) {
             const float v = s_top[vi];
@@ -1194,19 +1285,20 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
 
     // ---- candidates: every listed entry with cos_filter >= cut (from the registers loaded above)
 #pragma unroll
-    for (int j = 0; j < SEL_SLOTS; ++j) {
+    for (int j = 0; j < SLOTS; ++j) {
         if (my_key[j] != ~0ull && filter_key_cos(my_key[j]) >= cut) {
             const uint32_t pos = atomicAdd(&s_u[2], 1u);
-            if (pos < SEL_MAX_CAND) s_key[pos] = my_key[j];
+            if (pos < (BLK < SEL_MAX_CAND ? BLK : SEL_MAX_CAND)) s_key[pos] = my_key[j];
         }
     }
     __syncthreads();
     const uint32_t n_cand_raw = s_u[2];
-    const int n_cand = n_cand_raw < SEL_MAX_CAND ? (int)n_cand_raw : SEL_MAX_CAND;
-    const bool overflow = n_cand_raw > SEL_MAX_CAND;
+    constexpr uint32_t CAND_CAP = BLK < SEL_MAX_CAND ? BLK : SEL_MAX_CAND;  // one candidate per thread
+    const int n_cand = n_cand_raw < CAND_CAP ? (int)n_cand_raw : (int)CAND_CAP;
+    const bool overflow = n_cand_raw > CAND_CAP;
     PB_SEL_STAMP(3);
 #ifdef PB_SCAN_STAMP
-    if (blockIdx.x == 0 && threadIdx.x == SEL_BLOCK - 1) {
+    if (blockIdx.x == 0 && threadIdx.x == BLK - 1) {
         g_sel_stamp[8] = n_cand_raw;
         g_sel_stamp[9] = __float_as_uint(lb);
         g_sel_stamp[10] = __float_as_uint(cut);
@@ -1228,21 +1320,26 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
     if (d == 256) {
         // eight lanes per candidate (ref_fold_dot256_by8), 128 candidates per pass; the rows of the first two passes are
         // requested together (one round trip for up to 256 candidates); the sums go to thread `candidate` through LDS
-        constexpr int PER = SEL_BLOCK / 8;
+        constexpr int PER = BLK / 8;
+        constexpr int NCT = 2048 / BLK;  // candidates per lane group and trip: the rows of 256 candidates are requested together either way
         const int part = tid & 7;
-        for (int c0 = tid >> 3; c0 < n_cand; c0 += 2 * PER) {
-            const int c1 = c0 + PER;
-            const bool two = c1 < n_cand;  // uniform over the eight lanes
-            const uint8_t *r0 = rows + (uint64_t)(uint32_t)s_key[c0] * 256 + 32 * part;
-            const uint8_t *r1 = rows + (uint64_t)(uint32_t)s_key[two ? c1 : c0] * 256 + 32 * part;
-            const uint4 a0 = *reinterpret_cast<const uint4 *>(r0), a1 = *reinterpret_cast<const uint4 *>(r0 + 16);
-            const uint4 b0 = *reinterpret_cast<const uint4 *>(r1), b1 = *reinterpret_cast<const uint4 *>(r1 + 16);
-            const float d0 = ref_fold_dot256_by8(a0, a1, s_qf, s_lut, part);
-            if (part == 7) s_top[c0] = d0;
-            __builtin_amdgcn_sched_barrier(0);  // (the two folds interleaved need twice the product registers: scratch)
-            if (two) {
-                const float d1 = ref_fold_dot256_by8(b0, b1, s_qf, s_lut, part);
-                if (part == 7) s_top[c1] = d1;
+        for (int c0 = tid >> 3; c0 < n_cand; c0 += NCT * PER) {
+            uint4 ra[NCT][2];
+#pragma unroll
+            for (int j = 0; j < NCT; ++j) {
+                const int cj = c0 + j * PER;
+                const uint8_t *rj = rows + (uint64_t)(uint32_t)s_key[cj < n_cand ? cj : c0] * 256 + 32 * part;
+                ra[j][0] = *reinterpret_cast<const uint4 *>(rj);
+                ra[j][1] = *reinterpret_cast<const uint4 *>(rj + 16);
+            }
+#pragma unroll
+            for (int j = 0; j < NCT; ++j) {
+                const int cj = c0 + j * PER;
+                if (cj < n_cand) {  // uniform over the eight lanes
+                    const float dj = ref_fold_dot256_by8(ra[j][0], ra[j][1], s_qf, s_lut, part);
+                    if (part == 7) s_top[cj] = dj;
+                }
+                __builtin_amdgcn_sched_barrier(0);  // (two folds interleaved need twice the product registers: scratch)
             }
         }
         __syncthreads();
@@ -1272,7 +1369,7 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
     if ((tid & 63) == 0 && vm) atomicAdd(&s_u[3], (uint32_t)__popcll(vm));
     __syncthreads();
     cfilt = -2.0f;
-    for (int w = 0; w < SEL_BLOCK / WAVE; ++w) cfilt = fmaxf(cfilt, s_red[w]);
+    for (int w = 0; w < BLK / WAVE; ++w) cfilt = fmaxf(cfilt, s_red[w]);
     const uint32_t n_valid = s_u[3];
     const uint32_t n_out = n_valid < P.k ? n_valid : P.k;
     float ck = 3.0f;  // smallest exact cosine among the n_out selected
@@ -1325,7 +1422,7 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
     PB_SEL_STAMP(6);
     if (tid == 0) {
         ck = 3.0f;
-        for (int w = 0; w < SEL_BLOCK / WAVE; ++w) ck = fminf(ck, s_ck[w]);
+        for (int w = 0; w < BLK / WAVE; ++w) ck = fminf(ck, s_ck[w]);
         const float o_max = fmaxf(fmaxf(cut, dmax), P.thr0) + P.m;  // no unexamined row's exact cos reaches this
         // the rows the workgroups report add up to the table (u32: a table is < 2^32 rows).  A NECESSARY condition only: it catches a
         // tile that nobody read or that two workgroups read (the failure class of a dynamic partition), not a tile read twice
@@ -1333,7 +1430,7 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
         // out once by an atomic; what went wrong in round 4 was a chunk past the region's end hiding a valid one: a lost tile)
         // ... and (round 6) the sums of squared tile numbers come to the closed form for tiles 0 .. n_tiles - 1: a tile read twice while
         // another is skipped keeps the row count (full tiles hold the same number of rows) and breaks this one
-        bool ok = !overflow && s_u[4] == n_rows && s_sig64 == tile_sig_expected(((uint64_t)n_rows + (tile_rows - 1)) / tile_rows);
+        bool ok = !overflow && s_u[4] == A.n_rows && s_sig64 == tile_sig_expected(((uint64_t)A.n_rows + (A.tile_rows - 1)) / A.tile_rows);
         if (n_out == P.k) {
             ok = ok && (o_max <= ck * (1.0f - 1e-6f));
         } else {
@@ -1342,7 +1439,8 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
         }
         ResultHdr h;
         h.count = n_out;
-        h.status = ok ? 0u : 1u;
+        // FUSED with more candidates than threads: 2 = "the lists are in memory: run k_select_rescore" (the host does)
+        h.status = ok ? 0u : ((FUSED && overflow && n_cand_raw <= (uint32_t)SEL_MAX_CAND) ? 2u : 1u);
         h.n_cand = n_cand_raw;
         h.o_max = o_max;
         h.ck = n_out == P.k ? ck : -1.0f;
@@ -1350,9 +1448,38 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
             sel_put_granule(done_flag, 0, h.count, h.status, h.n_cand, done_seq);
             sel_put_granule(done_flag, 1, __float_as_uint(h.o_max), __float_as_uint(h.ck), 0u, done_seq);
         } else {
-            out_hdr[q] = h;
+            A.out_hdr[q] = h;
         }
         PB_SEL_STAMP(7);
+    }
+}
+
+__global__ __launch_bounds__(SEL_BLOCK) void k_select_rescore(
+    const uint8_t *__restrict__ rows, const int64_t *__restrict__ ids, const float *__restrict__ norms,
+    int d, const uint8_t *__restrict__ queries, const QParams *__restrict__ qp,
+    const float *__restrict__ lut, const uint64_t *__restrict__ lists, const ListHdr *__restrict__ hdrs,
+    int n_lists, int64_t *__restrict__ out_ids, float *__restrict__ out_dist, ResultHdr *__restrict__ out_hdr,
+    uint32_t out_stride, uint32_t *tail_ctr = nullptr, uint32_t *done_flag = nullptr, uint32_t done_seq = 0, uint32_t n_rows = 0,
+    uint32_t tile_rows = 32) {
+    SelArgs A;
+    A.rows = rows; A.ids = ids; A.norms = norms; A.lut = lut; A.lists = lists; A.hdrs = hdrs; A.out_ids = out_ids; A.out_dist = out_dist;
+    A.out_hdr = out_hdr; A.tail_ctr = tail_ctr; A.done_flag = done_flag; A.d = d; A.n_lists = n_lists; A.out_stride = out_stride;
+    A.done_seq = done_seq; A.n_rows = n_rows; A.tile_rows = tile_rows;
+    const int q = blockIdx.x;
+    const QParams P = qp[q];
+    select_rescore_body<SEL_BLOCK, false>(A, q, P, queries + (size_t)q * d);
+}
+
+template <bool FUSE>
+__device__ __forceinline__ void fused_select(const uint8_t *rows, uint64_t n_rows, const uint64_t *lists, const ListHdr *hdrs, uint32_t *tail_ctr,
+                                             const QArg256 &qarg, const FuseArgs &fa) {
+    if constexpr (FUSE) {
+        SelArgs A;
+        A.rows = rows; A.ids = fa.ids; A.norms = fa.norms; A.lut = fa.lut; A.lists = lists; A.hdrs = hdrs; A.out_ids = fa.out_ids;
+        A.out_dist = fa.out_dist; A.out_hdr = fa.out_hdr; A.tail_ctr = tail_ctr; A.done_flag = fa.done_flag; A.d = 256;
+        A.n_lists = (int)gridDim.x; A.out_stride = fa.out_stride; A.done_seq = fa.done_seq; A.n_rows = (uint32_t)n_rows; A.tile_rows = fa.tile_rows;
+        if (threadIdx.x == 0) __hip_atomic_store(fa.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // every workgroup has arrived: zero for the next launch
+        select_rescore_body<F_BLOCK, true>(A, 0, qarg.p, qarg.q);
     }
 }
 

@@ -147,9 +147,12 @@ def test_one_query_calls_repeat_exactly_in_every_form(monkeypatch):
         rows[r, j % 256] ^= np.uint8(1 + j % 7)
     qs = np.concatenate([q[None, :], rng.integers(0, 256, size=(3, 256), dtype=np.uint8)])
     want = [oracle.scan_topk(x, rows, ids, 100, 1e3) for x in qs]
-    for form in (None, "PB_FORCE_TAIL_TICKETS", "PB_STATIC_TAIL"):  # None: the default for this size, the chunked form
+    # PB_FUSE (round 6): the ONE-launch form -- the filter launch's last-arriving workgroup selects, re-scores and certifies
+    # (k_scan_filter FUSE: write-through lists, an arrival counter, sc1 loads) -- over the chunked and over the static partition
+    for form in (None, "PB_FORCE_TAIL_TICKETS", "PB_STATIC_TAIL", "PB_FUSE", "PB_FUSE+PB_STATIC_TAIL"):  # None: the default for this size, the chunked form
         if form:
-            monkeypatch.setenv(form, "1")
+            for f in form.split("+"):
+                monkeypatch.setenv(f, "1")
         ix = make_index(rows, ids)
         for rep in range(150):
             qi = rep % len(qs)
@@ -162,7 +165,27 @@ def test_one_query_calls_repeat_exactly_in_every_form(monkeypatch):
         # still_answer covers the give-up path; here only that polling is what normally completes a call)
         assert ix.stats().stamp_timeouts <= 15
         if form:
-            monkeypatch.delenv(form)
+            for f in form.split("+"):
+                monkeypatch.delenv(f)
+
+
+@pytest.mark.parametrize("n_dup", [300, 700])
+def test_one_launch_form_with_more_candidates_than_its_last_workgroup_has_threads(monkeypatch, n_dup):
+    # PB_FUSE: the selection runs on the 512 threads of the filter launch's last workgroup, one candidate per thread; a query with
+    # more candidates (700 near-duplicates within the margin of the 100th) reports status 2 and the host finishes the call with
+    # the selection kernel of its own -- same answer either way, and small tables (fewer workgroups than CUs) take the form too
+    monkeypatch.setenv("PB_FUSE", "1")
+    for n in (200003, 5000):
+        rng = np.random.default_rng(99 + n + n_dup)
+        rows = rng.integers(0, 256, size=(n, 256), dtype=np.uint8)
+        ids = np.arange(n, dtype=np.int64) * 5 + 2
+        q = rng.integers(0, 256, size=256, dtype=np.uint8)
+        for j, r in enumerate(rng.choice(n, n_dup, replace=False)):
+            rows[r] = q
+            rows[r, j % 256] ^= np.uint8(1)  # all at (nearly) the same distance: hundreds of candidates around the 100th
+        ix = make_index(rows, ids)
+        for _ in range(3):
+            check_against_oracle(ix, rows, ids, q[None, :])
 
 
 def test_one_query_calls_that_give_up_polling_still_answer(monkeypatch):
