@@ -125,6 +125,10 @@ struct pb_embedder {
     hipStream_t dual_stream = nullptr;
     hipEvent_t dual_e0 = nullptr, dual_e1 = nullptr;
     size_t ws_max_x = 0, ws_max_e = 0, ws_max_dw = 0;  // per-image workspace sizes (floats), for the second set
+    // k_se_multi (a few images: eight workgroups per image): the units' exchange granules [8 images][64] and arrival counters [8], zero between launches
+    unsigned long long *d_se_xchg = nullptr;
+    unsigned *d_se_arrive = nullptr;
+    int se_multi_max = 8;  // PB_SE_MULTI_MAX (0: always k_se)
     unsigned *d_se_cnt = nullptr;  // [max_batch] arrival counters of the squeeze-excite tails (zero between launches)
     bool fold_se = false;          // PB_FOLD_SE=1: the gates of the first six blocks come from the producing kernels' tails instead of k_se
                                    // launches (measured: +0.04 ms per batch-512 forward and per batch-1 forward -- see SeTail; off by default)
@@ -1131,6 +1135,19 @@ int launch_block(pb_embedder *e, const Block &bl, int shape, const float *x, int
 
 // squeeze-excite gates of n images from the pooled sums in buf_part -> buf_gate (k_se)
 int launch_se(pb_embedder *e, const Block &bl, int n_tiles, int n, int hw, int se_qp) {
+    // a few images: eight workgroups per image (k_se_multi: same bits, a workgroup reads an eighth of the weights)
+    if (n <= e->se_multi_max && bl.e / 4 <= 320 && e->d_se_xchg) {
+#define PB_SEM(SPV)                                                                                                              \
+    hipLaunchKernelGGL((k_se_multi<SPV>), dim3(SEM_WG, n), dim3(((bl.e / 4 + 63) / 64) * 64), 0, e->stream, e->buf_part, n_tiles, bl.e, \
+                       1.0f / (float)hw, bl.se_w1, bl.se_b1, bl.se_w2t, bl.se_b2, e->buf_gate, e->d_se_xchg, e->d_se_arrive)
+        if (bl.sp == 8) PB_SEM(8);
+        else if (bl.sp == 16) PB_SEM(16);
+        else if (bl.sp == 32) PB_SEM(32);
+        else PB_SEM(48);
+#undef PB_SEM
+        PB_HIP(hipGetLastError());
+        return PB_OK;
+    }
 #define PB_SE1(SPV, IMGV)                                                                                                  \
     hipLaunchKernelGGL((k_se<SPV, IMGV>), dim3((n + (IMGV) - 1) / (IMGV)), dim3(se_qp * ((SPV) < 16 ? 1 : (SPV) / 16)), 0, e->stream, \
                        e->buf_part, n_tiles, bl.e, 1.0f / (float)hw, bl.se_w1, bl.se_b1, bl.se_w2t, bl.se_b2, e->buf_gate, se_qp, n)
@@ -1731,6 +1748,7 @@ int pb_embed_create(pb_embedder **out, int device, const void *weights_blob, siz
     e->no_resize_fusion = getenv("PB_NO_RESIZE_FUSION") != nullptr;
     if (const char *v = getenv("PB_STEM_RPP")) e->stem_rpp = atoi(v) == 1 ? 1 : 2;
     e->fold_se = getenv("PB_FOLD_SE") != nullptr;
+    if (const char *v = getenv("PB_SE_MULTI_MAX")) e->se_multi_max = std::min(8, std::max(0, atoi(v)));
     if (const char *v = getenv("PB_DUAL")) e->dual_min = atoi(v);  // images from which a forward runs as two concurrent halves (0: never)
     e->no_gemm_t = getenv("PB_NO_GEMM_T") != nullptr;
     e->no_tail_fusion = getenv("PB_NO_TAIL_FUSION") != nullptr;
@@ -1814,6 +1832,9 @@ int pb_embed_create(pb_embedder **out, int device, const void *weights_blob, siz
         if ((rc = dalloc(e, &e->buf_pool, B * 1280))) return rc;
         if ((rc = dalloc(e, &e->d_se_cnt, B))) return rc;
         PB_HIP(hipMemset(e->d_se_cnt, 0, B * sizeof(unsigned)));
+        if ((rc = dalloc(e, &e->d_se_xchg, (size_t)8 * 64)) || (rc = dalloc(e, &e->d_se_arrive, (size_t)8))) return rc;
+        PB_HIP(hipMemset(e->d_se_xchg, 0, (size_t)8 * 64 * sizeof(unsigned long long)));
+        PB_HIP(hipMemset(e->d_se_arrive, 0, 8 * sizeof(unsigned)));
         if ((rc = dalloc(e, &e->d_out_f32, B * e->D)) || (rc = dalloc(e, &e->d_out_u8, B * e->D))) return rc;
         for (int i = 0; i < 2; ++i) {
             PB_HIP(hipHostMalloc(reinterpret_cast<void **>(&e->h_out_u8[i]), B * e->D, hipHostMallocDefault));

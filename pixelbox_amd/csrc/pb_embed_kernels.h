@@ -1853,6 +1853,114 @@ __global__ __launch_bounds__(256) void k_mbconv_small(
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_se for a FEW images (round 6): the same gates, bit for bit, from NWG workgroups per image instead of one.  At batch 1 k_se is
+// ONE workgroup pulling up to 442 KB of weights through one CU (7-10 us, 16 launches per forward: 109 of the one-image call's
+// 380 us); here workgroup w of an image computes the squeeze units [w JW, (w + 1) JW) -- the whole sum of a unit, with k_se's thread
+// layout over the channel quads, so the order of every addition is k_se's -- publishes them as 8-byte {value, 1} granules (one
+// sc1 store each), collects all SP of its image (one lane per granule polls with sc1 loads: the data-tagged hand-off of the
+// MI355X guide) and computes the gates of ITS slice of the channel quads (FC2 over all units in k_se's group order).  A workgroup
+// reads 1 / NWG of either weight matrix.  The granules and the arrival counter are left zero by the image's last-arriving
+// workgroup (every workgroup takes its number after it has read all granules), so a replayed graph -- whose kernel arguments are
+// frozen -- starts clean.  All NWG x n workgroups must be resident together: the host uses this form for n <= 8 images only.
+constexpr int SEM_WG = 8;
+template <int SP>
+__global__ __launch_bounds__(320) void k_se_multi(const long long *__restrict__ part, int n_tiles, int E, float inv_hw,
+                                                  const float *__restrict__ w1, const float *__restrict__ b1,
+                                                  const float *__restrict__ w2t, const float *__restrict__ b2,
+                                                  float *__restrict__ gate, unsigned long long *__restrict__ xchg,
+                                                  unsigned *__restrict__ arrive) {
+    constexpr int JG = SP < 16 ? SP : 16, G = SP / JG;  // k_se's unit groups (FC2 adds their partial sums in group order)
+    constexpr int JW = SP / SEM_WG;                     // units per workgroup
+    static_assert(SP % SEM_WG == 0, "whole units per workgroup");
+    __shared__ float s_part[5][JW];
+    __shared__ float s_s[SP];
+    const int w = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_quads = E >> 2, n_waves = (n_quads + 63) >> 6;
+    const bool on = tid < n_quads;
+    const int c = on ? 4 * tid : 0;
+    unsigned long long *xg = xchg + (size_t)b * 64;
+    // ---- squeeze: mean of this thread's quad (k_se's arithmetic)
+    f32x4 m;
+    {
+        ll4 t = {0, 0, 0, 0};
+        const long long *pp = part + (size_t)b * n_tiles * E + c;
+        int tl = 0;
+        for (; tl + 8 <= n_tiles; tl += 8) {
+            ll4 u[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) u[j] = *reinterpret_cast<const ll4 *>(pp + (size_t)(tl + j) * E);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) se_add(t, u[j]);
+        }
+        for (; tl < n_tiles; ++tl) se_add(t, *reinterpret_cast<const ll4 *>(pp + (size_t)tl * E));
+        const double sc = (1.0 / 16777216.0) * (double)inv_hw;
+        m = (f32x4){(float)((double)t.x * sc), (float)((double)t.y * sc), (float)((double)t.z * sc), (float)((double)t.w * sc)};
+        if (!on) m = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    // ---- FC1 of this workgroup's units: quad product, the wave's xor butterfly, the waves in index order (k_se's order)
+    {
+        f32x4 wv[JW];
+#pragma unroll
+        for (int j = 0; j < JW; ++j) wv[j] = *reinterpret_cast<const f32x4 *>(w1 + (size_t)(w * JW + j) * E + c);
+#pragma unroll
+        for (int j = 0; j < JW; ++j) {
+            float a = m.x * wv[j].x;
+            a = a + m.y * wv[j].y; a = a + m.z * wv[j].z; a = a + m.w * wv[j].w;
+            for (int off = 32; off >= 1; off >>= 1) a = a + __shfl_xor(a, off);
+            if (lane == 0) s_part[wave][j] = a;
+        }
+    }
+    __syncthreads();
+    if (tid < JW) {
+        const int jj = w * JW + tid;
+        float v = s_part[0][tid];
+        for (int wv2 = 1; wv2 < n_waves; ++wv2) v = v + s_part[wv2][tid];
+        const float sj = silu_f(v + b1[jj]);
+        const unsigned long long gnl = (unsigned long long)__float_as_uint(sj) | (1ull << 32);
+        __hip_atomic_store(xg + jj, gnl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // one 8-byte write-through store: arrives whole
+    }
+    // ---- all SP units of the image: one lane per granule polls
+    if (tid < SP) {
+        unsigned long long gnl;
+        while (((gnl = __hip_atomic_load(xg + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) == 0ull) __builtin_amdgcn_s_sleep(1);
+        s_s[tid] = __uint_as_float((uint32_t)gnl);
+    }
+    __syncthreads();
+    // every granule of the image has been read by this workgroup: take a number; the last one leaves the exchange zero
+    if (tid == 0) {
+        const unsigned pos = __hip_atomic_fetch_add(arrive + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (pos + 1u == (unsigned)SEM_WG) {
+            for (int j = 0; j < SP; ++j) __hip_atomic_store(xg + j, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(arrive + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // ---- FC2 for this workgroup's slice of the channel quads: groups of JG units, partial sums added in group order (k_se's order)
+    const int per = (n_quads + SEM_WG - 1) / SEM_WG;
+    const int cq = w * per + tid;
+    if (tid < per && cq < n_quads) {
+        const int c2 = 4 * cq;
+        f32x4 v = *reinterpret_cast<const f32x4 *>(b2 + c2);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            f32x4 wv[JG];
+#pragma unroll
+            for (int j = 0; j < JG; ++j) wv[j] = *reinterpret_cast<const f32x4 *>(w2t + (size_t)(g * JG + j) * E + c2);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < JG; ++j) {
+                const float sj = s_s[g * JG + j];
+                acc.x = acc.x + sj * wv[j].x; acc.y = acc.y + sj * wv[j].y;
+                acc.z = acc.z + sj * wv[j].z; acc.w = acc.w + sj * wv[j].w;
+            }
+            v.x = v.x + acc.x; v.y = v.y + acc.y; v.z = v.z + acc.z; v.w = v.w + acc.w;
+        }
+        const f32x4 r = {sigmoid_f(v.x), sigmoid_f(v.y), sigmoid_f(v.z), sigmoid_f(v.w)};
+        *reinterpret_cast<f32x4 *>(gate + (size_t)b * E + c2) = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // squeeze-excite gates for one image per block: mean over pixels (exact integer sum of the tile partials),
 // FC(E->S)+SiLU, FC(S->E)+sigmoid.  w1: [S][E]; w2t: [S][E] (transposed se_expand); gate: [B][E].
 // The kernel is a chain of three dependent global-memory round trips (partials, w1, w2t) and nothing else, so it is
