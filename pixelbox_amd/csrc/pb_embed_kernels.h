@@ -1880,6 +1880,21 @@ __global__ __launch_bounds__(320) void k_se_multi(const long long *__restrict__ 
     const bool on = tid < n_quads;
     const int c = on ? 4 * tid : 0;
     unsigned long long *xg = xchg + (size_t)b * 64;
+    // the weights of both layers are requested FIRST (they depend on nothing): FC1's land under the pooled sums' round trip, FC2's
+    // under FC1 and the hand-off
+    const int per = (n_quads + SEM_WG - 1) / SEM_WG;
+    const int cq2 = w * per + tid;
+    const bool on2 = tid < per && cq2 < n_quads;
+    const int c2 = on2 ? 4 * cq2 : 0;
+    f32x4 wv1[JW], wv2[G][JG];
+#pragma unroll
+    for (int j = 0; j < JW; ++j) wv1[j] = *reinterpret_cast<const f32x4 *>(w1 + (size_t)(w * JW + j) * E + c);
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int j = 0; j < JG; ++j) wv2[g][j] = *reinterpret_cast<const f32x4 *>(w2t + (size_t)(g * JG + j) * E + c2);
+    f32x4 bv2 = *reinterpret_cast<const f32x4 *>(b2 + c2);
+    __builtin_amdgcn_sched_barrier(0);
     // ---- squeeze: mean of this thread's quad (k_se's arithmetic)
     f32x4 m;
     {
@@ -1900,13 +1915,10 @@ __global__ __launch_bounds__(320) void k_se_multi(const long long *__restrict__ 
     }
     // ---- FC1 of this workgroup's units: quad product, the wave's xor butterfly, the waves in index order (k_se's order)
     {
-        f32x4 wv[JW];
-#pragma unroll
-        for (int j = 0; j < JW; ++j) wv[j] = *reinterpret_cast<const f32x4 *>(w1 + (size_t)(w * JW + j) * E + c);
 #pragma unroll
         for (int j = 0; j < JW; ++j) {
-            float a = m.x * wv[j].x;
-            a = a + m.y * wv[j].y; a = a + m.z * wv[j].z; a = a + m.w * wv[j].w;
+            float a = m.x * wv1[j].x;
+            a = a + m.y * wv1[j].y; a = a + m.z * wv1[j].z; a = a + m.w * wv1[j].w;
             for (int off = 32; off >= 1; off >>= 1) a = a + __shfl_xor(a, off);
             if (lane == 0) s_part[wave][j] = a;
         }
@@ -1936,22 +1948,16 @@ __global__ __launch_bounds__(320) void k_se_multi(const long long *__restrict__ 
         }
     }
     // ---- FC2 for this workgroup's slice of the channel quads: groups of JG units, partial sums added in group order (k_se's order)
-    const int per = (n_quads + SEM_WG - 1) / SEM_WG;
-    const int cq = w * per + tid;
-    if (tid < per && cq < n_quads) {
-        const int c2 = 4 * cq;
-        f32x4 v = *reinterpret_cast<const f32x4 *>(b2 + c2);
+    if (on2) {
+        f32x4 v = bv2;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            f32x4 wv[JG];
-#pragma unroll
-            for (int j = 0; j < JG; ++j) wv[j] = *reinterpret_cast<const f32x4 *>(w2t + (size_t)(g * JG + j) * E + c2);
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < JG; ++j) {
                 const float sj = s_s[g * JG + j];
-                acc.x = acc.x + sj * wv[j].x; acc.y = acc.y + sj * wv[j].y;
-                acc.z = acc.z + sj * wv[j].z; acc.w = acc.w + sj * wv[j].w;
+                acc.x = acc.x + sj * wv2[g][j].x; acc.y = acc.y + sj * wv2[g][j].y;
+                acc.z = acc.z + sj * wv2[g][j].z; acc.w = acc.w + sj * wv2[g][j].w;
             }
             v.x = v.x + acc.x; v.y = v.y + acc.y; v.z = v.z + acc.z; v.w = v.w + acc.w;
         }
