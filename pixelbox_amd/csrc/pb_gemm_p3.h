@@ -60,6 +60,14 @@ __device__ __forceinline__ P3Act p3_split8(const f32x4 &a0, const f32x4 &a1) {
     return p;
 }
 
+template <int I, int N, class F>
+__device__ __forceinline__ void p3_static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        p3_static_for<I + 1, N>(f);
+    }
+}
+
 __device__ __forceinline__ f32x4 p3_mfma(const u32x4 &w, const u32x4 &a, const f32x4 &c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), c, 0, 0, 0);
 }
@@ -100,7 +108,10 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_p3(const float *__restrict__ a
     // k-steps in flight (even: a step's parity is its ring slot's).  The one-wave form is a chain of K / 32 dependent steps fed
     // straight from memory, once per forward at batch 1: with 4 steps in flight a K = 1152 layer took 36 / 4 round trips = 11 us;
     // a lone wave has the whole register file, so the single-tile shape keeps 8 (28 registers per step)
-    constexpr int PD = DIRECT ? (NR == 1 ? 8 : 4) : (NR * MR >= 4 ? 4 : 6);
+#ifndef PB_P3_DIRECT_PD
+#define PB_P3_DIRECT_PD 8  // (round 6: 16 tried -- 28 registers per step in flight: past 256 architectural VGPRs hipcc spills 150-170 registers to scratch)
+#endif
+    constexpr int PD = DIRECT ? (NR == 1 ? PB_P3_DIRECT_PD : 4) : (NR * MR >= 4 ? 4 : 6);
     static_assert(PD % 2 == 0, "parity of a step = parity of its slot");
     constexpr int FR = NR * 192;                                               // 16-byte pieces per k-step of this block's tiles
     constexpr int WREGS = DIRECT ? 1 : (FR + NTHR - 1) / NTHR;
@@ -253,41 +264,20 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_p3(const float *__restrict__ a
         __builtin_amdgcn_sched_barrier(0);
     };
     using I0 = std::integral_constant<int, 0>;
-#pragma unroll
-    for (int q = 0; q < PD; ++q) {
-        if (q == 0) request(0, I0{});
-        else if (q == 1) request(1, std::integral_constant<int, 1 % PD>{});
-        else if (q == 2) request(2, std::integral_constant<int, 2 % PD>{});
-        else if (q == 3) request(3, std::integral_constant<int, 3 % PD>{});
-        else if (q == 4) request(4, std::integral_constant<int, 4 % PD>{});
-        else if (q == 5) request(5, std::integral_constant<int, 5 % PD>{});
-        else if (q == 6) request(6, std::integral_constant<int, 6 % PD>{});
-        else request(7, std::integral_constant<int, 7 % PD>{});
-    }
+    p3_static_for<0, PD>([&](auto qc) __attribute__((always_inline)) { request(decltype(qc)::value, qc); });
     load_w(0, I0{});
     store_w(0, I0{});
     load_w(1, std::integral_constant<int, 1>{});
     if constexpr (!DIRECT) __syncthreads();
     int t = 0;
-    for (; t + PD <= n_steps; t += PD) {
-        k_step(t, t & 1, I0{});
-        if constexpr (PD > 1) k_step(t + 1, (t + 1) & 1, std::integral_constant<int, 1 % PD>{});
-        if constexpr (PD > 2) k_step(t + 2, (t + 2) & 1, std::integral_constant<int, 2 % PD>{});
-        if constexpr (PD > 3) k_step(t + 3, (t + 3) & 1, std::integral_constant<int, 3 % PD>{});
-        if constexpr (PD > 4) k_step(t + 4, (t + 4) & 1, std::integral_constant<int, 4 % PD>{});
-        if constexpr (PD > 5) k_step(t + 5, (t + 5) & 1, std::integral_constant<int, 5 % PD>{});
-        if constexpr (PD > 6) k_step(t + 6, (t + 6) & 1, std::integral_constant<int, 6 % PD>{});
-        if constexpr (PD > 7) k_step(t + 7, (t + 7) & 1, std::integral_constant<int, 7 % PD>{});
-    }
+    for (; t + PD <= n_steps; t += PD)
+        p3_static_for<0, PD>([&](auto qc) __attribute__((always_inline)) { k_step(t + decltype(qc)::value, (t + decltype(qc)::value) & 1, qc); });
     {   // the steps left over (fewer than PD, once per kernel), each on the slot it was requested into
         const int rem = n_steps - t;
-        if (rem > 0) k_step(t, t & 1, I0{});
-        if constexpr (PD > 2) { if (rem > 1) k_step(t + 1, (t + 1) & 1, std::integral_constant<int, 1 % PD>{}); }
-        if constexpr (PD > 3) { if (rem > 2) k_step(t + 2, (t + 2) & 1, std::integral_constant<int, 2 % PD>{}); }
-        if constexpr (PD > 4) { if (rem > 3) k_step(t + 3, (t + 3) & 1, std::integral_constant<int, 3 % PD>{}); }
-        if constexpr (PD > 5) { if (rem > 4) k_step(t + 4, (t + 4) & 1, std::integral_constant<int, 4 % PD>{}); }
-        if constexpr (PD > 6) { if (rem > 5) k_step(t + 5, (t + 5) & 1, std::integral_constant<int, 5 % PD>{}); }
-        if constexpr (PD > 7) { if (rem > 6) k_step(t + 6, (t + 6) & 1, std::integral_constant<int, 6 % PD>{}); }
+        p3_static_for<0, PD - 1>([&](auto qc) __attribute__((always_inline)) {
+            constexpr int Q = decltype(qc)::value;
+            if (rem > Q) k_step(t + Q, (t + Q) & 1, qc);
+        });
     }
     // ---- epilogues (k_gemm_t's, per row tile)
 #pragma unroll
