@@ -824,6 +824,34 @@ def bench_embed(args, torch, device, distributed):
            "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
                         "traffic_profile": latest_profile("embed_pmc")}}
+    # Two batches of this size side by side (round 6, PB_OPT_EMBED_DUAL: a call of 2 x batch images runs as two halves on two streams
+    # and two workspaces, the halves' launches filling each other's ramp-ups, drains and latency-bound stretches).  Reported BESIDE
+    # the number above, which stays one batch at a time: configs[2] names batch 512.
+    try:
+        emb2x = capi.Embedder(blob, max_batch=2 * nb, device=device)
+        imgs2 = torch.empty((2 * nb, 128, 128, 3), dtype=torch.uint8, device=f"cuda:{device}")
+        capi.fill_synthetic_device(device, synth.SEED_IMAGES, 0, imgs2.numel(), imgs2.data_ptr())
+        out2 = torch.empty((2 * nb, 256), dtype=torch.uint8, device=f"cuda:{device}")
+        two = {}
+        for name, dual in (("side_by_side", nb + 1), ("one_chain_of_launches", 0)):
+            emb2x.set_option(capi.PB_OPT_EMBED_DUAL, dual)
+            for _ in range(3):
+                emb2x.embed_device(imgs2.data_ptr(), 2 * nb, out2.data_ptr())
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.embed_steps):
+                emb2x.embed_device(imgs2.data_ptr(), 2 * nb, out2.data_ptr())
+            torch.cuda.synchronize()
+            ms2 = (time.perf_counter() - t0) * 1e3 / args.embed_steps
+            ips2 = 2 * nb / (ms2 * 1e-3)
+            two[name] = {"images_per_s": round(ips2, 1), "ms_per_two_batches": round(ms2, 4),
+                         "frac_of_f32_mfma_peak": round(ips2 * EMBED_FLOP_PER_IMAGE / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)}
+        two["note"] = (f"one call of {2 * nb} images: as two halves of {nb} on two streams and two workspaces (the default from 1024 images on) "
+                       "against one chain of launches over all of them; wall time of synchronous calls; same bits")
+        res["two_batches_in_flight"] = two
+        del emb2x, imgs2, out2
+    except capi.PixelboxError as e:
+        res["two_batches_in_flight"] = {"error": str(e)}
     # the boundary as the reference's callers see it: host buffers in, host buffers out (PCIe inclusive), and
     # the batch-1 `mlhash` latency (efficientnet.rs:31-42; engine.rs:355-358 prints this for a query image)
     host_imgs = synth.fill_synthetic(synth.SEED_IMAGES, 0, nb * 128 * 128 * 3).reshape(nb, 128, 128, 3)
