@@ -41,4 +41,11 @@ timeout 300 python3 profiles/exact_probe.py > $O/exact_probe.txt 2>&1
 timeout 200 bash profiles/embed_kernel_trace.sh gpurun_out/$TAG/layers512 > /dev/null 2>&1; cp $O/layers512/layers.txt $O/embed_layers.txt
 timeout 200 bash profiles/embed_batch_trace.sh 1 gpurun_out/$TAG/layers1 > /dev/null 2>&1; cp $O/layers1/layers_b1.txt $O/embed_layers_batch1.txt
 timeout 300 python3 profiles/embed_f64.py 512 bench > $O/embed_f64.txt 2>&1; timeout 300 python3 profiles/embed_f64.py 512 parity >> $O/embed_f64.txt 2>&1
+# round 6: per-dispatch SQ counters of the last forward (three --pmc passes) + the issue-floor table built from them; the layer table of the
+# same run with the counters appended is the round's embed_layers.txt
+timeout 1500 bash profiles/embed_pmc_pass.sh gpurun_out/$TAG/pmc_layers > /dev/null 2>&1
+{ cat $O/pmc_layers/layers.txt; echo; echo "# SQ counters per dispatch of the same forward (separate --pmc passes; profiles/embed_pmc_pass.sh, profiles/pmc_last_forward.py)"; cat $O/pmc_layers/pmc1.txt; echo; cat $O/pmc_layers/pmc2.txt; echo; cat $O/pmc_layers/pmc3.txt; } > $O/embed_layers.txt
+cp $O/pmc_layers/issue_floor.txt $O/embed_issue_floor.txt
+timeout 300 python3 profiles/dual_probe.py 2>&1 | grep batch > $O/dual.txt
+timeout 200 ./build/block_small_bench p3 > $O/block_small.txt 2>&1
 du -sh $O; ls $O

@@ -16,7 +16,13 @@ def main():
     out, path = sys.argv[1], sys.argv[2]
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     launches = collections.Counter()
-    for r in csv.DictReader(open(path)):
+    rows = list(csv.DictReader(open(path)))
+    # round 6: only the LAST forward of the run -- the dispatches from its stem kernel on -- so that the per-layer
+    # timing loops' candidate launches (every form of every layer, several batch buckets) are not pooled with the forward that runs
+    stems = [int(r["Dispatch_Id"]) for r in rows if "k_stem" in r["Kernel_Name"]]
+    first = max(stems) if stems else 0
+    rows = [r for r in rows if int(r["Dispatch_Id"]) >= first]
+    for r in rows:
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
@@ -35,7 +41,7 @@ def main():
     for g, (mf, gui) in tot.items():
         res[g] = {"mfma_busy_frac": round(mf / (gui / 8 * 1024), 4) if gui else 0.0}
     res["_note"] = ("rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 bench.py --steps 2 --warmup 1 "
-                    "(embed forwards of 512 images incl. autotune launches, one 1024-query burst). mfma_busy_frac = "
+                    "of profiles/embed_probe.py: the dispatches of its LAST batch-512 forward only (from the stem kernel on; the timing loops' candidate launches are excluded). mfma_busy_frac = "
                     "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs).")
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
     for k in sorted(res):
