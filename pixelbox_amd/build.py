@@ -23,7 +23,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpixelbox_hip.so")
 STAMP = LIB + ".stamp"
 SOURCES = ["pb_scan.hip", "pb_embed.hip", "pb_gemm_p3.hip", "pb_sharded.hip", "pb_phash.hip"]
-HEADERS = ["pb_common.h", "pb_scan_kernels.h", "pb_embed_common.h", "pb_embed_kernels.h", "pb_gemm_p3.h", "pb_gemm_p3_launch.h", "pb_front_band.h", "pb_block_small.h", "pb_phash_kernels.h", "pb_merge_kernels.h",
+HEADERS = ["pb_common.h", "pb_scan_kernels.h", "pb_embed_common.h", "pb_embed_kernels.h", "pb_gemm_p3.h", "pb_p3_common.h", "pb_gemm_p3_launch.h", "pb_front_band.h", "pb_block_small.h", "pb_phash_kernels.h", "pb_merge_kernels.h",
            os.path.join("..", "..", "include", "pixelbox_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall",
          "-Wno-unused-function"]

@@ -140,7 +140,7 @@ struct pb_embedder {
     bool no_band = false, force_band = false;  // PB_NO_BAND / PB_FORCE_BAND: leave out / always take the LDS-ring front kernel where it applies (A/B runs, bit comparisons)
     int tune_pick = 0;    // PB_TUNE_PICK: 0 fastest candidate (default); 1 slowest; 2 a pseudo-random one -- test hook: every form must give the same bits
     uint32_t tune_rng = 12345u;
-    int p3e_min_k = 192;  // p3e_layer(): the expand layers of blocks 12-15 are P3 layers too; PB_P3E_MIN_K, PB_NO_P3E (PB_NO_P3 switches both off)
+    int p3e_min_k = 80;   // p3e_layer(): the expand layers of blocks 6-15 (K = 80, 112, 192) are P3 layers too; PB_P3E_MIN_K, PB_NO_P3E (PB_NO_P3 switches both off)
     int p3_min_k = 240;   // p3_layer(): the project layers of blocks 5-15, the head and the Linear are P3 layers (pb_gemm_p3.h); PB_P3_MIN_K, PB_NO_P3
     std::map<std::pair<const void *, long>, std::pair<int, int>> gemm_cfg;  // (layer weights, rows) -> (MR, NR), measured; MR < 0: eight-wave form
     std::map<std::pair<const void *, long>, DwGeom> dw_cfg;
@@ -297,9 +297,10 @@ int make_gemm(pb_embedder *e, Gemm *g, const float *w, const float *b, int N, in
 // tile's own matrix instructions (the 40-column project of block 4 is bound by its 126 MB of activations either way and ran
 // 44 us as a P3 layer against 39 us on the f32 chain).
 bool p3_layer(const pb_embedder *e, int K, int N) { return K >= e->p3_min_k && K % 8 == 0 && (N + 15) / 16 >= 5; }
-// EXPAND layers as P3 layers (round 6): whole k-steps of 32 and K >= 192 -- the 192 -> 1152 expands of blocks 12-15, whose f32 chain was
-// 38 % of the whole-block kernel (k_block_small: the block input is split once per workgroup; pb_block_small.h, P3E).
-bool p3e_layer(const pb_embedder *e, int K, int N) { return K >= e->p3e_min_k && K % 32 == 0 && (N + 15) / 16 >= 5; }
+// EXPAND layers as P3 layers (round 6): K >= 80 -- blocks 6-15 (80 -> 480, 112 -> 672, 192 -> 1152).  The operand is split by the
+// CONSUMER: once per workgroup in k_block_small (blocks 12-15, whose f32 expand chain was 38 % of the kernel), once per group and
+// k-step in k_mbconv_small (a lane's own 8 k), in the tile's own stream in k_gemm_p3 -- nothing for a producer to write.
+bool p3e_layer(const pb_embedder *e, int K, int N) { return K >= e->p3e_min_k && K % 8 == 0 && (N + 15) / 16 >= 5; }
 
 size_t blob_floats(int D) {
     size_t n = 32 * 27 + 32;
@@ -866,7 +867,8 @@ int launch_front(pb_embedder *e, const Block &bl, int cfg, const float *x, int B
 // ---- fused MBConv front for small maps (k_mbconv_small): cfg = 0x1000 + 256 * mr + 16 * nr + 8 * regs + log2(groups per workgroup)
 bool small_eligible(const Block &bl, int H, int W, int nr, int mr) {
     const int P = H * W;
-    if (bl.expand.p3) return false;  // k_mbconv_small expands on the f32 chain
+    // a P3 expand layer: the operands-in-registers form only (its P3E instances: k_mbconv_small, K = 80 / 112 / 192 on 8 x 8 and 4 x 4 maps)
+    if (bl.expand.p3 && !(mr == 1 && (bl.expand.Kpad == 80 || bl.expand.Kpad == 112 || bl.expand.Kpad == 192) && bl.cin % 8 == 0)) return false;
     if (!bl.has_expand || H != W || bl.e % (16 * nr) || bl.expand.Kpad % 16 || bl.cin % 4) return false;
     if (!((P == 256 && mr == 4) || (P == 64 && mr == 1) || (P == 16 && mr == 1))) return false;  // two row tiles per wave never won
     if (P == 256) return (bl.k == 5 && bl.stride == 1) || (bl.k == 3 && bl.stride == 2);
@@ -881,18 +883,20 @@ bool small_regs_form(const Block &bl, int mr) {
 
 size_t small_lds_bytes(const Block &bl, int H, int W, int nr, int mr) {
     const int nt = 16 * nr, pad = (bl.k - 1) / 2, g = 64 * mr / (H * W);
-    return ((size_t)bl.expand.Kpad * (nt + 4) + (size_t)g * (H + 2 * pad) * ((W + 2 * pad) | 1) * nt + (size_t)bl.k * bl.k * nt + 2 * nt) * sizeof(float);
+    const size_t w_floats = bl.expand.p3 ? (size_t)((bl.expand.Kpad / 16 + 1) / 2) * nr * 768 : (size_t)bl.expand.Kpad * (nt + 4);
+    return (w_floats + (size_t)g * (H + 2 * pad) * ((W + 2 * pad) | 1) * nt + (size_t)bl.k * bl.k * nt + 2 * nt) * sizeof(float);
 }
 
-template <int KS, int S, int NR, int MR, int NS>
+template <int KS, int S, int NR, int MR, int NS, bool P3E = false>
 int launch_small_t(pb_embedder *e, const Block &bl, int gpw, const float *x, int B, int H, int W, float *out, int Ho, int Wo) {
     const size_t lds = small_lds_bytes(bl, H, W, NR, MR);
-    auto kern = k_mbconv_small<KS, S, NR, MR, NS>;
+    auto kern = k_mbconv_small<KS, S, NR, MR, NS, P3E>;
     if (lds > 48 * 1024)
         PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int G = 64 * MR / (H * W), n_groups = (B + G - 1) / G;
     hipLaunchKernelGGL(kern, dim3((n_groups + gpw - 1) / gpw, 1, bl.e / (16 * NR)), dim3(256), lds, e->stream, x, H, W, bl.cin, bl.expand.wt,
-                       bl.expand.Kpad, bl.expand.Npad, bl.expand.bias, bl.dw_w, bl.dw_b, bl.e, out, Ho, Wo, e->buf_part, B, gpw);
+                       bl.expand.Kpad, bl.expand.Npad, bl.expand.bias, bl.dw_w, bl.dw_b, bl.e, out, Ho, Wo, e->buf_part, B, gpw,
+                       reinterpret_cast<const u32x4 *>(bl.expand.wt3), bl.expand.Npad / 16);
     PB_HIP(hipGetLastError());
     return PB_OK;
 }
@@ -902,6 +906,17 @@ template <int KS, int S, int NR, int MR>
 int launch_small_ns(pb_embedder *e, const Block &bl, int gpw, bool regs, const float *x, int B, int H, int W, float *out, int Ho, int Wo) {
     const int ns = regs ? bl.expand.Kpad / 16 : 0;
 #define PB_SMN(NSV) launch_small_t<KS, S, NR, MR, NSV>(e, bl, gpw, x, B, H, W, out, Ho, Wo)
+    if constexpr (MR == 1) {
+        if (bl.expand.p3) {  // the layer's arithmetic is P3: only the P3E instances compute it (small_eligible admits nothing else)
+            const int nsp = bl.expand.Kpad / 16;
+            if (nsp == 5) return launch_small_t<KS, S, NR, MR, 5, true>(e, bl, gpw, x, B, H, W, out, Ho, Wo);
+            if (nsp == 7) return launch_small_t<KS, S, NR, MR, 7, true>(e, bl, gpw, x, B, H, W, out, Ho, Wo);
+            if (nsp == 12) return launch_small_t<KS, S, NR, MR, 12, true>(e, bl, gpw, x, B, H, W, out, Ho, Wo);
+            return pb::fail(PB_ERR_INTERNAL, "launch_small: no P3 expand instance for K = %d", bl.expand.Kpad);
+        }
+    } else if (bl.expand.p3) {
+        return pb::fail(PB_ERR_INTERNAL, "launch_small: no P3 expand instance for MR = %d", MR);
+    }
     if constexpr (MR == 4) {
         if (ns == 3) return PB_SMN(3);
     } else {
@@ -1027,6 +1042,7 @@ int run_front(pb_embedder *e, const Block &bl, const float *x, int n, int H, int
                 for (int lg : {0, 1, 2, 9, 10}) {  // 8 + lg: operands-in-registers form (needs >= 2 groups per workgroup to pay)
                     if (!small_eligible(bl, H, W, nr, mr) || small_lds_bytes(bl, H, W, nr, mr) > 100 * 1024) continue;
                     if ((lg & 8) && !small_regs_form(bl, mr)) continue;
+                    if (bl.expand.p3 && !(lg & 8) && lg != 0) continue;  // a P3 layer always runs the operands-in-registers form: the plain cfgs alias it
                     const int cfg = 0x1000 + 256 * mr + 16 * nr + lg;
                     float ms = 0.f;
                     if ((rc = launch_small(e, bl, cfg, x, n, H, W, e->buf_dw, Ho, Wo))) return rc;  // warm-up

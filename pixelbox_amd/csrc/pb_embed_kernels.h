@@ -9,6 +9,7 @@
 // implementation.  Depthwise convolutions, squeeze-excite and the head are HBM/latency-bound VALU kernels.
 #pragma once
 #include "pb_embed_common.h"
+#include "pb_p3_common.h"
 
 namespace pbe {
 
@@ -1535,11 +1536,19 @@ __device__ unsigned long long g_sm_stamp[65536 * 12];  // [workgroup * 4 + wave]
 #else
 #define PB_ST(i) do {} while (0)
 #endif
-template <int KS, int S, int NR, int MR, int NS>
+// P3E (round 6): the expand layer is a P3 layer (pb_gemm_p3.h: K >= 80 -- blocks 6-15).  The group's activation operands are held as
+// raw floats while the previous group filters (as before) and split into the three bf16 planes at the start of the expand -- the
+// CONSUMER-side split (a lane splits its own 8 k per step: 44 vector instructions, once per group and step, used for NR tiles); the
+// weights sit in LDS as fragment planes ([k-step of 32][tile][plane][lane] x 16 B: staging is a straight copy of the layer's wt3
+// block, a fragment read one conflict-free ds_read_b128), a k-step is p3_step's six bf16 MFMAs per tile.  Same bits as k_gemm_p3.
+template <int KS, int S, int NR, int MR, int NS, bool P3E = false>
 __global__ __launch_bounds__(256) void k_mbconv_small(
     const float *__restrict__ x, int H, int W, int Cin, const float *__restrict__ wt, int Kpad, int Epad,
     const float *__restrict__ bias_e, const float *__restrict__ dw_w, const float *__restrict__ dw_b, int E,
-    float *__restrict__ out, int Ho, int Wo, long long *__restrict__ part, int n_img, int groups_per_wg) {
+    float *__restrict__ out, int Ho, int Wo, long long *__restrict__ part, int n_img, int groups_per_wg,
+    const u32x4 *__restrict__ wt3 = nullptr, int tiles16 = 0) {
+    static_assert(!P3E || NS > 0, "P3E: the operands-in-registers form");
+    constexpr int KS32 = (NS + 1) / 2;  // P3E: k-steps of 32 (NS = Kpad / 16 steps of 16)
     constexpr int NT = 16 * NR, LDW = NT + 4, CQ = NT / 4;
     constexpr int PAD = (KS - 1) / 2;
     constexpr int ROWS = 64 * MR;  // pixel rows per group: MR row tiles per wave (the weight fragments of a k-step serve all MR)
@@ -1548,8 +1557,8 @@ __global__ __launch_bounds__(256) void k_mbconv_small(
     const int P = H * W;       // 256, 64 or 16
     const int G = ROWS / P;    // images per group (1 .. 8)
     const int Hp = H + 2 * PAD, Wp = (W + 2 * PAD) | 1;  // odd row pitch: see the depthwise phase
-    float *s_w = s_ms;                          // [Kpad][LDW]
-    float *s_e = s_w + Kpad * LDW;              // [G][Hp * Wp][NT]
+    float *s_w = s_ms;                          // [Kpad][LDW]; P3E: [KS32][NR][3][64 lanes] x 16 B
+    float *s_e = s_w + (P3E ? KS32 * NR * 768 : Kpad * LDW);  // [G][Hp * Wp][NT]
     float *s_dw = s_e + G * Hp * Wp * NT;       // [KS * KS][NT]
     float *s_b = s_dw + KS * KS * NT;           // [NT] expand bias, [NT] depthwise bias
     const int tid = threadIdx.x;
@@ -1581,16 +1590,26 @@ __global__ __launch_bounds__(256) void k_mbconv_small(
     // streaming form (NS = 0: one k-step ahead, 8 MFMAs = 256 cycles of cover per load) left the MFMA pipe waiting
     // for L2 at every step: the expand phase alone ran at 45 % of the MFMA rate.  Loaded values are masked (image
     // past the batch, k past Cin) at use, not at load: a select after the load would wait for it on the spot.
-    f32x4 a_all[MR][NS > 0 ? NS : 1];
+    f32x4 a_all[MR][P3E ? 2 * KS32 : (NS > 0 ? NS : 1)];
     auto load_group = [&](int gi2) __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < MR; ++r) {
             const int img = gi2 * G + g_img[r];
             const float *arow = x + ((size_t)(img < n_img ? img : 0) * P + pix[r]) * Cin;
+            if constexpr (P3E) {  // lane (li, kq) of a k-step holds k = 32 s + 8 kq .. + 7 (Cin % 8 == 0: an 8-group is inside the row or past it)
+#pragma unroll
+                for (int s2 = 0; s2 < KS32; ++s2) {
+                    const int kb = 32 * s2 + 8 * kq;
+                    const int kc = kb < Cin ? kb : 0;
+                    a_all[r][2 * s2] = *reinterpret_cast<const f32x4 *>(arow + kc);
+                    a_all[r][2 * s2 + 1] = *reinterpret_cast<const f32x4 *>(arow + kc + 4);
+                }
+            } else {
 #pragma unroll
             for (int s2 = 0; s2 < NS; ++s2) {
                 const int kb = 16 * s2 + 4 * kq;
                 a_all[r][s2] = *reinterpret_cast<const f32x4 *>(arow + (kb < Cin ? kb : 0));
+            }
             }
         }
     };
@@ -1603,7 +1622,25 @@ __global__ __launch_bounds__(256) void k_mbconv_small(
     {
         constexpr int NTAP4 = KS * KS * (NT / 4);  // <= 300 float4
         constexpr int NTJ = (NTAP4 + 255) / 256;
-        const int n_w4 = Kpad * (NT / 4);
+        if constexpr (P3E) {  // the layer's fragment planes of this channel group: straight 16-byte copies, four in flight per thread
+            constexpr int NF = KS32 * NR * 192;  // 16-byte pieces
+            const int t0 = e0 / 16;
+            for (int i0 = tid; i0 < NF; i0 += 4 * 256) {
+                u32x4 f4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = i0 + 256 * j, ic = i < NF ? i : 0;
+                    const int sstep = ic / (NR * 192), rem = ic % (NR * 192);
+                    f4[j] = wt3[((size_t)sstep * tiles16 + t0) * 192 + rem];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = i0 + 256 * j;
+                    if (i < NF) reinterpret_cast<u32x4 *>(s_w)[i] = f4[j];
+                }
+            }
+        }
+        const int n_w4 = P3E ? 0 : Kpad * (NT / 4);
         f32x4 w4[4], t4[NTJ];
         float be = 0.f, bd = 0.f;
 #pragma unroll
@@ -1668,6 +1705,36 @@ __global__ __launch_bounds__(256) void k_mbconv_small(
 #pragma unroll
                 for (int c = 0; c < NR; ++c) acc[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
+            if constexpr (P3E) {
+                const u32x4 *sw3 = reinterpret_cast<const u32x4 *>(s_w) + lane;
+#pragma unroll
+                for (int s = 0; s < KS32; ++s) {
+                    // this step's fragments (all planes of all NR tiles, one burst), then the split of this step's operands
+                    u32x4 wq[NR][3];
+#pragma unroll
+                    for (int pl = 2; pl >= 0; --pl)
+#pragma unroll
+                        for (int c = 0; c < NR; ++c) wq[c][pl] = sw3[((s * NR + c) * 3 + pl) * 64];
+                    P3Act pa[MR];
+#pragma unroll
+                    for (int r = 0; r < MR; ++r) {
+                        f32x4 a0 = a_all[r][2 * s], a1 = a_all[r][2 * s + 1];
+                        if (!(iv[r] && 32 * s + 8 * kq < Cin)) a0 = a1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        pa[r] = p3_split8(a0, a1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#define PB_SM_PASS(WP_, AP_) \
+    _Pragma("unroll") for (int r = 0; r < MR; ++r) _Pragma("unroll") for (int c = 0; c < NR; ++c) acc[r][c] = p3_mfma(wq[c][WP_], pa[r].AP_, acc[r][c]);
+                    PB_SM_PASS(2, h)
+                    PB_SM_PASS(1, m)
+                    PB_SM_PASS(1, h)
+                    PB_SM_PASS(0, l)
+                    PB_SM_PASS(0, m)
+                    PB_SM_PASS(0, h)
+#undef PB_SM_PASS
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const int kbase = 16 * s + 4 * kq;
@@ -1693,6 +1760,7 @@ __global__ __launch_bounds__(256) void k_mbconv_small(
                         for (int c = 0; c < NR; ++c) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[e][c], av, acc[r][c], 0, 0, 0);
                     }
                 __builtin_amdgcn_sched_barrier(0);
+            }
             }
             PB_ST(1);
             if (gi + 1 < g_first + groups_per_wg && gi + 1 < n_groups) load_group(gi + 1);

@@ -49,7 +49,7 @@ bool dispatch(int nr, int mr, int nw, int epi, bool gate, bool kt, hipStream_t s
     const P3Args &aa = a ? *a : none;
     if (epi == 0) {
         if (gate) return kt ? launch_epi0<true, true>(nr, mr, nw, st, aa, probe) : launch_epi0<true, false>(nr, mr, nw, st, aa, probe);
-        return kt ? false : launch_epi0<false, false>(nr, mr, nw, st, aa, probe);
+        return kt ? launch_epi0<false, true>(nr, mr, nw, st, aa, probe) : launch_epi0<false, false>(nr, mr, nw, st, aa, probe);  // (un-gated with a half-empty last step: the K = 80 / 112 expand layers, round 6)
     }
     if (gate || kt) return false;
     if (epi == 1) {
