@@ -133,6 +133,8 @@ class Crawler {
 
     struct Stats {
         uint64_t files_seen = 0, files_matched = 0, decoded = 0, skipped = 0, batches = 0, largest_batch = 0;
+        uint64_t out_of_range = 0;  // images of batches the embedder refused with PB_ERR_RANGE (an activation outside the fixed-point domain of
+                                    // the squeeze-excite sums: pixelbox_hip.h) -- dropped like undecodable files, the crawl goes on
     };
     Stats stats() const {
         std::lock_guard<std::mutex> lk(mu_);
@@ -389,7 +391,17 @@ class Crawler {
             }
             std::vector<uint8_t> hashes((size_t)n * model.dim());
             const uint8_t *d_hashes = nullptr;
-            check(pb_embed_stage_commit(model.raw(), hashes.data(), &d_hashes));
+            {
+                const int rc_commit = pb_embed_stage_commit(model.raw(), hashes.data(), &d_hashes);
+                if (rc_commit == PB_ERR_RANGE) {  // as in embed_loop: the batch is dropped and counted, the crawl goes on
+                    std::lock_guard<std::mutex> lk(mu_);
+                    stats_.out_of_range += n;
+                    stats_.skipped += n;
+                    cv_space_.notify_all();
+                    continue;
+                }
+                check(rc_commit);
+            }
             {
                 std::lock_guard<std::mutex> lk(mu_);
                 cv_space_.notify_all();  // workers that found the batch full: the other slot is open for them (or this one is free again)
@@ -465,7 +477,16 @@ class Crawler {
             // and a query hashed on the same embedder meanwhile (ShardedEngine::query_by_image_hash_from_file) would overwrite it
             std::unique_lock<std::recursive_mutex> own(model.exclusive());
             const uint8_t *d_hashes = nullptr;
-            const std::vector<std::vector<uint8_t>> hashes = image_hashes::mlhash_batch(model, imgs, sink_ ? &d_hashes : nullptr);
+            std::vector<std::vector<uint8_t>> hashes;
+            try {
+                hashes = image_hashes::mlhash_batch(model, imgs, sink_ ? &d_hashes : nullptr);
+            } catch (const Error &ex) {
+                if (ex.code != PB_ERR_RANGE) throw;
+                std::lock_guard<std::mutex> lk(mu_);  // one out-of-domain image fails its batch, not the crawl: the batch is dropped and counted
+                stats_.out_of_range += batch.size();
+                stats_.skipped += batch.size();
+                continue;
+            }
             std::vector<std::vector<uint8_t>> phashes;
             if (hasher_) phashes = image_hashes::phash_batch(*hasher_, imgs);  // the batch's phashes in one call too
             std::vector<IndexedImage> recs(batch.size());

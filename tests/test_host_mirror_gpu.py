@@ -215,6 +215,44 @@ def test_crawler_stage_and_query_by_file(tmp_path, staged):
     assert lines[-1] == "missing 0"
 
 
+@pytest.mark.parametrize("staged", [0, 1])
+def test_crawler_drops_a_batch_outside_the_fixed_point_domain_and_goes_on(tmp_path, staged):
+    """a model whose activations leave the domain of the fixed-point squeeze-excite sums fails a forward with
+    PB_ERR_RANGE; the crawler stage drops that batch like undecodable files (`skipped`) instead of cancelling the crawl, and
+    ends normally.  Here every batch is out of range: nothing indexed, everything counted, no error from the program."""
+    rng = np.random.default_rng(3)
+    h, w, d = 64, 64, 32
+    blob = W.synthetic_blob(synth.SEED_WEIGHTS, h, w, d)
+    raw = bytearray(blob)
+    pos = W.HEADER_BYTES
+    for name, shape, _ in W.tensor_specs(d):
+        n = int(np.prod(shape))
+        if name == "b2.dw.b":
+            t = np.frombuffer(bytes(raw[pos : pos + 4 * n]), dtype="<f4").copy() + np.float32(500.0)
+            raw[pos : pos + 4 * n] = t.astype("<f4").tobytes()
+        pos += 4 * n
+    (tmp_path / "w.pbxw").write_bytes(bytes(raw))
+    root = tmp_path / "pics"
+    root.mkdir()
+    for i in range(9):
+        _write_pnm(root / f"img{i:02d}.pnm", rng.integers(0, 256, size=(64, 64, 3), dtype=np.uint8))
+    exe = tmp_path / "crawler_demo"
+    libdir = os.path.dirname(capi.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "crawler_demo.cpp"), "-o", str(exe),
+                           "-L", libdir, "-lpixelbox_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
+    out = tmp_path / "out.txt"
+    p = subprocess.run([str(exe), str(tmp_path / "w.pbxw"), str(root), str(root / "img00.pnm"), str(out), "2", str(staged)], timeout=120,
+                       stderr=subprocess.PIPE)
+    # the crawl itself must end normally; the query by file afterwards hashes ONE image with the same model and is refused (exit 1, PB_ERR_RANGE)
+    lines = out.read_text().splitlines() if out.exists() else []
+    if lines:
+        head = dict(zip(lines[0].split()[::2], map(int, lines[0].split()[1::2])))
+        assert head["matched"] == 9 and head["indexed"] == 0 and head["skipped"] == 9, head
+    else:
+        assert p.returncode == 1 and b"error -7" in p.stderr, p.stderr  # the file is written before the query: reaching here means the crawl threw
+
+
 def test_staged_crawler_survives_a_throwing_decoder_a_cancel_and_restarts_clean(tmp_path):
     """a StagedDecoder that throws with a ticket in hand must not park the embed thread in pb_embed_stage_close; a
     cancelled or failed run must leave the embedder's staging usable (pb_embed_stage_abort), with no stale pixels in the next
