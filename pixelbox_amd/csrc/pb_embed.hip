@@ -137,6 +137,7 @@ struct pb_embedder {
     bool no_tail_fusion = false;   // PB_NO_TAIL_FUSION: head conv, k_avgpool, FC GEMM and k_tanh_quant as four launches (A/B runs)
     bool no_gemm_stream = false;   // PB_NO_GEMM_STREAM: leave k_gemm_stream out of the per-layer timing loops (A/B runs)
     bool no_gemm_t = false;        // PB_NO_GEMM_T: leave k_gemm_t out of the per-layer timing loops (A/B runs)
+    bool no_band_ipw = false;  // PB_NO_BAND_IPW: one (image, band) item per band-kernel workgroup, as before round 6 (A/B runs)
     bool no_band = false, force_band = false;  // PB_NO_BAND / PB_FORCE_BAND: leave out / always take the LDS-ring front kernel where it applies (A/B runs, bit comparisons)
     int tune_pick = 0;    // PB_TUNE_PICK: 0 fastest candidate (default); 1 slowest; 2 a pseudo-random one -- test hook: every form must give the same bits
     uint32_t tune_rng = 12345u;
@@ -956,15 +957,16 @@ const BandShape *band_shape(const Block &bl, int H, int W) {
 }
 
 template <int KS, int S, int CIN, int WT, int RPS>
-int launch_band_t(pb_embedder *e, const Block &bl, int n_bands, const float *x, int B, float *out) {
+int launch_band_t(pb_embedder *e, const Block &bl, int n_bands_cfg, const float *x, int B, float *out) {
+    const int n_bands = n_bands_cfg & 63, ipw = 1 << (n_bands_cfg >> 6);  // items a workgroup walks (k_front_band ipw)
     using G = FrontBandGeom<KS, S, WT, RPS>;
     auto kern = k_front_band<KS, S, CIN, WT, RPS>;
     if (G::LDS_BYTES > 48 * 1024)
         PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
-    const unsigned n_items = (unsigned)B * (unsigned)n_bands;
-    hipLaunchKernelGGL(kern, dim3((n_items + 7) / 8 * 8 * (bl.e / 16)), dim3(256), G::LDS_BYTES, e->stream, x, bl.expand.wt, bl.expand.Npad,
+    const unsigned n_items = (unsigned)B * (unsigned)n_bands, n_wgi = (n_items + ipw - 1) / ipw;
+    hipLaunchKernelGGL(kern, dim3((n_wgi + 7) / 8 * 8 * (bl.e / 16)), dim3(256), G::LDS_BYTES, e->stream, x, bl.expand.wt, bl.expand.Npad,
                        bl.expand.bias, bl.dw_wq, bl.dw_b, bl.e, out, e->buf_part, n_bands, G::Wo / n_bands, n_items,
-                       se_tail(e, bl, G::Wo, G::Wo));
+                       se_tail(e, bl, G::Wo, G::Wo), ipw);
     PB_HIP(hipGetLastError());
     return PB_OK;
 }
@@ -1062,30 +1064,33 @@ int run_front(pb_embedder *e, const Block &bl, const float *x, int n, int H, int
                 }
         if (const BandShape *bs = band_shape(bl, H, W)) {
             const int steps = Ho / bs->rps;
-            for (int nb : {1, 2, 4, 8, 16}) {
-                if (steps % nb || (size_t)nb * bl.e > e->part_floats_per_image || e->no_band) continue;
-                float ms = 0.f;
-                if ((rc = launch_band(e, bl, *bs, nb, x, n, e->buf_dw))) return rc;  // warm-up
-                PB_HIP(hipEventRecord(e0, e->stream));
-                for (int rep = 0; rep < 2; ++rep)
-                    if ((rc = launch_band(e, bl, *bs, nb, x, n, e->buf_dw))) return rc;
-                PB_HIP(hipEventRecord(e1, e->stream));
-                PB_HIP(hipEventSynchronize(e1));
-                PB_HIP(hipEventElapsedTime(&ms, e0, e1));
-                if (e->trace_tune)
-                    fprintf(stderr, "front k%d s%d e%d n%d: LDS-ring band kernel, bands %d %.1f us (separate %.1f)\n", bl.k, bl.stride, bl.e, n, nb,
-                            ms * 500.f, sep_ms * 500.f);
-                if (tune_take(e, ms, best_ms) || e->force_band) {
-                    if (e->force_band && best >= 0x2000 && ms >= best_ms) continue;
-                    best_ms = ms;
-                    best = 0x2000 + nb;
+            for (int nb : {1, 2, 4, 8, 16})
+                for (int lg_ipw : {0, 1, 2, 3}) {  // items a workgroup walks: 1, 2, 4, 8 (round 6; one only with a squeeze-excite tail)
+                    if (steps % nb || (size_t)nb * bl.e > e->part_floats_per_image || e->no_band) continue;
+                    if (lg_ipw && (e->fold_se || e->no_band_ipw || (long)n * nb < (1L << lg_ipw) * 2L * e->n_cu / (bl.e / 16) + 1)) continue;
+                    const int cfgb = nb + 64 * lg_ipw;
+                    float ms = 0.f;
+                    if ((rc = launch_band(e, bl, *bs, cfgb, x, n, e->buf_dw))) return rc;  // warm-up
+                    PB_HIP(hipEventRecord(e0, e->stream));
+                    for (int rep = 0; rep < 2; ++rep)
+                        if ((rc = launch_band(e, bl, *bs, cfgb, x, n, e->buf_dw))) return rc;
+                    PB_HIP(hipEventRecord(e1, e->stream));
+                    PB_HIP(hipEventSynchronize(e1));
+                    PB_HIP(hipEventElapsedTime(&ms, e0, e1));
+                    if (e->trace_tune)
+                        fprintf(stderr, "front k%d s%d e%d n%d: LDS-ring band kernel, bands %d, %d item(s) per workgroup %.1f us (separate %.1f)\n", bl.k, bl.stride,
+                                bl.e, n, nb, 1 << lg_ipw, ms * 500.f, sep_ms * 500.f);
+                    if (tune_take(e, ms, best_ms) || (e->force_band && !lg_ipw)) {
+                        if (e->force_band && best >= 0x2000 && ms >= best_ms) continue;
+                        best_ms = ms;
+                        best = 0x2000 + cfgb;
+                    }
                 }
-            }
         }
         it = e->front_cfg.emplace(key, best).first;
     }
     if (it->second >= 0x2000) {
-        *n_part_tiles = it->second - 0x2000;
+        *n_part_tiles = (it->second - 0x2000) & 63;
         *folded = e->fold_se && bl.sp <= 16;  // the band kernel's last workgroup per image has written the gate
         return launch_band(e, bl, *band_shape(bl, H, W), it->second - 0x2000, x, n, e->buf_dw);
     }
@@ -1771,6 +1776,7 @@ int pb_embed_create(pb_embedder **out, int device, const void *weights_blob, siz
     e->no_block_fusion = getenv("PB_NO_BLOCK_FUSION") != nullptr;
     e->no_gemm_stream = getenv("PB_NO_GEMM_STREAM") != nullptr;
     e->no_band = getenv("PB_NO_BAND") != nullptr;
+    e->no_band_ipw = getenv("PB_NO_BAND_IPW") != nullptr;
     e->force_band = getenv("PB_FORCE_BAND") != nullptr;
     auto body = [&]() -> int {
         hipDeviceProp_t prop;

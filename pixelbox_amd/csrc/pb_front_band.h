@@ -82,7 +82,7 @@ template <int KS, int S, int CIN, int WT, int RPS>
 __global__ __launch_bounds__(256, PB_BAND_WAVES) void k_front_band(
     const float *__restrict__ x, const float *__restrict__ wt, int Epad, const float *__restrict__ bias_e,
     const f32x4 *__restrict__ dw_wq, const float *__restrict__ dw_b, int E, float *__restrict__ out,
-    long long *__restrict__ part, int n_bands, int rows_per_band, unsigned n_items, SeTail se) {
+    long long *__restrict__ part, int n_bands, int rows_per_band, unsigned n_items, SeTail se, int ipw = 1) {
     using G = FrontBandGeom<KS, S, WT, RPS>;
     constexpr int KC = (CIN + 15) / 16;
     constexpr int PAD = G::PAD, W = G::W, H = G::W, Wo = G::Wo, Ho = G::Wo, RR = G::RR, RN = G::RN, R0 = G::R0, PLS = G::PLS;
@@ -107,11 +107,13 @@ __global__ __launch_bounds__(256, PB_BAND_WAVES) void k_front_band(
     const unsigned item = (blockIdx.x >> 3) / nz * 8u + (blockIdx.x & 7u);  // (image, band) pair
     const int e0 = (int)((blockIdx.x >> 3) % nz) * 16;
 #endif
-    if (item >= n_items) return;
-    const int band = (int)(item % (unsigned)n_bands), b = (int)(item / (unsigned)n_bands);
-    const int oy_b = band * rows_per_band;
+    // ipw (round 6): a workgroup walks `ipw` consecutive (image, band) items of its channel tile one after the other -- weights, taps
+    // and biases are loaded once, and the grid has ipw times fewer workgroups.  Where a band is ONE step (block 5 at 128 x 128: the
+    // whole 16 x 16 -> 8 x 8 image; 7 680 workgroups of 2.3 us each) the launch was bound by the rate at which workgroups can be
+    // dispatched -- one wave per SIMD resident on average (profiles/r06_embed_issue_floor_before.txt); ipw is timed per (block, batch).
+    const unsigned item0 = item * (unsigned)ipw;
+    if (item0 >= n_items) return;
     const int n_steps = rows_per_band / RPS;
-    const int iy_origin = oy_b * S - PAD;  // input row of ring position 0
 
     // ---- zero columns of every plane (left / right depthwise padding): written once, never overwritten
     for (int i = tid; i < RR * NQ * 2 * PAD; i += 256) {
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(256, PB_BAND_WAVES) void k_front_band(
 #pragma unroll
         for (int e = 0; e < 4; ++e) wreg[s2][e] = wt[(size_t)(16 * s2 + 4 * kq + e) * Epad + e0 + li];
     const f32x4 bev = *reinterpret_cast<const f32x4 *>(bias_e + e0 + 4 * kq);
-    const float *xb = x + (size_t)b * H * W * CIN + 4 * kq;
+    const float *xb = x + 4 * kq;  // + the item's image (set per item below)
     // this lane's slot inside a ring row, for pixel tile 0 (a tile further on is + 16 slots, stride 2: + 8)
     const unsigned wr_slot = (unsigned)(kq * PLS + G::slot(li + PAD));
     constexpr unsigned WR_TILE = S == 2 ? 8u : 16u;
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(256, PB_BAND_WAVES) void k_front_band(
     const f32x4 dbv = *reinterpret_cast<const f32x4 *>(dw_b + e0 + 4 * q);  // wave-uniform
     // store role (after the step's closing barrier): lane = (pixel 16 wave + lane / 4 of the step, channel quad lane % 4)
     const int sp_px = 16 * wave + (lane >> 2), sp_q = lane & 3;
-    float *op = out + ((size_t)(b * Ho + oy_b + sp_px / Wo) * Wo + sp_px % Wo) * E + e0 + 4 * sp_q;
+    float *op = out;  // set per item below
     const f32x4 *stg_rd = s_stage + sp_px * G::STG_PITCH + sp_q;
     f32x4 *stg_wr = s_stage + lane * G::STG_PITCH + q;
     auto flush_stage = [&]() __attribute__((always_inline)) {
@@ -223,8 +225,16 @@ __global__ __launch_bounds__(256, PB_BAND_WAVES) void k_front_band(
         op += (size_t)RPS * Wo * E;
     };
     const unsigned rd_col = (unsigned)(q * PLS + ox);  // + compile-time slot offset of kx
-    ll4 psum = {0, 0, 0, 0};
     int qmax = 0;  // largest converted output seen (se_range_check)
+  for (int ii = 0; ii < ipw; ++ii) {
+    const unsigned item_i = item0 + (unsigned)ii;
+    if (item_i >= n_items) break;  // (uniform over the workgroup)
+    const int band = (int)(item_i % (unsigned)n_bands), b = (int)(item_i / (unsigned)n_bands);
+    const int oy_b = band * rows_per_band;
+    const int iy_origin = oy_b * S - PAD;  // input row of ring position 0
+    xb = x + (size_t)b * H * W * CIN + 4 * kq;
+    op = out + ((size_t)(b * Ho + oy_b + sp_px / Wo) * Wo + sp_px % Wo) * E + e0 + 4 * sp_q;
+    ll4 psum = {0, 0, 0, 0};
 
     // ---- priming rows (ring positions 0 .. R0-1) of the band
     if constexpr (G::NP0 > 0) {
@@ -356,7 +366,6 @@ __global__ __launch_bounds__(256, PB_BAND_WAVES) void k_front_band(
 #ifndef PB_BAND_DIRECT_STORE
     if (n_steps > 0) flush_stage();  // the last step's
 #endif
-    se_range_check(qmax, part - 1);
     // ---- SE partial of this (image, band, quad): exact integer sum over the 64 lanes
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) {
@@ -366,11 +375,14 @@ __global__ __launch_bounds__(256, PB_BAND_WAVES) void k_front_band(
         psum.w += __shfl_xor(psum.w, m, 64);
     }
     if (lane == 0) se_part_store(part + ((size_t)b * n_bands + band) * E + e0 + 4 * q, psum);
-    // ---- the workgroup that completes the image computes its squeeze-excite gate (se_gate_image; the ring is free by now)
+    // ---- the workgroup that completes the image computes its squeeze-excite gate (se_gate_image; the ring is free by now; the host
+    // launches ipw = 1 with a squeeze-excite tail)
     if (se.sp) {
         if (se_arrive(se.cnt + b, nz * (unsigned)n_bands, reinterpret_cast<unsigned *>(s_ring)))
             se_gate_image_sp<256>(part + (size_t)b * n_bands * E, n_bands, E, se, se.gate + (size_t)b * E, reinterpret_cast<float *>(s_ring + 1));
     }
+  }
+    se_range_check(qmax, part - 1);
 }
 
 }  // namespace pbe
