@@ -2549,7 +2549,9 @@ int pb_embed_set_tuning(pb_embedder *e, const uint8_t *data, size_t len) {
         } else {
             const int c = t.v[0];
             const bool small = c >= 0x1000 && c < 0x2000 && (((c >> 8) & 15) == 1 || ((c >> 8) & 15) == 4) && (((c >> 4) & 15) == 2 || ((c >> 4) & 15) == 3) && (c & 7) <= 2;
-            const bool band = c >= 0x2000 && c <= 0x2000 + 16 && ((c - 0x2000) & (c - 0x2000 - 1)) == 0 && c > 0x2000;
+            // k_front_band: 0x2000 + bands per image (1, 2, 4, 8, 16) + 64 lg(items a workgroup walks: 1, 2, 4, 8)
+            const int bnb = (c - 0x2000) & 63, bip = (c - 0x2000) >> 6;
+            const bool band = c > 0x2000 && bip >= 0 && bip <= 3 && bnb >= 1 && bnb <= 16 && (bnb & (bnb - 1)) == 0;
             PB_CHECK(c == 0 || c == 1 || small || band || (c > 1 && c < 0x1000), PB_ERR_FORMAT, "tuning data: front form %d of layer %u is not a form of this build", c, t.key);
         }
     }

@@ -2438,20 +2438,32 @@ __global__ __launch_bounds__(NWQ * WAVE) void k_scan_multi_wg(
     constexpr int MAGIC = 0x4B400000;  // bits of 12582912.0f
     constexpr int QCAP = 1024;         // survivor queue entries
     static_assert(TR % 32 == 0 && TR <= NWQ * WAVE, "step shape");
-    __shared__ __attribute__((aligned(16))) uint8_t s_tile[2][TR * MQ_LDROW];
+    // (A 496-byte pitch with a per-row shift that makes every ds_read_b128 lane group hit sixteen distinct 16-byte slots -- the 272-byte
+    // pitch has one two-way conflict per group, 8 LDS cycles per read instead of 4 -- was measured in round 6: 2.44 ms against 2.41.
+    // The operand reads cost 0.55 ms of the pass (profiles/r06_burst_collect.txt), but not through the LDS array's cycles.)
+    constexpr int WROW = MQ_LDROW;
+    __shared__ __attribute__((aligned(16))) uint8_t s_tile[2][TR * WROW];
     __shared__ __attribute__((aligned(16))) float s_iw[2][TR];  // per row: 4 / W
     __shared__ __attribute__((aligned(16))) float s_c2[2][TR];  // (cr - 4 * 12582912) / W
-    __shared__ float s_iw4[2][TR / 4];  // per group of 4 rows: 4 / min W
-    __shared__ float s_c24[2][TR / 4];  // (max cr - 4 * 12582912) / min W
+    __shared__ __attribute__((aligned(8))) float s_f4[2][TR / 4][2];  // per group of 4 rows: {4 / min W, (max cr - 4 * 12582912) / min W}: one ds_read_b64
     __shared__ i32x4 s_qacc[QCAP];  // survivor queue: accumulator quad, query, first row of the quad
     __shared__ uint32_t s_qq[QCAP], s_qrow[QCAP];
-    __shared__ uint32_t s_qcnt;
+    // Round 6: the queue is eight SEGMENTS, one per wave, and a wave's fill count lives in a scalar register: appending is a ballot, a
+    // lane count and three LDS stores -- no LDS atomic whose return the wave would wait for, with the matrix pipe idle, on ~0.8 tiles
+    // of every step (PB_MQ_STAMP: the waves of a step differ by how many of their tiles held a survivor, and all eight wait at the
+    // step's barrier for the unluckiest: 1 225 of a step's 6 900 clocks).  s_qn publishes the counts for drain(); s_qflag asks for one.
+    constexpr int QSEG = QCAP / NWQ;
+    __shared__ uint32_t s_qn[NWQ];
+    __shared__ uint32_t s_qflag;
+    uint32_t wq_cnt = 0;  // entries in this wave's segment (uniform over the wave)
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;  // (a scalar wave index measured 2.5 % slower here: 2.82 vs 2.75 ms)
     const int li = lane & 15, kq = lane >> 4;
+    const int a_off = li * WROW + 16 * kq;  // this lane's A-fragment bytes of k slice 0 inside a 16-row tile
     const int qbase = (int)blockIdx.y * (NWQ * 64) + wave * 64;
     const bool active = qbase < n_q;  // a wave whose 64 queries lie past n_q only helps loading
-    if (tid == 0) s_qcnt = 0;
+    if (tid < NWQ) s_qn[tid] = 0;
+    if (tid == 0) s_qflag = 0;
     i32x4 bq[QT][4];
     i32x4 cinit[QT];
     float gthr[QT];
@@ -2488,13 +2500,24 @@ __global__ __launch_bounds__(NWQ * WAVE) void k_scan_multi_wg(
             db = den_b[rr];
         }
     };
-    auto stage = [&](uint64_t stp, int buf, const u32x4 (&src)[LPT], int sb, int db) __attribute__((always_inline)) {
+    auto stage_tile = [&](int buf, const u32x4 (&src)[LPT]) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < LPT; ++j) {
             u32x4 v = src[j];
             v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u;
-            *reinterpret_cast<u32x4 *>(&s_tile[buf][(ld_row + j * 4 * NWQ) * MQ_LDROW + ld_col]) = v;
+            *reinterpret_cast<u32x4 *>(&s_tile[buf][(ld_row + j * 4 * NWQ) * WROW + ld_col]) = v;
         }
+    };
+    // The per-row and per-group factors of a step (the first TR threads: two waves).  Round 6: (1) called at the TOP of the step before,
+    // not beside the tile staging in front of the barrier -- there the other six waves waited at the barrier while these two worked
+    // (PB_MQ_STAMP: 1 243 of a step's 7 214 clocks spent waiting at the barrier); here the work overlaps the MFMAs of the waves these
+    // two share their SIMDs with.  The factor buffer written is the one the step before last read, behind a barrier.  (2) ONE
+    // v_rcp_f32 per row and per group instead of four correctly rounded divisions (-fno-fast-math: ~10 dependent instructions each).
+    // v_rcp_f32 is within 1 ulp; the two quotients take it with DIRECTED margins -- 4 / W from rcp * (1 + 2^-21) >= 1 / W, and
+    // (cr - 4 * 12582912) / W, whose numerator is always negative, from rcp * (1 - 2^-21) <= 1 / W -- so both terms of t can only be
+    // over-estimated against the divisions they replace (by <= 2^-20 of ~2.1e4 each on ordinary rows: 0.02; more rows pass the
+    // first stage by that margin, none fewer) and the threshold's "- 1" keeps covering what it covered.
+    auto stage_factors = [&](uint64_t stp, int buf, int sb, int db) __attribute__((always_inline)) {
         if (tid < TR) {  // TR is a multiple of 64: whole waves
             // the 4 rows a lane tests together (one accumulator quad) share ONE pair of factors: the smallest W and the
             // largest cr of the group bound every row's t from above, (4 acc' + cr_r) / W_r <= (4 max acc' + max cr) / min W
@@ -2502,24 +2525,31 @@ __global__ __launch_bounds__(NWQ * WAVE) void k_scan_multi_wg(
             const bool ok = stp * TR + (uint64_t)tid < n_rows;  // rows past the end can never pass
             float w = ok ? __builtin_amdgcn_sqrtf((float)db) * (1.0f - 1e-6f) : 3.0e38f;
             int cr = ok ? 2 * sb - 511 * D : -0x40000000;
-            s_iw[buf][tid] = ok ? 4.0f / w : 0.0f;  // the row's own factors: the second, per-row stage of the test
-            s_c2[buf][tid] = ok ? (float)(cr - 50331648) / w : -3.0e38f;
+            constexpr float UP = 1.0f + 4.76837158203125e-7f, DN = 1.0f - 4.76837158203125e-7f;  // 1 +- 2^-21
+            const float rw = __builtin_amdgcn_rcpf(w);
+            s_iw[buf][tid] = ok ? 4.0f * (rw * UP) : 0.0f;  // the row's own factors: the second, per-row stage of the test
+            s_c2[buf][tid] = ok ? (float)(cr - 50331648) * (rw * DN) : -3.0e38f;
             w = fminf(w, __shfl_xor(w, 1));
             w = fminf(w, __shfl_xor(w, 2));
             const int c1 = __shfl_xor(cr, 1);
             cr = cr > c1 ? cr : c1;
             const int c2 = __shfl_xor(cr, 2);
             cr = cr > c2 ? cr : c2;
+            // |cr - 4 * 12582912| < 2^26 loses <= 2 units in the conversion, i.e. <= 2 / W <= 0.125 more in t -- with the 0.125 of
+            // the dropped remainder and the roundings of the products and of the fma still inside the "- 1" of the threshold.
+            // Every lane of a group computes the group's pair (same inputs, same bits) and one stores it: no divergent branch.
+            const bool any_ok = w < 1.0e38f;
+            const float rg = __builtin_amdgcn_rcpf(w);
+            const float iw4 = any_ok ? 4.0f * (rg * UP) : 0.0f;
+            const float c24 = any_ok ? (float)(cr - 50331648) * (rg * DN) : -3.0e38f;
             if ((tid & 3) == 0) {
-                // correctly rounded f32 quotients (-fno-fast-math): |cr - 4 * 12582912| < 2^26 loses <= 2 units in the
-                // conversion, i.e. <= 2 / W <= 0.125 more in t -- with the 0.125 of the dropped remainder and <= 0.6 of
-                // roundings still inside the "- 1" of the threshold (the f64 divisions this replaces were ~13 % of a step
-                // on the two SIMDs that ran them)
-                const bool any_ok = w < 1.0e38f;
-                s_iw4[buf][tid >> 2] = any_ok ? 4.0f / w : 0.0f;
-                s_c24[buf][tid >> 2] = any_ok ? (float)(cr - 50331648) / w : -3.0e38f;
+                *reinterpret_cast<float2 *>(&s_f4[buf][tid >> 2][0]) = make_float2(iw4, c24);
             }
         }
+    };
+    auto stage = [&](uint64_t stp, int buf, const u32x4 (&src)[LPT], int sb, int db) __attribute__((always_inline)) {
+        stage_tile(buf, src);
+        stage_factors(stp, buf, sb, db);
     };
     // exact integer re-test of one queued (row, query) and append to the query's candidate list
     auto retest_append = [&](int acc_bits, int q, uint32_t row) __attribute__((always_inline)) {
@@ -2531,28 +2561,40 @@ __global__ __launch_bounds__(NWQ * WAVE) void k_scan_multi_wg(
             if (idx < MQ_CAP) cand[(size_t)q * MQ_CAP + idx] = filter_key(cs, row);
         }
     };
-    auto mfma_tile = [&](const uint8_t *tile, i32x4 (&acc)[QT]) __attribute__((always_inline)) {
+    // A fragments of one 16-row tile (the lane's 16 bytes of each of the four 64-byte k slices) and the factors of the lane's row
+    // group: read ONE TILE AHEAD of their use (round 6), so no block of the step's pipeline starts by waiting for LDS
+    auto load_a = [&](const uint8_t *tile, i32x4 (&a)[4]) __attribute__((always_inline)) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
 #if defined(PB_MQ_ABL) && PB_MQ_ABL == 3  // ablation 3: no tests AND no LDS operand reads (a resident register instead)
-            const i32x4 a = bq[0][s];
+            a[s] = bq[0][s];
 #else
-            const i32x4 a = *reinterpret_cast<const i32x4 *>(tile + li * MQ_LDROW + 64 * s + 16 * kq);
+            a[s] = *reinterpret_cast<const i32x4 *>(tile + a_off + 64 * s);
 #endif
+        }
+    };
+    auto load_f = [&](int buf, int tl, float (&f)[2]) __attribute__((always_inline)) {
+        const float2 v = *reinterpret_cast<const float2 *>(&s_f4[buf][4 * tl + kq][0]);
+        f[0] = v.x;
+        f[1] = v.y;
+    };
+    auto mfma_a = [&](const i32x4 (&a)[4], i32x4 (&acc)[QT]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
 #if defined(PB_MQ_ABL) && PB_MQ_ABL == 2  // ablation 2: no MFMAs (the operand reads stay)
-                acc[qt] = s == 0 ? cinit[qt] : (i32x4){acc[qt][0] + a[0], acc[qt][1], acc[qt][2], acc[qt][3]};
+                acc[qt] = s == 0 ? cinit[qt] : (i32x4){acc[qt][0] + a[s][0], acc[qt][1], acc[qt][2], acc[qt][3]};
 #else
-                acc[qt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bq[qt][s], s == 0 ? cinit[qt] : acc[qt], 0, 0, 0);
+                acc[qt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[s], bq[qt][s], s == 0 ? cinit[qt] : acc[qt], 0, 0, 0);
 #endif
             }
         }
     };
-    auto test_tile = [&](const i32x4 (&acc)[QT], int buf, int tl, uint64_t stp) __attribute__((always_inline)) {
+    auto test_tile = [&](const i32x4 (&acc)[QT], int buf, int tl, uint64_t stp, const float (&f)[2]) __attribute__((always_inline)) {
         // lane holds rows rbase + r (r = 0..3) of query column li
         const int rl = 16 * tl + 4 * kq;
-        const float iw = s_iw4[buf][rl >> 2], c2 = s_c24[buf][rl >> 2];
+        const float iw = f[0], c2 = f[1];  // s_f4 of the lane's row group (load_f)
         float dq[QT];
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
@@ -2570,48 +2612,67 @@ __global__ __launch_bounds__(NWQ * WAVE) void k_scan_multi_wg(
         // step's 64 wave-tiles nearly always holding a survivor, whatever this branch costs is paid by the whole
         // workgroup on almost every step.  The exact re-test (which also discards the quad's non-survivors: it
         // implies the test above) and the append to the candidate lists happen in drain().
-        if (any) {
+        // (a branch of the WHOLE wave: every lane keeps the same wq_cnt)
+        if (__builtin_amdgcn_ballot_w64(any) != 0) {
             // second stage, per row with the row's own factors (what the test was before the group bound): on a table whose
-            // neighbouring rows have very different norms the group bound alone would pass whole quads and flood the queue
+            // neighbouring rows have very different norms the group bound alone would pass whole quads and flood the queue.
+            // Straight-line per query tile (four fma, four compares, no short-circuit cascade of exec-mask branches); a query tile
+            // none of whose lanes passed the first stage is skipped on the scalar side.
             const uint32_t row0 = (uint32_t)(stp * TR) + (uint32_t)rl;
             const f32x4_t iwr = *reinterpret_cast<const f32x4_t *>(&s_iw[buf][rl]);
             const f32x4_t c2r = *reinterpret_cast<const f32x4_t *>(&s_c2[buf][rl]);
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
+                if (__builtin_amdgcn_ballot_w64(hit[qt]) == 0) continue;
                 const int q = qbase + qt * 16 + li;
-                bool pass = false;
 #ifdef PB_MQ_NO_STAGE2  // test-of-the-test build: the group bound alone
-                pass = hit[qt];
+                bool pass = hit[qt];
+#else
+                const bool p0 = fma_plain(__int_as_float(acc[qt][0]), iwr[0], c2r[0]) >= gthr[qt];
+                const bool p1 = fma_plain(__int_as_float(acc[qt][1]), iwr[1], c2r[1]) >= gthr[qt];
+                const bool p2 = fma_plain(__int_as_float(acc[qt][2]), iwr[2], c2r[2]) >= gthr[qt];
+                const bool p3 = fma_plain(__int_as_float(acc[qt][3]), iwr[3], c2r[3]) >= gthr[qt];
+                bool pass = hit[qt] & (p0 | p1 | p2 | p3);
 #endif
-                if (hit[qt]) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) pass = pass || fma_plain(__int_as_float(acc[qt][r]), iwr[r], c2r[r]) >= gthr[qt];
-                }
-                if (pass && q < n_q) {
-                    const uint32_t slot = atomicAdd(&s_qcnt, 1u);
-                    if (slot < (uint32_t)QCAP) {
-                        s_qacc[slot] = acc[qt];
-                        s_qq[slot] = (uint32_t)q;
-                        s_qrow[slot] = row0;
-                    } else {
-                        // queue full: only a burst of (near-)duplicates of a query inside one 128-row step does
-                        // that.  Mark the list as overflowed; the query takes the exhaustive pass.
-                        atomicOr(&cand_cnt[q], 0x80000000u);
+                pass = pass & (q < n_q);
+                const uint64_t pm = __builtin_amdgcn_ballot_w64(pass);
+                if (pm != 0) {
+                    const uint32_t slot = wq_cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+                    if (pass) {
+                        if (slot < (uint32_t)QSEG) {
+                            const uint32_t e = (uint32_t)wave * QSEG + slot;
+                            s_qacc[e] = acc[qt];
+                            s_qq[e] = (uint32_t)q;
+                            s_qrow[e] = row0;
+                        } else {
+                            // segment full: only a burst of (near-)duplicates of a query inside a step or two does
+                            // that.  Mark the list as overflowed; the query takes the exhaustive pass.
+                            atomicOr(&cand_cnt[q], 0x80000000u);
+                        }
                     }
+                    wq_cnt += (uint32_t)__builtin_popcountll(pm);
                 }
+            }
+            if (lane == 0) {
+                s_qn[wave] = wq_cnt < (uint32_t)QSEG ? wq_cnt : (uint32_t)QSEG;
+                if (wq_cnt >= (uint32_t)(QSEG / 2)) s_qflag = 1u;
             }
         }
     };
     // drain the survivor queue (called by all threads between two barriers)
     auto drain = [&]() __attribute__((always_inline)) {
-        const uint32_t n = s_qcnt < (uint32_t)QCAP ? s_qcnt : (uint32_t)QCAP;
-        for (uint32_t i = tid; i < 4 * n; i += NWQ * WAVE) {
-            const uint32_t e = i >> 2, r = i & 3;
-            const uint32_t row = s_qrow[e] + r;
-            if ((uint64_t)row < n_rows) retest_append(reinterpret_cast<const int *>(&s_qacc[e])[r], (int)s_qq[e], row);
+        for (int w = 0; w < NWQ; ++w) {
+            const uint32_t n = s_qn[w];
+            for (uint32_t i = tid; i < 4 * n; i += NWQ * WAVE) {
+                const uint32_t e = (uint32_t)w * QSEG + (i >> 2), r = i & 3;
+                const uint32_t row = s_qrow[e] + r;
+                if ((uint64_t)row < n_rows) retest_append(reinterpret_cast<const int *>(&s_qacc[e])[r], (int)s_qq[e], row);
+            }
         }
         __syncthreads();
-        if (tid == 0) s_qcnt = 0;
+        if (tid < NWQ) s_qn[tid] = 0;
+        if (tid == 0) s_qflag = 0;
+        wq_cnt = 0;
         __syncthreads();
     };
 #ifdef PB_MQ_STAMP
@@ -2625,35 +2686,62 @@ __global__ __launch_bounds__(NWQ * WAVE) void k_scan_multi_wg(
 #ifdef PB_MQ_STAMP
         const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
 #endif
+        // the drain request of the step before (written before the barrier that ended it): read here, beside the first operand reads,
+        // and acted on after block 0 -- the first point of the step at which a test could append -- so the step does not begin with
+        // two LDS round trips one after the other (flag, then operands)
+        const uint32_t dflag = s_qflag;
+        if (s1 < n_steps) stage_factors(s1, buf ^ 1, sb_near, db_near);
+        i32x4 acc0[QT], acc1[QT];
+        i32x4 ae[4], ao[4];  // A fragments of the even / odd tile in flight
+        float fe[2], fo[2];  // factors of the even / odd tile under test
+        const uint8_t *tb = &s_tile[buf][0];
         if (active) {
-            i32x4 acc0[QT], acc1[QT];
-            mfma_tile(&s_tile[buf][0], acc0);
+            load_a(tb, ae);
             // ld_far's registers were staged one step ago: free again
             if (s2 < n_steps) issue(s2, ld_far, sb_far, db_far);
-            // two tiles per trip and NOT unrolled further: with all NT tiles (and their rarely-taken re-test
-            // blocks) unrolled the loop body outgrows the instruction cache and every step refetches it
-#pragma nounroll
-            for (int tp = 0; tp < NT / 2; ++tp) {
-                mfma_tile(&s_tile[buf][(16 * (2 * tp + 1)) * MQ_LDROW], acc1);
-#if !defined(PB_MQ_ABL) || (PB_MQ_ABL != 1 && PB_MQ_ABL != 3)  // ablation 1 / 3: no survivor tests (timing only: nothing is collected)
-                test_tile(acc0, buf, 2 * tp, stp);
-#else
-                if ((acc0[0][0] ^ acc0[1][1] ^ acc0[2][2] ^ acc0[3][3]) == 0x7fffffff) s_qcnt = 1;
-#endif
-                if (tp + 1 < NT / 2) mfma_tile(&s_tile[buf][(16 * (2 * tp + 2)) * MQ_LDROW], acc0);
-#if !defined(PB_MQ_ABL) || (PB_MQ_ABL != 1 && PB_MQ_ABL != 3)
-                test_tile(acc1, buf, 2 * tp + 1, stp);
-#else
-                if ((acc1[0][0] ^ acc1[1][1] ^ acc1[2][2] ^ acc1[3][3]) == 0x7fffffff) s_qcnt = 1;
-#endif
-            }
+            load_a(tb + 16 * WROW, ao);
+            load_f(buf, 0, fe);
+            mfma_a(ae, acc0);  // block 0
         } else if (s2 < n_steps) {
             issue(s2, ld_far, sb_far, db_far);
+        }
+        if (dflag != 0u) drain();  // uniform over the workgroup
+        if (active) {
+            // The step as a pipeline of NT blocks, block t = "MFMAs of tile t, with the survivor test of tile t - 1 in their shadow",
+            // each block straight-line up to its rarely-taken re-test branch; block t also requests tile t + 1's A fragments and tile
+            // t's factors from LDS, so every block finds its operands in registers.  (Until round 6 the loop body was [MFMA t + 1 |
+            // test t] [MFMA t + 2, conditional] [test t + 1]: every second test ran as a block of its own -- vector work with the
+            // matrix pipe idle, in both waves of a SIMD at once, the barrier keeps them in step -- and every tile's MFMAs began with
+            // a wait for their own ds_reads.)
+#if !defined(PB_MQ_ABL) || (PB_MQ_ABL != 1 && PB_MQ_ABL != 3)  // ablation 1 / 3: no survivor tests (timing only: nothing is collected)
+#define PB_MQ_TEST(ACC, TL, F) test_tile(ACC, buf, TL, stp, F)
+#else
+#define PB_MQ_TEST(ACC, TL, F) \
+    if ((ACC[0][0] ^ ACC[1][1] ^ ACC[2][2] ^ ACC[3][3]) == 0x7fffffff) s_qflag = 1
+#endif
+            // two blocks per trip and NOT unrolled further: with all NT tiles (and their rarely-taken re-test
+            // blocks) unrolled the loop body outgrows the instruction cache and every step refetches it
+#pragma nounroll
+            for (int tp = 0; tp < NT / 2 - 1; ++tp) {
+                load_a(tb + (16 * (2 * tp + 2)) * WROW, ae);
+                load_f(buf, 2 * tp + 1, fo);
+                mfma_a(ao, acc1);  // block 2 tp + 1
+                PB_MQ_TEST(acc0, 2 * tp, fe);
+                load_a(tb + (16 * (2 * tp + 3)) * WROW, ao);
+                load_f(buf, 2 * tp + 2, fe);
+                mfma_a(ae, acc0);  // block 2 tp + 2
+                PB_MQ_TEST(acc1, 2 * tp + 1, fo);
+            }
+            load_f(buf, NT - 1, fo);
+            mfma_a(ao, acc1);  // block NT - 1
+            PB_MQ_TEST(acc0, NT - 2, fe);
+            PB_MQ_TEST(acc1, NT - 1, fo);
+#undef PB_MQ_TEST
         }
 #ifdef PB_MQ_STAMP
         const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
 #endif
-        if (s1 < n_steps) stage(s1, buf ^ 1, ld_near, sb_near, db_near);
+        if (s1 < n_steps) stage_tile(buf ^ 1, ld_near);
 #ifdef PB_MQ_STAMP
         const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
 #endif
@@ -2662,7 +2750,6 @@ __global__ __launch_bounds__(NWQ * WAVE) void k_scan_multi_wg(
         const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
         st_c += ts1 - ts0; st_s += ts2 - ts1; st_b += ts3 - ts2; st_n += 1;
 #endif
-        if (s_qcnt >= (uint32_t)(QCAP / 2)) drain();  // uniform: read after the barrier
     };
     uint64_t st = blockIdx.x;
     if (st < n_steps) {

@@ -23,3 +23,11 @@ for rep in range(3):
     dt = time.perf_counter() - t0
     st = ix.stats()
     print(f"burst {nq}: {dt * 1e3:.3f} ms wall, {nq / dt:.0f} q/s; collect kernel {st.profiled_ms:.3f} ms; certified {st.fast_path} fallback {st.fallback}")
+# a -DPB_MQ_STAMP build (profiles/build_scan_ablation.sh): s_memtime clocks of the collect kernel's phases, summed over its waves
+import ctypes  # noqa: E402
+
+if hasattr(capi.lib(), "pb_debug_mq_stamps"):
+    out = (ctypes.c_ulonglong * 8)()
+    capi.lib().pb_debug_mq_stamps(out, 1)
+    c, s, b, nsteps = out[0], out[1], out[2], max(out[3], 1)
+    print(f"stamps per wave-step (100 MHz ticks): compute {c / nsteps:.1f} stage {s / nsteps:.1f} barrier wait {b / nsteps:.1f}  ({nsteps} wave-steps)")

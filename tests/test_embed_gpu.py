@@ -479,6 +479,15 @@ def test_tuning_picks_can_be_saved_and_restored():
     assert np.array_equal(f_b.view(np.uint32), f_a.view(np.uint32)) and np.array_equal(u8_b, u8_a)
     assert np.array_equal(f_1.view(np.uint32), f_a[:1].view(np.uint32))
     assert b.get_tuning() == saved
+    # the picks of a full batch as well: forms only the large buckets choose (k_front_band workgroups walking several items)
+    big = synth.synthetic_images(synth.SEED_IMAGES + 3, 1200, 512, 128, 128)
+    c = capi.Embedder(blob, max_batch=512)
+    u8_c, f_c = c.embed(big)
+    d = capi.Embedder(blob, max_batch=512)
+    d.set_tuning(c.get_tuning())
+    u8_d, f_d = d.embed(big)
+    assert d.tune_ms() == 0.0
+    assert np.array_equal(f_d.view(np.uint32), f_c.view(np.uint32)) and np.array_equal(u8_d, u8_c)
     # a block of another model shape, a truncated block and garbage are refused whole
     other = capi.Embedder(W.synthetic_blob(synth.SEED_WEIGHTS, 96, 96, 64), max_batch=4)
     for bad in (saved, saved[:-8], b"PBTN" + bytes(40)):
