@@ -275,6 +275,13 @@ int pb_embed_batch(pb_embedder *e, const uint8_t *rgb, uint32_t n, uint8_t *out_
 int pb_embed_batch_device(pb_embedder *e, const uint8_t *d_rgb, uint32_t n, uint8_t *d_out_u8,
                           float *d_out_f32);
 
+/* For PB_OPT_EMBED_ASYNC callers: PB_ERR_RANGE if a forward pass that has completed since the last check left the domain of the
+ * fixed-point squeeze-excite sums (its outputs are not valid), PB_OK otherwise; clears the flag.  Call it after waiting for the
+ * embedder's stream and before using the outputs of the batches queued since the last check: a queued pb_embed_batch_device call
+ * itself never reports (or consumes) the flag.  Every synchronous entry point checks by itself (efficientnet.rs:34: tract evaluates
+ * any range; this path refuses instead of hashing a saturated sum). */
+int pb_embed_check_range(pb_embedder *e);
+
 /* mlhash(img) -> Vec<u8> for one image: writes D bytes to out (out_len must be >= D).
  * One-image calls (this, pb_embed_batch with n = 1, pb_mlhash_image) replay the forward pass as one hipGraph from the third call on
  * (input copy + ~50 kernels + output copies captured once on the embedder's stream; same results; PB_NO_GRAPH=1 in the environment at

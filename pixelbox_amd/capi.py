@@ -43,7 +43,7 @@ SYMBOLS = [
     "pb_sharded_search", "pb_sharded_append_device", "pb_sharded_shard_device", "pb_sharded_contains", "pb_sharded_fill_synthetic", "pb_sharded_set_option", "pb_sharded_get_stats", "pb_topk_merge_packed_device", "pb_index_append", "pb_index_append_device", "pb_index_load",
     "pb_index_search", "pb_index_search_device", "pb_index_search_packed", "pb_topk_merge_packed", "pb_topk_merge", "pb_index_read", "pb_index_fill_synthetic",
     "pb_index_set_option", "pb_index_get_stats",
-    "pb_embed_create", "pb_embed_destroy", "pb_embed_info", "pb_embed_batch", "pb_embed_batch_device", "pb_mlhash",
+    "pb_embed_create", "pb_embed_destroy", "pb_embed_info", "pb_embed_batch", "pb_embed_batch_device", "pb_embed_check_range", "pb_mlhash",
     "pb_mlhash_image", "pb_embed_batch_images", "pb_embed_batch_images_device", "pb_embed_stage_acquire", "pb_embed_stage_release", "pb_embed_stage_close",
     "pb_embed_stage_commit", "pb_embed_stage_abort", "pb_resize_to_fill",
     "pb_embed_set_option", "pb_pinned_alloc", "pb_pinned_free", "pb_embed_tune_ms", "pb_embed_get_tuning", "pb_embed_set_tuning", "pb_fill_synthetic", "pb_fill_synthetic_images", "pb_fill_synthetic_scenes",
@@ -124,6 +124,7 @@ def lib():
         L.pb_embed_info.argtypes = [vp, u32p, u32p, u32p, u32p]
         L.pb_embed_batch.argtypes = [vp, u8p, C.c_uint32, u8p, f32p]
         L.pb_embed_batch_device.argtypes = [vp, vp, C.c_uint32, vp, vp]
+        L.pb_embed_check_range.argtypes = [vp]
         L.pb_mlhash.argtypes = [vp, u8p, u8p, C.c_size_t]
         L.pb_mlhash_image.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, u8p, C.c_size_t]
         L.pb_embed_batch_images.argtypes = [vp, C.POINTER(u8p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint32, u8p, C.POINTER(C.c_float)]
@@ -435,6 +436,10 @@ class Embedder:
     def embed_device(self, d_rgb_ptr: int, n: int, d_out_u8_ptr: int, d_out_f32_ptr: int = 0):
         _check(lib().pb_embed_batch_device(self._h, C.c_void_p(d_rgb_ptr), n, C.c_void_p(d_out_u8_ptr),
                                            C.c_void_p(d_out_f32_ptr) if d_out_f32_ptr else None))
+
+    def check_range(self):
+        """PB_OPT_EMBED_ASYNC callers, after their stream wait: raises PB_ERR_RANGE if a completed forward pass left the SE sums' domain"""
+        _check(lib().pb_embed_check_range(self._h))
 
     def tune_ms(self) -> float:
         """host milliseconds this embedder has spent timing kernel forms at first use"""

@@ -1924,7 +1924,16 @@ int pb_embed_batch_device(pb_embedder *e, const uint8_t *d_rgb, uint32_t n, uint
         PB_HIP(hipStreamSynchronize(e->stream));
         return range_status(e);
     }
-    return range_status(e);  // of the batches queued before this one (their waits are the caller's)
+    // Queued: the range flag belongs to work whose wait is the caller's, so this call neither reads nor clears it (until round 6 it
+    // returned -- and consumed -- the flag of EARLIER batches: an error for a call whose own work was still in flight, and the batch
+    // that raised it reported to whichever call came next).  The caller asks pb_embed_check_range after its stream wait.
+    return PB_OK;
+}
+
+int pb_embed_check_range(pb_embedder *e) {
+    PB_CHECK(e, PB_ERR_INVALID, "pb_embed_check_range: null embedder");
+    std::lock_guard<std::mutex> lock(e->mu);
+    return range_status(e);
 }
 
 // host copy split over a few threads (one thread moves ~10 GB/s: 2.5 ms for a chunk of 512 images, longer than its forward)

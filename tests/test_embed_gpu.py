@@ -309,6 +309,40 @@ def test_activation_outside_the_fixed_point_domain_fails_loudly(tensor):
     assert np.array_equal(u8, u8b)
 
 
+def test_queued_calls_leave_the_range_flag_to_pb_embed_check_range():
+    # PB_OPT_EMBED_ASYNC: a queued pb_embed_batch_device call neither reports nor consumes the out-of-domain flag (its own work is still
+    # in flight, and the flag it could see belongs to an earlier batch); the caller asks pb_embed_check_range after ITS stream wait
+    # (ADVICE r5).  A good model's check is quiet; a bad batch is reported exactly once.
+    import torch
+
+    blob = W.synthetic_blob(synth.SEED_WEIGHTS, 128, 128, 256)
+    h, w, d, tensors = W.parse_blob(blob)
+    raw = bytearray(blob)
+    pos = W.HEADER_BYTES
+    for name, shape, _ in W.tensor_specs(d):
+        n = int(np.prod(shape))
+        if name == "stem.w":
+            t = np.frombuffer(bytes(raw[pos : pos + 4 * n]), dtype="<f4").copy() * np.float32(2000.0)
+            raw[pos : pos + 4 * n] = t.astype("<f4").tobytes()
+        pos += 4 * n
+    imgs = synth.synthetic_images(synth.SEED_IMAGES, 0, 8, 128, 128)
+    d_img = torch.from_numpy(imgs).cuda()
+    d_u8 = torch.zeros((8, 256), dtype=torch.uint8, device="cuda")
+    s = torch.cuda.Stream()
+    for model, is_bad in ((bytes(raw), True), (blob, False)):
+        emb = capi.Embedder(model, max_batch=8)
+        emb.set_option(capi.PB_OPT_EMBED_STREAM, s.cuda_stream)
+        emb.set_option(capi.PB_OPT_EMBED_ASYNC, 1)
+        emb.embed_device(d_img.data_ptr(), 8, d_u8.data_ptr())  # queued: no error from the call itself
+        emb.embed_device(d_img.data_ptr(), 8, d_u8.data_ptr())  # nor from the next one
+        s.synchronize()
+        if is_bad:
+            with pytest.raises(capi.PixelboxError) as ei:
+                emb.check_range()
+            assert ei.value.code == capi.PB_ERR_RANGE
+        emb.check_range()  # consumed (or never raised)
+
+
 def test_one_image_calls_replay_a_graph_and_keep_the_bits(monkeypatch):
     # pb_mlhash / pb_embed_batch with one image replay the whole forward as one hipGraph from the third quiet call on (pb_embed.hip,
     # one_image_graph: a dependent launch is 3.1 us on a stream, 1.9 us as a graph node).  Same bits as the plain launches of an
