@@ -12,10 +12,15 @@ R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/$TAG; mkdir -p $O
 # the plain bench FIRST, on a device that streams at its idle rate (wait_quiet.py: a box can arrive, or be left by our own test suite, with
 # minutes of driver scrubbing ahead of it); then the tests; then the profiled runs, each behind the same wait
 cd /tmp; export TMPDIR=/tmp
+run_tests() { cd $R && timeout 1500 python -m pytest tests -q -m gpu > $O/gpu_tests_full.txt 2>&1; grep -E "passed|failed" $O/gpu_tests_full.txt > $O/gpu_tests.txt; cd /tmp; }
+TESTS_DONE=0
 timeout 400 python3 $R/profiles/wait_quiet.py > $O/wait_quiet.txt 2>&1
-timeout 900 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
-cd $R && timeout 1500 python -m pytest tests -q -m gpu > $O/gpu_tests_full.txt 2>&1; grep -E "passed|failed" $O/gpu_tests_full.txt > $O/gpu_tests.txt
-cd /tmp
+if [ $? -ne 0 ]; then  # a box that streams 2-3 % under its idle rate for minutes on end (seen: 250 s at 0.876, then 0.902 for the rest of the hour): tests first, then ask again
+  run_tests; TESTS_DONE=1
+  timeout 400 python3 $R/profiles/wait_quiet.py >> $O/wait_quiet.txt 2>&1
+fi
+T0=$SECONDS; timeout 900 python3 $R/bench.py > $O/bench.json 2> $O/bench.err; echo "plain bench.py: $((SECONDS - T0)) s wall" > $O/bench_wall.txt
+[ $TESTS_DONE = 1 ] || run_tests
 timeout 400 python3 $R/profiles/wait_quiet.py >> $O/wait_quiet.txt 2>&1
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/full -o full -- python3 $R/bench.py > $O/bench_under_rocprof.json 2> $O/full.err
 # the headline legs alone (default steps): the LOOPQ filter instance's average in this stats file is the 10M-row launches only
