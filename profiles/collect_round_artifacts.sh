@@ -53,4 +53,8 @@ timeout 1500 bash profiles/embed_pmc_pass.sh gpurun_out/$TAG/pmc_layers > /dev/n
 cp $O/pmc_layers/issue_floor.txt $O/embed_issue_floor.txt
 timeout 300 python3 profiles/dual_probe.py 2>&1 | grep batch > $O/dual.txt
 timeout 200 ./build/block_small_bench p3 > $O/block_small.txt 2>&1
+# round 6: the burst collect kernel -- ablation builds (pixelbox_amd/abl/libpixelbox_hip_scan_abl{1,3}.so from profiles/build_scan_ablation.sh, if present)
+# and its per-dispatch counters
+timeout 600 bash profiles/mq_ablate.sh gpurun_out/$TAG/mq_ablate > $O/burst_ablate.txt 2>&1
+timeout 600 bash profiles/mq_pmc_pass.sh gpurun_out/$TAG/mq_pmc > /dev/null 2>&1; cp $O/mq_pmc/mq_issue_account.txt $O/burst_issue_account.txt
 du -sh $O; ls $O
